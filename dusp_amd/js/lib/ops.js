@@ -1,0 +1,39 @@
+'use strict'
+/* Opcode table of the flat render-program descriptor ("DUSP words", see
+ * include/dusp_hip.h and DESIGN.md §3).  The same numbers live in
+ * dusp_amd/descriptor.py, dusp_amd/csrc/program.hpp and oracle/dusp_oracle.c;
+ * tests/test_descriptor.py keeps the four in step.
+ *
+ * The descriptor is a Float64Array so that JS, Python and C can all produce /
+ * parse it with no framing code: every field is one little-endian f64 word.
+ */
+
+const MAGIC = 1146442576 // 'DUSP' big-endian as an integer
+const VERSION = 1
+const HEADER_WORDS = 12
+
+const OP = Object.freeze({
+  OSC: 1, RAMP: 2, MULTIPLY: 3, SUM: 4, FILTER: 5, DELAY: 6,
+  CB_READER: 7, CB_WRITER: 8, REPEATER: 9,
+})
+
+const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
+
+const WAVEFORMS = Object.freeze({ sin: 0, sine: 0, saw: 1, square: 2, triangle: 3, '8bit': 4 })
+const WAVEFORM_NAMES = Object.freeze(['sin', 'saw', 'square', 'triangle', '8bit'])
+const FILTER_KINDS = Object.freeze({ LP: 0, HP: 1 })
+
+/* constructor name -> { op, inlets (data inlets, in descriptor order) } */
+const UNITS = Object.freeze({
+  Osc: { op: OP.OSC, inlets: ['f'] },
+  Ramp: { op: OP.RAMP, inlets: [] },
+  Multiply: { op: OP.MULTIPLY, inlets: ['a', 'b'] },
+  Sum: { op: OP.SUM, inlets: ['a', 'b'] },
+  Filter: { op: OP.FILTER, inlets: ['in', 'f'] },
+  Delay: { op: OP.DELAY, inlets: ['in', 'delay'] },
+  CircleBufferReader: { op: OP.CB_READER, inlets: ['offset'] },
+  CircleBufferWriter: { op: OP.CB_WRITER, inlets: ['offset', 'in'] },
+  Repeater: { op: OP.REPEATER, inlets: ['in'] },
+})
+
+module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, UNITS }
