@@ -1,0 +1,19 @@
+"""dusp_amd — MI355X-native offline render path for Dusp graphs.
+
+Host side (this package): graph construction with the reference's constructor
+signatures (graph.py), extraction to a flat descriptor (descriptor.py), and the
+ctypes binding of the HIP library (runtime.py).  Device side: dusp_amd/csrc/.
+"""
+from . import config, descriptor, quick, runtime  # noqa: F401
+from .descriptor import DuspError  # noqa: F401
+from .graph import (Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Delay, Filter, Multiply, Osc,  # noqa: F401
+                    Ramp, Repeater, Sum, Unit)
+from .render import ChannelData, render_many, renderChannelData  # noqa: F401
+from .runtime import Context, DuspHipError, Program  # noqa: F401
+
+
+def configure(sample_rate=None):
+    """Set the process-wide sample rate (the reference does this with `--sampleRate=` on argv,
+    src/config.js:1,17).  Call before building graphs."""
+    if sample_rate is not None:
+        config.sampleRate = int(sample_rate)

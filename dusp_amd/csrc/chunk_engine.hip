@@ -1,0 +1,297 @@
+// chunk_engine.hip — the universal ("chunk") engine.
+//
+// One lane per circuit INSTANCE, one wavefront per 64 instances, one persistent
+// launch per render: every wave loops over all chunks, and inside a chunk over
+// the device ops in the circuit's own process order, each op running its 256
+// samples sequentially — i.e. the schedule of reference src/Circuit.js:19-41
+// executed 64 instances at a time.  Because the schedule is the reference's,
+// feedback edges (a unit reading a buffer whose producer ticks later gets the
+// PREVIOUS chunk), Delay rings and shared CircleBuffers
+// need no special handling.
+//
+// Memory layout (all instance-interleaved so that the 64 lanes of a wave touch
+// 64 consecutive floats — one 256-byte coalesced access per wave instruction):
+//   scratch [buffer][t][instance]   chunk buffers = SignalChunk channels (SignalChunk.js:5-8)
+//   state   [slot][instance]  f64   Osc.phase, Ramp.t/playing, Filter x1..y2 + coefficients, node t
+//   rings   [ring sample][instance] Delay / CircleBuffer rings
+// PCM leaves through a 64x64 LDS transpose so that each store instruction
+// writes 256 contiguous bytes of one instance's channel.
+//
+// Arithmetic follows the JS semantics exactly: f64 for every expression JS
+// evaluates in Number, one f32 rounding per store into a chunk
+// (compile with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace dusp {
+
+__device__ __forceinline__ double or0(double v) { return (v != v || v == 0.0) ? 0.0 : v; }  // JS `v || 0`
+
+struct Src {
+    const float *ptr;
+    size_t stride;
+    float c;
+    bool is_buf;
+    __device__ __forceinline__ float at(int t) const { return is_buf ? ptr[(size_t)t * stride] : c; }
+};
+
+__device__ __forceinline__ Src make_src(const DevOperand &o, const ChunkArgs &a, uint32_t i) {
+    Src s;
+    s.is_buf = o.kind == SRC_BUF;
+    s.stride = a.n_pad;
+    s.ptr = a.scratch + (size_t)(s.is_buf ? o.idx : 0) * kChunk * a.n_pad + i;
+    s.c = o.cval;
+    if (o.kind == SRC_PARAM) s.c = i < a.n_inst ? a.params[(size_t)o.idx * a.n_inst + i] : 0.f;
+    return s;
+}
+
+// `phase += f; phase %= sr; if(phase < 0) phase += sr` (Osc.js:39-42).  fmod is exact, and for
+// sr <= p < 2sr it equals p - sr (exact by Sterbenz), so only far-out values pay for the libcall.
+__device__ __forceinline__ double osc_advance(double phase, double f, double sr) {
+    double p = phase + f;
+    if (fabs(p) >= sr) p = (p < 2.0 * sr && p > 0.0) ? p - sr : fmod(p, sr);
+    if (p < 0.0) p += sr;
+    return p;
+}
+
+// waveTable[floor(phase)]*(1-fraction) + waveTable[ceil(phase)]*fraction  (Osc.js:43-45).
+// Table row has sr+2 entries (one pad) so idx+1 is always in range.
+__device__ __forceinline__ float osc_lookup(const float *tbl, double phase, double sr) {
+    if (!(phase >= 0.0 && phase <= sr)) return __builtin_nanf("");  // typed-array[NaN / OOB] is undefined
+    const double lo = floor(phase);
+    const double fraction = phase - lo;  // == phase % 1 for phase >= 0
+    const int idx = (int)lo;
+    const double a = (double)tbl[idx];
+    const double b = (double)tbl[fraction != 0.0 ? idx + 1 : idx];  // ceil(phase)
+    return (float)(a * (1.0 - fraction) + b * fraction);
+}
+
+// CircleBuffer.read/write/mix index (CircleBuffer.js:16-18): floor(t % len), then wrap negatives.
+__device__ __forceinline__ int64_t ring_index(double t, double len) {
+    double m = (t >= 0.0 && t < len) ? t : fmod(t, len);
+    m = floor(m);
+    if (m < 0.0) m += len;
+    return (m >= 0.0 && m < len) ? (int64_t)m : -1;  // NaN -> dropped / undefined
+}
+
+__global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
+    __shared__ float tile[64 * 65];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;  // < n_pad by construction of the grid
+    const size_t NP = a.n_pad;
+    const double sr = (double)a.sample_rate;
+
+    for (uint32_t k = 0; k < a.n_chunks; ++k) {
+        const int64_t clock = a.clock0 + (int64_t)k * kChunk;
+        for (uint32_t u = 0; u < a.n_ops; ++u) {
+            const DevOp &op = a.ops[u];
+            float *outp = a.scratch + (size_t)(op.out_buf >= 0 ? op.out_buf : 0) * kChunk * NP + i;
+            double *st = a.state + (size_t)op.state_slot * NP + i;
+            switch (op.op) {
+            case OP_OSC: {  // Osc.js:35-47
+                const Src f = make_src(op.in[0], a, i);
+                const float *tbl = a.tables + (size_t)op.attr * a.table_stride;
+                double phase = st[0];
+                for (int t = 0; t < kChunk; ++t) {
+                    phase = osc_advance(phase, (double)f.at(t), sr);
+                    outp[(size_t)t * NP] = osc_lookup(tbl, phase, sr);
+                }
+                st[0] = phase;
+                break;
+            }
+            case OP_RAMP: {  // Ramp.js:25-40
+                const double duration = op.d[0], y0 = op.d[1], y1 = op.d[2];
+                double tt = st[0];
+                bool playing = st[NP] != 0.0;
+                for (int t = 0; t < kChunk; ++t) {
+                    if (playing) {
+                        tt += 1.0;
+                        if (tt > duration) { playing = false; tt = duration; }
+                        if (tt < 0.0) { playing = false; tt = 0.0; }
+                    }
+                    outp[(size_t)t * NP] = (float)(y0 + (tt / duration) * (y1 - y0));
+                }
+                st[0] = tt;
+                st[NP] = playing ? 1.0 : 0.0;
+                break;
+            }
+            case OP_MULTIPLY: {  // Multiply.js:23-34
+                const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
+                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t) * y.at(t);
+                break;
+            }
+            case OP_SUM: {  // Sum.js:33-44
+                const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
+                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t) + y.at(t);
+                break;
+            }
+            case OP_REPEATER: {  // Repeater.js:23-30
+                const Src x = make_src(op.in[0], a, i);
+                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t);
+                break;
+            }
+            case OP_FILTER: {  // Filter.js:27-51, coefficients :66-84
+                const Src x = make_src(op.in[0], a, i), f = make_src(op.in[1], a, i);
+                bool has_lastF = st[0] != 0.0;
+                double lastF = st[NP], a0 = st[2 * NP], a1 = st[3 * NP], a2 = st[4 * NP], b1 = st[5 * NP],
+                       b2 = st[6 * NP];
+                double x1 = st[7 * NP], x2 = st[8 * NP], y1 = st[9 * NP], y2 = st[10 * NP];
+                const double PI = 3.141592653589793;
+                for (int t = 0; t < kChunk; ++t) {
+                    const double ft = (double)f.at(t);
+                    if (!has_lastF || ft != lastF) {
+                        has_lastF = true;
+                        lastF = ft;
+                        if (op.attr == 0) {  // LP
+                            const double lamda = 1.0 / tan(PI * ft / sr);
+                            const double l2 = lamda * lamda;
+                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
+                            a1 = 2.0 * a0;
+                            a2 = a0;
+                            b1 = 2.0 * a0 * (1.0 - l2);
+                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
+                        } else {  // HP
+                            const double lamda = tan(PI * ft / sr);
+                            const double l2 = lamda * lamda;
+                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
+                            a1 = 0.0;
+                            a2 = -a0;
+                            b1 = 2.0 * a0 * (l2 - 1.0);
+                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
+                        }
+                    }
+                    const double xin = (double)x.at(t);
+                    const float y = (float)(a0 * xin + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));
+                    outp[(size_t)t * NP] = y;
+                    y2 = or0(y1);
+                    y1 = (double)y;
+                    x2 = or0(x1);
+                    x1 = xin;
+                }
+                st[0] = has_lastF ? 1.0 : 0.0;
+                st[NP] = lastF; st[2 * NP] = a0; st[3 * NP] = a1; st[4 * NP] = a2; st[5 * NP] = b1; st[6 * NP] = b2;
+                st[7 * NP] = x1; st[8 * NP] = x2; st[9 * NP] = y1; st[10 * NP] = y2;
+                break;
+            }
+            case OP_DELAY: {  // Delay.js:20-41
+                const Src x = make_src(op.in[0], a, i), dl = make_src(op.in[1], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const int64_t len = op.ring_len;
+                const double dlen = (double)len;
+                int64_t tBuffer = clock % len;
+                for (int t = 0; t < kChunk; ++t) {
+                    outp[(size_t)t * NP] = ring[(size_t)tBuffer * NP];
+                    ring[(size_t)tBuffer * NP] = 0.f;
+                    double tWrite = (double)tBuffer + (double)dl.at(t);
+                    if (!(tWrite >= 0.0 && tWrite < dlen))
+                        tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
+                    const double lo = floor(tWrite), hi = ceil(tWrite);
+                    const double frac = tWrite - trunc(tWrite);  // tWrite % 1
+                    const double xin = (double)x.at(t);
+                    // indices outside [0, len) (and NaN) are silently dropped; hi == len does NOT wrap
+                    if (lo >= 0.0 && lo < dlen) {
+                        float *p = ring + (size_t)(int64_t)lo * NP;
+                        *p = (float)((double)*p + xin * (1.0 - frac));
+                    }
+                    if (hi >= 0.0 && hi < dlen) {
+                        float *p = ring + (size_t)(int64_t)hi * NP;
+                        *p = (float)((double)*p + xin * frac);
+                    }
+                    if (++tBuffer == len) tBuffer = 0;
+                }
+                break;
+            }
+            case OP_CB_READER: {  // CircleBufferReader.js:12-25
+                const Src off = make_src(op.in[0], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const double dlen = (double)op.ring_len;
+                const double T = st[0];
+                for (int t = 0; t < kChunk; ++t) {
+                    const double tRead = T + (double)t - sr * (double)off.at(t);
+                    const int64_t idx = ring_index(tRead, dlen);
+                    outp[(size_t)t * NP] = idx >= 0 ? ring[(size_t)idx * NP] : __builtin_nanf("");
+                    if ((op.attr & 1) && idx >= 0) ring[(size_t)idx * NP] = 0.f;  // postWipe
+                }
+                st[0] = T + (double)kChunk;
+                break;
+            }
+            case OP_CB_WRITER: {  // CircleBufferWriter.js:12-25
+                const Src off = make_src(op.in[0], a, i), x = make_src(op.in[1], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const double dlen = (double)op.ring_len;
+                const double T = st[0];
+                for (int t = 0; t < kChunk; ++t) {
+                    const double tWrite = T + (double)t + sr * (double)off.at(t);
+                    const int64_t idx = ring_index(tWrite, dlen);
+                    if (idx < 0) continue;
+                    float *p = ring + (size_t)idx * NP;
+                    if (op.attr & 1) *p = 0.f;              // preWipe
+                    if (!(op.attr & 2)) *p = *p + x.at(t);  // mix
+                }
+                st[0] = T + (double)kChunk;
+                break;
+            }
+            default: break;
+            }
+        }
+
+        // copy-out (renderChannelData.js:35-44): `|| 0` maps NaN and -0 to +0; samples past
+        // n_samples in the last chunk are dropped.
+        for (uint32_t oc = 0; oc < a.n_out; ++oc) {
+            const float *src = a.scratch + (size_t)a.out_bufs[oc] * kChunk * NP + i;
+            for (int tb = 0; tb < kChunk / 64; ++tb) {
+                for (int tt = 0; tt < 64; ++tt) {
+                    float v = src[(size_t)(tb * 64 + tt) * NP];
+                    v = (v != v) ? 0.f : v + 0.f;
+                    tile[tt * 65 + lane] = v;
+                }
+                __syncthreads();
+                const uint64_t t = (uint64_t)k * kChunk + (uint64_t)tb * 64 + lane;
+                if (t < a.n_samples) {
+                    for (int r = 0; r < 64; ++r) {
+                        const uint32_t inst = blockIdx.x * 64 + r;
+                        if (inst >= a.n_inst) break;
+                        a.out[((size_t)inst * a.n_out + oc) * a.n_samples + t] = tile[lane * 65 + r];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream) {
+    const uint32_t blocks = a.n_pad / 64;
+    hipLaunchKernelGGL(dusp_chunk_kernel, dim3(blocks), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+// Broadcast the per-slot initial state to every instance column.
+__global__ void dusp_state_init_kernel(double *state, const double *init, uint32_t n_slots, uint32_t n_pad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)n_slots * n_pad) state[idx] = init[idx / n_pad];
+}
+
+hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream) {
+    const size_t n = (size_t)n_slots * n_pad;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(dusp_state_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, init,
+                       n_slots, n_pad);
+    return hipGetLastError();
+}
+
+// Fill kernel: the measured HBM write ceiling (16 B per lane, fully coalesced, nothing else).
+__global__ void __launch_bounds__(256) dusp_fill_kernel(f32x4 *out, size_t n4, float value) {
+    const f32x4 v = {value, value, value, value};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(v, out + i);
+}
+
+hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream) {
+    const size_t n4 = n_floats / 4;
+    if (n4) hipLaunchKernelGGL(dusp_fill_kernel, dim3(256 * 8), dim3(256), 0, stream, (f32x4 *)out, n4, value);
+    return hipGetLastError();
+}
+
+}  // namespace dusp

@@ -1,0 +1,48 @@
+// device_types.hpp — PODs shared by the host compiler and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace dusp {
+
+enum : int { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER };
+enum : int { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };   // descriptor inlet kinds
+enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand kinds
+constexpr int kNumTables = 5;
+constexpr int kChunk = 256;
+
+#if defined(__HIPCC__)
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what __builtin_nontemporal_store accepts
+#endif
+
+struct DevOperand {
+    int32_t kind;  // SRC_*
+    int32_t idx;   // SRC_BUF: chunk buffer; SRC_PARAM: parameter slot
+    float cval;    // SRC_CONST: the f32-rounded constant
+    int32_t pad;
+};
+
+// One mono operation: a (unit, output channel) pair of the circuit.
+struct DevOp {
+    int32_t op, unit, out_buf, state_slot;
+    int32_t attr, pad0;      // Osc: table id; Filter: kind; CircleBuffer node: bit0 wipe, bit1 no-input
+    DevOperand in[2];
+    double d[3];             // Ramp: duration, y0, y1
+    int64_t ring_base, ring_len;  // Delay / CircleBuffer nodes: ring location (samples, per instance)
+};
+
+// Arguments of the chunk engine's kernel (chunk_engine.hip).
+struct ChunkArgs {
+    const DevOp *ops;
+    const int32_t *out_bufs;
+    float *scratch;         // [n_bufs][256][n_pad]   chunk buffers, instance-interleaved
+    double *state;          // [n_slots][n_pad]
+    float *rings;           // [ring_samples][n_pad]
+    const float *params;    // [n_params][n_inst]
+    const float *tables;    // [kNumTables][table_stride]
+    float *out;             // [n_inst][n_out][n_samples]
+    uint64_t n_samples;
+    int64_t clock0;
+    uint32_t n_ops, n_out, n_inst, n_pad, n_chunks, sample_rate, table_stride, pad;
+};
+
+}  // namespace dusp

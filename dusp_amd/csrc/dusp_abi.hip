@@ -1,0 +1,425 @@
+// dusp_abi.hip — implementation of the C ABI declared in include/dusp_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dusp_hip.h"
+#include "device_types.hpp"
+#include "fused_plan.hpp"
+#include "program.hpp"
+
+namespace dusp {
+hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
+hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
+hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
+hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
+}  // namespace dusp
+
+static thread_local std::string g_error;
+
+struct dusp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    float *d_tables = nullptr;  // [kNumTables][table_stride]
+    uint32_t table_len = 0;     // entries per uploaded table (= sample_rate + 1), 0 until the first upload
+    uint32_t table_stride = 0;
+    bool table_set[dusp::kNumTables] = {false, false, false, false, false};
+    bool table_antisym[dusp::kNumTables] = {false, false, false, false, false};
+    int n_cus = 256;
+};
+
+template <class T>
+struct DevBuf {  // grow-only device allocation
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct dusp_program {
+    dusp_ctx *ctx = nullptr;
+    dusp::Program P;
+    int engine = DUSP_ENGINE_CHUNK;
+    dusp::FusedPlan fused;
+    // program constants on the device
+    DevBuf<dusp::DevOp> d_ops;
+    DevBuf<int32_t> d_out_bufs;
+    DevBuf<double> d_init;
+    // per-render workspaces (grown on demand)
+    DevBuf<float> d_scratch, d_rings;
+    DevBuf<double> d_state;
+    DevBuf<double> d_fused_state;  // FUSED: [n_state_words][n_inst] end-of-render state
+    uint32_t last_n_inst = 0, last_n_pad = 0;
+    bool rendered = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define CTX_FAIL(ctx, code, msg)  \
+    do {                          \
+        (ctx)->err = (msg);       \
+        return (code);            \
+    } while (0)
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string("HIP error: ") + hipGetErrorString(e_) + " in " + #expr;     \
+            return DUSP_ERR_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+extern "C" {
+
+const char *dusp_version(void) { return "dusp-hip 0.1.0 (gfx950)"; }
+int dusp_abi_version(void) { return DUSP_ABI_VERSION; }
+
+const char *dusp_last_error(const dusp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
+
+int dusp_ctx_create(int device, dusp_ctx **out) {
+    if (!out) {
+        g_error = "dusp_ctx_create: out is NULL";
+        return DUSP_ERR_ARG;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        g_error = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                  " (this library has no CPU fallback)";
+        return DUSP_ERR_HIP;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) {
+        g_error = "device index out of range";
+        return DUSP_ERR_ARG;
+    }
+    std::unique_ptr<dusp_ctx> ctx(new (std::nothrow) dusp_ctx);
+    if (!ctx) {
+        g_error = "out of memory";
+        return DUSP_ERR_ARG;
+    }
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        g_error = std::string("HIP error: ") + hipGetErrorString(e);
+        return DUSP_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cus = prop.multiProcessorCount;
+    *out = ctx.release();
+    return DUSP_OK;
+}
+
+void dusp_ctx_destroy(dusp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    delete ctx;
+}
+
+int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (table_id < 0 || table_id >= dusp::kNumTables || !table || n < 9 || n > (1u << 22) + 1)
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_table_upload: bad table id, pointer or length");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_tables) {
+        ctx->table_len = (uint32_t)n;
+        ctx->table_stride = (uint32_t)((n + 1 + 3) & ~(size_t)3);  // >= n+1 entries (one pad for idx+1), 16-byte rows
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tables, sizeof(float) * dusp::kNumTables * ctx->table_stride));
+        HIP_TRY(ctx, hipMemset(ctx->d_tables, 0, sizeof(float) * dusp::kNumTables * ctx->table_stride));
+    } else if (n != ctx->table_len) {
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_table_upload: all tables of a context must have the same length");
+    }
+    std::vector<float> row(ctx->table_stride, 0.f);
+    std::memcpy(row.data(), table, n * sizeof(float));
+    for (size_t k = n; k < row.size(); k++) row[k] = table[n - 1];  // pad: keeps an idx+1 read finite and in range
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tables + (size_t)table_id * ctx->table_stride, row.data(),
+                           row.size() * sizeof(float), hipMemcpyHostToDevice));
+    // T[N-t] == -T[t] for t = 1..N-1 lets a fused kernel keep half the table in LDS
+    bool antisym = (n % 2) == 1;
+    for (size_t t = 1; antisym && t < n; t++) antisym = table[n - t] == -table[t];
+    ctx->table_antisym[table_id] = antisym;
+    ctx->table_set[table_id] = true;
+    return DUSP_OK;
+}
+
+int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
+    *out = nullptr;
+    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED)
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
+    std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
+    if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
+    prog->ctx = ctx;
+    std::string err;
+    if (!dusp::compile(desc, n_words, prog->P, err)) {
+        const bool unsupported = err.find("not supported") != std::string::npos || err.find("only ") != std::string::npos;
+        CTX_FAIL(ctx, unsupported ? DUSP_ERR_UNSUPPORTED : DUSP_ERR_ARG, "dusp_program_build: " + err);
+    }
+    if (ctx->table_len && ctx->table_len != (uint32_t)prog->P.g.sample_rate + 1)
+        CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_build: uploaded wave tables do not match the program's sample rate");
+
+    const bool fusable = dusp::plan_fused(prog->P, prog->fused);
+    if (engine == DUSP_ENGINE_FUSED && !fusable)
+        CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
+    prog->engine = (engine == DUSP_ENGINE_CHUNK || !fusable) ? DUSP_ENGINE_CHUNK : DUSP_ENGINE_FUSED;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const dusp::Program &P = prog->P;
+    HIP_TRY(ctx, prog->d_ops.ensure(P.ops.size()));
+    HIP_TRY(ctx, hipMemcpy(prog->d_ops.p, P.ops.data(), P.ops.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, prog->d_out_bufs.ensure(P.out_bufs.size()));
+    HIP_TRY(ctx, hipMemcpy(prog->d_out_bufs.p, P.out_bufs.data(), P.out_bufs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!P.init_state.empty()) {
+        HIP_TRY(ctx, prog->d_init.ensure(P.init_state.size()));
+        HIP_TRY(ctx, hipMemcpy(prog->d_init.p, P.init_state.data(), P.init_state.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipEventCreate(&prog->ev0));
+    HIP_TRY(ctx, hipEventCreate(&prog->ev1));
+    *out = prog.release();
+    return DUSP_OK;
+}
+
+void dusp_program_destroy(dusp_program *prog) {
+    if (!prog) return;
+    (void)hipSetDevice(prog->ctx->device);
+    (void)hipStreamSynchronize(prog->ctx->stream);
+    prog->d_ops.release();
+    prog->d_out_bufs.release();
+    prog->d_init.release();
+    prog->d_scratch.release();
+    prog->d_rings.release();
+    prog->d_state.release();
+    prog->d_fused_state.release();
+    if (prog->ev0) (void)hipEventDestroy(prog->ev0);
+    if (prog->ev1) (void)hipEventDestroy(prog->ev1);
+    delete prog;
+}
+
+int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
+    if (!prog || !info) return DUSP_ERR_ARG;
+    std::memset(info, 0, sizeof *info);
+    const dusp::Graph &g = prog->P.g;
+    info->sample_rate = (uint32_t)g.sample_rate;
+    info->chunk_size = (uint32_t)g.chunk;
+    info->n_units = (uint32_t)g.units.size();
+    info->n_out_channels = (uint32_t)prog->P.out_bufs.size();
+    info->n_params = (uint32_t)g.n_params;
+    info->engine = (uint32_t)prog->engine;
+    info->n_device_ops = (uint32_t)prog->P.ops.size();
+    if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
+    return DUSP_OK;
+}
+
+static int check_tables(dusp_program *prog) {
+    dusp_ctx *ctx = prog->ctx;
+    for (const auto &u : prog->P.g.units)
+        if (u.op == dusp::OP_OSC) {
+            const int w = (int)u.attrs[0];
+            if (!ctx->d_tables || !ctx->table_set[w])
+                CTX_FAIL(ctx, DUSP_ERR_STATE, "render: wave table " + std::to_string(w) + " has not been uploaded (dusp_table_upload)");
+            if (ctx->table_len != (uint32_t)prog->P.g.sample_rate + 1)
+                CTX_FAIL(ctx, DUSP_ERR_STATE, "render: wave table length != sample_rate + 1");
+        }
+    return DUSP_OK;
+}
+
+int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, float *d_out,
+                       void *stream_) {
+    if (!prog) return DUSP_ERR_ARG;
+    dusp_ctx *ctx = prog->ctx;
+    const dusp::Program &P = prog->P;
+    if (n_instances < 1 || n_instances > (1u << 24)) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: n_instances must be in [1, 2^24]");
+    if (n_samples < 1 || n_samples > (1ull << 31)) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: n_samples must be in [1, 2^31]");
+    if (!d_out) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: d_out is NULL");
+    if (P.g.n_params > 0 && !d_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but d_params is NULL");
+    if (int rc = check_tables(prog)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    const uint32_t n_inst = (uint32_t)n_instances;
+    const uint32_t n_chunks = (uint32_t)((n_samples + dusp::kChunk - 1) / dusp::kChunk);
+
+    if (prog->engine == DUSP_ENGINE_FUSED) {
+        dusp::FusedLaunch L{};
+        L.params = d_params;
+        L.tables = ctx->d_tables;
+        L.table_stride = ctx->table_stride;
+        L.out = d_out;
+        L.n_inst = n_inst;
+        L.n_samples = n_samples;
+        L.n_chunks = n_chunks;
+        L.sample_rate = (uint32_t)P.g.sample_rate;
+        L.n_cus = ctx->n_cus;
+        L.table_antisym = ctx->table_antisym[prog->fused.table_id];
+        HIP_TRY(ctx, prog->d_fused_state.ensure((size_t)std::max(1, prog->fused.n_state_words) * n_inst));
+        L.end_state = prog->d_fused_state.p;
+        HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+        HIP_TRY(ctx, dusp::launch_fused(prog->fused, L, stream));
+        HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+        prog->last_n_inst = n_inst;
+        prog->rendered = true;
+        return DUSP_OK;
+    }
+
+    const uint32_t n_pad = (n_inst + 63u) & ~63u;
+    const size_t n_slots = P.init_state.size();
+    HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
+    HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+    HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
+    // outlets' chunks and all rings start as zeros (SignalChunk.js:7, Delay.js:14, CircleBuffer.js:12)
+    HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad * sizeof(float), stream));
+    if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+    HIP_TRY(ctx, dusp::launch_state_init(prog->d_state.p, prog->d_init.p, (uint32_t)n_slots, n_pad, stream));
+
+    dusp::ChunkArgs a{};
+    a.ops = prog->d_ops.p;
+    a.out_bufs = prog->d_out_bufs.p;
+    a.scratch = prog->d_scratch.p;
+    a.state = prog->d_state.p;
+    a.rings = prog->d_rings.p;
+    a.params = d_params;
+    a.tables = ctx->d_tables;
+    a.out = d_out;
+    a.n_samples = n_samples;
+    a.clock0 = P.g.clock0;
+    a.n_ops = (uint32_t)P.ops.size();
+    a.n_out = (uint32_t)P.out_bufs.size();
+    a.n_inst = n_inst;
+    a.n_pad = n_pad;
+    a.n_chunks = n_chunks;
+    a.sample_rate = (uint32_t)P.g.sample_rate;
+    a.table_stride = ctx->table_stride;
+    HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+    HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
+    HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+    prog->last_n_inst = n_inst;
+    prog->last_n_pad = n_pad;
+    prog->rendered = true;
+    return DUSP_OK;
+}
+
+int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out) {
+    if (!prog) return DUSP_ERR_ARG;
+    dusp_ctx *ctx = prog->ctx;
+    if (!h_out) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: h_out is NULL");
+    const size_t n_par = (size_t)prog->P.g.n_params * n_instances;
+    if (n_par && !h_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but h_params is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_out = n_instances * prog->P.out_bufs.size() * n_samples;
+    float *d_out = nullptr, *d_par = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d_out, std::max<size_t>(1, n_out) * sizeof(float)));
+    int rc = DUSP_OK;
+    hipError_t e = hipSuccess;
+    if (n_par) {
+        e = hipMalloc((void **)&d_par, n_par * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        rc = dusp_render_device(prog, n_instances, n_samples, d_par, d_out, ctx->stream);
+        if (rc == DUSP_OK) {
+            e = hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    (void)hipFree(d_out);
+    if (d_par) (void)hipFree(d_par);
+    if (rc != DUSP_OK) return rc;
+    if (e != hipSuccess) CTX_FAIL(ctx, DUSP_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e));
+    return DUSP_OK;
+}
+
+int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double *out, size_t cap) {
+    if (!prog) return DUSP_ERR_ARG;
+    dusp_ctx *ctx = prog->ctx;
+    if (!prog->rendered) CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_state_download: nothing has been rendered yet");
+    const dusp::Graph &g = prog->P.g;
+    if (unit >= g.units.size() || instance >= prog->last_n_inst || !out)
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_state_download: unit / instance out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const dusp::UnitDesc &u = g.units[unit];
+    std::vector<double> words;
+    auto or0 = [](double v) { return (v != v || v == 0) ? 0.0 : v; };
+    if (prog->engine == DUSP_ENGINE_FUSED) {
+        const int first = prog->fused.unit_state_first[unit], n = prog->fused.unit_state_count[unit];
+        for (int k = 0; k < n; k++) {
+            double v = 0;
+            HIP_TRY(ctx, hipMemcpy(&v, prog->d_fused_state.p + (size_t)(first + k) * prog->last_n_inst + instance,
+                                   sizeof(double), hipMemcpyDeviceToHost));
+            words.push_back(v);
+        }
+    } else {
+        auto rd = [&](int slot, double &v) {
+            return hipMemcpy(&v, prog->d_state.p + (size_t)slot * prog->last_n_pad + instance, sizeof(double), hipMemcpyDeviceToHost);
+        };
+        const int n_ch = (u.op == dusp::OP_FILTER) ? u.n_out : 1;
+        const int per = u.slots_per_ch;
+        if (u.op == dusp::OP_FILTER) {
+            for (int k = 0; k < 7; k++) {
+                double v;
+                HIP_TRY(ctx, rd(u.first_slot + k, v));
+                words.push_back(v);
+            }
+            words.push_back((double)n_ch);
+            for (int c = 0; c < n_ch; c++)
+                for (int k = 7; k < 11; k++) {
+                    double v;
+                    HIP_TRY(ctx, rd(u.first_slot + c * per + k, v));
+                    words.push_back(or0(v));
+                }
+        } else {
+            for (int k = 0; k < per; k++) {
+                double v;
+                HIP_TRY(ctx, rd(u.first_slot + k, v));
+                words.push_back(v);
+            }
+        }
+    }
+    for (size_t k = 0; k < words.size() && k < cap; k++) out[k] = words[k];
+    return (int)words.size();
+}
+
+int dusp_last_kernel_ms(dusp_program *prog, float *ms) {
+    if (!prog || !ms) return DUSP_ERR_ARG;
+    dusp_ctx *ctx = prog->ctx;
+    if (!prog->rendered) CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_last_kernel_ms: nothing has been rendered yet");
+    HIP_TRY(ctx, hipEventSynchronize(prog->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, prog->ev0, prog->ev1));
+    return DUSP_OK;
+}
+
+int dusp_fill_device(dusp_ctx *ctx, float *d_out, size_t n_floats, float value, void *stream_) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (!d_out || (n_floats & 3) || ((uintptr_t)d_out & 15)) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_fill_device: need a 16-byte aligned buffer of 4k floats");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, dusp::launch_fill(d_out, n_floats, value, stream_ ? (hipStream_t)stream_ : ctx->stream));
+    return DUSP_OK;
+}
+
+}  // extern "C"

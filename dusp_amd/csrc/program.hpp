@@ -1,0 +1,375 @@
+// program.hpp — host-side compiler: descriptor words -> device program.
+//
+// Stage 1 (parse)      words -> Graph (units in the reference's process order,
+//                      src/Circuit.js:125-131; the order is taken as given).
+// Stage 2 (channels)   static channel-count inference.  The reference grows
+//                      channel lists lazily at tick time (Multiply.js:29,
+//                      Filter.js:31-32, Delay.js:22-24); for the graphs accepted
+//                      here the count every outlet ends up with is a function of
+//                      the graph alone, so it is fixed before launch.
+// Stage 3 (expand)     every (unit, output channel) becomes one mono DevOp that
+//                      reads / writes mono chunk buffers, so kernels never see
+//                      channel lists.
+// Stage 4 (shape)      feed-forward Osc/Ramp/Multiply/Sum trees are matched
+//                      against the fused kernels' signatures (fused_engine.hip).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+
+namespace dusp {
+
+constexpr double kMagic = 1146442576.0;
+constexpr size_t kHeaderWords = 12;
+
+struct InletDesc {
+    int kind = IN_CONST;       // IN_CONST / IN_CONNECT / IN_PARAM
+    std::vector<double> vals;  // CONST: channel values; PARAM: slot per channel
+    int src_unit = -1;
+    int n_channels(const std::vector<struct UnitDesc> &units) const;
+};
+
+struct UnitDesc {
+    int op = 0;
+    std::vector<InletDesc> inlets;
+    std::vector<double> attrs, state;
+    int n_out = 1;       // output channels (0: no data outlet)
+    int first_buf = -1;  // chunk buffer of output channel 0
+    int first_op = -1;   // first DevOp of this unit
+    int first_slot = -1; // first state slot of channel 0
+    int slots_per_ch = 0;
+};
+
+struct RingDesc {
+    int nch = 1;
+    int64_t len = 0;
+    int first_dev_ring = -1;
+};
+
+struct DevRing {
+    int64_t base = 0, len = 0;  // in samples; arena index = (base + idx) * n_pad + instance
+};
+
+struct Graph {
+    int sample_rate = 0, chunk = 0, n_params = 0, out_unit = 0;
+    int64_t clock0 = 0;
+    std::vector<RingDesc> rings;
+    std::vector<UnitDesc> units;
+};
+
+struct Program {
+    Graph g;
+    std::vector<DevOp> ops;
+    std::vector<int32_t> out_bufs;
+    std::vector<double> init_state;  // one value per state slot, broadcast to every instance
+    std::vector<DevRing> dev_rings;
+    int n_bufs = 0;
+    int64_t ring_samples = 0;  // per instance
+    bool feed_forward = true;  // every connection goes from an earlier unit to a later one
+};
+
+inline int InletDesc::n_channels(const std::vector<UnitDesc> &units) const {
+    if (kind == IN_CONNECT) return units[(size_t)src_unit].n_out;
+    return (int)vals.size();
+}
+
+inline bool fail(std::string &err, const std::string &msg) {
+    err = msg;
+    return false;
+}
+
+inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
+    if (!d || nw < kHeaderWords) return fail(err, "descriptor too short");
+    if (d[0] != kMagic) return fail(err, "descriptor magic mismatch");
+    if (d[1] != 1) return fail(err, "unsupported descriptor version");
+    auto as_count = [&](double v, double max, int64_t &out) {
+        if (!(v >= 0 && v <= max) || v != std::floor(v)) return false;
+        out = (int64_t)v;
+        return true;
+    };
+    int64_t sr, chunk, n_units, n_rings, n_params, out_unit, clock0;
+    if (!as_count(d[2], 1 << 22, sr) || sr < 8) return fail(err, "bad sample rate");
+    if (!as_count(d[3], 4096, chunk) || chunk != 256)
+        return fail(err, "only the standard chunk size 256 is supported (reference src/config.js:6)");
+    if (!as_count(d[4], 1 << 20, n_units) || n_units < 1) return fail(err, "bad unit count");
+    if (!as_count(d[5], 1 << 16, n_rings)) return fail(err, "bad ring count");
+    if (!as_count(d[6], 1 << 20, n_params)) return fail(err, "bad parameter count");
+    if (!as_count(d[7], (double)n_units - 1, out_unit)) return fail(err, "output unit out of range");
+    if (d[8] != 0) return fail(err, "only outlet 0 (\"out\") can be rendered");
+    if (!as_count(d[9], 9e15, clock0)) return fail(err, "bad clock");
+    if (clock0 != 0) return fail(err, "circuit has already been ticked; render a fresh circuit");
+    g.sample_rate = (int)sr;
+    g.chunk = (int)chunk;
+    g.n_params = (int)n_params;
+    g.out_unit = (int)out_unit;
+    g.clock0 = clock0;
+    size_t p = kHeaderWords;
+    g.rings.resize((size_t)n_rings);
+    for (auto &r : g.rings) {
+        if (p + 2 > nw) return fail(err, "truncated ring table");
+        int64_t nch, len;
+        if (!as_count(d[p], 64, nch) || nch < 1) return fail(err, "bad ring channel count");
+        if (!as_count(d[p + 1], 1e9, len) || len < 1) return fail(err, "bad ring length");
+        r.nch = (int)nch;
+        r.len = len;
+        p += 2;
+    }
+    g.units.resize((size_t)n_units);
+    for (size_t i = 0; i < g.units.size(); i++) {
+        UnitDesc &u = g.units[i];
+        const std::string where = "unit " + std::to_string(i) + ": ";
+        if (p + 4 > nw) return fail(err, where + "truncated record");
+        int64_t op, n_in, n_attr, n_state;
+        if (!as_count(d[p], 64, op) || !as_count(d[p + 1], 2, n_in) || !as_count(d[p + 2], 64, n_attr) ||
+            !as_count(d[p + 3], 1 << 12, n_state))
+            return fail(err, where + "bad record header");
+        p += 4;
+        u.op = (int)op;
+        u.inlets.resize((size_t)n_in);
+        for (auto &in : u.inlets) {
+            if (p + 2 > nw) return fail(err, where + "truncated inlet");
+            int64_t kind, n;
+            if (!as_count(d[p], 2, kind) || !as_count(d[p + 1], 64, n)) return fail(err, where + "bad inlet header");
+            p += 2;
+            if (p + (size_t)n > nw) return fail(err, where + "truncated inlet values");
+            in.kind = (int)kind;
+            if (kind == IN_CONNECT) {
+                int64_t src;
+                if (n != 3 || !as_count(d[p], (double)n_units - 1, src)) return fail(err, where + "bad connection");
+                if (d[p + 1] != 0) return fail(err, where + "only outlet 0 carries data");
+                in.src_unit = (int)src;
+            } else {
+                if (n < 1) return fail(err, where + "empty constant");
+                in.vals.assign(d + p, d + p + n);
+                if (kind == IN_PARAM)
+                    for (double v : in.vals) {
+                        int64_t slot;
+                        if (!as_count(v, (double)n_params - 1, slot)) return fail(err, where + "parameter slot out of range");
+                    }
+            }
+            p += (size_t)n;
+        }
+        if (p + (size_t)(n_attr + n_state) > nw) return fail(err, where + "truncated attributes/state");
+        u.attrs.assign(d + p, d + p + n_attr);
+        u.state.assign(d + p + n_attr, d + p + n_attr + n_state);
+        p += (size_t)(n_attr + n_state);
+        auto need = [&](size_t inl, size_t at, size_t st) {
+            return u.inlets.size() == inl && u.attrs.size() == at && (st == SIZE_MAX || u.state.size() == st);
+        };
+        switch (u.op) {
+        case OP_OSC:
+            if (!need(1, 1, 1)) return fail(err, where + "bad Osc record");
+            if (!(u.attrs[0] >= 0 && u.attrs[0] < kNumTables && u.attrs[0] == std::floor(u.attrs[0])))
+                return fail(err, where + "waveform doesn't exist");
+            break;
+        case OP_RAMP:
+            if (!need(0, 3, 2)) return fail(err, where + "bad Ramp record");
+            break;
+        case OP_MULTIPLY:
+        case OP_SUM:
+            if (!need(2, 0, 0)) return fail(err, where + "bad Multiply/Sum record");
+            break;
+        case OP_FILTER: {
+            if (!need(2, 1, SIZE_MAX) || u.state.size() < 8) return fail(err, where + "bad Filter record");
+            if (u.attrs[0] != 0 && u.attrs[0] != 1) return fail(err, where + "filter kind not supported (LP/HP only)");
+            int64_t nch;
+            if (!as_count(u.state[7], 64, nch) || u.state.size() != (size_t)(8 + 4 * nch))
+                return fail(err, where + "bad Filter state");
+            break;
+        }
+        case OP_DELAY: {
+            int64_t md;
+            if (!need(2, 1, 0) || !as_count(u.attrs[0], 1e9, md) || md < 1) return fail(err, where + "bad Delay record");
+            break;
+        }
+        case OP_CB_READER:
+        case OP_CB_WRITER: {
+            int64_t ring;
+            if (!need(u.op == OP_CB_READER ? 1 : 2, 2, 1) || !as_count(u.attrs[0], (double)n_rings - 1, ring))
+                return fail(err, where + "bad CircleBuffer node record");
+            break;
+        }
+        case OP_REPEATER:
+            if (!need(1, 0, 0)) return fail(err, where + "bad Repeater record");
+            break;
+        default:
+            return fail(err, where + "unknown opcode " + std::to_string(u.op));
+        }
+    }
+    if (p != nw) return fail(err, "trailing words after the last unit");
+    return true;
+}
+
+inline int unit_channels(const Graph &g, const UnitDesc &u) {
+    auto nin = [&](size_t k) { return u.inlets[k].n_channels(g.units); };
+    switch (u.op) {
+    case OP_OSC:
+    case OP_RAMP: return 1;                                               // mono outlets (Osc.js:12, Ramp.js:6)
+    case OP_MULTIPLY:
+    case OP_SUM: return std::max(nin(0), nin(1));                         // Multiply.js:26, Sum.js:35-37
+    case OP_FILTER: return std::max(1, nin(0));                           // Filter.js:31-32
+    case OP_DELAY: return std::max(1, std::max(nin(0), nin(1)));          // Delay.js:21
+    case OP_CB_READER: return std::max(1, g.rings[(size_t)u.attrs[0]].nch);  // CircleBufferNode.js:19-22
+    case OP_CB_WRITER: return 0;                                          // no data outlet
+    case OP_REPEATER: return std::max(1, nin(0));                         // Repeater.js:24-25
+    }
+    return 1;
+}
+
+inline bool infer_channels(Graph &g, std::string &err) {
+    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER) ? 0 : 1;  // outlets start with one channel (Piglet.js:13)
+    std::vector<int> first_pass;
+    for (int pass = 0; pass < 66; pass++) {
+        bool changed = false;
+        for (auto &u : g.units) {
+            for (auto &in : u.inlets)
+                if (in.kind == IN_CONNECT && g.units[(size_t)in.src_unit].n_out == 0)
+                    return fail(err, "a unit without a data outlet (CircleBufferWriter) feeds an inlet");
+            int n = unit_channels(g, u);
+            if (n != u.n_out) { u.n_out = n; changed = true; }
+        }
+        if (pass == 0)
+            for (auto &u : g.units) first_pass.push_back(u.n_out);
+        if (!changed) break;
+        if (pass == 65) return fail(err, "channel counts do not settle");
+    }
+    for (size_t i = 0; i < g.units.size(); i++)
+        if (g.units[i].n_out != first_pass[i])
+            return fail(err, "channel count grows through a feedback edge (not supported on the GPU path)");
+    for (auto &u : g.units) {
+        if (u.op == OP_DELAY && u.inlets[1].n_channels(g.units) > u.inlets[0].n_channels(g.units))
+            return fail(err, "Delay with more delay channels than input channels is not supported "
+                             "(the reference aliases its input chunk, Delay.js:23)");
+        if (u.op == OP_FILTER && u.inlets[1].n_channels(g.units) < 1) return fail(err, "Filter without f");
+    }
+    if (g.units[(size_t)g.out_unit].n_out < 1) return fail(err, "the rendered unit has no data outlet");
+    return true;
+}
+
+inline DevOperand make_operand(const Graph &g, const InletDesc &in, int ch) {
+    DevOperand o{};
+    const int n = in.n_channels(g.units);
+    const int c = ch % n;
+    if (in.kind == IN_CONNECT) {
+        o.kind = SRC_BUF;
+        o.idx = g.units[(size_t)in.src_unit].first_buf + c;
+    } else if (in.kind == IN_PARAM) {
+        o.kind = SRC_PARAM;
+        o.idx = (int)in.vals[(size_t)c];
+    } else {
+        o.kind = SRC_CONST;
+        o.cval = (float)in.vals[(size_t)c];  // setConstant stores into a Float32Array (Inlet.js:88-91)
+    }
+    return o;
+}
+
+inline bool expand(Program &P, std::string &err) {
+    Graph &g = P.g;
+    int nb = 0;
+    for (auto &u : g.units) {
+        u.first_buf = nb;
+        nb += u.n_out;
+    }
+    P.n_bufs = nb;
+    int64_t ring_pos = 0;
+    for (auto &r : g.rings) {
+        r.first_dev_ring = (int)P.dev_rings.size();
+        for (int c = 0; c < r.nch; c++) {
+            P.dev_rings.push_back({ring_pos, r.len});
+            ring_pos += r.len;
+        }
+    }
+    auto slot = [&](double init) {
+        P.init_state.push_back(init);
+        return (int)P.init_state.size() - 1;
+    };
+    for (size_t ui = 0; ui < g.units.size(); ui++) {
+        UnitDesc &u = g.units[ui];
+        u.first_op = (int)P.ops.size();
+        u.first_slot = (int)P.init_state.size();
+        for (auto &in : u.inlets)
+            if (in.kind == IN_CONNECT && (size_t)in.src_unit >= ui) P.feed_forward = false;
+        const int n_dev = (u.op == OP_CB_WRITER) ? g.rings[(size_t)u.attrs[0]].nch : u.n_out;
+        for (int c = 0; c < n_dev; c++) {
+            DevOp op{};
+            op.op = u.op;
+            op.unit = (int)ui;
+            op.out_buf = u.n_out ? u.first_buf + c : -1;
+            op.state_slot = (int)P.init_state.size();
+            op.ring_base = op.ring_len = 0;
+            switch (u.op) {
+            case OP_OSC:
+                op.attr = (int)u.attrs[0];
+                op.in[0] = make_operand(g, u.inlets[0], 0);  // mono inlet: channel 0 (Piglet.js:56-61)
+                slot(u.state[0]);
+                break;
+            case OP_RAMP:
+                op.d[0] = u.attrs[0];
+                op.d[1] = u.attrs[1];
+                op.d[2] = u.attrs[2];
+                slot(u.state[0]);
+                slot(u.state[1] != 0 ? 1.0 : 0.0);
+                break;
+            case OP_MULTIPLY:
+            case OP_SUM:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], c);
+                break;
+            case OP_FILTER: {
+                op.attr = (int)u.attrs[0];
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], 0);  // f is a mono inlet (Filter.js:9)
+                const int have = (int)u.state[7];
+                for (int k = 0; k < 7; k++) slot(u.state[(size_t)k]);  // has_lastF, lastF, a0, a1, a2, b1, b2
+                for (int k = 0; k < 4; k++) slot(c < have ? u.state[(size_t)(8 + 4 * c + k)] : 0.0);  // x1 x2 y1 y2
+                break;
+            }
+            case OP_DELAY: {
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], c);
+                op.ring_len = (int64_t)u.attrs[0];
+                op.ring_base = ring_pos;
+                P.dev_rings.push_back({ring_pos, op.ring_len});
+                ring_pos += op.ring_len;
+                break;
+            }
+            case OP_CB_READER:
+            case OP_CB_WRITER: {
+                const RingDesc &r = g.rings[(size_t)u.attrs[0]];
+                const DevRing &dr = P.dev_rings[(size_t)(r.first_dev_ring + c)];
+                op.ring_base = dr.base;
+                op.ring_len = dr.len;
+                op.attr = u.attrs[1] != 0 ? 1 : 0;  // postWipe / preWipe
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                if (u.op == OP_CB_WRITER) {
+                    const int nin = u.inlets[1].n_channels(g.units);
+                    if (c < nin) op.in[1] = make_operand(g, u.inlets[1], c);  // `if(this.in[c])`: no modulo (Writer.js:19)
+                    else op.attr |= 2;                                          // nothing to mix on this channel
+                }
+                slot(u.state[0]);
+                break;
+            }
+            case OP_REPEATER:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                break;
+            }
+            if (c == 0) u.slots_per_ch = (int)P.init_state.size() - u.first_slot;
+            P.ops.push_back(op);
+        }
+    }
+    P.ring_samples = ring_pos;
+    const UnitDesc &ou = g.units[(size_t)g.out_unit];
+    for (int c = 0; c < ou.n_out; c++) P.out_bufs.push_back(ou.first_buf + c);
+    (void)err;
+    return true;
+}
+
+inline bool compile(const double *d, size_t nw, Program &P, std::string &err) {
+    return parse(d, nw, P.g, err) && infer_channels(P.g, err) && expand(P, err);
+}
+
+}  // namespace dusp

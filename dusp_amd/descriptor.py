@@ -1,0 +1,189 @@
+"""Graph extractor: live unit graph -> flat descriptor words (float64).
+
+Python twin of dusp_amd/js/lib/extract.js (same words for the same graph;
+tests/test_descriptor.py compares the two byte for byte).  Layout: DESIGN.md §3.
+
+The unit ORDER is never re-derived here: it is whatever `circuit.units` holds,
+i.e. the result of the reference's own ordering algorithm
+(src/Unit.js:171-209 + src/Circuit.js:125-131, restated in dusp_amd/graph.py).
+"""
+import numpy as np
+
+MAGIC = 1146442576  # 'DUSP'
+VERSION = 1
+HEADER_WORDS = 12
+
+OP_OSC, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER = range(1, 10)
+IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
+FILTER_KINDS = {"LP": 0, "HP": 1}
+
+UNITS = {
+    "Osc": (OP_OSC, ["f"]),
+    "Ramp": (OP_RAMP, []),
+    "Multiply": (OP_MULTIPLY, ["a", "b"]),
+    "Sum": (OP_SUM, ["a", "b"]),
+    "Filter": (OP_FILTER, ["in", "f"]),
+    "Delay": (OP_DELAY, ["in", "delay"]),
+    "CircleBufferReader": (OP_CB_READER, ["offset"]),
+    "CircleBufferWriter": (OP_CB_WRITER, ["offset", "in"]),
+    "Repeater": (OP_REPEATER, ["in"]),
+}
+
+
+class DuspError(Exception):
+    """Raised with the reference's own message strings where it has them."""
+
+
+class Extraction:
+    def __init__(self, words, const_sites, labels, sample_rate, chunk_size, circuit):
+        self.words = words
+        self.const_sites = const_sites  # [(kind_pos, val_pos, n)]
+        self.labels = labels
+        self.sample_rate = sample_rate
+        self.chunk_size = chunk_size
+        self.circuit = circuit
+
+
+def to_outlet(x):
+    # same checks and messages as reference src/renderChannelData.js:12-17
+    if x is None:
+        raise DuspError("renderAudioBuffer expects an outlet")
+    if getattr(x, "isUnit", False) or getattr(x, "isPatch", False):
+        x = x.defaultOutlet
+    if not getattr(x, "isOutlet", False):
+        raise DuspError("renderAudioBuffer expects an outlet")
+    return x
+
+
+def extract(target):
+    from .wavetables import WAVEFORMS
+
+    outlet = to_outlet(target)
+    out_unit = outlet.unit
+    circuit = out_unit.circuit if out_unit.circuit is not None else out_unit.getOrBuildCircuit()
+    if circuit.events:
+        raise DuspError("dusp-hip: circuits with scheduled events are not supported on the GPU path")
+    if getattr(circuit, "promises", None):
+        raise DuspError("dusp-hip: circuits with pending promises are not supported on the GPU path")
+    if circuit.clock:
+        raise DuspError("dusp-hip: circuit has already been ticked (clock=%s); render a fresh circuit" % circuit.clock)
+
+    units = circuit.units
+    chunk = outlet.chunkSize
+    rings = []
+
+    def ring_id(buf):
+        for i, r in enumerate(rings):
+            if r is buf:
+                return i
+        rings.append(buf)
+        return len(rings) - 1
+
+    body, sites, labels = [], [], []
+    for unit in units:
+        kind = type(unit).__name__
+        if kind not in UNITS:
+            raise DuspError("dusp-hip: unit type not supported on the GPU path: %s (%s)" % (kind, unit.label))
+        op, inlet_names = UNITS[kind]
+        if unit.tickInterval != chunk:
+            raise DuspError("dusp-hip: unit %s has tickInterval %s != chunk size %s" % (unit.label, unit.tickInterval, chunk))
+        labels.append(unit.label)
+        attrs, state = [], []
+        if op == OP_OSC:
+            attrs, state = [WAVEFORMS[unit.waveform]], [unit.phase]
+        elif op == OP_RAMP:
+            attrs, state = [unit.duration, unit.y0, unit.y1], [unit.t, 1 if unit.playing else 0]
+        elif op == OP_FILTER:
+            if unit.kind not in FILTER_KINDS:
+                raise DuspError("dusp-hip: filter kind not supported on the GPU path: %s" % unit.kind)
+            attrs = [FILTER_KINDS[unit.kind]]
+            nch = max(len(unit.x1), len(unit.x2), len(unit.y1), len(unit.y2))
+            has = unit.lastF is not None
+            state = [1 if has else 0, unit.lastF if has else 0, unit.a0, unit.a1, unit.a2, unit.b1, unit.b2, nch]
+            for c in range(nch):
+                state += [unit.x1[c] or 0, unit.x2[c] or 0, unit.y1[c] or 0, unit.y2[c] or 0]
+        elif op == OP_DELAY:
+            attrs = [unit.maxDelay]
+        elif op == OP_CB_READER:
+            attrs, state = [ring_id(unit.buffer), 1 if unit.postWipe else 0], [unit.t]
+        elif op == OP_CB_WRITER:
+            attrs, state = [ring_id(unit.buffer), 1 if unit.preWipe else 0], [unit.t]
+        body += [op, len(inlet_names), len(attrs), len(state)]
+        for name in inlet_names:
+            inlet = unit.inlets[name]
+            if inlet.connected:
+                src_unit = inlet.outlet.unit
+                if src_unit not in units:
+                    raise DuspError("dusp-hip: inlet %s is fed from outside the circuit" % inlet.label)
+                if inlet.outlet.name != "out":
+                    raise DuspError('dusp-hip: only "out" outlets carry data on the GPU path (%s)' % inlet.outlet.label)
+                body += [IN_CONNECT, 3, units.index(src_unit), 0, 0]
+            else:
+                vals = list(inlet.values)
+                sites.append((len(body), len(body) + 2, len(vals)))
+                body += [IN_CONST, len(vals)] + vals
+        body += attrs + state
+
+    if outlet.name != "out":
+        raise DuspError('dusp-hip: only "out" outlets can be rendered on the GPU path')
+    ring_words = []
+    for r in rings:
+        ring_words += [r.numberOfChannels, r.lengthInSamples]
+    head = [MAGIC, VERSION, outlet.sampleRate, chunk, len(units), len(rings), 0, units.index(out_unit), 0,
+            circuit.clock or 0, 0, 0]
+    base = HEADER_WORDS + len(ring_words)
+    words = np.array(head + ring_words + body, dtype=np.float64)
+    sites = [(k + base, v + base, n) for (k, v, n) in sites]
+    return Extraction(words, sites, labels, outlet.sampleRate, chunk, circuit)
+
+
+class Unified:
+    def __init__(self, words, params, n_params, n_instances, extraction):
+        self.words = words
+        self.params = params  # float32 [n_params, n_instances] (slot-major) or None
+        self.n_params = n_params
+        self.n_instances = n_instances
+        self.sample_rate = extraction.sample_rate
+        self.chunk_size = extraction.chunk_size
+        self.labels = extraction.labels
+
+
+def _same(a, b):
+    return a == b or (a != a and b != b)
+
+
+def unify(extractions):
+    """N structurally identical circuits (voices / a parameter sweep) -> ONE program plus
+    a per-instance parameter table: every unconnected inlet whose constant differs
+    between instances becomes a PARAM inlet (twin of extract.js `unify`)."""
+    n = len(extractions)
+    if n == 0:
+        raise DuspError("dusp-hip: no instances")
+    first = extractions[0]
+    words = first.words.copy()
+    for i, e in enumerate(extractions):
+        if e.words.shape != words.shape:
+            raise DuspError("dusp-hip: instance %d differs in structure from instance 0" % i)
+    all_words = np.stack([e.words for e in extractions])
+    is_const_val = np.zeros(words.size, dtype=bool)
+    for (_, vpos, cnt) in first.const_sites:
+        is_const_val[vpos:vpos + cnt] = True
+    same = (all_words == words) | (np.isnan(all_words) & np.isnan(words))
+    struct_bad = ~same[:, ~is_const_val].all(axis=1)
+    if struct_bad.any():
+        raise DuspError("dusp-hip: instance %d differs from instance 0 outside inlet constants" % int(np.argmax(struct_bad)))
+    columns = []
+    for (kpos, vpos, cnt) in first.const_sites:
+        if same[:, vpos:vpos + cnt].all():
+            continue
+        words[kpos] = IN_PARAM
+        for k in range(cnt):
+            words[vpos + k] = len(columns)
+            columns.append(all_words[:, vpos + k].astype(np.float32))
+    words[6] = len(columns)
+    params = np.ascontiguousarray(np.stack(columns)) if columns else None
+    return Unified(words, params, len(columns), n, first)
+
+
+def single(extraction):
+    return Unified(extraction.words, None, 0, 1, extraction)

@@ -1,0 +1,174 @@
+"""ctypes binding of the C ABI in include/dusp_hip.h (dusp_amd/libdusp_hip.so).
+
+There is deliberately no CPU fallback here: if the HIP library is missing or no
+GPU is usable, every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .wavetables import make_table
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdusp_hip.so")
+
+ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED = 0, 1, 2
+ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused"}
+
+EXPORTS = [
+    "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",
+    "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_info_get",
+    "dusp_render_device", "dusp_render_host", "dusp_state_download", "dusp_last_kernel_ms", "dusp_fill_device",
+]
+
+
+class DuspHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s (status %d)" % (message, status))
+        self.status = status
+        self.message = message
+
+
+class ProgramInfo(ctypes.Structure):
+    _fields_ = [("sample_rate", ctypes.c_uint32), ("chunk_size", ctypes.c_uint32), ("n_units", ctypes.c_uint32),
+                ("n_out_channels", ctypes.c_uint32), ("n_params", ctypes.c_uint32), ("engine", ctypes.c_uint32),
+                ("n_device_ops", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("shape", ctypes.c_char * 64)]
+
+
+_lib = None
+
+
+def load():
+    """Load libdusp_hip.so (built by dusp_amd/csrc/Makefile).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DuspHipError(-3, "HIP extension %s is missing: build it with `make -C dusp_amd/csrc` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.dusp_version.restype = ctypes.c_char_p
+    L.dusp_abi_version.restype = ci
+    L.dusp_last_error.restype = ctypes.c_char_p
+    L.dusp_last_error.argtypes = [vp]
+    L.dusp_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.dusp_ctx_destroy.argtypes = [vp]
+    L.dusp_ctx_destroy.restype = None
+    L.dusp_table_upload.argtypes = [vp, ci, vp, sz]
+    L.dusp_program_build.argtypes = [vp, vp, sz, ci, ctypes.POINTER(vp)]
+    L.dusp_program_destroy.argtypes = [vp]
+    L.dusp_program_destroy.restype = None
+    L.dusp_program_info_get.argtypes = [vp, ctypes.POINTER(ProgramInfo)]
+    L.dusp_render_device.argtypes = [vp, sz, sz, vp, vp, vp]
+    L.dusp_render_host.argtypes = [vp, sz, sz, vp, vp]
+    L.dusp_state_download.argtypes = [vp, sz, sz, vp, sz]
+    L.dusp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.dusp_fill_device.argtypes = [vp, vp, sz, ctypes.c_float, vp]
+    _lib = L
+    return L
+
+
+class Context:
+    """One HIP device + stream + the uploaded wave tables."""
+
+    def __init__(self, device=-1, sample_rate=None):
+        self._L = load()
+        h = ctypes.c_void_p()
+        rc = self._L.dusp_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise DuspHipError(rc, self._L.dusp_last_error(None).decode())
+        self._h = h
+        self.sample_rate = None
+        if sample_rate is not None:
+            self.upload_tables(sample_rate)
+
+    def _check(self, rc):
+        if rc < 0:
+            raise DuspHipError(rc, self._L.dusp_last_error(self._h).decode())
+        return rc
+
+    def upload_tables(self, sample_rate, tables=None):
+        """Compute (or take) the five wave tables for this sample rate and hand them to the device."""
+        for tid in range(5):
+            try:
+                t = tables[tid] if tables is not None else make_table(tid, sample_rate)
+            except ValueError:
+                continue  # e.g. no triangle table at a sample rate not divisible by 4
+            t = np.ascontiguousarray(t, dtype=np.float32)
+            self._check(self._L.dusp_table_upload(self._h, tid, t.ctypes.data, t.size))
+        self.sample_rate = sample_rate
+
+    def build(self, words, engine=ENGINE_AUTO):
+        return Program(self, words, engine)
+
+    def fill(self, d_ptr, n_floats, value=0.0, stream=None):
+        self._check(self._L.dusp_fill_device(self._h, d_ptr, n_floats, value, stream))
+
+    def close(self):
+        if self._h:
+            self._L.dusp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Program:
+    def __init__(self, ctx, words, engine=ENGINE_AUTO):
+        self.ctx = ctx
+        self._L = ctx._L
+        words = np.ascontiguousarray(words, dtype=np.float64)
+        h = ctypes.c_void_p()
+        ctx._check(self._L.dusp_program_build(ctx._h, words.ctypes.data, words.size, engine, ctypes.byref(h)))
+        self._h = h
+        info = ProgramInfo()
+        ctx._check(self._L.dusp_program_info_get(self._h, ctypes.byref(info)))
+        self.sample_rate = info.sample_rate
+        self.n_units = info.n_units
+        self.n_out_channels = info.n_out_channels
+        self.n_params = info.n_params
+        self.engine = ENGINE_NAMES.get(info.engine, str(info.engine))
+        self.shape = info.shape.decode()
+        self.n_device_ops = info.n_device_ops
+
+    def render(self, n_samples, n_instances=1, params=None):
+        """Host round trip: float32 [n_instances, n_out_channels, n_samples]."""
+        out = np.empty((n_instances, self.n_out_channels, n_samples), dtype=np.float32)
+        pp = None
+        if self.n_params:
+            params = np.ascontiguousarray(params, dtype=np.float32)
+            if params.shape != (self.n_params, n_instances):
+                raise ValueError("params must have shape (n_params=%d, n_instances=%d)" % (self.n_params, n_instances))
+            pp = params.ctypes.data
+        self.ctx._check(self._L.dusp_render_host(self._h, n_instances, n_samples, pp, out.ctypes.data))
+        return out
+
+    def render_device(self, n_samples, n_instances, d_params, d_out, stream=None):
+        """Asynchronous render between device pointers (ints), e.g. torch tensors' data_ptr()."""
+        self.ctx._check(self._L.dusp_render_device(self._h, n_instances, n_samples, d_params, d_out, stream))
+
+    def state(self, unit, instance=0):
+        buf = np.zeros(128, dtype=np.float64)
+        n = self.ctx._check(self._L.dusp_state_download(self._h, instance, unit, buf.ctypes.data, buf.size))
+        return buf[:n].copy()
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self.ctx._check(self._L.dusp_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self._L.dusp_program_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

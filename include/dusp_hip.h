@@ -1,0 +1,134 @@
+/* dusp_hip.h — C ABI of the MI355X (gfx950) offline render path for Dusp.
+ *
+ * This library replaces ONE path of the reference: the chunk loop of
+ *   src/renderChannelData.js:5-49  ->  src/Circuit.js:19-47 (tick/tickUntil)
+ *   ->  src/Unit.js:111-119 (tick)  ->  per-unit `_tick` loops in src/components/
+ * The reference has no FFI boundary on this path (it is pure in-process JS), so
+ * the entry points below are the ones a Node N-API addon / ctypes stub binds in
+ * order to stand in for `renderChannelData(outlet, duration)`; INTEGRATION.md
+ * shows that binding.  Plain pointers and sizes only, no C++ or torch types.
+ *
+ * Hand-off format: a host-side extractor (dusp_amd/js/lib/extract.js, or
+ * dusp_amd/descriptor.py) flattens the live Unit/Inlet/Outlet graph — in the
+ * order `circuit.units` already holds (src/Circuit.js:125-131) — into an array of
+ * little-endian f64 "descriptor words" (layout: DESIGN.md §3).  Many
+ * structurally identical circuits (voices, a parameter sweep) are rendered by
+ * ONE program plus a per-instance f32 parameter table.
+ *
+ * Error convention mirrors the reference's (thrown strings that surface as
+ * Promise rejections, src/renderChannelData.js:12-17): every call returns 0 on
+ * success or a negative dusp_status, and dusp_last_error() returns the message.
+ * Nothing here ever falls back to a CPU implementation: without a usable HIP
+ * device the calls fail with DUSP_ERR_HIP.
+ *
+ * Threading: a dusp_ctx is bound to one HIP device and is not thread-safe;
+ * different contexts are independent (one context per GPU for multi-GPU use).
+ */
+#ifndef DUSP_HIP_H
+#define DUSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUSP_ABI_VERSION 1
+
+typedef struct dusp_ctx dusp_ctx;
+typedef struct dusp_program dusp_program;
+
+typedef enum {
+    DUSP_OK = 0,
+    DUSP_ERR_ARG = -1,         /* bad argument / malformed descriptor */
+    DUSP_ERR_UNSUPPORTED = -2, /* graph uses something the GPU path does not implement */
+    DUSP_ERR_HIP = -3,         /* HIP runtime error (no device, out of memory, launch failure) */
+    DUSP_ERR_STATE = -4        /* call sequence error (e.g. wave table not uploaded) */
+} dusp_status;
+
+/* Engine that executes a program (chosen at build time from the graph's shape):
+ *   CHUNK — universal engine: one lane per instance, units ticked chunk by chunk
+ *           exactly in circuit order (feedback, filters, delays, CircleBuffers).
+ *   FUSED — time-parallel fused kernel for feed-forward graphs of Osc / Ramp /
+ *           Multiply / Sum: one lane per sample, 16-byte coalesced PCM stores. */
+typedef enum { DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2 } dusp_engine;
+
+typedef struct {
+    uint32_t sample_rate;
+    uint32_t chunk_size;
+    uint32_t n_units;        /* units in the circuit */
+    uint32_t n_out_channels; /* channels of the rendered outlet == result.length of renderChannelData */
+    uint32_t n_params;       /* per-instance parameter slots the descriptor references */
+    uint32_t engine;         /* dusp_engine actually selected */
+    uint32_t n_device_ops;   /* channel-expanded ops the kernel executes per chunk */
+    uint32_t reserved;
+    char shape[64];          /* FUSED: signature of the fused kernel, e.g. "mul(osc(k),ramp)" */
+} dusp_program_info;
+
+/* Library / ABI identification. */
+const char *dusp_version(void);
+int dusp_abi_version(void);
+
+/* Message of the last failing call on this context (or, with ctx == NULL, of
+ * the last failing dusp_ctx_create on this thread).  Never NULL. */
+const char *dusp_last_error(const dusp_ctx *ctx);
+
+/* Create a context on HIP device `device` (-1 = current device). */
+int dusp_ctx_create(int device, dusp_ctx **out);
+void dusp_ctx_destroy(dusp_ctx *ctx);
+
+/* Upload one wave table (replaces src/components/Osc/waveTables.js:5-40: the
+ * host computes the tables exactly as the reference does and hands them over as
+ * data).  table_id: 0 sin, 1 saw, 2 square, 3 triangle, 4 8bit.  n must equal
+ * sample_rate + 1 of every program later built on this context. */
+int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n);
+
+/* Compile a descriptor into a device program (replaces `new Circuit(unit)` +
+ * computeOrders as the thing that fixes the schedule, src/Circuit.js:67-148 —
+ * the ORDER itself comes from the descriptor).  `engine` = DUSP_ENGINE_AUTO
+ * normally; tests force CHUNK to cross-check the engines. */
+int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out);
+void dusp_program_destroy(dusp_program *prog);
+int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info);
+
+/* Render n_instances independent instances of the program for n_samples samples
+ * each, starting from the descriptor's initial state (replaces the loop at
+ * src/renderChannelData.js:29-45; like it, ticks ceil(n_samples/chunk) chunks
+ * and maps NaN / -0 to +0 on copy-out).
+ *
+ *   d_params  device pointer, f32 [n_params][n_instances] (slot-major); may be
+ *             NULL when the program has no parameters.
+ *   d_out     device pointer, f32 [n_instances][n_out_channels][n_samples].
+ *   stream    hipStream_t to launch on (NULL = the context's own stream).
+ *
+ * Asynchronous: returns once the work is enqueued.  Inputs and outputs stay
+ * resident in HBM; nothing crosses PCIe. */
+int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
+                       const float *d_params, float *d_out, void *stream);
+
+/* Convenience wrapper for host callers (the N-API addon): uploads h_params,
+ * renders, downloads into h_out (same layouts as above) and synchronises. */
+int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
+                     const float *h_params, float *h_out);
+
+/* State write-back (SURVEY.md §5 "checkpoint/resume"): after a render, copy the
+ * state of `unit` for `instance` into out[] in the layout of the descriptor's
+ * state words for that unit's opcode (Osc: phase; Ramp: t, playing; Filter:
+ * has_lastF,lastF,a0,a1,a2,b1,b2,nch,(x1,x2,y1,y2)*nch; CircleBuffer nodes: t).
+ * Returns the number of words (>= 0) or a negative dusp_status. */
+int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double *out, size_t cap);
+
+/* Duration in milliseconds of the most recent render's kernel(s) on this
+ * program, measured with HIP events on the launch stream (synchronises). */
+int dusp_last_kernel_ms(dusp_program *prog, float *ms);
+
+/* Fill-kernel ceiling: writes n_floats f32 to d_out with 16-byte coalesced
+ * stores and nothing else — the measured HBM write roofline the render kernels
+ * are compared with. */
+int dusp_fill_device(dusp_ctx *ctx, float *d_out, size_t n_floats, float value, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUSP_HIP_H */

@@ -1,0 +1,99 @@
+"""The golden cases of oracle/js/gen_golden.js, rebuilt with this package's own
+graph classes (dusp_amd/graph.py).  Used to check that the host mirror produces
+the same descriptor — constants, state AND unit order — as the reference objects
+did, and as ready-made graphs for the GPU parity tests."""
+import dusp_amd as d
+from dusp_amd import (CircleBuffer, CircleBufferReader, CircleBufferWriter, Delay, Filter, Multiply, Osc, Ramp,
+                      Repeater, Sum, quick)
+
+
+def _loop(f_osc, delay, max_delay, cutoff, gain):
+    s = Sum(Osc(f_osc), 0)
+    dl = Delay(s, delay, max_delay)
+    f = Filter(dl, cutoff)
+    fb = Multiply(f, gain)
+    s.B = fb
+    return f
+
+
+def _taps():
+    buffer = CircleBuffer(1, 0.05)
+    writer = CircleBufferWriter(buffer)
+    writer.preWipe = True
+    writer.IN = Osc(330)
+    tap = CircleBufferReader(buffer, 0.01)
+    tap.chain(writer)
+    fb_tap = CircleBufferReader(buffer, 0.02)
+    fb_tap.chain(writer)
+    fb_writer = CircleBufferWriter(buffer, 0.005)
+    fb_writer.IN = quick.multiply(fb_tap, 0.5)
+    fb_writer.chain(writer)
+    return Sum(tap, fb_tap)
+
+
+def _cb2():
+    buffer = CircleBuffer(2, 0.011)
+    writer = CircleBufferWriter(buffer, 0.001)
+    writer.IN = Multiply(Osc(700), [1, 0.5])
+    reader = CircleBufferReader(buffer, [0.002, 0.0035])
+    reader.postWipe = True
+    reader.chain(writer)
+    return reader
+
+
+def _mult_inlet_zero():
+    m = Multiply(Osc(440), 2)
+    m.B = 0
+    return m
+
+
+def builders(sr):
+    """name -> zero-argument builder; call d.configure(sr) first (done by build())."""
+    voices = lambda n: [Osc(k * 10) for k in range(1, n + 1)]
+    b = {
+        "osc440_1s": lambda: Osc(440),
+        "cfg2_literal": lambda: Multiply(Osc(Ramp(200, 100, 2)), Osc(3)),
+        "cfg2_sweep": lambda: Multiply(Osc(Ramp(2 * sr, 200, 100).trigger()), Osc(3)),
+        "ramp_300": lambda: Ramp(300, 0.25, 2).trigger(),
+        "ramp_default_idle": lambda: Ramp(),
+        "ramp_1": lambda: Ramp(1, 5, -5).trigger(),
+        "ramp_frac": lambda: Ramp(1000.5, -1, 1).trigger(),
+        "summany_8": lambda: Sum.many(voices(8)),
+        "summany_1024": lambda: Sum.many(voices(1024)),
+        "loop_220": lambda: _loop(220, 480, 4096, 2000, 0.5),
+        "loop_110p5_short": lambda: _loop(110.5, 100, 4096, 2000, 0.5),
+        "loop_frac_delay": lambda: _loop(330, 300.25, 2048, 1500, 0.7),
+        "delay_default": lambda: Delay(Osc(100), 0, 0),
+        "delay_wrap": lambda: Delay(Osc(1000), 700.5, 1000),
+        "delay_mod": lambda: Delay(Osc(500), Sum(Multiply(Osc(2), 40), 200), 1024),
+        "delay_2ch": lambda: Delay(Multiply(Osc(300), [1, -0.5]), [64, 333.75], 2048),
+        "filter_lp_mod": lambda: Filter(Osc(150, "saw"), Sum(Multiply(Osc(5), 800), 1000)),
+        "filter_hp": lambda: Filter(Osc(150, "square"), 3000, "HP"),
+        "filter_2ch": lambda: Filter(Multiply(Osc(440), [0.5, 0.25]), 1200),
+        "fm_mixed": lambda: Osc(Multiply(Osc(70), 9000)),
+        "fm_sum": lambda: Osc(Sum(Multiply(Osc(3.5, "triangle"), 300), 220.25)),
+        "circlebuffer_taps": _taps,
+        "circlebuffer_2ch": _cb2,
+        "osc440_480": lambda: Osc(440),
+        "mult_2ch": lambda: Multiply(Osc(440), [0.5, 0.25]),
+        "repeater": lambda: Repeater(quick.mult(Osc(123.4), 1)),
+        "sum_const": lambda: quick.add(Osc(50), 0.75),
+        "mult_inlet_zero": _mult_inlet_zero,
+    }
+    for tag, f in [("440p5", 440.5), ("0p1", 0.1), ("neg3", -3), ("47999p5", 47999.5), ("neg0p37", -0.37),
+                   ("12345p678", 12345.678), ("tiny", 3e-5)]:
+        b["osc_f_" + tag] = (lambda f=f: Osc(f))
+    for w in ["saw", "square", "triangle", "8bit"]:
+        b["osc_" + w] = (lambda w=w: Osc(441.3, w))
+    for k in [1, 7, 512, 1024]:
+        b["voice3_k%d" % k] = (lambda k=k: Multiply(Osc(10 * k), Ramp(sr, 1, 0).trigger()))
+    for k in [0, 3, 4097, 65535]:
+        b["voice5_k%d" % k] = (lambda k=k: Multiply(Osc(20 + k / 8), Ramp(sr, 1, 0).trigger()))
+    return b
+
+
+def build(name, sr):
+    """Build the graph of golden case `name` (48 kHz names carry no suffix)."""
+    d.configure(sr)
+    base = name[: -len("_sr%d" % sr)] if name.endswith("_sr%d" % sr) else name
+    return builders(sr)[base]()

@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names(sample_rate=48000):
+    name = "index.json" if sample_rate == 48000 else "index_sr%d.json" % sample_rate
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+class Golden:
+    """One reference-generated vector: descriptor (input) + PCM windows (expected output)."""
+
+    def __init__(self, name):
+        self.name = name
+        with open(os.path.join(GOLDEN, name + ".json")) as f:
+            self.meta = json.load(f)
+        self.desc = np.fromfile(os.path.join(GOLDEN, name + ".desc.f64"), dtype=np.float64)
+        self.pcm = np.fromfile(os.path.join(GOLDEN, name + ".pcm.f32"), dtype=np.float32)
+        self.n_samples = self.meta["n_samples"]
+        self.n_channels = self.meta["n_channels"]
+        self.windows = [tuple(w) for w in self.meta["windows"]]
+        self.sample_rate = self.meta["sample_rate"]
+
+    def windowed(self, pcm):
+        """Cut [n_channels, n_samples] PCM down to the stored windows (same order as the file)."""
+        parts = []
+        for c in range(self.n_channels):
+            for a, n in self.windows:
+                parts.append(pcm[c, a:a + n])
+        return np.concatenate(parts)
+
+
+ALL_GOLDEN = golden_names(48000) + golden_names(44100)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o

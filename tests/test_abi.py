@@ -1,0 +1,41 @@
+"""The C-ABI library: builds, loads without a GPU, exports exactly what include/dusp_hip.h declares,
+and fails loudly (no CPU fallback) when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from dusp_amd import runtime
+
+HEADER = os.path.join(ROOT, "include", "dusp_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dusp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(runtime.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), "libdusp_hip.so does not export " + name
+    assert sorted(runtime.EXPORTS) == names
+
+
+def test_version_and_abi():
+    L = runtime.load()
+    assert L.dusp_abi_version() == 1
+    assert b"gfx950" in L.dusp_version()
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(runtime.DuspHipError, match="no usable HIP device|HIP error"):
+        runtime.Context()
