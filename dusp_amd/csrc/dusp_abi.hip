@@ -1,6 +1,7 @@
 // dusp_abi.hip — implementation of the C ABI declared in include/dusp_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -31,6 +32,7 @@ struct dusp_ctx {
     uint32_t table_stride = 0;
     bool table_set[dusp::kNumTables] = {false, false, false, false, false};
     bool table_antisym[dusp::kNumTables] = {false, false, false, false, false};
+    bool table_finite[dusp::kNumTables] = {false, false, false, false, false};
     int n_cus = 256;
 };
 
@@ -164,6 +166,9 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     bool antisym = (n % 2) == 1;
     for (size_t t = 1; antisym && t < n; t++) antisym = table[n - t] == -table[t];
     ctx->table_antisym[table_id] = antisym;
+    bool finite = true;
+    for (size_t t = 0; finite && t < n; t++) finite = std::isfinite(table[t]);
+    ctx->table_finite[table_id] = finite;
     ctx->table_set[table_id] = true;
     return DUSP_OK;
 }
@@ -277,6 +282,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         L.sample_rate = (uint32_t)P.g.sample_rate;
         L.n_cus = ctx->n_cus;
         L.table_antisym = ctx->table_antisym[prog->fused.table_id];
+        L.table_finite = ctx->table_finite[prog->fused.table_id];
         HIP_TRY(ctx, prog->d_fused_state.ensure((size_t)std::max(1, prog->fused.n_state_words) * n_inst));
         L.end_state = prog->d_fused_state.p;
         HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));

@@ -44,7 +44,7 @@ struct FusedLaunch {
     uint64_t n_samples;
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
-    bool table_antisym;
+    bool table_antisym, table_finite;
 };
 
 // Kernel arguments (by value).
