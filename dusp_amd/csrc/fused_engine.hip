@@ -100,10 +100,12 @@ struct Table {
     const float *g;
     const float *h;
     uint32_t N, M;
+    __device__ __forceinline__ float lds_at(uint32_t k) const {  // word k of the 33-pitch image
+        return *(const float *)((const char *)h + ((k << 2) + ((k >> 5) << 2)));
+    }
     __device__ __forceinline__ float at(uint32_t i) const {
         if (TBL == 0) return g[i];
-        const uint32_t k = min(i, N - i);
-        const float v = h[k + (k >> 5)];
+        const float v = lds_at(min(i, N - i));
         return i > M ? -v : v;
     }
     // (T[i], T[i+1]) for the lerp
@@ -115,8 +117,8 @@ struct Table {
         }
         const bool upper = i > M;
         const uint32_t k = upper ? N - i - 1 : i;
-        const uint32_t p = k + (k >> 5);
-        const float x = h[p], y = h[p + 1];
+        const float *p = (const float *)((const char *)h + ((k << 2) + ((k >> 5) << 2)));
+        const float x = p[0], y = p[1];
         a = upper ? -y : x;
         b = upper ? -x : y;
     }
@@ -194,12 +196,14 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
         uint64_t P[R][4], step256[R];
         double u[R];
         float gain[R];
-        bool live[R], bad[R];
+        bool bad[R];
+        size_t roff[R];  // row offset of instance r; a short last block repeats its last instance (same data, same address)
         bool all_integer = true;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t inst = min(blk * R + r, A.n_inst - 1);
-            live[r] = blk * R + r < A.n_inst;
+            const bool live = blk * R + r < A.n_inst;
+            roff[r] = (size_t)inst * A.n_samples;
             const float f = operand_value(A.f, A.params, A.n_inst, inst);
             const OscFix o = osc_setup(f, A.phase0, sr);
             const uint64_t step4 = mulmod(o.Fm, 4, o.S);
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
             all_integer = all_integer && o.E == 0 && !o.bad;
             gain[r] = KIND == FUSED_OSC_GAIN ? operand_value(A.gain, A.params, A.n_inst, inst) : 1.f;
 
-            if (seg == 0 && lane == 0 && live[r]) {  // state write-back: state after ceil(n_samples/256) ticks
+            if (seg == 0 && lane == 0 && live) {  // state write-back: state after ceil(n_samples/256) ticks
                 const uint64_t T_end = (uint64_t)A.n_chunks * kChunk;
                 double phase_end = (double)addmod(o.P0, mulmod(o.Fm, T_end, o.S), o.S) * o.u;
                 if (o.bad) phase_end = __builtin_nan("");
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
         double tn = A.r_t0 + (A.r_playing ? (double)(t_start + lane * 4 + 1) : 0.0);
         const double tn_step = A.r_playing ? (double)kChunk : 0.0;
         const double tn_c = A.r_playing ? 1.0 : 0.0;
-        float *row = A.out + (size_t)blk * R * A.n_samples + t_start + lane * 4;
+        float *row = A.out + t_start + lane * 4;
 
         auto ramp4 = [&](float (&rv)[4]) {
             if (KIND == FUSED_OSC_RAMP) {
@@ -263,7 +267,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
                             if (KIND == FUSED_OSC_GAIN) v[c] = v[c] * gain[r];
                             v[c] = fix_out<FINITE>(v[c]);
                         }
-                        if (live[r]) store4<decltype(vec)::value>(row + (size_t)r * A.n_samples, v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
+                        store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
                     }
                     row += kChunk;
                 }
@@ -299,7 +303,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
                             if (KIND == FUSED_OSC_GAIN) v[c] = v[c] * gain[r];
                             v[c] = fix_out<FINITE>(v[c]);
                         }
-                        if (live[r]) store4<decltype(vec)::value>(row + (size_t)r * A.n_samples, v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
+                        store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
                     }
                     row += kChunk;
                 }
