@@ -33,6 +33,7 @@ struct dusp_ctx {
     bool table_set[dusp::kNumTables] = {false, false, false, false, false};
     bool table_antisym[dusp::kNumTables] = {false, false, false, false, false};
     bool table_finite[dusp::kNumTables] = {false, false, false, false, false};
+    bool table_fx32_ok[dusp::kNumTables] = {false, false, false, false, false};  // min nonzero |T| >= 2^-20
     int n_cus = 256;
 };
 
@@ -69,6 +70,7 @@ struct dusp_program {
     DevBuf<float> d_scratch, d_rings;
     DevBuf<double> d_state;
     DevBuf<double> d_fused_state;  // FUSED: [n_state_words][n_inst] end-of-render state
+    DevBuf<dusp::OscRec> d_recs;   // FUSED: per-voice oscillator records
     uint32_t last_n_inst = 0, last_n_pad = 0;
     bool rendered = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -169,6 +171,9 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     bool finite = true;
     for (size_t t = 0; finite && t < n; t++) finite = std::isfinite(table[t]);
     ctx->table_finite[table_id] = finite;
+    bool big = finite;
+    for (size_t t = 0; big && t < n; t++) big = table[t] == 0.f || std::fabs(table[t]) >= 9.5367431640625e-07f;
+    ctx->table_fx32_ok[table_id] = big;
     ctx->table_set[table_id] = true;
     return DUSP_OK;
 }
@@ -222,6 +227,7 @@ void dusp_program_destroy(dusp_program *prog) {
     prog->d_rings.release();
     prog->d_state.release();
     prog->d_fused_state.release();
+    prog->d_recs.release();
     if (prog->ev0) (void)hipEventDestroy(prog->ev0);
     if (prog->ev1) (void)hipEventDestroy(prog->ev1);
     delete prog;
@@ -283,6 +289,9 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         L.n_cus = ctx->n_cus;
         L.table_antisym = ctx->table_antisym[prog->fused.table_id];
         L.table_finite = ctx->table_finite[prog->fused.table_id];
+        L.table_fx32_ok = ctx->table_fx32_ok[prog->fused.table_id];
+        HIP_TRY(ctx, prog->d_recs.ensure(n_inst));
+        L.recs = prog->d_recs.p;
         HIP_TRY(ctx, prog->d_fused_state.ensure((size_t)std::max(1, prog->fused.n_state_words) * n_inst));
         L.end_state = prog->d_fused_state.p;
         HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));

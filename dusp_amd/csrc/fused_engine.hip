@@ -1,29 +1,35 @@
 // fused_engine.hip — fused, time-parallel render kernels for feed-forward voices.
 //
-// One LANE per SAMPLE: a wavefront renders 256 consecutive samples of one
-// circuit instance per step (lane l owns samples 4l..4l+3 of the group), so the
-// PCM leaves as one fully coalesced 1 KiB `global_store_dwordx4` per wave per
-// step and nothing is staged through HBM.  The whole unit tree of the circuit
-// is evaluated in registers — this is the "one fused kernel per topologically
-// sorted Circuit" of the north star for the shapes listed in fused_plan.hpp.
+// One LANE per SAMPLE: a wavefront renders 256 consecutive samples of a circuit
+// instance per step (lane l owns samples 4l..4l+3 of the group), so the PCM
+// leaves as one fully coalesced 1 KiB `global_store_dwordx4` per wave per voice
+// per step and nothing is staged through HBM.  The whole unit tree of the
+// circuit is evaluated in registers — this is the "one fused kernel per
+// topologically sorted Circuit" of the north star for the shapes listed in
+// fused_plan.hpp.
 //
-// Time is split into segments so that a 1024-voice x 60 s render exposes ~10^5
-// independent (instance, segment) work items instead of 1024 serial voices.
-// That is legal because every stateful unit in these shapes can JUMP to any
-// sample index exactly:
+// Work decomposition.  A work item is (block of R voices, time segment); one
+// wave takes one item at a time from a static stride over a persistent grid
+// (one 1024-thread workgroup per CU).  Splitting TIME is legal because every
+// stateful unit in these shapes can jump to any sample index exactly:
 //   * Osc with a lane-constant f (Osc.js:38-46): phase(t) = (phase0 + (t+1) f) mod sr.
-//     The reference accumulates in f64; for |f| >= 2^-13 every partial sum is an
-//     exact multiple of lsb(f) below 2^17, so no rounding ever happens
+//     The reference accumulates in f64; while lsb(f) >= 2^-36 every partial sum
+//     is an exact multiple of lsb(f) below 2^17, so no rounding ever happens
 //     (SURVEY.md §8a note ii) and the closed form — evaluated in exact u64
 //     fixed-point modular arithmetic — is bit-identical to the sequential loop.
-//     Inside a segment each lane then advances its own f64 phase by
-//     (256 f) mod sr per step with one conditional subtract: also exact.
-//     When f and phase0 are integers every phase is an integer, the lerp
-//     degenerates to table[phase] and a pure u32 path is taken (wave-uniform).
-//   * Ramp (Ramp.js:25-40): t(n) = min(t0 + n + 1, duration) while playing.
-// Wave-table lookups come either from L2 (global gather) or, when the table is
-// antisymmetric (T[N-t] == -T[t], true for the sine table), from a 96 KB
-// half-table held in LDS — the full 192 KB table does not fit the 160 KB LDS.
+//     Inside a segment each lane advances its own phase by (256 f) mod sr per
+//     step.  Three representations, chosen per voice block (wave-uniform):
+//       INT   f and phase0 integers: phase is a u32 table index, the lerp
+//             degenerates to table[phase] (fraction == 0, Osc.js:43-45);
+//       FX32  lsb(f) >= 2^-32: phase = u32 index + u32 fraction (32.32 fixed
+//             point, add-with-carry), lerp weights are exact f64 integers;
+//       F64   anything else: f64 phase, conditional subtract.
+//   * Ramp (Ramp.js:25-40): t(n) = min(t0 + n + 1, duration) while playing.  It
+//     depends on the sample index only, so a wave evaluates it ONCE per step and
+//     reuses it for the R voices of its block.
+// Wave-table lookups come from a half-table in LDS when the table is
+// antisymmetric (T[N-t] == -T[t], true for the sine table; the full 192 KB
+// table does not fit the 160 KB LDS), else from L2 (global gather, ~5x slower).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -54,70 +60,38 @@ __device__ __forceinline__ uint64_t mulmod(uint64_t a, uint64_t n, uint64_t S) {
     return acc;
 }
 
-struct OscFix {
-    uint64_t S, Fm, P0;  // modulus, per-sample increment and start phase in units of u = 2^E
-    double u;
-    int E;
-    bool bad;            // non-finite f: every sample is NaN -> 0 after `|| 0`
-};
-
-__device__ __forceinline__ OscFix osc_setup(float f, double phase0, uint32_t sr) {
-    OscFix o;
-    double fd = (double)f;
-    const double srd = (double)sr;
-    o.bad = !(fabs(fd) <= 3.0e38);
-    if (o.bad) fd = 0.0;
-    if (fabs(fd) >= srd) fd = fmod(fd, srd);
-    int E = 0;
-    if (fd != 0.0) E = min(E, lsb_exponent(fd));
-    if (phase0 != 0.0) E = min(E, lsb_exponent(phase0));
-    const int Emin = -(62 - (32 - __builtin_clz(sr)));  // keep S = sr * 2^-E below 2^62
-    if (E < Emin) E = Emin;                              // (only reachable for |f| < 2^-13: inexact regime)
-    o.E = E;
-    o.u = ldexp(1.0, E);
-    o.S = (uint64_t)sr << (-E);
-    const long long F = (long long)rint(ldexp(fd, -E));
-    o.Fm = F >= 0 ? (uint64_t)F : o.S - (uint64_t)(-F);
-    if (o.Fm >= o.S) o.Fm -= o.S;
-    o.P0 = (uint64_t)rint(ldexp(phase0, -E));
-    if (o.P0 >= o.S) o.P0 %= o.S;
-    return o;
-}
-
 __device__ __forceinline__ float operand_value(const DevOperand &o, const float *params, uint32_t n_inst, uint32_t inst) {
     return o.kind == SRC_PARAM ? params[(size_t)o.idx * n_inst + inst] : o.cval;
 }
 
 // Table access.  TBL == 0: padded full table in global memory (served by L2).
 // TBL == 1: half table H[0..M+1] = T[0..M+1] in LDS (M = sr/2, N = sr+1); T[i] = -H[N-i] above M.
-//   LDS layout: blocks of 33 words, block b = H[32b .. 32b+32] (the 33rd word repeats the next
-//   block's first).  position(h) = h + (h >> 5).  The odd block pitch spreads the arithmetic
-//   progressions a wave reads (lane l looks up phase0 + 4 l f) over the 32 banks — a linear layout
-//   measured 9-way conflicts on average for the 1024-voice sweep, this one 2.8 — and position+1
-//   always holds H[h+1], so the lerp's pair is one ds_read2_b32.
+//   LDS image: blocks of 33 words, block b = H[32b .. 32b+32] (the 33rd word repeats the next
+//   block's first), so word(k) = k + (k >> 5).  The odd pitch spreads the arithmetic progressions a
+//   wave reads (lane l looks up phase0 + 4 l f) over the 32 banks — a linear image measured 9-way
+//   conflicts on average over the 1024-voice sweep, this one 2.8 — and word(k)+1 always holds
+//   H[k+1], so the lerp's pair is two adjacent words.
 template <int TBL>
 struct Table {
     const float *g;
     const float *h;
     uint32_t N, M;
-    __device__ __forceinline__ float lds_at(uint32_t k) const {  // word k of the 33-pitch image
-        return *(const float *)((const char *)h + ((k << 2) + ((k >> 5) << 2)));
+    __device__ __forceinline__ const float *word(uint32_t k) const {
+        return (const float *)((const char *)h + ((k + (k >> 5)) << 2));  // v_lshrrev + v_add_lshl
     }
     __device__ __forceinline__ float at(uint32_t i) const {
         if (TBL == 0) return g[i];
-        const float v = lds_at(min(i, N - i));
+        const float v = *word(min(i, N - i));
         return i > M ? -v : v;
     }
-    // (T[i], T[i+1]) for the lerp
-    __device__ __forceinline__ void pair(uint32_t i, float &a, float &b) const {
+    __device__ __forceinline__ void pair(uint32_t i, float &a, float &b) const {  // (T[i], T[i+1])
         if (TBL == 0) {
             a = g[i];
             b = g[i + 1];
             return;
         }
         const bool upper = i > M;
-        const uint32_t k = upper ? N - i - 1 : i;
-        const float *p = (const float *)((const char *)h + ((k << 2) + ((k >> 5) << 2)));
+        const float *p = word(upper ? N - i - 1 : i);
         const float x = p[0], y = p[1];
         a = upper ? -y : x;
         b = upper ? -x : y;
@@ -153,13 +127,65 @@ __device__ __forceinline__ void store4(float *row, const float (&v)[4], uint64_t
             if (t + c < n_samples) row[c] = v[c];
 }
 
+// phase (in units of 2^E) of this lane's 4 samples at the start of segment `seg`:
+// P(t) = P0 + (t+1) Fm  with  t = seg * seg_len + 4 lane + c
+__device__ __forceinline__ void start_phase(const OscRec &rc, uint32_t seg, uint32_t lane, uint64_t (&P)[4]) {
+    const uint64_t base = addmod(addmod(rc.P0, rc.Fm, rc.S), mulmod(rc.segstep, seg, rc.S), rc.S);
+    P[0] = addmod(base, mulmod(rc.step4, lane, rc.S), rc.S);
+    for (int c = 1; c < 4; ++c) P[c] = addmod(P[c - 1], rc.Fm, rc.S);
+}
+
 }  // namespace
 
-// KIND: fused shape.  TBL: table placement.  R: instances per wave (the Ramp, which depends only on
-// the sample index, is evaluated once per step and reused for all R voices).  FASTDIV / FINITE: host-
-// verified strength reductions (see ramp_value / fix_out).
+// One thread per voice: decompose f into exact fixed point, precompute the strides the render
+// kernel needs, and write the end-of-render state (state write-back).
+__global__ void dusp_fused_prepare(FusedArgs A, OscRec *recs) {
+    const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= A.n_inst) return;
+    const uint32_t sr = A.sample_rate;
+    const double srd = (double)sr;
+    OscRec rc;
+    double fd = (double)operand_value(A.f, A.params, A.n_inst, inst);
+    rc.bad = !(fabs(fd) <= 3.0e38);  // non-finite f: every sample is NaN -> 0 after `|| 0`
+    if (rc.bad) fd = 0.0;
+    if (fabs(fd) >= srd) fd = fmod(fd, srd);
+    int E = 0;
+    if (fd != 0.0) E = min(E, lsb_exponent(fd));
+    if (A.phase0 != 0.0) E = min(E, lsb_exponent(A.phase0));
+    const int Emin = -(62 - (32 - __builtin_clz(sr)));  // keep S = sr * 2^-E below 2^62
+    if (E < Emin) E = Emin;                              // (only reachable for |f| < 2^-13: inexact regime)
+    rc.E = E;
+    rc.u = ldexp(1.0, E);
+    rc.S = (uint64_t)sr << (-E);
+    const long long F = (long long)rint(ldexp(fd, -E));
+    rc.Fm = F >= 0 ? (uint64_t)F : rc.S - (uint64_t)(-F);
+    if (rc.Fm >= rc.S) rc.Fm -= rc.S;
+    rc.P0 = (uint64_t)rint(ldexp(A.phase0, -E));
+    if (rc.P0 >= rc.S) rc.P0 %= rc.S;
+    rc.step4 = mulmod(rc.Fm, 4, rc.S);
+    rc.step256 = mulmod(rc.Fm, kChunk, rc.S);
+    rc.segstep = mulmod(rc.Fm, (uint64_t)A.seg_groups * kChunk, rc.S);
+    rc.gain = A.gain.kind == SRC_PARAM || A.gain.kind == SRC_CONST ? operand_value(A.gain, A.params, A.n_inst, inst) : 1.f;
+    rc.pad = 0;
+    recs[inst] = rc;
+
+    // the state every unit holds after ceil(n_samples/256) ticks
+    const uint64_t T_end = (uint64_t)A.n_chunks * kChunk;
+    double phase_end = (double)addmod(rc.P0, mulmod(rc.Fm, T_end, rc.S), rc.S) * rc.u;
+    if (rc.bad) phase_end = __builtin_nan("");
+    A.end_state[(size_t)A.osc_state_word * A.n_inst + inst] = phase_end;
+    if (A.ramp_state_word >= 0) {
+        const double t_end = A.r_playing ? fmin(A.r_t0 + (double)T_end, A.r_d) : A.r_t0;
+        const bool playing_end = A.r_playing && (A.r_t0 + (double)T_end <= A.r_d);
+        A.end_state[(size_t)A.ramp_state_word * A.n_inst + inst] = t_end;
+        A.end_state[(size_t)(A.ramp_state_word + 1) * A.n_inst + inst] = playing_end ? 1.0 : 0.0;
+    }
+}
+
+// KIND: fused shape.  TBL: table placement.  R: voices per work item.  FASTDIV / FINITE:
+// host-verified strength reductions (ramp_value, fix_out).
 template <int KIND, int TBL, int R, bool FASTDIV, bool FINITE, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
+__global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const OscRec *__restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) float lds_table[];
     Table<TBL> table;
     table.g = A.table;
@@ -177,6 +203,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
     }
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t waves_per_block = BLOCK / 64;
+    constexpr int RS = R < 4 ? R : 4;  // voices handled together by the FX32 / F64 paths (register budget)
     const uint32_t n_blk = (A.n_inst + R - 1) / R;
     const uint64_t n_items = (uint64_t)n_blk * A.n_seg;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
@@ -191,49 +218,24 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
         const uint32_t seg = (uint32_t)(item / n_blk);
         const uint32_t g0 = seg * A.seg_groups;
         const uint32_t g1 = min(g0 + A.seg_groups, A.n_groups);
+        const uint32_t gm = max(g0, min(g1, n_full));
         const uint64_t t_start = (uint64_t)g0 * kChunk;
 
-        uint64_t P[R][4], step256[R];
-        double u[R];
-        float gain[R];
-        bool bad[R];
-        size_t roff[R];  // row offset of instance r; a short last block repeats its last instance (same data, same address)
-        bool all_integer = true;
+        // a short last block repeats its last voice: same data stored to the same address, no branches
+        uint32_t inst[R];
+        int e_min = 0;
+        bool any_bad = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t inst = min(blk * R + r, A.n_inst - 1);
-            const bool live = blk * R + r < A.n_inst;
-            roff[r] = (size_t)inst * A.n_samples;
-            const float f = operand_value(A.f, A.params, A.n_inst, inst);
-            const OscFix o = osc_setup(f, A.phase0, sr);
-            const uint64_t step4 = mulmod(o.Fm, 4, o.S);
-            step256[r] = mulmod(o.Fm, 256, o.S);
-            P[r][0] = addmod(addmod(o.P0, mulmod(o.Fm, t_start + 1, o.S), o.S), mulmod(step4, lane, o.S), o.S);
-            for (int c = 1; c < 4; ++c) P[r][c] = addmod(P[r][c - 1], o.Fm, o.S);
-            u[r] = o.u;
-            bad[r] = o.bad;
-            all_integer = all_integer && o.E == 0 && !o.bad;
-            gain[r] = KIND == FUSED_OSC_GAIN ? operand_value(A.gain, A.params, A.n_inst, inst) : 1.f;
-
-            if (seg == 0 && lane == 0 && live) {  // state write-back: state after ceil(n_samples/256) ticks
-                const uint64_t T_end = (uint64_t)A.n_chunks * kChunk;
-                double phase_end = (double)addmod(o.P0, mulmod(o.Fm, T_end, o.S), o.S) * o.u;
-                if (o.bad) phase_end = __builtin_nan("");
-                A.end_state[(size_t)A.osc_state_word * A.n_inst + inst] = phase_end;
-                if (KIND == FUSED_OSC_RAMP) {
-                    const double t_end = A.r_playing ? fmin(A.r_t0 + (double)T_end, A.r_d) : A.r_t0;
-                    const bool playing_end = A.r_playing && (A.r_t0 + (double)T_end <= A.r_d);
-                    A.end_state[(size_t)A.ramp_state_word * A.n_inst + inst] = t_end;
-                    A.end_state[(size_t)(A.ramp_state_word + 1) * A.n_inst + inst] = playing_end ? 1.0 : 0.0;
-                }
-            }
+            inst[r] = min(blk * R + r, A.n_inst - 1);
+            e_min = min(e_min, recs[inst[r]].E);
+            any_bad = any_bad || recs[inst[r]].bad;
         }
-        // Ramp: tn = t0 + (n + 1) for this lane's first sample n; +256 per step.  Idle ramp: t stays t0.
-        double tn = A.r_t0 + (A.r_playing ? (double)(t_start + lane * 4 + 1) : 0.0);
+        float *const row0 = A.out + t_start + lane * 4;
+        const double tn0 = A.r_t0 + (A.r_playing ? (double)(t_start + lane * 4 + 1) : 0.0);
         const double tn_step = A.r_playing ? (double)kChunk : 0.0;
         const double tn_c = A.r_playing ? 1.0 : 0.0;
-        float *row = A.out + t_start + lane * 4;
-
+        double tn;  // Ramp: t0 + (n + 1) for this lane's first sample n of the current step; idle ramp: t0
         auto ramp4 = [&](float (&rv)[4]) {
             if (KIND == FUSED_OSC_RAMP) {
                 rv[0] = ramp_value<FASTDIV>(A, tn, dy);
@@ -242,95 +244,172 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A) {
                 tn += tn_step;
             }
         };
+        auto finish = [&](float v, float rv, float gain) {
+            if (KIND == FUSED_OSC_RAMP) v = v * rv;
+            if (KIND == FUSED_OSC_GAIN) v = v * gain;
+            return fix_out<FINITE>(v);
+        };
 
-        if (all_integer) {
-            // every phase is an integer: fraction == 0 and out = table[phase] exactly (Osc.js:43-45)
+        if (e_min == 0 && !any_bad) {
+            // ---- INT: every phase is an integer, out = table[phase] exactly
             uint32_t idx[R][4], step[R];
+            size_t roff[R];
+            float gain[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                step[r] = (uint32_t)step256[r];
-                for (int c = 0; c < 4; ++c) idx[r][c] = (uint32_t)P[r][c];
+                const OscRec rc = recs[inst[r]];
+                uint64_t P[4];
+                start_phase(rc, seg, lane, P);
+                for (int c = 0; c < 4; ++c) idx[r][c] = (uint32_t)P[c];
+                step[r] = (uint32_t)rc.step256;
+                roff[r] = (size_t)inst[r] * A.n_samples;
+                gain[r] = rc.gain;
             }
+            tn = tn0;
+            float *row = row0;
             auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
                 for (uint32_t g = ga; g < gb; ++g) {
-                    float rv[4];
+                    float rv[4] = {1.f, 1.f, 1.f, 1.f};
                     ramp4(rv);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         float v[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            v[c] = table.at(idx[r][c]);
+                            v[c] = finish(table.at(idx[r][c]), rv[c], gain[r]);
                             idx[r][c] += step[r];
                             idx[r][c] = min(idx[r][c], idx[r][c] - sr);  // wrap (idx < 2 sr; underflow loses the min)
-                            if (KIND == FUSED_OSC_RAMP) v[c] = v[c] * rv[c];
-                            if (KIND == FUSED_OSC_GAIN) v[c] = v[c] * gain[r];
-                            v[c] = fix_out<FINITE>(v[c]);
                         }
                         store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
                     }
                     row += kChunk;
                 }
             };
-            const uint32_t gm = max(g0, min(g1, n_full));
             run(g0, gm, std::true_type{});
             run(gm, g1, std::false_type{});
-        } else {
-            double ph[R][4], D[R];
+        } else if (e_min >= -32 && !any_bad && A.fx32_ok) {
+            // ---- FX32: phase = I + F 2^-32.  Advance with add-with-carry; lerp on exact f64 integers:
+            // table[I] (2^32 - F) + table[I+1] F, each product / the sum rounded exactly like the reference's
+            // a*(1-fraction) + b*fraction scaled by 2^32 (a power of two commutes with rounding), then one
+            // f32 rounding and an exact 2^-32 (results stay far above the f32 subnormal range: the host
+            // checks min |table| >= 2^-20 before setting fx32_ok).
+            for (int sub = 0; sub < R; sub += RS) {
+                uint32_t I[RS][4], F[RS][4], dI[RS], dF[RS];
+                size_t roff[RS];
+                float gain[RS];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                D[r] = (double)step256[r] * u[r];
-                for (int c = 0; c < 4; ++c) ph[r][c] = (double)P[r][c] * u[r];
+                for (int r = 0; r < RS; ++r) {
+                    const OscRec rc = recs[inst[sub + r]];
+                    const int sh = -rc.E;  // 0..32
+                    uint64_t P[4];
+                    start_phase(rc, seg, lane, P);
+                    for (int c = 0; c < 4; ++c) {
+                        I[r][c] = (uint32_t)(P[c] >> sh);
+                        F[r][c] = sh ? (uint32_t)(P[c] << (32 - sh)) : 0u;
+                    }
+                    dI[r] = (uint32_t)(rc.step256 >> sh);
+                    dF[r] = sh ? (uint32_t)(rc.step256 << (32 - sh)) : 0u;
+                    roff[r] = (size_t)inst[sub + r] * A.n_samples;
+                    gain[r] = rc.gain;
+                }
+                tn = tn0;
+                float *row = row0;
+                auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
+                    for (uint32_t g = ga; g < gb; ++g) {
+                        float rv[4] = {1.f, 1.f, 1.f, 1.f};
+                        ramp4(rv);
+#pragma unroll
+                        for (int r = 0; r < RS; ++r) {
+                            float v[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                float ta, tb;
+                                table.pair(I[r][c], ta, tb);
+                                const double wb = (double)F[r][c];
+                                const double wa = 4294967296.0 - wb;
+                                const float x = (float)((double)ta * wa + (double)tb * wb);
+                                v[c] = finish(ldexpf(x, -32), rv[c], gain[r]);
+                                const uint32_t f2 = F[r][c] + dF[r];
+                                uint32_t i2 = I[r][c] + dI[r] + (f2 < F[r][c] ? 1u : 0u);
+                                i2 = min(i2, i2 - sr);
+                                F[r][c] = f2;
+                                I[r][c] = i2;
+                            }
+                            store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
+                        }
+                        row += kChunk;
+                    }
+                };
+                run(g0, gm, std::true_type{});
+                run(gm, g1, std::false_type{});
             }
-            auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
-                for (uint32_t g = ga; g < gb; ++g) {
-                    float rv[4];
-                    ramp4(rv);
+        } else {
+            // ---- F64: general path
+            for (int sub = 0; sub < R; sub += RS) {
+                double ph[RS][4], D[RS];
+                size_t roff[RS];
+                float gain[RS];
+                bool bad[RS];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float v[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t idx = (uint32_t)(int)ph[r][c];
-                            const double fraction = ph[r][c] - (double)(int)idx;
-                            float ta, tb;
-                            table.pair(idx, ta, tb);
-                            v[c] = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
-                            if (bad[r]) v[c] = 0.f;
-                            ph[r][c] += D[r];
-                            if (ph[r][c] >= srd) ph[r][c] -= srd;
-                            if (KIND == FUSED_OSC_RAMP) v[c] = v[c] * rv[c];
-                            if (KIND == FUSED_OSC_GAIN) v[c] = v[c] * gain[r];
-                            v[c] = fix_out<FINITE>(v[c]);
-                        }
-                        store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
-                    }
-                    row += kChunk;
+                for (int r = 0; r < RS; ++r) {
+                    const OscRec rc = recs[inst[sub + r]];
+                    uint64_t P[4];
+                    start_phase(rc, seg, lane, P);
+                    for (int c = 0; c < 4; ++c) ph[r][c] = (double)P[c] * rc.u;
+                    D[r] = (double)rc.step256 * rc.u;
+                    roff[r] = (size_t)inst[sub + r] * A.n_samples;
+                    gain[r] = rc.gain;
+                    bad[r] = rc.bad;
                 }
-            };
-            const uint32_t gm = max(g0, min(g1, n_full));
-            run(g0, gm, std::true_type{});
-            run(gm, g1, std::false_type{});
+                tn = tn0;
+                float *row = row0;
+                auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
+                    for (uint32_t g = ga; g < gb; ++g) {
+                        float rv[4] = {1.f, 1.f, 1.f, 1.f};
+                        ramp4(rv);
+#pragma unroll
+                        for (int r = 0; r < RS; ++r) {
+                            float v[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const uint32_t idx = (uint32_t)(int)ph[r][c];
+                                const double fraction = ph[r][c] - (double)(int)idx;
+                                float ta, tb;
+                                table.pair(idx, ta, tb);
+                                float x = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+                                if (bad[r]) x = 0.f;
+                                v[c] = finish(x, rv[c], gain[r]);
+                                ph[r][c] += D[r];
+                                if (ph[r][c] >= srd) ph[r][c] -= srd;
+                            }
+                            store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
+                        }
+                        row += kChunk;
+                    }
+                };
+                run(g0, gm, std::true_type{});
+                run(gm, g1, std::false_type{});
+            }
         }
     }
 }
 
 template <int KIND, int TBL, int R, bool FASTDIV, bool FINITE, int BLOCK>
-static hipError_t launch_one(const FusedArgs &A, int grid, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_one(const FusedArgs &A, const OscRec *recs, int grid, size_t lds_bytes, hipStream_t stream) {
     auto kernel = dusp_fused_kernel<KIND, TBL, R, FASTDIV, FINITE, BLOCK>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, A, recs);
     return hipGetLastError();
 }
 
-// DUSP_FUSED_TABLE=global|lds overrides the table placement (used by the A/B benchmarks).
-static int table_mode_override() {
-    const char *e = getenv("DUSP_FUSED_TABLE");
-    if (!e) return -1;
-    return e[0] == 'l' ? 1 : 0;
+// A/B knobs for tools/abench.py: DUSP_FUSED_TABLE=global|lds, DUSP_FUSED_R=1|4|8, DUSP_FUSED_FX32=0|1,
+// DUSP_FUSED_ITEMS=<items per wave>
+static int env_int(const char *name, int fallback) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : fallback;
 }
 
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream) {
@@ -346,49 +425,64 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     A.n_chunks = L.n_chunks;
     A.f = plan.f;
     A.gain = plan.gain;
+    if (plan.kind != FUSED_OSC_GAIN) A.gain.kind = -1;
     A.phase0 = plan.phase0;
     A.r_d = plan.r_d; A.r_y0 = plan.r_y0; A.r_y1 = plan.r_y1; A.r_t0 = plan.r_t0; A.r_rcp = plan.r_rcp;
     A.r_playing = plan.r_playing;
     A.r_fastdiv = plan.r_fastdiv;
     A.vec4_ok = (L.n_samples % 4 == 0) && (((uintptr_t)L.out & 15) == 0);
     A.osc_state_word = 0;
-    A.ramp_state_word = 1;
+    A.ramp_state_word = plan.kind == FUSED_OSC_RAMP ? 1 : -1;
+    A.fx32_ok = L.table_fx32_ok && env_int("DUSP_FUSED_FX32", 1) ? 1 : 0;
 
     int tbl = (L.table_antisym && L.sample_rate % 2 == 0) ? 1 : 0;
-    if (table_mode_override() == 0) tbl = 0;
+    const char *tenv = getenv("DUSP_FUSED_TABLE");
+    if (tenv && tenv[0] == 'g') tbl = 0;
     const uint32_t last = L.sample_rate / 2 + 1;
     const size_t lds_bytes = tbl ? ((size_t)(last + (last >> 5) + 2) * sizeof(float) + 15) & ~(size_t)15 : 0;
     if (lds_bytes > 160 * 1024) tbl = 0;
 
-    // R voices per wave share one Ramp evaluation per step; without a Ramp there is nothing to share
-    constexpr int kR = 4;
-    const int R = plan.kind == FUSED_OSC_RAMP ? kR : 1;
-    // segment length: enough (instance block, segment) items to keep every wave slot busy several times over
+    // R voices per item share one Ramp evaluation per step; without a Ramp there is nothing to share
+    int R = 4;
+    R = env_int("DUSP_FUSED_R", R);
+    if (R != 1 && R != 4 && R != 8) R = 4;
+    // Items: (voice block, segment).  Aim at `per_wave` equal items for every resident wave so that all
+    // waves finish together; segments of at least 16 steps keep the per-item jump-ahead negligible.
     const int block = tbl ? 1024 : 256;
     const int grid = tbl ? L.n_cus : L.n_cus * 8;
     const uint64_t total_waves = (uint64_t)grid * (block / 64);
     const uint64_t n_blk = (A.n_inst + R - 1) / R;
-    const uint64_t all_groups = n_blk * A.n_groups;
-    uint64_t seg = all_groups / (total_waves * 8);
-    if (seg < 32) seg = 32;
-    if (seg > 1024) seg = 1024;
+    const uint64_t per_wave = (uint64_t)env_int("DUSP_FUSED_ITEMS", 4);
+    uint64_t n_seg = (total_waves * per_wave + n_blk - 1) / n_blk;
+    if (n_seg < 1) n_seg = 1;
+    uint64_t seg = (A.n_groups + n_seg - 1) / n_seg;
+    if (seg < 16) seg = 16;
+    if (seg > 4096) seg = 4096;
     A.seg_groups = (uint32_t)seg;
     A.n_seg = (A.n_groups + A.seg_groups - 1) / A.seg_groups;
     const bool finite = L.table_finite && plan.kind != FUSED_OSC_GAIN && std::isfinite(plan.r_y0) && std::isfinite(plan.r_y1);
 
-#define DUSP_LAUNCH2(KIND, RR, FD, FIN) \
-    return tbl ? launch_one<KIND, 1, RR, FD, FIN, 1024>(A, grid, lds_bytes, stream) : launch_one<KIND, 0, RR, FD, FIN, 256>(A, grid, 0, stream)
+    hipLaunchKernelGGL(dusp_fused_prepare, dim3((A.n_inst + 255) / 256), dim3(256), 0, stream, A, L.recs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+#define DUSP_L3(KIND, RR, FD, FIN) \
+    return tbl ? launch_one<KIND, 1, RR, FD, FIN, 1024>(A, L.recs, grid, lds_bytes, stream) \
+               : launch_one<KIND, 0, RR, FD, FIN, 256>(A, L.recs, grid, 0, stream)
+#define DUSP_L2(KIND, FD, FIN) \
+    do { if (R == 8) { DUSP_L3(KIND, 8, FD, FIN); } if (R == 4) { DUSP_L3(KIND, 4, FD, FIN); } DUSP_L3(KIND, 1, FD, FIN); } while (0)
     switch (plan.kind) {
     case FUSED_OSC:
-        if (finite) { DUSP_LAUNCH2(FUSED_OSC, 1, false, true); }
-        DUSP_LAUNCH2(FUSED_OSC, 1, false, false);
+        if (finite) DUSP_L2(FUSED_OSC, false, true);
+        DUSP_L2(FUSED_OSC, false, false);
     case FUSED_OSC_RAMP:
-        if (plan.r_fastdiv && finite) { DUSP_LAUNCH2(FUSED_OSC_RAMP, kR, true, true); }
-        if (plan.r_fastdiv) { DUSP_LAUNCH2(FUSED_OSC_RAMP, kR, true, false); }
-        DUSP_LAUNCH2(FUSED_OSC_RAMP, kR, false, false);
-    case FUSED_OSC_GAIN: DUSP_LAUNCH2(FUSED_OSC_GAIN, 1, false, false);
+        if (plan.r_fastdiv && finite) DUSP_L2(FUSED_OSC_RAMP, true, true);
+        if (plan.r_fastdiv) DUSP_L2(FUSED_OSC_RAMP, true, false);
+        DUSP_L2(FUSED_OSC_RAMP, false, false);
+    case FUSED_OSC_GAIN: DUSP_L2(FUSED_OSC_GAIN, false, false);
     }
-#undef DUSP_LAUNCH2
+#undef DUSP_L2
+#undef DUSP_L3
     return hipErrorInvalidValue;
 }
 

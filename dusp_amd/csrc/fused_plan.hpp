@@ -35,16 +35,27 @@ struct FusedPlan {
     std::vector<int> unit_state_first, unit_state_count;
 };
 
+// Per-voice oscillator record, written by the prepare kernel: f in exact fixed point (units of 2^E)
+// plus the strides the render kernel steps by.
+struct OscRec {
+    uint64_t S, Fm, P0;               // modulus sr * 2^-E, increment f * 2^-E mod S, start phase
+    uint64_t step4, step256, segstep; // (4 f), (256 f), (segment length * f) mod S
+    double u;                         // 2^E
+    int32_t E, bad;                   // bad: non-finite f (every sample NaN -> 0)
+    float gain, pad;
+};
+
 // Launch-time arguments filled in by dusp_render_device.
 struct FusedLaunch {
     const float *params;
     const float *tables;
     float *out;
     double *end_state;
+    OscRec *recs;  // [n_inst] workspace
     uint64_t n_samples;
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
-    bool table_antisym, table_finite;
+    bool table_antisym, table_finite, table_fx32_ok;
 };
 
 // Kernel arguments (by value).
@@ -58,7 +69,7 @@ struct FusedArgs {
     DevOperand f, gain;
     double phase0;
     double r_d, r_y0, r_y1, r_t0, r_rcp;
-    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, pad;
+    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok;
 };
 
 // q' of Markstein's division-by-reciprocal: q = t*r; rem = fma(-q, d, t); q' = fma(rem, r, q).

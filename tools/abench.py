@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--voices", type=int, default=1024)
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--globaltbl", action="store_true")
     args = ap.parse_args()
     import torch
     import dusp_amd as d
@@ -38,20 +39,28 @@ def main():
             return d.Multiply(d.Osc(f), 0.5)
 
     variants = []
+    envsets = [("R8", {"DUSP_FUSED_R": "8"}), ("R4", {"DUSP_FUSED_R": "4"}), ("R4/nofx", {"DUSP_FUSED_R": "4", "DUSP_FUSED_FX32": "0"}),
+               ("R8/it4", {"DUSP_FUSED_R": "8", "DUSP_FUSED_ITEMS": "4"}), ("R8/it16", {"DUSP_FUSED_R": "8", "DUSP_FUSED_ITEMS": "16"})]
+    if args.globaltbl:
+        envsets.append(("R4/global", {"DUSP_FUSED_R": "4", "DUSP_FUSED_TABLE": "global"}))
     for kind in ["osc", "oscramp"]:
         for fname, fs in [("int", 10.0 * np.arange(1, V + 1)), ("frac", 20 + np.arange(V) / 8.0)]:
             uni = descriptor.unify([descriptor.extract(graph(kind, float(f))) for f in fs[:2]])
             params = torch.from_numpy(fs.astype(np.float32).reshape(1, V)).cuda()
             prog = ctx.build(uni.words)
-            for tbl in ["global", "lds"]:
-                variants.append(("%s/%s/%s" % (kind, fname, tbl), prog, params, tbl))
+            for ename, env in envsets:
+                variants.append(("%s/%s/%s" % (kind, fname, ename), prog, params, env))
+
+    KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE"]
 
     def run(v):
-        name, prog, params, tbl = v
+        name, prog, params, env = v
         if prog is None:
             ctx.fill(out.data_ptr(), out.numel(), 1.0, stream)
         else:
-            os.environ["DUSP_FUSED_TABLE"] = tbl
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(env)
             prog.render_device(n, V, params.data_ptr(), out.data_ptr(), stream)
 
     variants.insert(0, ("fill", None, None, None))
