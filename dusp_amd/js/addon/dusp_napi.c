@@ -1,0 +1,389 @@
+/* dusp_napi.c — thin N-API addon binding the C ABI of include/dusp_hip.h for Node.js.
+ *
+ * Raw C against <node_api.h> (N-API v4+, present in Node 12): no node-gyp, no node-addon-api.
+ *   ctxCreate(device) -> ctx            tableUpload(ctx, id, Float32Array)
+ *   programBuild(ctx, Float64Array words, engine) -> prog
+ *   programInfo(prog) -> { sampleRate, nUnits, nOutChannels, nParams, engine, shape, nDeviceOps }
+ *   render(prog, nInstances, nSamples, Float32Array params | null) -> Promise<Float32Array>
+ *         (runs dusp_render_host on the libuv pool so the event loop stays live)
+ *   stateDownload(prog, instance, unit) -> Float64Array
+ *   programDestroy(prog), ctxDestroy(ctx), version(), abiVersion()
+ * Failures surface the way the reference's do: synchronous calls THROW A STRING, render() REJECTS
+ * WITH A STRING (reference src/renderChannelData.js:12-17 throws strings inside an async function).
+ */
+#include <node_api.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/dusp_hip.h"
+
+/* a dusp_ctx is not thread-safe and async renders run on pool threads: serialise library calls */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
+#define NAPI_OK(call)                                                          \
+    do {                                                                       \
+        if ((call) != napi_ok) {                                               \
+            throw_string(env, "dusp-hip: N-API call failed: " #call);         \
+            return NULL;                                                       \
+        }                                                                      \
+    } while (0)
+
+static void throw_string(napi_env env, const char *msg) {
+    napi_value s;
+    if (napi_create_string_utf8(env, msg, NAPI_AUTO_LENGTH, &s) == napi_ok) napi_throw(env, s);
+}
+
+typedef struct {
+    dusp_ctx *ctx;
+} ctx_box;
+typedef struct {
+    dusp_program *prog;
+    dusp_ctx *ctx;
+} prog_box;
+
+static void ctx_finalize(napi_env env, void *data, void *hint) {
+    (void)env; (void)hint;
+    ctx_box *b = (ctx_box *)data;
+    /* contexts are kept for the life of the process by the JS layer; an explicit ctxDestroy clears ctx */
+    free(b);
+}
+static void prog_finalize(napi_env env, void *data, void *hint) {
+    (void)env; (void)hint;
+    prog_box *b = (prog_box *)data;
+    if (b->prog) {
+        pthread_mutex_lock(&g_lock);
+        dusp_program_destroy(b->prog);
+        pthread_mutex_unlock(&g_lock);
+    }
+    free(b);
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        throw_string(env, "dusp-hip: wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+static ctx_box *as_ctx(napi_env env, napi_value v) {
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((ctx_box *)p)->ctx) {
+        throw_string(env, "dusp-hip: not a live context");
+        return NULL;
+    }
+    return (ctx_box *)p;
+}
+static prog_box *as_prog(napi_env env, napi_value v) {
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((prog_box *)p)->prog) {
+        throw_string(env, "dusp-hip: not a live program");
+        return NULL;
+    }
+    return (prog_box *)p;
+}
+static int typed_array(napi_env env, napi_value v, napi_typedarray_type want, void **data, size_t *len) {
+    bool is = false;
+    napi_typedarray_type type;
+    napi_value ab;
+    size_t off;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return 0;
+    if (napi_get_typedarray_info(env, v, &type, len, data, &ab, &off) != napi_ok || type != want) return 0;
+    return 1;
+}
+
+static napi_value fn_version(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value s;
+    NAPI_OK(napi_create_string_utf8(env, dusp_version(), NAPI_AUTO_LENGTH, &s));
+    return s;
+}
+static napi_value fn_abi_version(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, dusp_abi_version(), &v));
+    return v;
+}
+
+static napi_value fn_ctx_create(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    int32_t device = -1;
+    napi_get_value_int32(env, argv[0], &device);
+    dusp_ctx *ctx = NULL;
+    pthread_mutex_lock(&g_lock);
+    int rc = dusp_ctx_create(device, &ctx);
+    char msg[512];
+    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(NULL));
+    pthread_mutex_unlock(&g_lock);
+    if (rc != DUSP_OK) {
+        throw_string(env, msg);
+        return NULL;
+    }
+    ctx_box *b = (ctx_box *)calloc(1, sizeof *b);
+    b->ctx = ctx;
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, b, ctx_finalize, NULL, &ext));
+    return ext;
+}
+
+static napi_value fn_ctx_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ctx_box *b = as_ctx(env, argv[0]);
+    if (!b) return NULL;
+    pthread_mutex_lock(&g_lock);
+    dusp_ctx_destroy(b->ctx);
+    pthread_mutex_unlock(&g_lock);
+    b->ctx = NULL;
+    return NULL;
+}
+
+static napi_value fn_table_upload(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ctx_box *b = as_ctx(env, argv[0]);
+    if (!b) return NULL;
+    int32_t id = -1;
+    napi_get_value_int32(env, argv[1], &id);
+    void *data;
+    size_t len;
+    if (!typed_array(env, argv[2], napi_float32_array, &data, &len)) {
+        throw_string(env, "dusp-hip: tableUpload expects a Float32Array");
+        return NULL;
+    }
+    pthread_mutex_lock(&g_lock);
+    int rc = dusp_table_upload(b->ctx, id, (const float *)data, len);
+    char msg[512];
+    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(b->ctx));
+    pthread_mutex_unlock(&g_lock);
+    if (rc != DUSP_OK) throw_string(env, msg);
+    return NULL;
+}
+
+static napi_value fn_program_build(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ctx_box *b = as_ctx(env, argv[0]);
+    if (!b) return NULL;
+    void *data;
+    size_t len;
+    if (!typed_array(env, argv[1], napi_float64_array, &data, &len)) {
+        throw_string(env, "dusp-hip: programBuild expects a Float64Array of descriptor words");
+        return NULL;
+    }
+    int32_t engine = 0;
+    napi_get_value_int32(env, argv[2], &engine);
+    dusp_program *prog = NULL;
+    pthread_mutex_lock(&g_lock);
+    int rc = dusp_program_build(b->ctx, (const double *)data, len, engine, &prog);
+    char msg[512];
+    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(b->ctx));
+    pthread_mutex_unlock(&g_lock);
+    if (rc != DUSP_OK) {
+        throw_string(env, msg);
+        return NULL;
+    }
+    prog_box *pb = (prog_box *)calloc(1, sizeof *pb);
+    pb->prog = prog;
+    pb->ctx = b->ctx;
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, pb, prog_finalize, NULL, &ext));
+    return ext;
+}
+
+static napi_value fn_program_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    prog_box *pb = as_prog(env, argv[0]);
+    if (!pb) return NULL;
+    pthread_mutex_lock(&g_lock);
+    dusp_program_destroy(pb->prog);
+    pthread_mutex_unlock(&g_lock);
+    pb->prog = NULL;
+    return NULL;
+}
+
+static napi_value fn_program_info(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    prog_box *pb = as_prog(env, argv[0]);
+    if (!pb) return NULL;
+    dusp_program_info pi;
+    dusp_program_info_get(pb->prog, &pi);
+    napi_value obj, v;
+    NAPI_OK(napi_create_object(env, &obj));
+#define SET_U32(name, val)                                   \
+    NAPI_OK(napi_create_uint32(env, (val), &v));             \
+    NAPI_OK(napi_set_named_property(env, obj, name, v))
+    SET_U32("sampleRate", pi.sample_rate);
+    SET_U32("chunkSize", pi.chunk_size);
+    SET_U32("nUnits", pi.n_units);
+    SET_U32("nOutChannels", pi.n_out_channels);
+    SET_U32("nParams", pi.n_params);
+    SET_U32("nDeviceOps", pi.n_device_ops);
+#undef SET_U32
+    NAPI_OK(napi_create_string_utf8(env, pi.engine == DUSP_ENGINE_FUSED ? "fused" : "chunk", NAPI_AUTO_LENGTH, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "engine", v));
+    NAPI_OK(napi_create_string_utf8(env, pi.shape, NAPI_AUTO_LENGTH, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "shape", v));
+    return obj;
+}
+
+static napi_value fn_state_download(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    prog_box *pb = as_prog(env, argv[0]);
+    if (!pb) return NULL;
+    uint32_t instance = 0, unit = 0;
+    napi_get_value_uint32(env, argv[1], &instance);
+    napi_get_value_uint32(env, argv[2], &unit);
+    double words[512];
+    pthread_mutex_lock(&g_lock);
+    int n = dusp_state_download(pb->prog, instance, unit, words, 512);
+    char msg[512];
+    if (n < 0) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->ctx));
+    pthread_mutex_unlock(&g_lock);
+    if (n < 0) {
+        throw_string(env, msg);
+        return NULL;
+    }
+    if (n > 512) n = 512;
+    napi_value ab, arr;
+    void *mem;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)n * sizeof(double), &mem, &ab));
+    memcpy(mem, words, (size_t)n * sizeof(double));
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)n, ab, 0, &arr));
+    return arr;
+}
+
+/* ---- async render ---- */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref prog_ref; /* keeps the program external alive while the render is in flight */
+    dusp_program *prog;
+    dusp_ctx *ctx;
+    size_t n_instances, n_samples, n_floats;
+    float *params;
+    float *out;
+    int rc;
+    char err[512];
+} render_job;
+
+static void render_execute(napi_env env, void *data) {
+    (void)env;
+    render_job *j = (render_job *)data;
+    pthread_mutex_lock(&g_lock);
+    j->rc = dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
+    if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->ctx));
+    pthread_mutex_unlock(&g_lock);
+}
+static void free_pcm(napi_env env, void *data, void *hint) {
+    (void)env; (void)hint;
+    free(data);
+}
+static void render_complete(napi_env env, napi_status status, void *data) {
+    render_job *j = (render_job *)data;
+    napi_value result;
+    if (status != napi_ok && j->rc == DUSP_OK) {
+        j->rc = DUSP_ERR_STATE;
+        snprintf(j->err, sizeof j->err, "dusp-hip: render was cancelled");
+    }
+    if (j->rc == DUSP_OK) {
+        napi_value ab;
+        if (napi_create_external_arraybuffer(env, j->out, j->n_floats * sizeof(float), free_pcm, NULL, &ab) == napi_ok &&
+            napi_create_typedarray(env, napi_float32_array, j->n_floats, ab, 0, &result) == napi_ok) {
+            j->out = NULL; /* owned by the ArrayBuffer now */
+            napi_resolve_deferred(env, j->deferred, result);
+        } else {
+            napi_create_string_utf8(env, "dusp-hip: could not wrap the PCM buffer", NAPI_AUTO_LENGTH, &result);
+            napi_reject_deferred(env, j->deferred, result);
+        }
+    } else {
+        napi_create_string_utf8(env, j->err, NAPI_AUTO_LENGTH, &result);
+        napi_reject_deferred(env, j->deferred, result); /* a string, like the reference's rejections */
+    }
+    napi_delete_reference(env, j->prog_ref);
+    napi_delete_async_work(env, j->work);
+    free(j->params);
+    free(j->out);
+    free(j);
+}
+
+static napi_value fn_render(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    prog_box *pb = as_prog(env, argv[0]);
+    if (!pb) return NULL;
+    double n_inst = 0, n_samples = 0;
+    napi_get_value_double(env, argv[1], &n_inst);
+    napi_get_value_double(env, argv[2], &n_samples);
+    if (!(n_inst >= 1 && n_inst <= 16777216.0 && n_samples >= 1 && n_samples <= 2147483648.0)) {
+        throw_string(env, "dusp-hip: render: nInstances / nSamples out of range");
+        return NULL;
+    }
+    dusp_program_info pi;
+    dusp_program_info_get(pb->prog, &pi);
+    render_job *j = (render_job *)calloc(1, sizeof *j);
+    j->prog = pb->prog;
+    j->ctx = pb->ctx;
+    j->n_instances = (size_t)n_inst;
+    j->n_samples = (size_t)n_samples;
+    j->n_floats = j->n_instances * pi.n_out_channels * j->n_samples;
+    napi_valuetype vt;
+    napi_typeof(env, argv[3], &vt);
+    if (vt != napi_null && vt != napi_undefined) {
+        void *data;
+        size_t len;
+        if (!typed_array(env, argv[3], napi_float32_array, &data, &len) || len != (size_t)pi.n_params * j->n_instances) {
+            free(j);
+            throw_string(env, "dusp-hip: render: params must be a Float32Array of nParams * nInstances values");
+            return NULL;
+        }
+        j->params = (float *)malloc(len * sizeof(float) + 1);
+        memcpy(j->params, data, len * sizeof(float));
+    } else if (pi.n_params) {
+        free(j);
+        throw_string(env, "dusp-hip: render: this program needs a parameter table");
+        return NULL;
+    }
+    j->out = (float *)malloc(j->n_floats * sizeof(float) + 1);
+    if (!j->out) {
+        free(j->params);
+        free(j);
+        throw_string(env, "dusp-hip: render: out of host memory for the PCM buffer");
+        return NULL;
+    }
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(napi_create_reference(env, argv[0], 1, &j->prog_ref));
+    NAPI_OK(napi_create_string_utf8(env, "dusp-hip render", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work));
+    NAPI_OK(napi_queue_async_work(env, j->work));
+    return promise;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct {
+        const char *name;
+        napi_callback fn;
+    } fns[] = {
+        {"version", fn_version},          {"abiVersion", fn_abi_version},     {"ctxCreate", fn_ctx_create},
+        {"ctxDestroy", fn_ctx_destroy},   {"tableUpload", fn_table_upload},   {"programBuild", fn_program_build},
+        {"programDestroy", fn_program_destroy}, {"programInfo", fn_program_info}, {"stateDownload", fn_state_download},
+        {"render", fn_render},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[i].name, f) != napi_ok)
+            return NULL;
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

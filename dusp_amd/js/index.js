@@ -1,0 +1,23 @@
+'use strict'
+/* dusp-hip: the `renderChannelData` / `quick` surface of Dusp (reference src/index.js:6,11) plus the
+ * constructors of the units the MI355X render path executes. */
+const graph = require('./lib/graph')
+const renderChannelData = require('./lib/renderChannelData')
+
+module.exports = {
+  renderChannelData,
+  renderMany: renderChannelData.renderMany,
+  quick: require('./lib/quick'),
+  config: require('./lib/config'),
+  extract: require('./lib/extract').extract,
+  unify: require('./lib/extract').unify,
+  Unit: graph.Unit,
+  Circuit: graph.Circuit,
+  CircleBuffer: graph.CircleBuffer,
+  components: {
+    Osc: graph.Osc, Ramp: graph.Ramp, Multiply: graph.Multiply, Sum: graph.Sum, Filter: graph.Filter,
+    Delay: graph.Delay, CircleBufferReader: graph.CircleBufferReader, CircleBufferWriter: graph.CircleBufferWriter,
+    Repeater: graph.Repeater,
+  },
+  ...graph,
+}

@@ -1,0 +1,372 @@
+'use strict'
+/* Graph-construction classes for the GPU render path: the constructor surface of the
+ * reference units this package executes, so graphs can be written exactly as with `dusp`:
+ *
+ *   const { Osc, Ramp, Multiply } = require('dusp-hip')
+ *   renderChannelData(new Multiply(new Osc(440), new Ramp(48000, 1, 0).trigger()), 1)
+ *
+ * Nothing here ticks — there is no JS `_tick`: the classes only record structure and state
+ * for lib/extract.js.  Behaviour restated from the reference (file:line under src/):
+ *   ports and constants   Piglet.js:5-23, Inlet.js:40-93, Outlet.js:4-8
+ *   accessor sugar        Unit.js:48-86  (unit.F = 440 | unit.F = otherUnit | unit.OUT)
+ *   chain edges           Unit.js:88-105
+ *   process index         Unit.js:171-209
+ *   circuit flood fill    Circuit.js:67-107, ordering Circuit.js:125-148
+ * The same objects also work with the real `dusp` package's graphs: extract.js is duck-typed.
+ */
+const config = require('./config')
+const { WAVEFORMS } = require('./ops')
+
+class Port {
+  constructor(unit, name, opts = {}) {
+    this.unit = unit
+    this.name = name
+    this.mono = !!opts.mono
+    this.chunkSize = config.standardChunkSize
+    this.sampleRate = config.sampleRate
+  }
+  get label() { return this.unit.label + '.' + this.name.toUpperCase() }
+  get circuit() { return this.unit.circuit }
+}
+
+class Outlet extends Port {
+  constructor(unit, name, opts) {
+    super(unit, name, opts)
+    this.connections = []
+  }
+  get isOutlet() { return true }
+}
+
+class Inlet extends Port {
+  constructor(unit, name, opts) {
+    super(unit, name, opts)
+    this.connected = false
+    this.outlet = null
+    this.constant = 0
+    // stands in for the reference's own constant-filled chunk: one f32 per channel
+    this.signalChunk = { channelData: [new Float32Array(1)] }
+  }
+  get isInlet() { return true }
+
+  disconnect() {
+    if (!this.outlet) return
+    this.outlet.connections.splice(this.outlet.connections.indexOf(this), 1)
+    this.outlet = null
+    this.connected = false
+    this.signalChunk = { channelData: this.signalChunk.channelData.map(() => new Float32Array(1)) }
+  }
+
+  setConstant(value) {
+    if (this.outlet) this.disconnect()
+    this.constant = value
+    const vals = Array.isArray(value) ? value : [value]
+    const chans = this.signalChunk.channelData
+    for (let c = 0; c < chans.length || c < vals.length; c++) {
+      chans[c] = chans[c] || new Float32Array(1)
+      chans[c][0] = vals[c % vals.length]
+    }
+  }
+
+  connect(target) {
+    let outlet = target
+    if (outlet.isUnit || outlet.isPatch) outlet = outlet.defaultOutlet
+    if (this.connected) this.disconnect()
+    this.connected = true
+    this.outlet = outlet
+    outlet.connections.push(this)
+    const mine = this.unit.circuit, theirs = outlet.unit.circuit
+    if (mine && theirs && mine !== theirs) throw 'SHIT: Circuit conflict' // the reference's message (Inlet.js:58)
+    let touched = null
+    if (mine) { mine.add(outlet.unit); touched = mine } else if (theirs) { theirs.add(this.unit); touched = theirs }
+    if (touched) {
+      this.unit.computeProcessIndex()
+      outlet.unit.computeProcessIndex()
+      touched.computeOrders()
+    }
+  }
+}
+
+const timesUsed = new Map()
+
+class Unit {
+  constructor() {
+    this.inlets = {}
+    this.inletsOrdered = []
+    this.outlets = {}
+    this.outletsOrdered = []
+    this.events = []
+    this.promises = []
+    this.circuit = undefined
+    this.clock = 0
+    this.tickInterval = config.standardChunkSize
+    this.processIndex = undefined
+    this.nChains = 0
+    this.sampleRate = config.sampleRate
+    const kind = this.constructor.name
+    timesUsed.set(kind, (timesUsed.get(kind) || 0) + 1)
+    this.label = kind + timesUsed.get(kind)
+  }
+  get isUnit() { return true }
+  get isUnitOrPatch() { return true }
+
+  addInlet(name, opts) {
+    const inlet = new Inlet(this, name, opts)
+    this.inlets[name] = inlet
+    this.inletsOrdered.push(inlet)
+    Object.defineProperty(this, name.toUpperCase(), {
+      configurable: true,
+      get: () => inlet,
+      set: (val) => {
+        if (val === undefined || val === null) throw 'Passed bad value to ' + inlet.label
+        if (typeof val === 'number' || Array.isArray(val)) inlet.setConstant(val)
+        else if (val.isOutlet || val.isUnit || val.isPatch) inlet.connect(val)
+      },
+    })
+    return inlet
+  }
+
+  addOutlet(name, opts) {
+    const outlet = new Outlet(this, name, opts)
+    this.outlets[name] = outlet
+    this.outletsOrdered.push(outlet)
+    Object.defineProperty(this, name.toUpperCase(), { configurable: true, value: outlet })
+    return outlet
+  }
+
+  chainAfter(unit) { // data-less ordering edge
+    if (!unit || !unit.isUnit) throw 'chainAfter expects a Unit'
+    this.addInlet('chain' + this.nChains++).connect(unit.addOutlet('chain' + unit.nChains++))
+  }
+  chain(unit) { return this.chainAfter(unit) }
+  chainBefore(unit) { return unit.chainAfter(this) }
+
+  get defaultInlet() { return this.inletsOrdered[0] }
+  get defaultOutlet() { return this.outletsOrdered[0] }
+
+  get inputUnits() {
+    const found = []
+    for (const name of Object.keys(this.inlets)) {
+      const inlet = this.inlets[name]
+      if (inlet.connected && !found.includes(inlet.outlet.unit)) found.push(inlet.outlet.unit)
+    }
+    return found
+  }
+  get outputUnits() {
+    const found = []
+    for (const name of Object.keys(this.outlets))
+      for (const inlet of this.outlets[name].connections)
+        if (!found.includes(inlet.unit)) found.push(inlet.unit)
+    return found
+  }
+
+  /* 1 + the largest index among inputs not already on this walk, then push every dependent whose
+   * index is not above ours.  `history` cuts feedback loops, and WHERE it cuts decides which edge of
+   * a loop carries the implicit one-chunk delay. */
+  computeProcessIndex(history) {
+    const walk = (history || []).concat([this])
+    let best = -1
+    for (const unit of this.inputUnits) {
+      if (walk.includes(unit)) continue
+      if (unit.processIndex === undefined) unit.computeProcessIndex(walk)
+      if (unit.processIndex > best) best = unit.processIndex
+    }
+    this.processIndex = best + 1
+    for (const unit of this.outputUnits) {
+      if (walk.includes(unit)) continue
+      if (unit.processIndex === undefined || unit.processIndex <= this.processIndex) unit.computeProcessIndex(walk)
+    }
+    return this.processIndex
+  }
+
+  getOrBuildCircuit() { return this.circuit || new Circuit(this) }
+
+  trigger() {
+    for (const unit of this.inputUnits) unit.trigger()
+    return this
+  }
+}
+
+class Circuit {
+  constructor(...units) {
+    this.units = []
+    this.tickIntervals = []
+    this.clock = 0
+    this.events = []
+    this.promises = []
+    for (const unit of units) this.add(unit)
+  }
+
+  add(unit) {
+    if (unit.circuit && unit.circuit !== this) throw 'circuit clash, oh god ' + unit.label
+    if (this.units.includes(unit)) return null
+    this.units.push(unit)
+    unit.circuit = this
+    if (!this.tickIntervals.includes(unit.tickInterval)) {
+      this.tickIntervals.push(unit.tickInterval)
+      this.tickIntervals.sort((a, b) => a - b)
+    }
+    if (unit.events) {
+      for (const e of unit.events) this.events.push(e)
+      this.events.sort((a, b) => a.t - b.t)
+      unit.events = null
+    }
+    if (unit.promises) {
+      for (const p of unit.promises) this.promises.push(p)
+      unit.promises = null
+    }
+    for (const other of unit.inputUnits) this.add(other)
+    for (const other of unit.outputUnits) this.add(other)
+    unit.computeProcessIndex()
+    this.computeOrders()
+    return true
+  }
+
+  computeOrders() {
+    // same comparator as the reference: undefined indices give NaN, which the engine's stable sort
+    // treats as "equal" while a flood fill is still in flight
+    this.units.sort((a, b) => a.processIndex - b.processIndex)
+    const gcd = (a, b) => { while (b) { [a, b] = [b, a % b] } return a }
+    this.gcdTickInterval = this.tickIntervals.reduce(gcd)
+  }
+}
+
+/* ------------------------------------------------------------------ units */
+
+class Osc extends Unit { // Osc.js:7-17
+  constructor(f, waveform) {
+    super()
+    this.addInlet('f', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.F = f || 440
+    this.phase = 0
+    this.waveform = waveform || 'sin'
+  }
+  get waveform() { return this._waveform }
+  set waveform(w) {
+    if (WAVEFORMS[w] === undefined) throw "waveform doesn't exist: " + w
+    this._waveform = w
+  }
+}
+
+class Ramp extends Unit { // Ramp.js:3-23 — (duration in SAMPLES, y0, y1); idle until trigger()
+  constructor(duration, y0, y1) {
+    super()
+    this.addOutlet('out', { mono: true })
+    this.duration = duration || this.sampleRate
+    this.y0 = y0 || 1
+    this.y1 = y1 || 0
+    this.t = 0
+    this.playing = false
+  }
+  trigger() {
+    this.playing = true
+    this.t = 0
+    return this
+  }
+}
+
+class Multiply extends Unit { // Multiply.js:4-12
+  constructor(a, b) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addOutlet('out')
+    this.A = a || 1
+    this.B = b || 1
+  }
+}
+
+class Sum extends Unit { // Sum.js + SignalCombiner.js:3-12
+  constructor(a, b) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addOutlet('out')
+    this.A = a || 0
+    this.B = b || 0
+  }
+  static many(inputs) { // left-deep chain (Sum.js:18-29)
+    if (inputs.length === 1) return inputs[0]
+    let acc = new Sum(inputs[0], inputs[1])
+    for (let i = 2; i < inputs.length; i++) acc = new Sum(acc, inputs[i])
+    return acc
+  }
+}
+
+class Filter extends Unit { // Filter.js:5-22
+  constructor(input, f, kind) {
+    super()
+    this.addInlet('in')
+    this.addInlet('f', { mono: true })
+    this.addOutlet('out')
+    if (input) this.IN = input
+    if (f) this.F = f
+    this.kind = kind || 'LP'
+    if (this.kind !== 'LP' && this.kind !== 'HP') throw 'invalid filter type: ' + this.kind
+    this.lastF = undefined
+    // the reference's kind setter runs the coefficient function with f undefined (Filter.js:63)
+    this.a0 = this.a2 = this.b1 = this.b2 = NaN
+    this.a1 = this.kind === 'HP' ? 0 : NaN
+    this.x1 = []; this.x2 = []; this.y1 = []; this.y2 = []
+  }
+}
+
+class Delay extends Unit { // Delay.js:6-18 — delay in SAMPLES, ring of maxDelay samples
+  constructor(input, delay, maxDelay) {
+    super()
+    this.addInlet('in')
+    this.addInlet('delay')
+    this.addOutlet('out')
+    this.maxDelay = maxDelay || this.sampleRate * 5
+    this.IN = input || 0
+    this.DELAY = delay || 4410
+  }
+}
+
+class CircleBuffer { // CircleBuffer.js:3-13
+  constructor(numberOfChannels, lengthInSeconds) {
+    this.numberOfChannels = numberOfChannels || 1
+    this.lengthInSeconds = lengthInSeconds
+    this.sampleRate = config.sampleRate
+    this.lengthInSamples = Math.ceil(this.lengthInSeconds * this.sampleRate)
+  }
+}
+
+class CircleBufferNode extends Unit { // CircleBufferNode.js:7-31
+  constructor(buffer, offset) {
+    super()
+    this.t = 0
+    this.buffer = buffer
+    this.addInlet('offset')
+    this.OFFSET = offset || 0
+  }
+}
+
+class CircleBufferReader extends CircleBufferNode { // CircleBufferReader.js:4-10
+  constructor(buffer, offset) {
+    super(buffer, offset)
+    this.addOutlet('out')
+    this.postWipe = false
+  }
+}
+
+class CircleBufferWriter extends CircleBufferNode { // CircleBufferWriter.js:4-10
+  constructor(buffer, offset) {
+    super(buffer, offset)
+    this.addInlet('in')
+    this.preWipe = false
+  }
+}
+
+class Repeater extends Unit { // Repeater.js:3-11
+  constructor(val, measuredIn) {
+    super()
+    this.addInlet('in')
+    this.addOutlet('out')
+    this.measuredIn = measuredIn
+    this.IN = val || 0
+  }
+}
+
+module.exports = { Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
+  CircleBuffer, CircleBufferNode, CircleBufferReader, CircleBufferWriter, Repeater }

@@ -47,6 +47,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DuspHipError(-3, "HIP extension %s is missing: build it with `make -C dusp_amd/csrc` "
                                "(there is no CPU fallback)" % LIB_PATH)
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; whichever HIP runtime initialises first owns the GPU
+        # in this process, so let torch's copy load first and have this library bind to the same one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.dusp_version.restype = ctypes.c_char_p

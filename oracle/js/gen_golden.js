@@ -43,108 +43,9 @@ const CircleBufferWriter = ref('components/CircleBufferWriter.js')
 const quick = ref('quick.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
+const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
+  CircleBufferReader, CircleBufferWriter, quick }, SR)
 const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
-const cases = []
-const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
-
-// G1: configs[0] — single [Osc 440], 1 s
-add('osc440_1s', () => new Osc(440), 1)
-
-// G2: wrap / negative / fractional / tiny increments
-for (const [tag, f] of [['440p5', 440.5], ['0p1', 0.1], ['neg3', -3], ['47999p5', 47999.5],
-  ['neg0p37', -0.37], ['12345p678', 12345.678], ['tiny', 3e-5]])
-  add('osc_f_' + tag, () => new Osc(f), 0.1)
-
-// G3: every wave table, fractional phase so the lerp is exercised
-for (const w of ['saw', 'square', 'triangle', '8bit'])
-  add('osc_' + w, () => new Osc(441.3, w), 0.05)
-
-// G4: configs[1] — [Multiply A:[Osc f:[Ramp 200 100 2]] B:[Osc 3]]; literal reading (idle ramp = 100 Hz)
-add('cfg2_literal', () => new Multiply(new Osc(new Ramp(200, 100, 2)), new Osc(3)), 10,
-  [[0, 4096], [5 * SR - 128, 512], [10 * SR - 256, 256]])
-// ... and the intended 200->100 Hz sweep over 2 s
-add('cfg2_sweep', () => new Multiply(new Osc(new Ramp(2 * SR, 200, 100).trigger()), new Osc(3)), 10,
-  [[0, 4096], [2 * SR - 2048, 4096], [10 * SR - 256, 256]])
-
-// ramp edge cases: duration not a multiple of the chunk, rising ramp, 1-sample ramp, idle default ramp
-add('ramp_300', () => new Ramp(300, 0.25, 2).trigger(), 0.02)
-add('ramp_default_idle', () => new Ramp(), 0.01)
-add('ramp_1', () => new Ramp(1, 5, -5).trigger(), 0.01)
-add('ramp_frac', () => new Ramp(1000.5, -1, 1).trigger(), 0.03)
-
-// G5: Sum.many left-deep chain (configs[2] mix-down mode), 8 and 1024 voices
-const voices = (n) => { const v = []; for (let k = 1; k <= n; k++) v.push(new Osc(k * 10)); return v }
-add('summany_8', () => Sum.many(voices(8)), 2048 / SR)
-add('summany_1024', () => Sum.many(voices(1024)), 2048 / SR)
-
-// configs[2]/[4] per-voice mode: Multiply(Osc(f), Ramp(T,1,0) triggered); a few voices of each sweep
-for (const k of [1, 7, 512, 1024])
-  add('voice3_k' + k, () => new Multiply(new Osc(10 * k), new Ramp(SR, 1, 0).trigger()), 1,
-    [[0, 2048], [SR - 1024, 1024]])
-for (const k of [0, 3, 4097, 65535])
-  add('voice5_k' + k, () => new Multiply(new Osc(20 + k / 8), new Ramp(SR, 1, 0).trigger()), 1,
-    [[0, 2048], [SR - 1024, 1024]])
-
-// G6: configs[3] — feedback loop Osc -> Sum -> Delay -> Filter -> Multiply -> (back into Sum)
-const loop = (fOsc, delay, maxDelay, cutoff, gain) => {
-  const sum = new Sum(new Osc(fOsc), 0)
-  const d = new Delay(sum, delay, maxDelay)
-  const f = new Filter(d, cutoff)
-  const fb = new Multiply(f, gain)
-  sum.B = fb
-  return f
-}
-add('loop_220', () => loop(220, 480, 4096, 2000, 0.5), 0.1)
-add('loop_110p5_short', () => loop(110.5, 100, 4096, 2000, 0.5), 0.05) // delay < chunk
-add('loop_frac_delay', () => loop(330, 300.25, 2048, 1500, 0.7), 0.05)
-
-// delay on its own: default 5 s ring, integer / fractional / wrapping write position
-add('delay_default', () => new Delay(new Osc(100), 0, 0), 0.12) // literal 0s fall back to 4410 / 5*sr
-add('delay_wrap', () => new Delay(new Osc(1000), 700.5, 1000), 0.1)
-add('delay_mod', () => new Delay(new Osc(500), new Sum(new Multiply(new Osc(2), 40), 200), 1024), 0.1)
-add('delay_2ch', () => new Delay(new Multiply(new Osc(300), [1, -0.5]), [64, 333.75], 2048), 0.05)
-
-// filter: LP with modulated cutoff (per-sample coefficient refresh), HP, 2 channels, no cutoff given
-add('filter_lp_mod', () => new Filter(new Osc(150, 'saw'), new Sum(new Multiply(new Osc(5), 800), 1000)), 0.1)
-add('filter_hp', () => new Filter(new Osc(150, 'square'), 3000, 'HP'), 0.05)
-add('filter_2ch', () => new Filter(new Multiply(new Osc(440), [0.5, 0.25]), 1200), 0.03)
-
-// FM: connected f with mixed-sign increments (exercises the modular phase scan)
-add('fm_mixed', () => new Osc(new Multiply(new Osc(70), 9000)), 0.1)
-add('fm_sum', () => new Osc(new Sum(new Multiply(new Osc(3.5, 'triangle'), 300), 220.25)), 0.1)
-
-// G7: CircleBuffer writer / reader / feedback writer, MultiTapDelay topology
-//     (reference src/patches/MultiTapDelay.js:27-43), built by hand from its parts
-add('circlebuffer_taps', () => {
-  const buffer = new CircleBuffer(1, 0.05)
-  const writer = new CircleBufferWriter(buffer)
-  writer.preWipe = true
-  writer.IN = new Osc(330)
-  const tap = new CircleBufferReader(buffer, 0.01)
-  tap.chain(writer)
-  const fbTap = new CircleBufferReader(buffer, 0.02)
-  fbTap.chain(writer)
-  const fbWriter = new CircleBufferWriter(buffer, 0.005)
-  fbWriter.IN = quick.multiply(fbTap, 0.5)
-  fbWriter.chain(writer)
-  return new Sum(tap, fbTap)
-}, 0.15)
-add('circlebuffer_2ch', () => {
-  const buffer = new CircleBuffer(2, 0.011)
-  const writer = new CircleBufferWriter(buffer, 0.001)
-  writer.IN = new Multiply(new Osc(700), [1, 0.5])
-  const reader = new CircleBufferReader(buffer, [0.002, 0.0035])
-  reader.postWipe = true
-  reader.chain(writer)
-  return reader
-}, 0.05)
-
-// G8: length not a multiple of the chunk; 2-channel output; Repeater; quick.mult(x, 1) elision
-add('osc440_480', () => new Osc(440), 0.01)
-add('mult_2ch', () => new Multiply(new Osc(440), [0.5, 0.25]), 0.02)
-add('repeater', () => new Repeater(quick.mult(new Osc(123.4), 1)), 0.01)
-add('sum_const', () => quick.add(new Osc(50), 0.75), 0.01)
-add('mult_inlet_zero', () => { const m = new Multiply(new Osc(440), 2); m.B = 0; return m }, 0.01)
 
 async function main() {
   fs.mkdirSync(OUT, { recursive: true })

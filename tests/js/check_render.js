@@ -1,0 +1,55 @@
+'use strict'
+/* GPU parity through the JS surface: renderChannelData(unit, duration) via the N-API addon against
+ * the reference's golden PCM.  usage: node check_render.js --sampleRate=48000 */
+const fs = require('fs')
+const path = require('path')
+const lib = require('../../dusp_amd/js')
+const SR = lib.config.sampleRate
+const GOLDEN = path.join(__dirname, '..', 'golden')
+const cases = require('./cases')(lib, SR)
+const USES_DEVICE_TAN = /^(loop_|filter_)/
+
+async function main() {
+  const report = { sampleRate: SR, checked: 0, exact: 0, withinTol: 0, failed: [] }
+  for (const c of cases) {
+    const metaFile = path.join(GOLDEN, c.name + '.json')
+    if (!fs.existsSync(metaFile)) continue
+    const meta = JSON.parse(fs.readFileSync(metaFile))
+    const buf = fs.readFileSync(path.join(GOLDEN, c.name + '.pcm.f32'))
+    const want = new Float32Array(buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength))
+    const target = c.build()
+    const cd = await lib.renderChannelData(target, c.duration)
+    let ok = cd.length === meta.n_channels && cd.sampleRate === SR && cd[0].length === meta.n_samples
+    let at = 0, maxErr = 0, scale = 0, exact = true
+    for (let ch = 0; ok && ch < meta.n_channels; ch++)
+      for (const [a, len] of meta.windows)
+        for (let t = 0; t < len; t++, at++) {
+          const g = cd[ch][a + t], w = want[at]
+          if (g !== w) exact = false
+          maxErr = Math.max(maxErr, Math.abs(g - w)); scale = Math.max(scale, Math.abs(w))
+        }
+    report.checked++
+    if (ok && exact) report.exact++
+    else if (ok && USES_DEVICE_TAN.test(c.name) && maxErr <= 1e-5 * scale) report.withinTol++
+    else report.failed.push({ name: c.name, maxErr, ok })
+  }
+  // state write-back into the JS objects, as the reference leaves them after a render
+  const osc = new lib.Osc(440.5)
+  await lib.renderChannelData(osc, 1000 / SR)
+  report.oscPhaseAfter = osc.phase           // 1024 ticks of 440.5 -> (1024 * 440.5) mod sr
+  report.oscPhaseExpected = (1024 * 440.5) % SR
+  report.clockAfter = osc.circuit.clock
+  const again = await lib.renderChannelData(osc, 0.01).then(() => 'resolved', (e) => e)
+  report.secondRenderRejects = again
+  // batched voices
+  const voices = [1, 2, 3, 4, 5].map((k) => new lib.Multiply(new lib.Osc(110 * k + 0.5), new lib.Ramp(2000, 1, 0).trigger()))
+  const many = await lib.renderMany(voices, 2048 / SR)
+  const solo = await lib.renderChannelData(new lib.Multiply(new lib.Osc(110 * 3 + 0.5), new lib.Ramp(2000, 1, 0).trigger()), 2048 / SR)
+  report.manyMatchesSolo = many.length === 5 && many[2][0].every((v, i) => v === solo[0][i])
+  // unsupported graphs reject with a string
+  class Noise extends lib.Unit { constructor() { super(); this.addOutlet('out') } }
+  report.unsupported = await lib.renderChannelData(new lib.Multiply(new Noise(), 0.5), 0.01).then(() => 'resolved', (e) => e)
+  console.log(JSON.stringify(report))
+  process.exit(report.failed.length ? 1 : 0)
+}
+main().catch((e) => { console.log(JSON.stringify({ fatal: String(e && e.stack || e) })); process.exit(2) })
