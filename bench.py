@@ -40,19 +40,21 @@ def voice_program(sample_rate, n_samples, n_voices, first_voice):
     return uni.words, params.reshape(1, n_voices)
 
 
-def cpu_baseline(words, params, n_samples, budget_voices):
-    """Oracle (scalar C restatement of the reference) on a bounded sample of the same workload."""
+def cpu_baseline(words, params, n_samples, budget_s):
+    """Oracle (scalar C restatement of the reference, oracle/dusp_oracle.c) on a bounded sample of the
+    same workload: whole voices, spread over the sweep, until ~budget_s seconds of CPU have been spent."""
     from oracle import oracle
     oracle.build()
     n_inst = params.shape[1]
-    picks = np.linspace(0, n_inst - 1, budget_voices).astype(int)
-    t0 = time.perf_counter()
-    for i in picks:
-        oracle.render(words, n_samples, params=params, n_instances=n_inst, instance=int(i), max_channels=1)
+    order = np.random.RandomState(0).permutation(n_inst)
+    done, t0 = 0, time.perf_counter()
+    while done < n_inst and (done < 4 or time.perf_counter() - t0 < budget_s):
+        oracle.render(words, n_samples, params=params, n_instances=n_inst, instance=int(order[done]), max_channels=1)
+        done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(len(picks) * n_samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d voices x %d samples (%.1f s of CPU), single thread of %d host cores"
-                      % (len(picks), n_inst, n_samples, dt, os.cpu_count() or 0)}
+    return {"value": round(done * n_samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d voices x %d samples (%.1f s of CPU), one thread of %d host cores"
+                      % (done, n_inst, n_samples, dt, os.cpu_count() or 0)}
 
 
 def main():
@@ -63,7 +65,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0, help="rendered duration per voice")
     ap.add_argument("--voices", type=int, default=1024, help="voices per GPU")
     ap.add_argument("--sample-rate", type=int, default=48000)
-    ap.add_argument("--cpu-voices", type=int, default=16, help="voices timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle baseline budget in seconds (0 = skip)")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the PCM onto rank 0 (reported separately)")
     ap.add_argument("--engine", default="auto", choices=["auto", "chunk", "fused"])
     args = ap.parse_args()
 
@@ -127,6 +130,26 @@ def main():
     if not np.isfinite(head).all() or float(np.abs(head).max()) == 0.0:
         raise SystemExit("bench: rendered buffer is empty or non-finite")
 
+    gather_info = None
+    if args.gather and world > 1:
+        # the north star's "trivial RCCL gather of rendered PCM over xGMI": timed on its own, never part of `value`
+        from dusp_amd.shard import gather_pcm
+        seen = [0]
+
+        def sink(lo, hi, t):
+            seen[0] += int(t.numel())
+
+        barrier()
+        g0 = time.perf_counter()
+        # every rank holds global instances [rank*V, (rank+1)*V): gather them all, tile by tile, onto rank 0
+        gather_pcm(d_out, n_voices * world, tile=16, sink=sink)
+        barrier()
+        gdt = time.perf_counter() - g0
+        if rank == 0:
+            gbytes = 4.0 * n_voices * n_samples * (world - 1)
+            gather_info = {"seconds": round(gdt, 4), "inbound_GBps": round(gbytes / gdt / 1e9, 1),
+                           "note": "PCM of %d peers sent point-to-point to rank 0 in 16-voice tiles" % (world - 1)}
+
     if rank == 0:
         total_samples = float(n_voices) * n_samples * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -156,8 +179,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if world == 1 and args.cpu_voices > 0:
-            line["cpu_baseline"] = cpu_baseline(words, params, n_samples, args.cpu_voices)
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(words, params, n_samples, args.cpu_seconds)
+        if gather_info:
+            line["gather"] = gather_info
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
