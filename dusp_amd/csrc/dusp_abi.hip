@@ -19,6 +19,7 @@ hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
+hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
 }  // namespace dusp
 
 static thread_local std::string g_error;
@@ -71,6 +72,9 @@ struct dusp_program {
     DevBuf<double> d_state;
     DevBuf<double> d_fused_state;  // FUSED: [n_state_words][n_inst] end-of-render state
     DevBuf<dusp::OscRec> d_recs;   // FUSED: per-voice oscillator records
+    DevBuf<dusp::SumVoice> d_sum_voices;  // FUSED sum chain: per-oscillator records
+    std::vector<dusp::SumVoice> h_sum_voices;
+    std::vector<double> h_sum_end;
     uint32_t last_n_inst = 0, last_n_pad = 0;
     bool rendered = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -228,6 +232,7 @@ void dusp_program_destroy(dusp_program *prog) {
     prog->d_state.release();
     prog->d_fused_state.release();
     prog->d_recs.release();
+    prog->d_sum_voices.release();
     if (prog->ev0) (void)hipEventDestroy(prog->ev0);
     if (prog->ev1) (void)hipEventDestroy(prog->ev1);
     delete prog;
@@ -294,9 +299,30 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         L.recs = prog->d_recs.p;
         HIP_TRY(ctx, prog->d_fused_state.ensure((size_t)std::max(1, prog->fused.n_state_words) * n_inst));
         L.end_state = prog->d_fused_state.p;
-        HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
-        HIP_TRY(ctx, dusp::launch_fused(prog->fused, L, stream));
-        HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+        if (prog->fused.kind == dusp::FUSED_SUMCHAIN) {
+            if (!L.table_fx32_ok) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: wave table has entries below 2^-20; build this program with DUSP_ENGINE_CHUNK");
+            // blocks of 8 groups when that still leaves every wave slot an item, else 4
+            const uint64_t groups = (n_samples + dusp::kChunk - 1) / dusp::kChunk;
+            const uint64_t slots = (uint64_t)ctx->n_cus * 16;
+            int gb = (uint64_t)n_inst * ((groups + 7) / 8) >= slots ? 8 : 4;
+            if ((groups + gb - 1) / gb > 65535) gb = 8;
+            if ((groups + gb - 1) / gb > 65535) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: too many samples for the fused sum chain; use DUSP_ENGINE_CHUNK");
+            dusp::build_sum_voices(prog->fused, (uint32_t)P.g.sample_rate, gb, (uint64_t)n_chunks * dusp::kChunk, prog->h_sum_voices, prog->h_sum_end);
+            HIP_TRY(ctx, prog->d_sum_voices.ensure(prog->h_sum_voices.size()));
+            HIP_TRY(ctx, hipMemcpyAsync(prog->d_sum_voices.p, prog->h_sum_voices.data(), prog->h_sum_voices.size() * sizeof(dusp::SumVoice), hipMemcpyHostToDevice, stream));
+            std::vector<double> end((size_t)prog->fused.n_state_words * n_inst);
+            for (int w = 0; w < prog->fused.n_state_words; w++)
+                for (uint32_t i = 0; i < n_inst; i++) end[(size_t)w * n_inst + i] = prog->h_sum_end[(size_t)w];
+            HIP_TRY(ctx, hipMemcpyAsync(prog->d_fused_state.p, end.data(), end.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));  // the staging vectors above are reused by the next call
+            HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+            HIP_TRY(ctx, dusp::launch_sumchain(prog->fused, L, prog->d_sum_voices.p, gb, stream));
+            HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+        } else {
+            HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+            HIP_TRY(ctx, dusp::launch_fused(prog->fused, L, stream));
+            HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+        }
         prog->last_n_inst = n_inst;
         prog->rendered = true;
         return DUSP_OK;

@@ -19,7 +19,7 @@
 
 namespace dusp {
 
-enum : int { FUSED_OSC = 0, FUSED_OSC_RAMP = 1, FUSED_OSC_GAIN = 2 };
+enum : int { FUSED_OSC = 0, FUSED_OSC_RAMP = 1, FUSED_OSC_GAIN = 2, FUSED_SUMCHAIN = 3 };
 
 struct FusedPlan {
     std::string shape, why;
@@ -30,6 +30,10 @@ struct FusedPlan {
     // Ramp (Ramp.js:3-14): duration, y0, y1, initial t / playing; rcp = RN(1/duration)
     double r_d = 1, r_y0 = 0, r_y1 = 0, r_t0 = 0, r_rcp = 1;
     int r_playing = 0, r_fastdiv = 0;
+    // FUSED_SUMCHAIN: the oscillators of a left-deep Sum.many chain, in chain order
+    std::vector<double> sum_f, sum_phase0;
+    std::vector<int> sum_units;
+    bool sum_all_int = false;
     // state write-back: words [first, first+count) of the end-state block belong to unit u
     int n_state_words = 0;
     std::vector<int> unit_state_first, unit_state_count;
@@ -43,6 +47,21 @@ struct OscRec {
     double u;                         // 2^E
     int32_t E, bad;                   // bad: non-finite f (every sample NaN -> 0)
     float gain, pad;
+};
+
+// One oscillator of a Sum.many chain in exact 32.32 fixed point (units of 2^-32 table steps):
+// phase of (block b, lane l, sample c) = (B0 + b*bs + l*step4 + c*Fm) mod (sampleRate << 32).
+struct SumVoice {
+    uint64_t B0, bs, step4, step256, Fm;
+};
+
+struct SumArgs {
+    const SumVoice *voices;
+    const float *table;
+    float *out;
+    uint64_t n_samples, S;
+    double inv_S, inv_sr;
+    uint32_t n_voices, n_inst, n_groups, n_blocks, sample_rate, vec4_ok;
 };
 
 // Launch-time arguments filled in by dusp_render_device.
@@ -153,8 +172,67 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
             plan.shape = "mul(osc(k),k)";
         } else
             return no("Multiply of two Oscs");
+    } else if (root.op == OP_SUM) {
+        // left-deep chain of Sum units over constant-f oscillators (Sum.many, Sum.js:18-29)
+        std::vector<int> rev;  // oscillators from the outermost Sum inwards
+        int cur = g.out_unit;
+        for (;;) {
+            const UnitDesc &su = g.units[(size_t)cur];
+            int next = -1, oscs[2] = {-1, -1};
+            for (int k = 0; k < 2; k++) {
+                const InletDesc &in = su.inlets[(size_t)k];
+                if (in.kind != IN_CONNECT) return no("Sum with a constant operand");
+                const UnitDesc &s = g.units[(size_t)in.src_unit];
+                if (s.op == OP_SUM && next < 0) next = in.src_unit;
+                else if (s.op == OP_OSC) oscs[k] = in.src_unit;
+                else return no("unsupported Sum operand");
+            }
+            if (next >= 0) {
+                rev.push_back(oscs[0] >= 0 ? oscs[0] : oscs[1]);
+                used[(size_t)next]++;
+                cur = next;
+            } else {  // innermost Sum(a, b): a is voice 0, b is voice 1
+                rev.push_back(oscs[1]);
+                rev.push_back(oscs[0]);
+                break;
+            }
+            if (rev.size() > 70000) return no("chain too long");
+        }
+        plan.kind = FUSED_SUMCHAIN;
+        plan.shape = "sumchain(osc(k) x " + std::to_string(rev.size()) + ")";
+        plan.sum_all_int = true;
+        for (auto it = rev.rbegin(); it != rev.rend(); ++it) {
+            const int ui = *it;
+            if (ui < 0) return no("malformed chain");
+            const UnitDesc &o = g.units[(size_t)ui];
+            used[(size_t)ui]++;
+            const InletDesc &fin = o.inlets[0];
+            if (fin.kind != IN_CONST || fin.vals.size() != 1) return no("chain oscillator needs a constant f");
+            const double f = (double)(float)fin.vals[0];
+            if (!std::isfinite(f)) return no("non-finite f");
+            const double fr = std::fmod(f, (double)g.sample_rate), p0 = o.state[0];
+            if (std::ldexp(fr, 32) != std::floor(std::ldexp(fr, 32))) return no("f finer than 2^-32");
+            if (!(p0 >= 0 && p0 < g.sample_rate) || std::ldexp(p0, 32) != std::floor(std::ldexp(p0, 32)))
+                return no("start phase not on the 2^-32 grid");
+            if (fr != std::floor(fr) || p0 != std::floor(p0)) plan.sum_all_int = false;
+            if (plan.sum_units.empty()) plan.table_id = (int)o.attrs[0];
+            else if (plan.table_id != (int)o.attrs[0]) return no("mixed waveforms");
+            plan.sum_units.push_back(ui);
+            plan.sum_f.push_back(fr);
+            plan.sum_phase0.push_back(p0);
+        }
+        for (size_t i = 0; i < used.size(); i++)
+            if (used[i] != 1) return no("circuit has units outside the fused tree");
+        plan.unit_state_first.assign(g.units.size(), 0);
+        plan.unit_state_count.assign(g.units.size(), 0);
+        plan.n_state_words = 0;
+        for (int ui : plan.sum_units) {
+            plan.unit_state_first[(size_t)ui] = plan.n_state_words++;
+            plan.unit_state_count[(size_t)ui] = 1;
+        }
+        return true;
     } else
-        return no("root is neither Osc nor Multiply");
+        return no("root is not an Osc, a Multiply or a Sum chain");
     for (size_t i = 0; i < used.size(); i++)
         if (used[i] != 1) return no("circuit has units outside the fused tree");
 
@@ -192,6 +270,29 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         plan.n_state_words += 2;
     }
     return true;
+}
+
+// Exact 32.32 fixed-point records of a Sum.many chain's oscillators, and their phases after T_end samples.
+inline void build_sum_voices(const FusedPlan &plan, uint32_t sample_rate, int gb, uint64_t T_end, std::vector<SumVoice> &voices,
+                             std::vector<double> &end_phase) {
+    typedef unsigned __int128 u128;
+    const uint64_t S = (uint64_t)sample_rate << 32;
+    voices.clear();
+    end_phase.clear();
+    for (size_t j = 0; j < plan.sum_f.size(); j++) {
+        const double f = plan.sum_f[j];
+        const long long F = (long long)std::ldexp(f, 32);  // |F| < S, exact by plan_fused's check
+        const uint64_t Fm = F >= 0 ? (uint64_t)F % S : (S - (uint64_t)(-F) % S) % S;
+        const uint64_t P0 = (uint64_t)std::ldexp(plan.sum_phase0[j], 32);
+        SumVoice v;
+        v.Fm = Fm;
+        v.B0 = (uint64_t)(((u128)P0 + Fm) % S);
+        v.bs = (uint64_t)(((u128)Fm * (uint64_t)(gb * kChunk)) % S);
+        v.step4 = (uint64_t)(((u128)Fm * 4) % S);
+        v.step256 = (uint64_t)(((u128)Fm * kChunk) % S);
+        voices.push_back(v);
+        end_phase.push_back(std::ldexp((double)(uint64_t)(((u128)P0 + (u128)Fm * T_end) % S), -32));
+    }
 }
 
 }  // namespace dusp

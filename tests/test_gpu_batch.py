@@ -92,3 +92,36 @@ def test_headline_config_full_size(oracle):
     env = (1.0 - (t + 1) / n).float()
     assert bool((out[::37, 0].abs() <= env + 1e-7).all())
     prog.close()
+
+
+@pytest.mark.parametrize("fs", [
+    [10.0 * k for k in range(1, 41)],                         # integer f: INT path of the fused sum chain
+    [20 + k / 8 for k in range(33)] + [-3.25, 47999.5, 0.5],  # 32.32 fixed-point path, negative / near-sr f
+])
+def test_sum_many_chain_fused_matches_oracle(fs, oracle):
+    """Sum.many left-deep chain (configs[2] mix-down): f32 rounding after every add, in chain order."""
+    d.configure(48000)
+    ex = descriptor.extract(d.Sum.many([d.Osc(f) for f in fs]))
+    n = 256 * 37 + 10
+    want, states = oracle.render(ex.words, n, return_state=True)
+    for engine in (runtime.ENGINE_AUTO, runtime.ENGINE_CHUNK):
+        prog = render.context(48000).build(ex.words, engine)
+        if engine == runtime.ENGINE_AUTO:
+            assert prog.engine == "fused" and prog.shape.startswith("sumchain(")
+        got = prog.render(n)[0]
+        assert np.array_equal(got, want)
+        for u, st in enumerate(states):
+            assert np.array_equal(prog.state(u), st), u
+        prog.close()
+
+
+def test_sum_chain_shapes_that_must_not_fuse():
+    d.configure(48000)
+    ctx = render.context(48000)
+    for g in (d.Sum(d.Osc(100), 0.5),                                    # constant operand
+              d.Sum(d.Sum(d.Osc(1), d.Osc(2)), d.Sum(d.Osc(3), d.Osc(4))),  # a tree, not a chain
+              d.Sum.many([d.Osc(100), d.Osc(200, "saw"), d.Osc(300)]),      # mixed waveforms
+              d.Sum.many([d.Osc(100), d.Osc(2.0 ** -40)])):                 # f finer than 2^-32
+        prog = ctx.build(descriptor.extract(g).words)
+        assert prog.engine == "chunk"
+        prog.close()

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Time every BASELINE.json config on one GPU (kernel time by HIP events; PCM stays in HBM).
+  configs[1] cfg2   Multiply(Osc(f: Ramp), Osc(3)), 10 s, 1 instance (literal + sweep readings)
+  configs[2] cfg3a  1024 voices Multiply(Osc(10k), Ramp), 60 s, per-voice PCM   (= bench.py)
+             cfg3b  the same 1024 Osc(10k) through Sum.many, mix-down to one channel
+  configs[3] cfg4   8192 instances of the Osc->Sum->Delay->Filter->Multiply feedback loop, 10 s
+  configs[4] cfg5   65536-voice sweep Multiply(Osc(20+k/8), Ramp): one GPU's shard = 8192 voices x 1 s
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="scale durations (for quick runs)")
+    args = ap.parse_args()
+    import torch
+    import dusp_amd as d
+    from dusp_amd import descriptor, runtime
+    sr = 48000
+    d.configure(sr)
+    ctx = runtime.Context(0, sr)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def loop(k):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        s.B = d.Multiply(f, 0.5)
+        return f
+
+    def uni_of(graphs):
+        return descriptor.unify([descriptor.extract(g) for g in graphs])
+
+    cfgs = {}
+    T10 = int(10 * sr * args.scale)
+    T60 = int(60 * sr * args.scale)
+    T1 = int(1 * sr * args.scale)
+    cfgs["cfg2_literal"] = (lambda: uni_of([d.Multiply(d.Osc(d.Ramp(200, 100, 2)), d.Osc(3))]), T10, None)
+    cfgs["cfg2_sweep"] = (lambda: uni_of([d.Multiply(d.Osc(d.Ramp(2 * sr, 200, 100).trigger()), d.Osc(3))]), T10, None)
+    cfgs["cfg3a"] = (lambda: uni_of([d.Multiply(d.Osc(10 * k), d.Ramp(T60, 1, 0).trigger()) for k in (1, 2)]), T60,
+                     (10.0 * np.arange(1, 1025)).astype(np.float32).reshape(1, -1))
+    cfgs["cfg3b_sum1024"] = (lambda: uni_of([d.Sum.many([d.Osc(10 * k) for k in range(1, 1025)])]), T60, None)
+    cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
+                             (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
+    cfgs["cfg5_shard8192"] = (lambda: uni_of([d.Multiply(d.Osc(20 + k / 8), d.Ramp(T1, 1, 0).trigger()) for k in (0, 1)]), T1,
+                              (20 + np.arange(8192) / 8.0).astype(np.float32).reshape(1, -1))
+    for name, (build, n, params) in cfgs.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        t0 = time.time()
+        uni = build()
+        prog = ctx.build(uni.words)
+        n_inst = params.shape[1] if params is not None else 1
+        dp = torch.from_numpy(params).cuda() if params is not None else None
+        out = torch.empty((n_inst, prog.n_out_channels, n), dtype=torch.float32, device="cuda")
+        host_s = time.time() - t0
+        ts = []
+        for r in range(args.rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            prog.render_device(n, n_inst, dp.data_ptr() if dp is not None else None, out.data_ptr(), stream)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ms = float(np.median(ts))
+        samples = float(n_inst) * prog.n_out_channels * n
+        print("%-16s engine=%-5s %-18s inst=%-6d n=%-8d  %10.3f ms  %12.1f Msamples/s out  %8.1f GB/s  (host build %.2fs)"
+              % (name, prog.engine, prog.shape, n_inst, n, ms, samples / ms / 1e3, 4 * samples / ms / 1e6, host_s), flush=True)
+        prog.close()
+        del out
+
+
+if __name__ == "__main__":
+    main()
