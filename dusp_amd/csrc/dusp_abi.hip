@@ -19,6 +19,7 @@ hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
+hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
 }  // namespace dusp
 
@@ -63,6 +64,7 @@ struct dusp_program {
     dusp::Program P;
     int engine = DUSP_ENGINE_CHUNK;
     dusp::FusedPlan fused;
+    dusp::WavePlan wave;
     // program constants on the device
     DevBuf<dusp::DevOp> d_ops;
     DevBuf<int32_t> d_out_bufs;
@@ -186,7 +188,7 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     if (!ctx) return DUSP_ERR_ARG;
     if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
     *out = nullptr;
-    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED)
+    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
     std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
     if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
@@ -200,9 +202,13 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
         CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_build: uploaded wave tables do not match the program's sample rate");
 
     const bool fusable = dusp::plan_fused(prog->P, prog->fused);
+    const bool wavable = dusp::plan_wave(prog->P, prog->wave);
     if (engine == DUSP_ENGINE_FUSED && !fusable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
-    prog->engine = (engine == DUSP_ENGINE_CHUNK || !fusable) ? DUSP_ENGINE_CHUNK : DUSP_ENGINE_FUSED;
+    if (engine == DUSP_ENGINE_WAVE && !wavable)
+        CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: the wave engine cannot run this graph (" + prog->wave.why + ")");
+    if (engine == DUSP_ENGINE_AUTO) engine = fusable ? DUSP_ENGINE_FUSED : wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
+    prog->engine = engine;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const dusp::Program &P = prog->P;
@@ -250,6 +256,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     info->engine = (uint32_t)prog->engine;
     info->n_device_ops = (uint32_t)prog->P.ops.size();
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
+    if (prog->engine == DUSP_ENGINE_WAVE) std::snprintf(info->shape, sizeof info->shape, "feed-forward, %d chunk buffers in LDS", prog->P.n_bufs);
     return DUSP_OK;
 }
 
@@ -330,6 +337,36 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
 
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
+    if (prog->engine == DUSP_ENGINE_WAVE) {
+        HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+        dusp::WaveArgs w{};
+        w.ops = prog->d_ops.p;
+        w.out_bufs = prog->d_out_bufs.p;
+        w.params = d_params;
+        w.tables = ctx->d_tables;
+        w.out = d_out;
+        w.state = prog->d_state.p;
+        w.init_state = prog->d_init.p;
+        w.n_samples = n_samples;
+        w.n_ops = (uint32_t)P.ops.size();
+        w.n_out = (uint32_t)P.out_bufs.size();
+        w.n_inst = n_inst;
+        w.n_pad = n_pad;
+        w.n_bufs = (uint32_t)P.n_bufs;
+        w.n_groups = n_chunks;
+        w.sample_rate = (uint32_t)P.g.sample_rate;
+        w.table_stride = ctx->table_stride;
+        w.vec4_ok = (n_samples % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
+        w.lds_table_id = prog->wave.lds_table_id;
+        const bool lds_ok = w.lds_table_id >= 0 && ctx->table_antisym[w.lds_table_id] && P.g.sample_rate % 2 == 0;
+        HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+        HIP_TRY(ctx, dusp::launch_wave_engine(w, lds_ok, stream));
+        HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+        prog->last_n_inst = n_inst;
+        prog->last_n_pad = n_pad;
+        prog->rendered = true;
+        return DUSP_OK;
+    }
     HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
     HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));

@@ -66,6 +66,27 @@ struct Table {
 };
 
 
+__device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t m, double inv_m) {
+    const uint32_t q = (uint32_t)((double)x * inv_m);
+    uint32_t r = x - q * m;
+    if ((int32_t)r < 0) r += m;
+    if (r >= m) r -= m;
+    return r;
+}
+__device__ __forceinline__ uint64_t mod_u64(uint64_t x, uint64_t m, double inv_m) {  // x < 2^64, m < 2^48
+    const uint64_t q = (uint64_t)((double)x * inv_m);
+    uint64_t r = x - q * m;
+    if ((int64_t)r < 0) r += m;
+    if ((int64_t)r < 0) r += m;
+    if (r >= m) r -= m;
+    if (r >= m) r -= m;
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long mod_u64_lifted(unsigned long long x, unsigned long long m, double inv_m) {
+    return mod_u64(x, m, inv_m);  // x already lifted to a non-negative value below 2^63
+}
+
 template <bool FINITE>
 __device__ __forceinline__ float fix_out(float v) {  // `x || 0` (renderChannelData.js:44): NaN, -0 -> +0
     if (FINITE) return v + 0.f;                       // operands verified finite on the host: only -0 can occur

@@ -64,6 +64,27 @@ struct SumArgs {
     uint32_t n_voices, n_inst, n_groups, n_blocks, sample_rate, vec4_ok;
 };
 
+// Arguments of the wave engine's kernel (wave_engine.hip).
+struct WaveArgs {
+    const DevOp *ops;
+    const int32_t *out_bufs;
+    const float *params;
+    const float *tables;
+    float *out;
+    double *state;             // [n_slots][n_pad]  end-of-render state (chunk engine's slot layout)
+    const double *init_state;  // [n_slots]
+    uint64_t n_samples;
+    uint32_t n_ops, n_out, n_inst, n_pad, n_bufs, n_groups, sample_rate, table_stride, vec4_ok;
+    int32_t lds_table_id;
+    uint32_t table_bytes, wave_bytes;
+};
+
+struct WavePlan {
+    bool ok = false;
+    int lds_table_id = -1;
+    std::string why;
+};
+
 // Launch-time arguments filled in by dusp_render_device.
 struct FusedLaunch {
     const float *params;
@@ -293,6 +314,44 @@ inline void build_sum_voices(const FusedPlan &plan, uint32_t sample_rate, int gb
         voices.push_back(v);
         end_phase.push_back(std::ldexp((double)(uint64_t)(((u128)P0 + (u128)Fm * T_end) % S), -32));
     }
+}
+
+// Can the wave engine (one wavefront per instance, chunk buffers in LDS) run this program?
+inline bool plan_wave(const Program &P, WavePlan &plan) {
+    const Graph &g = P.g;
+    auto no = [&](const std::string &why) {
+        plan.why = why;
+        plan.ok = false;
+        return false;
+    };
+    if (!P.feed_forward) return no("feedback edge");
+    if (P.ring_samples) return no("rings");
+    if (g.sample_rate > 131072) return no("sample rate above 2^17");
+    if ((size_t)P.n_bufs * 1024 + P.ops.size() * 12 + 16 > 160 * 1024) return no("too many chunk buffers for LDS");
+    for (const DevOp &op : P.ops) {
+        switch (op.op) {
+        case OP_OSC: {
+            const double p0 = P.init_state[(size_t)op.state_slot];
+            if (!(p0 >= 0 && p0 < g.sample_rate) || std::ldexp(p0, 36) != std::floor(std::ldexp(p0, 36)))
+                return no("Osc start phase outside [0, sampleRate) or finer than 2^-36");
+            if (plan.lds_table_id < 0) plan.lds_table_id = op.attr;
+            break;
+        }
+        case OP_RAMP: {
+            const double d = op.d[0], t0 = P.init_state[(size_t)op.state_slot];
+            const bool playing = P.init_state[(size_t)op.state_slot + 1] != 0;
+            if (!(d > 0) || !std::isfinite(d) || !std::isfinite(t0) || t0 > d || (playing && !(t0 + 1 >= 0)))
+                return no("Ramp outside the closed-form regime");
+            break;
+        }
+        case OP_MULTIPLY:
+        case OP_SUM:
+        case OP_REPEATER: break;
+        default: return no("unit with a recurrence (Filter / Delay / CircleBuffer)");
+        }
+    }
+    plan.ok = true;
+    return true;
 }
 
 }  // namespace dusp

@@ -21,27 +21,6 @@
 
 namespace dusp {
 
-namespace {
-
-__device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t m, double inv_m) {
-    const uint32_t q = (uint32_t)((double)x * inv_m);
-    uint32_t r = x - q * m;
-    if ((int32_t)r < 0) r += m;
-    if (r >= m) r -= m;
-    return r;
-}
-__device__ __forceinline__ uint64_t mod_u64(uint64_t x, uint64_t m, double inv_m) {  // x < 2^64, m < 2^48
-    const uint64_t q = (uint64_t)((double)x * inv_m);
-    uint64_t r = x - q * m;
-    if ((int64_t)r < 0) r += m;
-    if ((int64_t)r < 0) r += m;
-    if (r >= m) r -= m;
-    if (r >= m) r -= m;
-    return r;
-}
-
-}  // namespace
-
 template <int TBL, bool INT, int GB, bool FINITE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds_table[];

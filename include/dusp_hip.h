@@ -50,9 +50,14 @@ typedef enum {
 /* Engine that executes a program (chosen at build time from the graph's shape):
  *   CHUNK — universal engine: one lane per instance, units ticked chunk by chunk
  *           exactly in circuit order (feedback, filters, delays, CircleBuffers).
- *   FUSED — time-parallel fused kernel for feed-forward graphs of Osc / Ramp /
- *           Multiply / Sum: one lane per sample, 16-byte coalesced PCM stores. */
-typedef enum { DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2 } dusp_engine;
+ *   FUSED — time-parallel fused kernels for recognised voice shapes (Osc, Osc x Ramp,
+ *           Osc x gain, Sum.many chains): one lane per sample, time split across waves,
+ *           16-byte coalesced PCM stores.
+ *   WAVE  — any feed-forward graph of Osc / Ramp / Multiply / Sum / Repeater (incl. FM):
+ *           one wavefront per instance, per-unit chunk buffers in LDS, wavefront-wide
+ *           phase accumulation.
+ * AUTO picks FUSED, else WAVE, else CHUNK. */
+typedef enum { DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3 } dusp_engine;
 
 typedef struct {
     uint32_t sample_rate;

@@ -123,5 +123,5 @@ def test_sum_chain_shapes_that_must_not_fuse():
               d.Sum.many([d.Osc(100), d.Osc(200, "saw"), d.Osc(300)]),      # mixed waveforms
               d.Sum.many([d.Osc(100), d.Osc(2.0 ** -40)])):                 # f finer than 2^-32
         prog = ctx.build(descriptor.extract(g).words)
-        assert prog.engine == "chunk"
+        assert prog.engine == "wave"  # feed-forward, but not a Sum.many chain of constant oscillators
         prog.close()

@@ -16,9 +16,14 @@ REL_TOL = 1e-5  # north_star: "within 1e-5 relative float tolerance" (of full sc
 USES_DEVICE_TAN = ("loop_", "filter_")
 
 
-def check(name, got, ref):
+# |f| < 2^-13: the reference's own f64 phase accumulation rounds there (SURVEY.md §8a note ii), so the wave
+# engine's 2^-36 fixed-point scan is only within tolerance for it (the fused and chunk engines stay exact)
+BELOW_EXACT_REGIME = {("osc_f_tiny", "wave")}
+
+
+def check(name, got, ref, engine=None):
     assert got.shape == ref.shape
-    if name.startswith(USES_DEVICE_TAN):
+    if name.startswith(USES_DEVICE_TAN) or (name, engine) in BELOW_EXACT_REGIME:
         scale = max(1e-30, float(np.max(np.abs(ref))))
         err = float(np.max(np.abs(got.astype(np.float64) - ref.astype(np.float64))))
         assert err <= REL_TOL * scale, "max abs err %.3g vs full scale %.3g" % (err, scale)
@@ -26,25 +31,41 @@ def check(name, got, ref):
         assert np.array_equal(got, ref), "first mismatch at %d" % int(np.argmax(got != ref))
 
 
-@pytest.mark.parametrize("engine", ["auto", "chunk"])
+ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE}
+# what AUTO must pick for a few cases (fused voice shapes / feed-forward wave engine / universal chunk engine)
+EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
+                   "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
+                   "loop_220": "chunk", "delay_mod": "chunk", "circlebuffer_taps": "chunk", "filter_2ch": "chunk"}
+
+
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave"])
 @pytest.mark.parametrize("name", ALL_GOLDEN)
 def test_render_matches_reference_golden(name, engine, oracle):
     g = Golden(name)
     ctx = render.context(g.sample_rate)
-    prog = ctx.build(g.desc, runtime.ENGINE_AUTO if engine == "auto" else runtime.ENGINE_CHUNK)
+    try:
+        prog = ctx.build(g.desc, ENGINES[engine])
+    except runtime.DuspHipError as e:
+        assert engine == "wave" and e.status == -2, e  # only feed-forward Osc/Ramp/Multiply/Sum graphs run there
+        pytest.skip("not a feed-forward graph")
+    if engine == "auto" and name in EXPECTED_ENGINE:
+        assert prog.engine == EXPECTED_ENGINE[name]
     assert prog.n_out_channels == g.n_channels
     pcm = prog.render(g.n_samples)[0]
-    check(name, g.windowed(pcm), g.pcm)            # vs the JS reference's own output
-    check(name, pcm, oracle.render(g.desc, g.n_samples))  # vs the oracle, full length
+    check(name, g.windowed(pcm), g.pcm, engine)            # vs the JS reference's own output
+    check(name, pcm, oracle.render(g.desc, g.n_samples), engine)  # vs the oracle, full length
     prog.close()
 
 
-@pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep"])
-@pytest.mark.parametrize("engine", ["auto", "chunk"])
+@pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
     n = min(g.n_samples, 5000)
-    prog = render.context(g.sample_rate).build(g.desc, runtime.ENGINE_AUTO if engine == "auto" else runtime.ENGINE_CHUNK)
+    try:
+        prog = render.context(g.sample_rate).build(g.desc, ENGINES[engine])
+    except runtime.DuspHipError:
+        pytest.skip("not a feed-forward graph")
     prog.render(n)
     _, states = oracle.render(g.desc, n, return_state=True)
     for u, want in enumerate(states):
