@@ -34,7 +34,25 @@ struct Src {
     float c;
     bool is_buf;
     __device__ __forceinline__ float at(int t) const { return is_buf ? ptr[(size_t)t * stride] : c; }
+    // kBatch independent loads in flight: a lane's 256 samples are a serial recurrence for the ALU, but
+    // their chunk-buffer reads need not wait for each other (one L2 round trip per batch, not per sample)
+    __device__ __forceinline__ void load(int t0, float (&v)[16]) const {
+        if (is_buf) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = ptr[(size_t)(t0 + k) * stride];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = c;
+        }
+    }
 };
+
+constexpr int kBatch = 16;
+
+__device__ __forceinline__ void store_batch(float *outp, size_t NP, int t0, const float (&r)[kBatch]) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) outp[(size_t)(t0 + k) * NP] = r[k];
+}
 
 __device__ __forceinline__ Src make_src(const DevOperand &o, const ChunkArgs &a, uint32_t i) {
     Src s;
@@ -93,9 +111,15 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 const Src f = make_src(op.in[0], a, i);
                 const float *tbl = a.tables + (size_t)op.attr * a.table_stride;
                 double phase = st[0];
-                for (int t = 0; t < kChunk; ++t) {
-                    phase = osc_advance(phase, (double)f.at(t), sr);
-                    outp[(size_t)t * NP] = osc_lookup(tbl, phase, sr);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float fv[kBatch], r[kBatch];
+                    double ph[kBatch];
+                    f.load(t0, fv);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) ph[k] = phase = osc_advance(phase, (double)fv[k], sr);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) r[k] = osc_lookup(tbl, ph[k], sr);  // 2 x kBatch gathers in flight
+                    store_batch(outp, NP, t0, r);
                 }
                 st[0] = phase;
                 break;
@@ -116,19 +140,19 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[NP] = playing ? 1.0 : 0.0;
                 break;
             }
-            case OP_MULTIPLY: {  // Multiply.js:23-34
+            case OP_MULTIPLY:   // Multiply.js:23-34
+            case OP_SUM:        // Sum.js:33-44
+            case OP_REPEATER: { // Repeater.js:23-30
                 const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
-                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t) * y.at(t);
-                break;
-            }
-            case OP_SUM: {  // Sum.js:33-44
-                const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
-                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t) + y.at(t);
-                break;
-            }
-            case OP_REPEATER: {  // Repeater.js:23-30
-                const Src x = make_src(op.in[0], a, i);
-                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = x.at(t);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float xv[kBatch], yv[kBatch], r[kBatch];
+                    x.load(t0, xv);
+                    if (op.op != OP_REPEATER) y.load(t0, yv);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k)
+                        r[k] = op.op == OP_MULTIPLY ? xv[k] * yv[k] : op.op == OP_SUM ? xv[k] + yv[k] : xv[k];
+                    store_batch(outp, NP, t0, r);
+                }
                 break;
             }
             case OP_FILTER: {  // Filter.js:27-51, coefficients :66-84
@@ -138,36 +162,43 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                        b2 = st[6 * NP];
                 double x1 = st[7 * NP], x2 = st[8 * NP], y1 = st[9 * NP], y2 = st[10 * NP];
                 const double PI = 3.141592653589793;
-                for (int t = 0; t < kChunk; ++t) {
-                    const double ft = (double)f.at(t);
-                    if (!has_lastF || ft != lastF) {
-                        has_lastF = true;
-                        lastF = ft;
-                        if (op.attr == 0) {  // LP
-                            const double lamda = 1.0 / tan(PI * ft / sr);
-                            const double l2 = lamda * lamda;
-                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                            a1 = 2.0 * a0;
-                            a2 = a0;
-                            b1 = 2.0 * a0 * (1.0 - l2);
-                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
-                        } else {  // HP
-                            const double lamda = tan(PI * ft / sr);
-                            const double l2 = lamda * lamda;
-                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                            a1 = 0.0;
-                            a2 = -a0;
-                            b1 = 2.0 * a0 * (l2 - 1.0);
-                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float xv[kBatch], fv[kBatch], r[kBatch];
+                    x.load(t0, xv);
+                    f.load(t0, fv);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const double ft = (double)fv[k];
+                        if (!has_lastF || ft != lastF) {
+                            has_lastF = true;
+                            lastF = ft;
+                            if (op.attr == 0) {  // LP
+                                const double lamda = 1.0 / tan(PI * ft / sr);
+                                const double l2 = lamda * lamda;
+                                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
+                                a1 = 2.0 * a0;
+                                a2 = a0;
+                                b1 = 2.0 * a0 * (1.0 - l2);
+                                b2 = a0 * (1.0 - 2.0 * lamda + l2);
+                            } else {  // HP
+                                const double lamda = tan(PI * ft / sr);
+                                const double l2 = lamda * lamda;
+                                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
+                                a1 = 0.0;
+                                a2 = -a0;
+                                b1 = 2.0 * a0 * (l2 - 1.0);
+                                b2 = a0 * (1.0 - 2.0 * lamda + l2);
+                            }
                         }
+                        const double xin = (double)xv[k];
+                        const float y = (float)(a0 * xin + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));
+                        r[k] = y;
+                        y2 = or0(y1);
+                        y1 = (double)y;
+                        x2 = or0(x1);
+                        x1 = xin;
                     }
-                    const double xin = (double)x.at(t);
-                    const float y = (float)(a0 * xin + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));
-                    outp[(size_t)t * NP] = y;
-                    y2 = or0(y1);
-                    y1 = (double)y;
-                    x2 = or0(x1);
-                    x1 = xin;
+                    store_batch(outp, NP, t0, r);
                 }
                 st[0] = has_lastF ? 1.0 : 0.0;
                 st[NP] = lastF; st[2 * NP] = a0; st[3 * NP] = a1; st[4 * NP] = a2; st[5 * NP] = b1; st[6 * NP] = b2;
@@ -180,6 +211,55 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 const int64_t len = op.ring_len;
                 const double dlen = (double)len;
                 int64_t tBuffer = clock % len;
+                // Lane-constant delay (a constant or a per-instance parameter): every ring slot then receives
+                // exactly the ceil tap of sample n-1 followed by the floor tap of sample n (slot 0: floor tap
+                // only — the reference drops the ceil tap at index len), both onto the zero left by the read.
+                // So the slot's final f32 value is computed in registers from x[n-1], x[n] with the reference's
+                // two `+=` roundings and written ONCE: no read-modify-write chains through L2, and the ring
+                // reads of a batch are independent of its writes when kBatch <= D <= len - kBatch.
+                double dconst = (double)dl.c;
+                if (dconst >= dlen) dconst = fmod(dconst, dlen);
+                const double Dfl = floor(dconst);
+                const bool fast_lane = !dl.is_buf && dconst >= (double)kBatch && Dfl <= dlen - (double)kBatch;
+                if (__all(fast_lane)) {
+                    const int64_t D = (int64_t)Dfl;
+                    const double phi = dconst - Dfl;
+                    double xprev = st[0];
+                    for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                        float xv[kBatch], r[kBatch], w[kBatch];
+                        x.load(t0, xv);
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k) {
+                            int64_t s_ = tBuffer + k;
+                            if (s_ >= len) s_ -= len;
+                            r[k] = ring[(size_t)s_ * NP];
+                        }
+#pragma unroll
+                        for (int k = 0; k < kBatch; ++k) {
+                            int64_t s_ = tBuffer + k;
+                            if (s_ >= len) s_ -= len;
+                            int64_t lo = s_ + D;
+                            if (lo >= len) lo -= len;
+                            const double xin = (double)xv[k];
+                            float slot;
+                            if (phi != 0.0) {
+                                slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;   // ceil tap of sample n-1 (dropped at slot 0)
+                                slot = (float)((double)slot + xin * (1.0 - phi));    // floor tap of sample n
+                            } else {
+                                slot = (float)(0.0 + xin * 1.0);                     // floor(tWrite) == ceil(tWrite): both taps hit it
+                                slot = (float)((double)slot + xin * 0.0);
+                            }
+                            w[k] = slot;
+                            xprev = xin;
+                            ring[(size_t)lo * NP] = w[k];
+                        }
+                        store_batch(outp, NP, t0, r);
+                        tBuffer += kBatch;
+                        if (tBuffer >= len) tBuffer -= len;
+                    }
+                    st[0] = xprev;
+                    break;
+                }
                 for (int t = 0; t < kChunk; ++t) {
                     outp[(size_t)t * NP] = ring[(size_t)tBuffer * NP];
                     ring[(size_t)tBuffer * NP] = 0.f;

@@ -457,7 +457,7 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
             return hipMemcpy(&v, prog->d_state.p + (size_t)slot * prog->last_n_pad + instance, sizeof(double), hipMemcpyDeviceToHost);
         };
         const int n_ch = (u.op == dusp::OP_FILTER) ? u.n_out : 1;
-        const int per = u.slots_per_ch;
+        const int per = u.op == dusp::OP_DELAY ? 0 : u.slots_per_ch;  // Delay's slot is engine-internal, not unit state
         if (u.op == dusp::OP_FILTER) {
             for (int k = 0; k < 7; k++) {
                 double v;

@@ -333,6 +333,7 @@ inline bool expand(Program &P, std::string &err) {
                 op.in[1] = make_operand(g, u.inlets[1], c);
                 op.ring_len = (int64_t)u.attrs[0];
                 op.ring_base = ring_pos;
+                slot(0.0);  // previous input sample (chunk engine's constant-delay path)
                 P.dev_rings.push_back({ring_pos, op.ring_len});
                 ring_pos += op.ring_len;
                 break;
