@@ -125,3 +125,80 @@ def test_sum_chain_shapes_that_must_not_fuse():
         prog = ctx.build(descriptor.extract(g).words)
         assert prog.engine == "wave"  # feed-forward, but not a Sum.many chain of constant oscillators
         prog.close()
+
+
+# ---- the remaining BASELINE configs at their FULL sizes (parity through spot checks + size-independent properties)
+
+def test_config1_three_unit_dag_full_size(oracle):
+    """configs[1]: [Multiply A:[Osc f:[Ramp ...]] B:[Osc 3]], 10 s @ 48 kHz, both readings of the Ramp arguments."""
+    d.configure(48000)
+    for ramp in (lambda: d.Ramp(200, 100, 2), lambda: d.Ramp(2 * 48000, 200, 100).trigger()):
+        ex = descriptor.extract(d.Multiply(d.Osc(ramp()), d.Osc(3)))
+        prog = render.context(48000).build(ex.words)
+        assert prog.engine == "wave"
+        got = prog.render(480000)[0]
+        assert np.array_equal(got, oracle.render(ex.words, 480000))
+        prog.close()
+
+
+def test_config2_mixdown_full_size(oracle):
+    """configs[2], 'voices summed' reading: Sum.many of 1024 Osc(10k), 60 s -> one channel of 2 880 000 samples."""
+    d.configure(48000)
+    ex = descriptor.extract(d.Sum.many([d.Osc(10 * k) for k in range(1, 1025)]))
+    prog = render.context(48000).build(ex.words)
+    assert prog.engine == "fused"
+    n = 2880000
+    got = prog.render(n)[0, 0]
+    # the oracle needs ~1 s per 4000 samples of this 2047-unit circuit: check the first chunks exactly ...
+    head = oracle.render(ex.words, 4096)[0]
+    assert np.array_equal(got[:4096], head)
+    # ... and the rest through periodicity: every f is a multiple of 10 Hz, so the mix repeats every 4800 samples
+    assert np.array_equal(got[4800:9600], got[:4800]) and np.array_equal(got[-4800:], got[:4800])
+    prog.close()
+
+
+def test_config3_feedback_loops_full_size(oracle):
+    """configs[3]: 8192 instances of Osc->Sum->Delay->Filter->Multiply->(Sum), 10 s @ 48 kHz (15.7 GB of PCM)."""
+    import torch
+    d.configure(48000)
+    def loop(k):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
+    V, n = 8192, 480000
+    params = (110 + np.arange(V) / 64.0).astype(np.float32).reshape(1, V)
+    prog = render.context(48000).build(uni.words)
+    assert prog.engine == "chunk"
+    out = torch.empty((V, 1, n), dtype=torch.float32, device="cuda")
+    dp = torch.from_numpy(params).cuda()
+    prog.render_device(n, V, dp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in (0, 4095, 8191):
+        want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)[0]
+        got = out[i, 0].cpu().numpy()
+        assert np.max(np.abs(got.astype(np.float64) - want)) <= 1e-5 * np.max(np.abs(want)), i
+    assert bool(torch.isfinite(out[::64]).all())
+    assert bool((out[:, 0, :480] == 0).all())  # nothing leaves the 480-sample delay line before t = 480
+    prog.close()
+
+
+def test_config4_sweep_shard_full_size(oracle):
+    """configs[4]: one GPU's shard of the 65536-voice sweep: 8192 x Multiply(Osc(20 + k/8), Ramp(T,1,0) triggered), 1 s."""
+    import torch
+    d.configure(48000)
+    V, n = 8192, 48000
+    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Osc(20 + k / 8), d.Ramp(n, 1, 0).trigger())) for k in (0, 1)])
+    for shard in (0, 7):
+        params = (20 + (shard * V + np.arange(V)) / 8.0).astype(np.float32).reshape(1, V)
+        prog = render.context(48000).build(uni.words)
+        assert prog.engine == "fused"
+        out = torch.empty((V, 1, n), dtype=torch.float32, device="cuda")
+        dp = torch.from_numpy(params).cuda()
+        prog.render_device(n, V, dp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in (0, 1, 3, 4097, 8191):
+            want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)[0]
+            assert np.array_equal(out[i, 0].cpu().numpy(), want), (shard, i)
+        prog.close()
