@@ -19,6 +19,7 @@ hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
+hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
 }  // namespace dusp
@@ -65,6 +66,7 @@ struct dusp_program {
     int engine = DUSP_ENGINE_CHUNK;
     dusp::FusedPlan fused;
     dusp::WavePlan wave;
+    dusp::LoopShape loop;
     // program constants on the device
     DevBuf<dusp::DevOp> d_ops;
     DevBuf<int32_t> d_out_bufs;
@@ -188,7 +190,7 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     if (!ctx) return DUSP_ERR_ARG;
     if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
     *out = nullptr;
-    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE)
+    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE && engine != DUSP_ENGINE_LOOP)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
     std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
     if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
@@ -207,7 +209,12 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
     if (engine == DUSP_ENGINE_WAVE && !wavable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: the wave engine cannot run this graph (" + prog->wave.why + ")");
-    if (engine == DUSP_ENGINE_AUTO) engine = fusable ? DUSP_ENGINE_FUSED : wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
+    std::string loop_why;
+    const bool loopable = dusp::plan_loop(prog->P, prog->loop, loop_why);
+    if (engine == DUSP_ENGINE_LOOP && !loopable)
+        CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
+    if (engine == DUSP_ENGINE_AUTO)
+        engine = fusable ? DUSP_ENGINE_FUSED : wavable ? DUSP_ENGINE_WAVE : loopable ? DUSP_ENGINE_LOOP : DUSP_ENGINE_CHUNK;
     prog->engine = engine;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -256,6 +263,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     info->engine = (uint32_t)prog->engine;
     info->n_device_ops = (uint32_t)prog->P.ops.size();
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
+    if (prog->engine == DUSP_ENGINE_LOOP) std::snprintf(info->shape, sizeof info->shape, "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE) std::snprintf(info->shape, sizeof info->shape, "feed-forward, %d chunk buffers in LDS", prog->P.n_bufs);
     return DUSP_OK;
 }
@@ -394,7 +402,11 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     a.sample_rate = (uint32_t)P.g.sample_rate;
     a.table_stride = ctx->table_stride;
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
-    HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
+    if (prog->engine == DUSP_ENGINE_LOOP) {
+        const int w = prog->loop.osc.attr;
+        HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
+    } else
+        HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void load_half_table(float *lds, const float *table, 
     __syncthreads();
 }
 
-inline size_t half_table_lds_bytes(uint32_t sample_rate) {
+__host__ __device__ inline size_t half_table_lds_bytes(uint32_t sample_rate) {
     const uint32_t last = sample_rate / 2 + 1;
     return ((size_t)(last + (last >> 5) + 2) * sizeof(float) + 15) & ~(size_t)15;
 }

@@ -13,8 +13,8 @@ from .wavetables import make_table
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdusp_hip.so")
 
-ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED, ENGINE_WAVE = 0, 1, 2, 3
-ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave"}
+ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED, ENGINE_WAVE, ENGINE_LOOP = 0, 1, 2, 3, 4
+ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave", ENGINE_LOOP: "loop"}
 
 EXPORTS = [
     "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",

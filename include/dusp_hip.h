@@ -56,8 +56,12 @@ typedef enum {
  *   WAVE  — any feed-forward graph of Osc / Ramp / Multiply / Sum / Repeater (incl. FM):
  *           one wavefront per instance, per-unit chunk buffers in LDS, wavefront-wide
  *           phase accumulation.
- * AUTO picks FUSED, else WAVE, else CHUNK. */
-typedef enum { DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3 } dusp_engine;
+ *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum): the chunk
+ *           engine's mapping and memory layout with the five units evaluated per sample in registers.
+ * AUTO picks FUSED, else WAVE, else LOOP, else CHUNK. */
+typedef enum {
+    DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3, DUSP_ENGINE_LOOP = 4
+} dusp_engine;
 
 typedef struct {
     uint32_t sample_rate;

@@ -57,7 +57,7 @@ def test_feedback_loop_batch(engine, oracle):
     uni = descriptor.unify([descriptor.extract(loop(k)) for k in range(0, 8192, 97)])
     n = 2000
     prog = render.context(48000).build(uni.words, engine)
-    assert prog.engine == "chunk"
+    assert prog.engine == ("loop" if engine == runtime.ENGINE_AUTO else "chunk")
     pcm = prog.render(n, uni.n_instances, uni.params)
     for i in range(0, uni.n_instances, 7):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
@@ -170,7 +170,7 @@ def test_config3_feedback_loops_full_size(oracle):
     V, n = 8192, 480000
     params = (110 + np.arange(V) / 64.0).astype(np.float32).reshape(1, V)
     prog = render.context(48000).build(uni.words)
-    assert prog.engine == "chunk"
+    assert prog.engine == "loop"
     out = torch.empty((V, 1, n), dtype=torch.float32, device="cuda")
     dp = torch.from_numpy(params).cuda()
     prog.render_device(n, V, dp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)

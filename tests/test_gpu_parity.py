@@ -31,14 +31,14 @@ def check(name, got, ref, engine=None):
         assert np.array_equal(got, ref), "first mismatch at %d" % int(np.argmax(got != ref))
 
 
-ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE}
+ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "loop": runtime.ENGINE_LOOP}
 # what AUTO must pick for a few cases (fused voice shapes / feed-forward wave engine / universal chunk engine)
 EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
                    "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
-                   "loop_220": "chunk", "delay_mod": "chunk", "circlebuffer_taps": "chunk", "filter_2ch": "chunk"}
+                   "loop_220": "loop", "loop_110p5_short": "loop", "loop_frac_delay": "loop", "loop_220_sr44100": "loop", "delay_mod": "chunk", "circlebuffer_taps": "chunk", "filter_2ch": "chunk"}
 
 
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
 @pytest.mark.parametrize("name", ALL_GOLDEN)
 def test_render_matches_reference_golden(name, engine, oracle):
     g = Golden(name)
@@ -46,8 +46,8 @@ def test_render_matches_reference_golden(name, engine, oracle):
     try:
         prog = ctx.build(g.desc, ENGINES[engine])
     except runtime.DuspHipError as e:
-        assert engine == "wave" and e.status == -2, e  # only feed-forward Osc/Ramp/Multiply/Sum graphs run there
-        pytest.skip("not a feed-forward graph")
+        assert engine in ("wave", "loop") and e.status == -2, e  # shape-specific engines refuse other graphs
+        pytest.skip("graph shape not handled by this engine")
     if engine == "auto" and name in EXPECTED_ENGINE:
         assert prog.engine == EXPECTED_ENGINE[name]
     assert prog.n_out_channels == g.n_channels
@@ -58,7 +58,7 @@ def test_render_matches_reference_golden(name, engine, oracle):
 
 
 @pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum"])
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
     n = min(g.n_samples, 5000)
