@@ -95,9 +95,13 @@ __device__ __forceinline__ float fix_out(float v) {  // `x || 0` (renderChannelD
 
 template <bool VEC>
 __device__ __forceinline__ void store4(float *row, const float (&v)[4], uint64_t t, uint64_t n_samples) {
-    if (VEC)
+    if (VEC) {
+#ifdef DUSP_NT_STORES
         __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4 *)row);
-    else
+#else
+        *(f32x4 *)row = f32x4{v[0], v[1], v[2], v[3]};  // plain stores measured 1-2 % faster than `nt` here (tools/abench.py)
+#endif
+    } else
         for (int c = 0; c < 4; ++c)
             if (t + c < n_samples) row[c] = v[c];
 }

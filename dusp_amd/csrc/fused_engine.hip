@@ -135,8 +135,8 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
     const uint32_t n_full = A.vec4_ok ? (uint32_t)(A.n_samples / kChunk) : 0u;
 
     for (uint64_t item = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); item < n_items; item += total_waves) {
-        const uint32_t blk = (uint32_t)(item % n_blk);
-        const uint32_t seg = (uint32_t)(item / n_blk);
+        const uint32_t blk = A.seg_major ? (uint32_t)(item / A.n_seg) : (uint32_t)(item % n_blk);
+        const uint32_t seg = A.seg_major ? (uint32_t)(item % A.n_seg) : (uint32_t)(item / n_blk);
         const uint32_t g0 = seg * A.seg_groups;
         const uint32_t g1 = min(g0 + A.seg_groups, A.n_groups);
         const uint32_t gm = max(g0, min(g1, n_full));
@@ -355,6 +355,7 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     A.osc_state_word = 0;
     A.ramp_state_word = plan.kind == FUSED_OSC_RAMP ? 1 : -1;
     A.fx32_ok = L.table_fx32_ok && env_int("DUSP_FUSED_FX32", 1) ? 1 : 0;
+    A.seg_major = env_int("DUSP_FUSED_SEGMAJOR", 0);
 
     int tbl = (L.table_antisym && L.sample_rate % 2 == 0) ? 1 : 0;
     const char *tenv = getenv("DUSP_FUSED_TABLE");

@@ -116,7 +116,7 @@ struct FusedArgs {
     DevOperand f, gain;
     double phase0;
     double r_d, r_y0, r_y1, r_t0, r_rcp;
-    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok;
+    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok, seg_major, pad2;
 };
 
 // q' of Markstein's division-by-reciprocal: q = t*r; rem = fma(-q, d, t); q' = fma(rem, r, q).

@@ -39,19 +39,22 @@ def main():
             return d.Multiply(d.Osc(f), 0.5)
 
     variants = []
-    envsets = [("R8", {"DUSP_FUSED_R": "8"}), ("R4", {"DUSP_FUSED_R": "4"}), ("R4/nofx", {"DUSP_FUSED_R": "4", "DUSP_FUSED_FX32": "0"}),
-               ("R8/it4", {"DUSP_FUSED_R": "8", "DUSP_FUSED_ITEMS": "4"}), ("R8/it16", {"DUSP_FUSED_R": "8", "DUSP_FUSED_ITEMS": "16"})]
-    if args.globaltbl:
-        envsets.append(("R4/global", {"DUSP_FUSED_R": "4", "DUSP_FUSED_TABLE": "global"}))
+    envsets = [("nt", {}), ("nt/segmajor", {"DUSP_FUSED_SEGMAJOR": "1"}), ("nt/it8", {"DUSP_FUSED_ITEMS": "8"}), ("nt/it2", {"DUSP_FUSED_ITEMS": "2"})]
+    ctxs = [("", ctx)]
+    plain = os.path.join(os.path.dirname(runtime.LIB_PATH), "libdusp_hip_plain.so")
+    if os.path.exists(plain):  # same kernels built with plain instead of non-temporal stores
+        runtime.LIB_PATH, runtime._lib = plain, None
+        ctxs.append(("plain:", runtime.Context(0, sr)))
     for kind in ["osc", "oscramp"]:
         for fname, fs in [("int", 10.0 * np.arange(1, V + 1)), ("frac", 20 + np.arange(V) / 8.0)]:
             uni = descriptor.unify([descriptor.extract(graph(kind, float(f))) for f in fs[:2]])
             params = torch.from_numpy(fs.astype(np.float32).reshape(1, V)).cuda()
-            prog = ctx.build(uni.words)
-            for ename, env in envsets:
-                variants.append(("%s/%s/%s" % (kind, fname, ename), prog, params, env))
+            for cname, c in ctxs:
+                prog = c.build(uni.words)
+                for ename, env in (envsets if not cname else envsets[:2]):
+                    variants.append(("%s%s/%s/%s" % (cname, kind, fname, ename), prog, params, env))
 
-    KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE"]
+    KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE", "DUSP_FUSED_SEGMAJOR"]
 
     def run(v):
         name, prog, params, env = v
@@ -76,7 +79,7 @@ def main():
                 times[v[0]].append(a.elapsed_time(b))
     for name, ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
-        print("%-22s median %8.3f ms  min %8.3f ms   %7.1f GB/s (median)  %5.1f%% of 8 TB/s" %
+        print("%-30s median %8.3f ms  min %8.3f ms   %7.1f GB/s (median)  %5.1f%% of 8 TB/s" %
               (name, med, mn, nbytes / med / 1e6, nbytes / med / 1e6 / 80.0), flush=True)
 
 
