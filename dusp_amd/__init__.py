@@ -6,8 +6,9 @@ ctypes binding of the HIP library (runtime.py).  Device side: dusp_amd/csrc/.
 """
 from . import config, descriptor, quick, runtime  # noqa: F401
 from .descriptor import DuspError  # noqa: F401
-from .graph import (Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Delay, Filter, Multiply, Osc,  # noqa: F401
-                    Ramp, Repeater, Sum, Unit)
+from .graph import (Abs, Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, DecibelToScaler, Delay,  # noqa: F401
+                    Divide, Filter, FixedMultiply, Gain, HardClipAbove, HardClipBelow, Multiply, Osc, PolarityInvert, Pow,
+                    Ramp, Repeater, SecondsToSamples, SemitoneToRatio, Subtract, Sum, Unit)
 from .render import ChannelData, render_many, renderChannelData  # noqa: F401
 from .runtime import Context, DuspHipError, Program  # noqa: F401
 

@@ -24,6 +24,7 @@
 
 #include "device_types.hpp"
 #include "fused_device.hpp"
+#include "map_ops.hpp"
 
 namespace dusp {
 
@@ -313,7 +314,18 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[0] = T + (double)kChunk;
                 break;
             }
-            default: break;
+            default: {  // stateless elementwise maps (map_ops.hpp)
+                const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float xv[kBatch], yv[kBatch], r[kBatch];
+                    x.load(t0, xv);
+                    y.load(t0, yv);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) r[k] = map_apply(op.op, xv[k], yv[k], op.d[0]);
+                    store_batch(outp, NP, t0, r);
+                }
+                break;
+            }
             }
         }
 

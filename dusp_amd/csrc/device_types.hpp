@@ -4,7 +4,13 @@
 
 namespace dusp {
 
-enum : int { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER };
+enum : int {
+    OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER,
+    // elementwise maps
+    OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW,
+    OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW,
+    OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW
+};
 enum : int { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };   // descriptor inlet kinds
 enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand kinds
 constexpr int kNumTables = 5;
@@ -26,7 +32,7 @@ struct DevOp {
     int32_t op, unit, out_buf, state_slot;
     int32_t attr, pad0;      // Osc: table id; Filter: kind; CircleBuffer node: bit0 wipe, bit1 no-input
     DevOperand in[2];
-    double d[3];             // Ramp: duration, y0, y1
+    double d[3];             // Ramp: duration, y0, y1; FixedMultiply: sf; SecondsToSamples: sample rate
     int64_t ring_base, ring_len;  // Delay / CircleBuffer nodes: ring location (samples, per instance)
 };
 

@@ -354,7 +354,9 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         case OP_MULTIPLY:
         case OP_SUM:
         case OP_REPEATER: break;
-        default: return no("unit with a recurrence (Filter / Delay / CircleBuffer)");
+        default:
+            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) break;  // stateless elementwise maps
+            return no("unit with a recurrence (Filter / Delay / CircleBuffer)");
         }
     }
     plan.ok = true;

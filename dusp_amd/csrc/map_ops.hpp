@@ -1,0 +1,38 @@
+// map_ops.hpp — the stateless elementwise units as one device function.
+// JS computes each of them in f64 and rounds once when storing into the Float32Array chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace dusp {
+namespace {
+
+// Math.pow: C pow except pow(+-1, +-Inf) and pow(x, NaN) are NaN (ECMA-262 Number::exponentiate)
+__device__ __forceinline__ double js_pow(double x, double y) {
+    if (y != y) return __builtin_nan("");
+    if ((x == 1.0 || x == -1.0) && isinf(y)) return __builtin_nan("");
+    return pow(x, y);
+}
+
+__device__ __forceinline__ float map_apply(int op, float x, float y, double d0) {
+    switch (op) {
+    case OP_SUBTRACT: return x - y;                                           // Subtract.js:23
+    case OP_DIVIDE: return (float)((double)x / (double)y);                    // Divide.js:21
+    case OP_POW: return (float)js_pow((double)x, (double)y);                  // Pow.js:27
+    case OP_POLARITY_INVERT: return -x;                                       // PolarityInvert.js:15
+    case OP_ABS: return fabsf(x);                                             // Abs.js:19
+    case OP_DECIBEL_TO_SCALER: return (float)js_pow(10.0, (double)x / 20.0);  // DecibelToScaler.js:16
+    case OP_SEMITONE_TO_RATIO: return (float)js_pow(2.0, (double)x / 12.0);   // SemitoneToRatio.js:16
+    case OP_SECONDS_TO_SAMPLES:                                               // SecondsToSamples.js:19
+    case OP_FIXED_MULTIPLY: return (float)((double)x * d0);                   // FixedMultiply.js:20
+    case OP_CLIP: return fabsf(x) > fabsf(y) ? y : x;                         // Clip.js:19-21
+    case OP_HARD_CLIP_ABOVE: return x > y ? y : x;                            // HardClipAbove.js:18-22
+    case OP_HARD_CLIP_BELOW: return x < y ? y : x;                            // HardClipBelow.js:18-22
+    case OP_GAIN: return (float)(js_pow(10.0, (double)y / 20.0) * (double)x); // Gain.js:21,24-26
+    }
+    return x;
+}
+
+}  // namespace
+}  // namespace dusp

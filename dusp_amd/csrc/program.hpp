@@ -196,6 +196,15 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         case OP_REPEATER:
             if (!need(1, 0, 0)) return fail(err, where + "bad Repeater record");
             break;
+        case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: case OP_CLIP: case OP_HARD_CLIP_ABOVE: case OP_HARD_CLIP_BELOW: case OP_GAIN:
+            if (!need(2, 0, 0)) return fail(err, where + "bad binary map record");
+            break;
+        case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO: case OP_SECONDS_TO_SAMPLES:
+            if (!need(1, 0, 0)) return fail(err, where + "bad unary map record");
+            break;
+        case OP_FIXED_MULTIPLY:
+            if (!need(1, 1, 0)) return fail(err, where + "bad FixedMultiply record");
+            break;
         default:
             return fail(err, where + "unknown opcode " + std::to_string(u.op));
         }
@@ -216,7 +225,10 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_CB_READER: return std::max(1, g.rings[(size_t)u.attrs[0]].nch);  // CircleBufferNode.js:19-22
     case OP_CB_WRITER: return 0;                                          // no data outlet
     case OP_REPEATER: return std::max(1, nin(0));                         // Repeater.js:24-25
+    case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: return std::max(nin(0), nin(1));
+    case OP_FIXED_MULTIPLY: return 1;                                     // mono in / mono out
     }
+    if (u.op >= OP_MAP_FIRST && u.op <= OP_MAP_LAST) return std::max(1, nin(0));  // loop `c < this.in.length`
     return 1;
 }
 
@@ -355,6 +367,31 @@ inline bool expand(Program &P, std::string &err) {
                 break;
             }
             case OP_REPEATER:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                break;
+            case OP_SUBTRACT:  // `this.a[c] || zeroChunk`: a missing channel is silence, no modulo (Subtract.js:20-21)
+                for (int k = 0; k < 2; k++) {
+                    if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+                    else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
+                }
+                break;
+            case OP_DIVIDE: case OP_POW: case OP_CLIP: case OP_HARD_CLIP_ABOVE: case OP_HARD_CLIP_BELOW:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], c);  // modulo broadcast
+                break;
+            case OP_GAIN:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], 0);  // gain is a mono inlet (Gain.js:6)
+                break;
+            case OP_FIXED_MULTIPLY:
+                op.in[0] = make_operand(g, u.inlets[0], 0);
+                op.d[0] = u.attrs[0];
+                break;
+            case OP_SECONDS_TO_SAMPLES:
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.d[0] = (double)g.sample_rate;
+                break;
+            case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
                 op.in[0] = make_operand(g, u.inlets[0], c);
                 break;
             }

@@ -26,6 +26,7 @@
 
 #include "device_types.hpp"
 #include "fused_device.hpp"
+#include "map_ops.hpp"
 
 namespace dusp {
 
@@ -173,8 +174,14 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 for (int c = 0; c < 4; ++c) out.v[c] = x.v[c] + y.v[c];
                 break;
             }
-            default: {  // OP_REPEATER (Repeater.js:23-30)
+            case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                break;
+            }
+            default: {  // stateless elementwise maps (map_ops.hpp)
+                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 y = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                for (int c = 0; c < 4; ++c) out.v[c] = map_apply(op.op, x.v[c], y.v[c], op.d[0]);
                 break;
             }
             }

@@ -14,6 +14,8 @@ VERSION = 1
 HEADER_WORDS = 12
 
 OP_OSC, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER = range(1, 10)
+(OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW, OP_SECONDS_TO_SAMPLES,
+ OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW) = range(10, 23)  # elementwise maps
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
@@ -27,6 +29,19 @@ UNITS = {
     "CircleBufferReader": (OP_CB_READER, ["offset"]),
     "CircleBufferWriter": (OP_CB_WRITER, ["offset", "in"]),
     "Repeater": (OP_REPEATER, ["in"]),
+    "Subtract": (OP_SUBTRACT, ["a", "b"]),
+    "Divide": (OP_DIVIDE, ["a", "b"]),
+    "PolarityInvert": (OP_POLARITY_INVERT, ["in"]),
+    "Abs": (OP_ABS, ["in"]),
+    "Clip": (OP_CLIP, ["in", "threshold"]),
+    "HardClipAbove": (OP_HARD_CLIP_ABOVE, ["in", "threshold"]),
+    "HardClipBelow": (OP_HARD_CLIP_BELOW, ["in", "threshold"]),
+    "SecondsToSamples": (OP_SECONDS_TO_SAMPLES, ["in"]),
+    "FixedMultiply": (OP_FIXED_MULTIPLY, ["in"]),
+    "Gain": (OP_GAIN, ["in", "gain"]),
+    "DecibelToScaler": (OP_DECIBEL_TO_SCALER, ["in"]),
+    "SemitoneToRatio": (OP_SEMITONE_TO_RATIO, ["in"]),
+    "Pow": (OP_POW, ["a", "b"]),
 }
 
 
@@ -108,6 +123,8 @@ def extract(target):
             attrs, state = [ring_id(unit.buffer), 1 if unit.postWipe else 0], [unit.t]
         elif op == OP_CB_WRITER:
             attrs, state = [ring_id(unit.buffer), 1 if unit.preWipe else 0], [unit.t]
+        elif op == OP_FIXED_MULTIPLY:
+            attrs = [float(unit.sf)]  # a plain number on the unit, not an inlet (FixedMultiply.js:8,20)
         body += [op, len(inlet_names), len(attrs), len(state)]
         for name in inlet_names:
             inlet = unit.inlets[name]

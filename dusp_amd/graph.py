@@ -441,3 +441,125 @@ class Repeater(Unit):
         self.addOutlet("out")
         self.measuredIn = measuredIn
         self.IN = val or 0
+
+
+# --------------------------------------------------------------------------- elementwise maps
+class _Binary(Unit):
+    _defaults = (0, 0)
+
+    def __init__(self, a=None, b=None):
+        super().__init__()
+        self.addInlet("a")
+        self.addInlet("b")
+        self.addOutlet("out")
+        self.A = a or self._defaults[0]
+        self.B = b or self._defaults[1]
+
+
+class Subtract(_Binary):
+    """reference src/components/Subtract.js:4-11"""
+    _defaults = (0, 0)
+
+
+class Divide(_Binary):
+    """reference src/components/Divide.js:3-10"""
+    _defaults = (1, 1)
+
+
+class Pow(Unit):
+    """reference src/components/Pow.js:4-11 (no defaults: a missing operand raises, as the reference throws)"""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.addInlet("a")
+        self.addInlet("b")
+        self.addOutlet("out")
+        self.A = a
+        self.B = b
+
+
+class _Unary(Unit):
+    _default = 0
+
+    def __init__(self, input=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addOutlet("out")
+        self.IN = input or self._default
+
+
+class PolarityInvert(_Unary):
+    """reference src/components/PolarityInvert.js:4-9"""
+
+
+class Abs(_Unary):
+    """reference src/components/Abs.js:3-9"""
+
+
+class DecibelToScaler(_Unary):
+    """reference src/components/DecibelToScaler.js:3-8"""
+
+
+class SemitoneToRatio(_Unary):
+    """reference src/components/SemitoneToRatio.js:3-8"""
+    _default = 69
+
+
+class SecondsToSamples(Unit):
+    """reference src/components/SecondsToSamples.js:4-8 (no constructor argument)"""
+
+    def __init__(self):
+        super().__init__()
+        self.addInlet("in")
+        self.addOutlet("out")
+
+
+class FixedMultiply(Unit):
+    """reference src/components/FixedMultiply.js:3-9 — (sf, input); sf is a plain number"""
+
+    def __init__(self, sf, input=None):
+        super().__init__()
+        self.addInlet("in", mono=True)
+        self.addOutlet("out", mono=True)
+        self.sf = sf
+        self.IN = input or 0
+
+
+class Clip(Unit):
+    """reference src/components/Clip.js:4-11 — (threshold) only; `in` stays 0 until set"""
+
+    def __init__(self, threshold):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("threshold")
+        self.addOutlet("out")
+        self.THRESHOLD = threshold
+
+
+class _HardClip(Unit):
+    def __init__(self, input=None, threshold=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("threshold")
+        self.addOutlet("out")
+        self.IN = input or 0
+        self.THRESHOLD = threshold or 0
+
+
+class HardClipAbove(_HardClip):
+    """reference src/components/HardClipAbove.js:4-12"""
+
+
+class HardClipBelow(_HardClip):
+    """reference src/components/HardClipBelow.js:4-12"""
+
+
+class Gain(Unit):
+    """reference src/components/Gain.js:3-10 — (gain in dB); `in` stays 0 until set"""
+
+    def __init__(self, gain=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("gain", mono=True)
+        self.addOutlet("out")
+        self.GAIN = gain or 0

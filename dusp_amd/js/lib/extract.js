@@ -102,6 +102,9 @@ function extract(target) {
       case OP.CB_WRITER:
         attrs = [ringId(unit.buffer), unit.preWipe ? 1 : 0]; state = [unit.t]
         break
+      case OP.FIXED_MULTIPLY:
+        attrs = [Number(unit.sf)] // a plain JS number on the unit, not an inlet (FixedMultiply.js:8,20)
+        break
     }
 
     body.push(spec.op, spec.inlets.length, attrs.length, state.length)

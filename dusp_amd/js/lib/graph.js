@@ -368,5 +368,89 @@ class Repeater extends Unit { // Repeater.js:3-11
   }
 }
 
-module.exports = { Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
+/* ---- elementwise maps (SURVEY.md §8f-1); constructor defaults as in src/components/<Name>.js */
+const binary = (defA, defB) => class extends Unit {
+  constructor(a, b) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addOutlet('out')
+    this.A = a || defA
+    this.B = b || defB
+  }
+}
+const Subtract = class Subtract extends binary(0, 0) {} // Subtract.js:4-11
+const Divide = class Divide extends binary(1, 1) {} // Divide.js:3-10
+class Pow extends Unit { // Pow.js:4-11 — no defaults: undefined operands throw, as in the reference
+  constructor(a, b) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addOutlet('out')
+    this.A = a
+    this.B = b
+  }
+}
+const unary = (def) => class extends Unit {
+  constructor(input) {
+    super()
+    this.addInlet('in')
+    this.addOutlet('out')
+    this.IN = input || def
+  }
+}
+const PolarityInvert = class PolarityInvert extends unary(0) {} // PolarityInvert.js:4-9
+const Abs = class Abs extends unary(0) {} // Abs.js:3-9
+const DecibelToScaler = class DecibelToScaler extends unary(0) {} // DecibelToScaler.js:3-8
+const SemitoneToRatio = class SemitoneToRatio extends unary(69) {} // SemitoneToRatio.js:3-8
+class SecondsToSamples extends Unit { // SecondsToSamples.js:4-8 — no constructor argument
+  constructor() {
+    super()
+    this.addInlet('in')
+    this.addOutlet('out')
+  }
+}
+class FixedMultiply extends Unit { // FixedMultiply.js:3-9 — (sf, input); sf is a plain number
+  constructor(sf, input) {
+    super()
+    this.addInlet('in', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.sf = sf
+    this.IN = input || 0
+  }
+}
+class Clip extends Unit { // Clip.js:4-11 — (threshold) only; `in` stays 0 until set
+  constructor(threshold) {
+    super()
+    this.addInlet('in')
+    this.addInlet('threshold')
+    this.addOutlet('out')
+    this.THRESHOLD = threshold
+  }
+}
+const hardClip = () => class extends Unit { // HardClipAbove.js:4-12 / HardClipBelow.js:4-12
+  constructor(input, threshold) {
+    super()
+    this.addInlet('in')
+    this.addInlet('threshold')
+    this.addOutlet('out')
+    this.IN = input || 0
+    this.THRESHOLD = threshold || 0
+  }
+}
+const HardClipAbove = class HardClipAbove extends hardClip() {}
+const HardClipBelow = class HardClipBelow extends hardClip() {}
+class Gain extends Unit { // Gain.js:3-10 — (gain in dB); `in` stays 0 until set
+  constructor(gain) {
+    super()
+    this.addInlet('in')
+    this.addInlet('gain', { mono: true })
+    this.addOutlet('out')
+    this.GAIN = gain || 0
+  }
+}
+
+module.exports = { Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
+  FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
+  Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
   CircleBuffer, CircleBufferNode, CircleBufferReader, CircleBufferWriter, Repeater }

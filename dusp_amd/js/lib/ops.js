@@ -15,6 +15,9 @@ const HEADER_WORDS = 12
 const OP = Object.freeze({
   OSC: 1, RAMP: 2, MULTIPLY: 3, SUM: 4, FILTER: 5, DELAY: 6,
   CB_READER: 7, CB_WRITER: 8, REPEATER: 9,
+  // elementwise maps (SURVEY.md §8f-1)
+  SUBTRACT: 10, DIVIDE: 11, POLARITY_INVERT: 12, ABS: 13, CLIP: 14, HARD_CLIP_ABOVE: 15, HARD_CLIP_BELOW: 16,
+  SECONDS_TO_SAMPLES: 17, FIXED_MULTIPLY: 18, GAIN: 19, DECIBEL_TO_SCALER: 20, SEMITONE_TO_RATIO: 21, POW: 22,
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -34,6 +37,19 @@ const UNITS = Object.freeze({
   CircleBufferReader: { op: OP.CB_READER, inlets: ['offset'] },
   CircleBufferWriter: { op: OP.CB_WRITER, inlets: ['offset', 'in'] },
   Repeater: { op: OP.REPEATER, inlets: ['in'] },
+  Subtract: { op: OP.SUBTRACT, inlets: ['a', 'b'] },
+  Divide: { op: OP.DIVIDE, inlets: ['a', 'b'] },
+  PolarityInvert: { op: OP.POLARITY_INVERT, inlets: ['in'] },
+  Abs: { op: OP.ABS, inlets: ['in'] },
+  Clip: { op: OP.CLIP, inlets: ['in', 'threshold'] },
+  HardClipAbove: { op: OP.HARD_CLIP_ABOVE, inlets: ['in', 'threshold'] },
+  HardClipBelow: { op: OP.HARD_CLIP_BELOW, inlets: ['in', 'threshold'] },
+  SecondsToSamples: { op: OP.SECONDS_TO_SAMPLES, inlets: ['in'] },
+  FixedMultiply: { op: OP.FIXED_MULTIPLY, inlets: ['in'] },
+  Gain: { op: OP.GAIN, inlets: ['in', 'gain'] },
+  DecibelToScaler: { op: OP.DECIBEL_TO_SCALER, inlets: ['in'] },
+  SemitoneToRatio: { op: OP.SEMITONE_TO_RATIO, inlets: ['in'] },
+  Pow: { op: OP.POW, inlets: ['a', 'b'] },
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, UNITS }

@@ -1,7 +1,7 @@
 'use strict'
 /* Operator helpers with the reference's folding rules (src/quick.js:15-110): numbers fold, signals
  * build a unit.  Helpers whose unit the GPU path does not execute yet fold numbers and refuse signals. */
-const { Sum, Multiply } = require('./graph')
+const { Sum, Multiply, Subtract, Divide, PolarityInvert, SemitoneToRatio, Pow, HardClipAbove, HardClipBelow } = require('./graph')
 
 const isNum = (x) => typeof x === 'number'
 const isSignal = (x) => x && (x.isUnitOrPatch || x.isOutlet)
@@ -15,18 +15,23 @@ exports.mult = function (a, b) {
 }
 exports.multiply = exports.mult
 
-function numbersOnly(name, fold) {
-  return function (...args) {
-    if (args.some(isSignal)) throw 'dusp-hip: quick.' + name + ' on signals needs a unit the GPU path does not execute yet'
-    return fold(...args)
-  }
+exports.subtract = (a, b) => (isNum(a) && isNum(b) ? a - b : new Subtract(a, b))
+exports.divide = (a, b) => (isNum(a) && isNum(b) ? a / b : new Divide(a, b))
+exports.invert = (a) => (isNum(a) ? -a : new PolarityInvert(a))
+exports.semitoneToRatio = (p) => (isNum(p) ? Math.pow(2, p / 12) : new SemitoneToRatio(p))
+exports.pToF = function (p) {
+  if (isNum(p)) return Math.pow(2, (p - 69) / 12) * 440
+  throw 'quick.pToF(non number) has not been implemented' // the reference's own message (quick.js:55)
 }
-exports.subtract = numbersOnly('subtract', (a, b) => a - b)
-exports.divide = numbersOnly('divide', (a, b) => a / b)
-exports.invert = numbersOnly('invert', (a) => -a)
-exports.semitoneToRatio = numbersOnly('semitoneToRatio', (p) => Math.pow(2, p / 12))
-exports.pToF = numbersOnly('pToF', (p) => Math.pow(2, (p - 69) / 12) * 440)
-exports.pow = numbersOnly('pow', (a, b) => Math.pow(a, b))
-exports.concat = numbersOnly('concat', (a, b) => [].concat(a, b))
-exports.clipAbove = numbersOnly('clipAbove', (x, th) => (x > th ? th : x))
-exports.clipBelow = numbersOnly('clipBelow', (x, th) => (x < th ? th : x))
+exports.pow = (a, b) => (isSignal(a) || isSignal(b) ? new Pow(a, b) : Math.pow(a, b))
+exports.clipAbove = (input, th) => (isSignal(input) || isSignal(th) ? new HardClipAbove(input, th) : (input > th ? th : input))
+exports.clipBelow = (input, th) => (isSignal(input) || isSignal(th) ? new HardClipBelow(input, th) : (input < th ? th : input))
+exports.clip = function (input, th) {
+  // the reference's signal branch calls `new Clip(input, threshold)` without importing Clip: it throws (quick.js:102-104)
+  if (isSignal(input) || isSignal(th)) throw 'dusp-hip: quick.clip on signals is broken in the reference (Clip is not imported); build a Clip unit directly'
+  return Math.abs(input) < Math.abs(th) ? th : input // sic: the reference's number branch (quick.js:106-109)
+}
+exports.concat = function (a, b) {
+  if (isSignal(a) || isSignal(b)) throw 'dusp-hip: quick.concat on signals needs ConcatChannels, which the GPU path does not execute yet'
+  return [].concat(a, b)
+}

@@ -1,9 +1,9 @@
 """Operator helpers (reference src/quick.js:15-110): fold when both operands are
 numbers, otherwise build the unit.  Only the helpers whose units the GPU path
-executes build anything; the rest fold numbers and refuse signals."""
+executes build anything; the rest fold numbers and refuse signals (quick.concat needs ConcatChannels)."""
 import numbers
 
-from .graph import Multiply, Sum
+from .graph import Divide, HardClipAbove, HardClipBelow, Multiply, PolarityInvert, Pow, SemitoneToRatio, Subtract, Sum
 
 
 def _num(x):
@@ -25,20 +25,43 @@ def mult(a, b):
 multiply = mult
 
 
-def _numbers_only(name, fn):
-    def helper(*args):
-        if all(_num(a) for a in args):
-            return fn(*args)
-        raise NotImplementedError("quick.%s on signals needs a unit the GPU path does not execute yet" % name)
-    helper.__name__ = name
-    return helper
+def _is_signal(x):
+    return getattr(x, "isUnit", False) or getattr(x, "isOutlet", False)
 
 
-subtract = _numbers_only("subtract", lambda a, b: a - b)
-divide = _numbers_only("divide", lambda a, b: a / b)
-invert = _numbers_only("invert", lambda a: -a)
-semitoneToRatio = _numbers_only("semitoneToRatio", lambda p: 2 ** (p / 12))
-pToF = _numbers_only("pToF", lambda p: 2 ** ((p - 69) / 12) * 440)
-pow = _numbers_only("pow", lambda a, b: a ** b)
-clipAbove = _numbers_only("clipAbove", lambda x, th: th if x > th else x)
-clipBelow = _numbers_only("clipBelow", lambda x, th: th if x < th else x)
+def subtract(a, b):
+    return a - b if _num(a) and _num(b) else Subtract(a, b)
+
+
+def divide(a, b):
+    return a / b if _num(a) and _num(b) else Divide(a, b)
+
+
+def invert(a):
+    return -a if _num(a) else PolarityInvert(a)
+
+
+def semitoneToRatio(p):
+    return 2 ** (p / 12) if _num(p) else SemitoneToRatio(p)
+
+
+def pToF(p):
+    if _num(p):
+        return 2 ** ((p - 69) / 12) * 440
+    raise NotImplementedError("quick.pToF(non number) has not been implemented")  # the reference's message (quick.js:55)
+
+
+def pow(a, b):  # noqa: A001 - the reference's name
+    return Pow(a, b) if _is_signal(a) or _is_signal(b) else a ** b
+
+
+def clipAbove(input, threshold):
+    if _is_signal(input) or _is_signal(threshold):
+        return HardClipAbove(input, threshold)
+    return threshold if input > threshold else input
+
+
+def clipBelow(input, threshold):
+    if _is_signal(input) or _is_signal(threshold):
+        return HardClipBelow(input, threshold)
+    return threshold if input < threshold else input

@@ -20,7 +20,10 @@
 #define MAGIC 1146442576.0
 #define HEADER_WORDS 12
 
-enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER };
+enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER,
+       /* elementwise maps */
+       OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW,
+       OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW };
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
 
 /* ---- SignalChunk (reference src/SignalChunk.js:1-11): channelData[c] = Float32Array(chunkSize).
@@ -107,6 +110,8 @@ typedef struct unit {
     /* CircleBuffer nodes */
     int ring, wipe;
     double cb_t;
+    /* FixedMultiply */
+    double sf;
 } unit_t;
 
 struct dusp_oracle {
@@ -332,6 +337,61 @@ static void tick_repeater(dusp_oracle *o, unit_t *u) {
     }
 }
 
+/* Math.pow: like C pow except pow(+-1, +-Inf) and pow(x, NaN) are NaN (ECMA-262 Number::exponentiate) */
+static double js_pow(double x, double y) {
+    if (y != y) return NAN;
+    if ((x == 1 || x == -1) && isinf(y)) return NAN;
+    return pow(x, y);
+}
+
+/* elementwise units: reference src/components/{Subtract,Divide,Pow,PolarityInvert,Abs,DecibelToScaler,
+ * SemitoneToRatio,SecondsToSamples,FixedMultiply,Clip,HardClipAbove,HardClipBelow,Gain}.js `_tick` */
+static void tick_map(dusp_oracle *o, unit_t *u) {
+    chunk_t *a = inlet_chunk(o, u, 0);
+    chunk_t *b = u->n_inlets > 1 ? inlet_chunk(o, u, 1) : NULL;
+    static float zero[4096];
+    const int n = o->chunk;
+    switch (u->op) {
+    case OP_SUBTRACT: /* `this.a[c] || zeroChunk`: a missing channel is silence, NOT a modulo broadcast (Subtract.js:20-21) */
+        for (int c = 0; c < a->nch || c < b->nch; c++) {
+            float *oc = chunk_ensure(&u->out, c, n);
+            const float *ac = c < a->nch ? a->ch[c] : zero, *bc = c < b->nch ? b->ch[c] : zero;
+            for (int t = 0; t < n; t++) oc[t] = (float)((double)ac[t] - (double)bc[t]);
+        }
+        return;
+    case OP_DIVIDE: case OP_POW: /* Divide.js:13-23, Pow.js:19-30 */
+        for (int c = 0; c < a->nch || c < b->nch; c++) {
+            const float *ac = a->ch[c % a->nch], *bc = b->ch[c % b->nch];
+            float *oc = chunk_ensure(&u->out, c, n);
+            for (int t = 0; t < n; t++)
+                oc[t] = u->op == OP_DIVIDE ? (float)((double)ac[t] / (double)bc[t]) : (float)js_pow(ac[t], bc[t]);
+        }
+        return;
+    case OP_FIXED_MULTIPLY: /* mono in / mono out (FixedMultiply.js:18-21) */
+        for (int t = 0; t < n; t++) u->out.ch[0][t] = (float)((double)a->ch[0][t] * u->sf);
+        return;
+    default: break;
+    }
+    for (int c = 0; c < a->nch; c++) {
+        const float *x = a->ch[c];
+        const float *y = b ? (u->op == OP_GAIN ? b->ch[0] : b->ch[c % b->nch]) : NULL; /* gain is a mono inlet (Gain.js:6) */
+        float *oc = chunk_ensure(&u->out, c, n);
+        for (int t = 0; t < n; t++) {
+            switch (u->op) {
+            case OP_POLARITY_INVERT: oc[t] = -x[t]; break;                                   /* PolarityInvert.js:13-16 */
+            case OP_ABS: oc[t] = (float)fabs((double)x[t]); break;                           /* Abs.js:17-20 */
+            case OP_DECIBEL_TO_SCALER: oc[t] = (float)js_pow(10, (double)x[t] / 20); break;  /* DecibelToScaler.js:15-16 */
+            case OP_SEMITONE_TO_RATIO: oc[t] = (float)js_pow(2, (double)x[t] / 12); break;   /* SemitoneToRatio.js:15-16 */
+            case OP_SECONDS_TO_SAMPLES: oc[t] = (float)((double)x[t] * o->sr); break;        /* SecondsToSamples.js:18-19 */
+            case OP_CLIP: oc[t] = fabs((double)x[t]) > fabs((double)y[t]) ? y[t] : x[t]; break; /* Clip.js:19-21 */
+            case OP_HARD_CLIP_ABOVE: oc[t] = x[t] > y[t] ? y[t] : x[t]; break;               /* HardClipAbove.js:18-22 */
+            case OP_HARD_CLIP_BELOW: oc[t] = x[t] < y[t] ? y[t] : x[t]; break;               /* HardClipBelow.js:18-22 */
+            case OP_GAIN: oc[t] = (float)(js_pow(10, (double)y[t] / 20) * (double)x[t]); break; /* Gain.js:20-21,24-26 */
+            }
+        }
+    }
+}
+
 /* reference src/Circuit.js:19-41 (tick) with src/Unit.js:111-119; every unit's
  * tickInterval equals the chunk size here, so gcdTickInterval == chunk. */
 static void circuit_tick(dusp_oracle *o) {
@@ -347,6 +407,7 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_CB_READER: tick_cb_reader(o, u); break;
         case OP_CB_WRITER: tick_cb_writer(o, u); break;
         case OP_REPEATER: tick_repeater(o, u); break;
+        default: tick_map(o, u); break;
         }
     }
     o->clock += o->chunk;
@@ -484,6 +545,16 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             break;
         case OP_REPEATER:
             if (u->n_inlets != 1) FAIL("unit %zu: bad Repeater record", i);
+            break;
+        case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: case OP_CLIP: case OP_HARD_CLIP_ABOVE: case OP_HARD_CLIP_BELOW: case OP_GAIN:
+            if (u->n_inlets != 2 || n_attr || n_state) FAIL("unit %zu: bad binary map record", i);
+            break;
+        case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO: case OP_SECONDS_TO_SAMPLES:
+            if (u->n_inlets != 1 || n_attr || n_state) FAIL("unit %zu: bad unary map record", i);
+            break;
+        case OP_FIXED_MULTIPLY:
+            if (u->n_inlets != 1 || n_attr != 1 || n_state) FAIL("unit %zu: bad FixedMultiply record", i);
+            u->sf = a[0];
             break;
         default: FAIL("unit %zu: unknown opcode %d", i, u->op);
         }

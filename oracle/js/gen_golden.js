@@ -41,10 +41,13 @@ const CircleBuffer = ref('CircleBuffer.js')
 const CircleBufferReader = ref('components/CircleBufferReader.js')
 const CircleBufferWriter = ref('components/CircleBufferWriter.js')
 const quick = ref('quick.js')
+const more = {}
+for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardClipAbove', 'HardClipBelow', 'SecondsToSamples',
+  'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow']) more[n] = ref('components/' + n + '.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
 const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
-  CircleBufferReader, CircleBufferWriter, quick }, SR)
+  CircleBufferReader, CircleBufferWriter, quick, ...more }, SR)
 const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
 
 async function main() {

@@ -3,8 +3,9 @@ graph classes (dusp_amd/graph.py).  Used to check that the host mirror produces
 the same descriptor — constants, state AND unit order — as the reference objects
 did, and as ready-made graphs for the GPU parity tests."""
 import dusp_amd as d
-from dusp_amd import (CircleBuffer, CircleBufferReader, CircleBufferWriter, Delay, Filter, Multiply, Osc, Ramp,
-                      Repeater, Sum, quick)
+from dusp_amd import (Abs, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, DecibelToScaler, Delay, Divide, Filter,
+                      FixedMultiply, Gain, HardClipAbove, HardClipBelow, Multiply, Osc, Pow, Ramp, Repeater,
+                      SecondsToSamples, SemitoneToRatio, Subtract, Sum, quick)
 
 
 def _loop(f_osc, delay, max_delay, cutoff, gain):
@@ -47,6 +48,24 @@ def _mult_inlet_zero():
     return m
 
 
+def _clip():
+    c = Clip(Multiply(Osc(2), 0.8))
+    c.IN = Osc(333)
+    return c
+
+
+def _seconds():
+    s = SecondsToSamples()
+    s.IN = Multiply(Osc(10), 0.001)
+    return s
+
+
+def _gain():
+    g = Gain(Multiply(Osc(3), 12))
+    g.IN = Osc(220)
+    return g
+
+
 def builders(sr):
     """name -> zero-argument builder; call d.configure(sr) first (done by build())."""
     voices = lambda n: [Osc(k * 10) for k in range(1, n + 1)]
@@ -79,6 +98,21 @@ def builders(sr):
         "repeater": lambda: Repeater(quick.mult(Osc(123.4), 1)),
         "sum_const": lambda: quick.add(Osc(50), 0.75),
         "mult_inlet_zero": _mult_inlet_zero,
+        # elementwise maps
+        "map_subtract": lambda: Subtract(Osc(300), Multiply(Osc(7), [0.5, 0.25])),
+        "map_subtract_quick": lambda: quick.subtract(Osc(300, "saw"), 0.3),
+        "map_divide": lambda: Divide(Osc(200), Sum(Osc(3), 1.5)),
+        "map_divide_by_zero": lambda: Divide(Osc(100), Osc(50, "square")),
+        "map_invert_abs": lambda: Abs(quick.invert(Osc(440.5))),
+        "map_clip": _clip,
+        "map_hardclip": lambda: HardClipBelow(HardClipAbove(Osc(150), 0.5), [-0.25, -0.75]),
+        "map_seconds": _seconds,
+        "map_fixedmultiply": lambda: FixedMultiply(0.1, Osc(441)),
+        "map_gain": _gain,
+        "map_db_semitone": lambda: Multiply(DecibelToScaler(Multiply(Osc(5), 20)), SemitoneToRatio(Multiply(Osc(2), 7))),
+        "map_pow": lambda: Pow(Sum(Osc(100), 1.5), Multiply(Osc(1.5), 2)),
+        "map_pow_negative_base": lambda: quick.pow(Osc(100), 0.5),
+        "map_fm_semitone": lambda: Osc(Multiply(SemitoneToRatio(Multiply(Osc(4), 12)), 220)),
     }
     for tag, f in [("440p5", 440.5), ("0p1", 0.1), ("neg3", -3), ("47999p5", 47999.5), ("neg0p37", -0.37),
                    ("12345p678", 12345.678), ("tiny", 3e-5)]:

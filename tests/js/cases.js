@@ -8,7 +8,9 @@
  * L = { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader,
  *       CircleBufferWriter, quick };  SR = sample rate the library was configured with. */
 module.exports = function goldenCases(L, SR) {
-  const { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader, CircleBufferWriter, quick } = L
+  const { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader, CircleBufferWriter, quick,
+    Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
+    DecibelToScaler, SemitoneToRatio, Pow } = L
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -111,5 +113,23 @@ module.exports = function goldenCases(L, SR) {
   add('repeater', () => new Repeater(quick.mult(new Osc(123.4), 1)), 0.01)
   add('sum_const', () => quick.add(new Osc(50), 0.75), 0.01)
   add('mult_inlet_zero', () => { const m = new Multiply(new Osc(440), 2); m.B = 0; return m }, 0.01)
+
+  // SURVEY.md §8f-1: elementwise maps (only when the library provides them)
+  if (Subtract) {
+    add('map_subtract', () => new Subtract(new Osc(300), new Multiply(new Osc(7), [0.5, 0.25])), 0.02) // 1 ch - 2 ch: no modulo broadcast
+    add('map_subtract_quick', () => quick.subtract(new Osc(300, 'saw'), 0.3), 0.01)
+    add('map_divide', () => new Divide(new Osc(200), new Sum(new Osc(3), 1.5)), 0.02)
+    add('map_divide_by_zero', () => new Divide(new Osc(100), new Osc(50, 'square')), 0.01) // +-1 and a 0/x, x/0 mix -> Inf/NaN -> `|| 0`
+    add('map_invert_abs', () => new Abs(quick.invert(new Osc(440.5))), 0.01)
+    add('map_clip', () => { const c = new Clip(new Multiply(new Osc(2), 0.8)); c.IN = new Osc(333); return c }, 0.05)
+    add('map_hardclip', () => new HardClipBelow(new HardClipAbove(new Osc(150), 0.5), [-0.25, -0.75]), 0.02)
+    add('map_seconds', () => { const s = new SecondsToSamples(); s.IN = new Multiply(new Osc(10), 0.001); return s }, 0.01)
+    add('map_fixedmultiply', () => new FixedMultiply(0.1, new Osc(441)), 0.01)
+    add('map_gain', () => { const g = new Gain(new Multiply(new Osc(3), 12)); g.IN = new Osc(220); return g }, 0.05)
+    add('map_db_semitone', () => new Multiply(new DecibelToScaler(new Multiply(new Osc(5), 20)), new SemitoneToRatio(new Multiply(new Osc(2), 7))), 0.05)
+    add('map_pow', () => new Pow(new Sum(new Osc(100), 1.5), new Multiply(new Osc(1.5), 2)), 0.05)
+    add('map_pow_negative_base', () => quick.pow(new Osc(100), 0.5), 0.01) // NaN for negative bases -> `|| 0`
+    add('map_fm_semitone', () => new Osc(new Multiply(new SemitoneToRatio(new Multiply(new Osc(4), 12)), 220)), 0.05) // vibrato in semitones
+  }
   return cases
 }

@@ -1,7 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
 
 Bar: bit-exact wherever the device executes the same IEEE operations as JS (everything except the
-Filter's tan(), which comes from the device math library): there the north star's tolerance applies,
+Filter's tan() and the pow() of the dB / semitone / Pow units, which come from the device math library):
+there the north star's tolerance applies,
 1e-5 relative to full scale (SURVEY.md §7 "tolerance definition").
 """
 import numpy as np
@@ -13,7 +14,8 @@ from dusp_amd import render, runtime
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5  # north_star: "within 1e-5 relative float tolerance" (of full scale)
-USES_DEVICE_TAN = ("loop_", "filter_")
+# device tan() in the Filter coefficients, device pow() in Gain / DecibelToScaler / SemitoneToRatio / Pow
+USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow", "map_fm_semitone")
 
 
 # |f| < 2^-13: the reference's own f64 phase accumulation rounds there (SURVEY.md §8a note ii), so the wave
