@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer boundary (dusp_render_host = what the N-API addon calls):
+upload parameters, render, download the PCM into pageable host memory."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dusp_amd as d  # noqa: E402
+from dusp_amd import descriptor, runtime  # noqa: E402
+
+sr = 48000
+d.configure(sr)
+ctx = runtime.Context(0, sr)
+for V, seconds in [(1, 10), (64, 10), (1024, 1), (1024, 4)]:
+    n = sr * seconds
+    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Osc(10 * k), d.Ramp(n, 1, 0).trigger())) for k in (1, 2)])
+    params = (10.0 * np.arange(1, V + 1)).astype(np.float32).reshape(1, V)
+    prog = ctx.build(uni.words)
+    prog.render(n, V, params)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        pcm = prog.render(n, V, params)
+    dt = (time.perf_counter() - t0) / reps
+    print("host path: %5d voices x %2d s: %8.2f ms per call  %8.1f Msamples/s  %6.2f GB/s of PCM (kernel %.3f ms)"
+          % (V, seconds, dt * 1e3, V * n / dt / 1e6, 4.0 * V * n / dt / 1e9, prog.last_kernel_ms()), flush=True)
+    prog.close()
