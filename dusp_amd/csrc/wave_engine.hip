@@ -109,8 +109,10 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const V4 f = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 long long q[4];
                 bool bad = false;
+                const bool lane_constant = op.in[0].kind != SRC_BUF;  // wave-uniform: f is a constant / parameter
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    if (lane_constant && c > 0) { q[c] = q[0]; continue; }
                     double fd = (double)f.v[c];
                     const bool fin = fabs(fd) <= 3.0e38;
                     bad = bad || !fin;
@@ -118,24 +120,33 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     if (fabs(fd) >= srd) fd = fmod(fd, srd);  // (a + b) % m == (a + b % m) % m
                     q[c] = (long long)(fd * kTwo36);         // exact for |f| >= 2^-13 (or f == 0)
                 }
-                long long s[4];
-                s[0] = q[0];
-                s[1] = s[0] + q[1];
-                s[2] = s[1] + q[2];
-                s[3] = s[2] + q[3];
-                const long long incl = wave_inclusive_scan(s[3], lane);
-                const long long before = (long long)carry[u] + (incl - s[3]);
+                long long s0, before;
+                if (lane_constant) {  // equal increments: the prefix is a product, no scan needed
+                    before = (long long)carry[u] + q[0] * (long long)(lane * 4);
+                    s0 = q[0];
+                } else {
+                    const long long total = q[0] + q[1] + q[2] + q[3];
+                    const long long incl = wave_inclusive_scan(total, lane);
+                    before = (long long)carry[u] + (incl - total);
+                    s0 = q[0];
+                }
                 // poison: NaN/Inf increments make the reference's phase NaN from that sample on
                 const unsigned long long bad_lanes = __ballot(bad);
                 const bool poisoned_before = poison[u] != 0 || (bad_lanes & ((1ull << lane) - 1ull)) != 0;
                 const float *gtab = A.tables + (size_t)op.attr * A.table_stride;
                 const bool in_lds = TBL == 1 && op.attr == A.lds_table_id;
-                unsigned long long P = 0;
+                // phase of this lane's first sample by one exact modulo; the next three by add + single wrap (|q| < S)
+                unsigned long long P = mod_u64_lifted((unsigned long long)(before + s0) + lift, S, inv_S);
                 bool dead = poisoned_before;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    P = mod_u64_lifted((unsigned long long)(before + s[c]) + lift, S, inv_S);
-                    dead = dead || !(fabs((double)f.v[c]) <= 3.0e38);
+                    if (c > 0) {
+                        long long Pn = (long long)P + q[c];
+                        if (Pn < 0) Pn += (long long)S;
+                        if (Pn >= (long long)S) Pn -= (long long)S;
+                        P = (unsigned long long)Pn;
+                    }
+                    dead = dead || (lane_constant ? bad : !(fabs((double)f.v[c]) <= 3.0e38));
                     const uint32_t idx = (uint32_t)(P >> kFracBits);
                     const double fraction = (double)(P & ((1ull << kFracBits) - 1ull)) * (1.0 / kTwo36);
                     float ta, tb;
@@ -235,20 +246,31 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     if (A.wave_bytes > budget) return hipErrorInvalidValue;                   // plan_wave() guards this
     A.table_bytes = (uint32_t)table_bytes;
     if (!table_bytes) A.lds_table_id = -1;
-    int waves = (int)((budget - table_bytes) / A.wave_bytes);
-    // few instances: one wave per workgroup spreads them over the CUs; many: 4 waves share one table image
-    if (waves >= 4 && A.n_inst >= 1024) waves = 4;
-    else if (waves >= 2 && A.n_inst >= 512) waves = 2;
-    else waves = 1;
+    // waves per workgroup: as many as LDS holds next to the table image (they share it and hide each other's
+    // scan / lookup latency), but no more than needed to give every CU a workgroup
+    const int fit = (int)((budget - table_bytes) / A.wave_bytes);
+    const unsigned want = (A.n_inst + 255) / 256;  // instances per CU on a 256-CU part
+    int waves = 1;
+    while (waves < 16 && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * A.wave_bytes;
+#define DUSP_W(T, W) launch_wave_one<T, W>(A, lds_bytes, stream)
     if (table_bytes) {
-        if (waves == 4) return launch_wave_one<1, 4>(A, lds_bytes, stream);
-        if (waves == 2) return launch_wave_one<1, 2>(A, lds_bytes, stream);
-        return launch_wave_one<1, 1>(A, lds_bytes, stream);
+        switch (waves) {
+        case 16: return DUSP_W(1, 16);
+        case 8: return DUSP_W(1, 8);
+        case 4: return DUSP_W(1, 4);
+        case 2: return DUSP_W(1, 2);
+        default: return DUSP_W(1, 1);
+        }
     }
-    if (waves == 4) return launch_wave_one<0, 4>(A, lds_bytes, stream);
-    if (waves == 2) return launch_wave_one<0, 2>(A, lds_bytes, stream);
-    return launch_wave_one<0, 1>(A, lds_bytes, stream);
+    switch (waves) {
+    case 16: return DUSP_W(0, 16);
+    case 8: return DUSP_W(0, 8);
+    case 4: return DUSP_W(0, 4);
+    case 2: return DUSP_W(0, 2);
+    default: return DUSP_W(0, 1);
+    }
+#undef DUSP_W
 }
 
 }  // namespace dusp
