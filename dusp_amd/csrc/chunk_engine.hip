@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
     const size_t NP = a.n_pad;
     const double sr = (double)a.sample_rate;
 
-    for (uint32_t k = 0; k < a.n_chunks; ++k) {
-        const int64_t clock = a.clock0 + (int64_t)k * kChunk;
+    for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
+        const int64_t clock = a.clock0 + (int64_t)ck * kChunk;
         for (uint32_t u = 0; u < a.n_ops; ++u) {
             const DevOp &op = a.ops[u];
             float *outp = a.scratch + (size_t)(op.out_buf >= 0 ? op.out_buf : 0) * kChunk * NP + i;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                     tile[tt * 65 + lane] = v;
                 }
                 __syncthreads();
-                const uint64_t t = (uint64_t)k * kChunk + (uint64_t)tb * 64 + lane;
+                const uint64_t t = (uint64_t)ck * kChunk + (uint64_t)tb * 64 + lane;
                 if (t < a.n_samples) {
                     for (int r = 0; r < 64; ++r) {
                         const uint32_t inst = blockIdx.x * 64 + r;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
     const double PI = 3.141592653589793;
     int64_t tBuffer = a.clock0 % len;
 
-    for (uint32_t k = 0; k < a.n_chunks; ++k) {
+    for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
         for (int tb = 0; tb < kChunk / 64; ++tb) {
             for (int t0 = tb * 64; t0 < tb * 64 + 64; t0 += kBatch) {
                 float prev[kBatch], ringv[kBatch], r[kBatch];
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
             // 64 x 64 transpose: each store instruction writes 256 contiguous bytes of one instance
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint64_t t = (uint64_t)k * kChunk + (uint64_t)tb * 64 + lane;
+            const uint64_t t = (uint64_t)ck * kChunk + (uint64_t)tb * 64 + lane;
             if (t < a.n_samples) {
                 const uint32_t inst0 = (blockIdx.x * WAVES + wave) * 64;
                 for (int rr = 0; rr < 64; ++rr) {

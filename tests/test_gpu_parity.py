@@ -78,3 +78,28 @@ def test_state_write_back_matches_oracle(name, engine, oracle):
         else:
             assert np.array_equal(got, want, equal_nan=True), (u, got, want)
     prog.close()
+
+
+def test_malformed_descriptors_are_rejected_not_crashed():
+    """Truncations and single-word corruptions of real descriptors: program_build must either accept the
+    program or fail with a status + message — never crash, hang or read out of bounds."""
+    rng = np.random.RandomState(7)
+    ctx = render.context(48000)
+    poison = [np.nan, np.inf, -1.0, 0.5, 1e18, -1e18, 3.0, 65536.0, 2.0 ** 40]
+    built = rejected = 0
+    for name in ("cfg2_sweep", "loop_220", "circlebuffer_2ch", "filter_2ch", "summany_8", "map_db_semitone"):
+        g = Golden(name)
+        trials = [g.desc[:k] for k in range(0, g.desc.size, 3)]
+        for _ in range(150):
+            d2 = g.desc.copy()
+            d2[rng.randint(d2.size)] = poison[rng.randint(len(poison))]
+            trials.append(d2)
+        for words in trials:
+            try:
+                prog = ctx.build(words)
+                prog.close()
+                built += 1
+            except runtime.DuspHipError as e:
+                assert e.status in (-1, -2, -4) and e.message
+                rejected += 1
+    assert rejected > 300 and built > 50
