@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -19,6 +20,7 @@ hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
+hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, hipStream_t stream);
 hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
@@ -67,6 +69,7 @@ struct dusp_program {
     dusp::FusedPlan fused;
     dusp::WavePlan wave;
     dusp::LoopShape loop;
+    bool loop_two_stage = false;  // constant delay of at least one chunk: loop2_engine.hip
     // program constants on the device
     DevBuf<dusp::DevOp> d_ops;
     DevBuf<int32_t> d_out_bufs;
@@ -211,6 +214,16 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: the wave engine cannot run this graph (" + prog->wave.why + ")");
     std::string loop_why;
     const bool loopable = dusp::plan_loop(prog->P, prog->loop, loop_why);
+    if (loopable) {
+        const dusp::DevOperand &dl = prog->loop.delay.in[1];
+        const double len = (double)prog->loop.delay.ring_len;
+        double dconst = (double)dl.cval;
+        if (dconst >= len) dconst = std::fmod(dconst, len);
+        const char *knob = getenv("DUSP_LOOP2");
+        prog->loop_two_stage = dl.kind == dusp::SRC_CONST && std::floor(dconst) >= dusp::kChunk &&
+                               std::floor(dconst) + dusp::kChunk <= len && prog->P.g.sample_rate <= 131072 &&
+                               !(knob && knob[0] == '0');
+    }
     if (engine == DUSP_ENGINE_LOOP && !loopable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
     if (engine == DUSP_ENGINE_AUTO)
@@ -263,7 +276,8 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     info->engine = (uint32_t)prog->engine;
     info->n_device_ops = (uint32_t)prog->P.ops.size();
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
-    if (prog->engine == DUSP_ENGINE_LOOP) std::snprintf(info->shape, sizeof info->shape, "loop(osc,sum,delay,filter,gain)");
+    if (prog->engine == DUSP_ENGINE_LOOP)
+        std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE) std::snprintf(info->shape, sizeof info->shape, "feed-forward, %d chunk buffers in LDS", prog->P.n_bufs);
     return DUSP_OK;
 }
@@ -404,7 +418,10 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
     if (prog->engine == DUSP_ENGINE_LOOP) {
         const int w = prog->loop.osc.attr;
-        HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
+        if (prog->loop_two_stage)
+            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, stream));
+        else
+            HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
     } else
         HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));

@@ -202,3 +202,32 @@ def test_config4_sweep_shard_full_size(oracle):
             want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)[0]
             assert np.array_equal(out[i, 0].cpu().numpy(), want), (shard, i)
         prog.close()
+
+
+def test_loop_kernels_agree_bit_for_bit(monkeypatch):
+    """The two-stage feedback-voice kernel (delay >= one chunk), the one-stage loop kernel and the generic
+    chunk engine execute the same operations in the same order per sample: identical PCM and state."""
+    d.configure(48000)
+    def loop(k, delay):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, delay, 4096), 2000 + k)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    for delay in (480, 300.25, 3840):
+        uni = descriptor.unify([descriptor.extract(loop(k, delay)) for k in range(0, 1700, 41)])
+        n = 256 * 9 + 17
+        ctx = render.context(48000)
+        results = []
+        for engine, knob in ((runtime.ENGINE_LOOP, "1"), (runtime.ENGINE_LOOP, "0"), (runtime.ENGINE_CHUNK, "1")):
+            monkeypatch.setenv("DUSP_LOOP2", knob)
+            prog = ctx.build(uni.words, engine)
+            if engine == runtime.ENGINE_LOOP:
+                assert ("two-stage" in prog.shape) == (knob == "1")
+            pcm = prog.render(n, uni.n_instances, uni.params)
+            states = [prog.state(u, instance=3) for u in range(5)]
+            results.append((pcm, states))
+            prog.close()
+        for pcm, states in results[1:]:
+            assert np.array_equal(pcm, results[0][0])
+            for s_a, s_b in zip(states, results[0][1]):
+                assert np.array_equal(s_a, s_b, equal_nan=True)
