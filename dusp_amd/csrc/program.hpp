@@ -101,7 +101,6 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
     if (!as_count(d[7], (double)n_units - 1, out_unit)) return fail(err, "output unit out of range");
     if (d[8] != 0) return fail(err, "only outlet 0 (\"out\") can be rendered");
     if (!as_count(d[9], 9e15, clock0)) return fail(err, "bad clock");
-    if (clock0 != 0) return fail(err, "circuit has already been ticked; render a fresh circuit");
     g.sample_rate = (int)sr;
     g.chunk = (int)chunk;
     g.n_params = (int)n_params;
@@ -407,7 +406,13 @@ inline bool expand(Program &P, std::string &err) {
 }
 
 inline bool compile(const double *d, size_t nw, Program &P, std::string &err) {
-    return parse(d, nw, P.g, err) && infer_channels(P.g, err) && expand(P, err);
+    if (!(parse(d, nw, P.g, err) && infer_channels(P.g, err) && expand(P, err))) return false;
+    // A non-zero start clock is a continuation (event-segmented rendering).  Unit state travels in the
+    // descriptor, ring contents do not: refuse continuations of circuits that own delay lines.
+    if (P.g.clock0 != 0 && P.ring_samples != 0)
+        return fail(err, "continuing a circuit with Delay / CircleBuffer rings is not supported "
+                         "(scheduled events and delay lines cannot be combined on the GPU path yet)");
+    return true;
 }
 
 }  // namespace dusp

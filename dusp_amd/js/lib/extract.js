@@ -38,15 +38,15 @@ function inletConstants(inlet) {
   return Array.isArray(k) ? k.map(Math.fround) : [Math.fround(k || 0)]
 }
 
-function extract(target) {
+function extract(target, opts = {}) {
   const outlet = toOutlet(target)
   const outUnit = outlet.unit
   const circuit = outUnit.circuit || outUnit.getOrBuildCircuit()
-  if (circuit.events && circuit.events.length)
-    throw 'dusp-hip: circuits with scheduled events are not supported on the GPU path'
+  if (circuit.events && circuit.events.length && !opts.allowEvents)
+    throw 'dusp-hip: this circuit has scheduled events; extract() flattens a single segment (renderChannelData segments them)'
   if (circuit.promises && circuit.promises.length)
     throw 'dusp-hip: circuits with pending promises are not supported on the GPU path'
-  if (circuit.clock)
+  if (circuit.clock && !opts.allowClock)
     throw 'dusp-hip: circuit has already been ticked (clock=' + circuit.clock + '); render a fresh circuit'
 
   const units = circuit.units

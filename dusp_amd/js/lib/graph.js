@@ -86,6 +86,29 @@ class Inlet extends Port {
   }
 }
 
+/* Time-ordered host callbacks, run at the start of the chunk that contains them
+ * (reference src/Event.js:3-30, src/Circuit.js:57-65, src/UnitOrPatch.js:9-33). */
+class Event {
+  constructor(time, func, unit, circuit) {
+    this.time = time // seconds; `t` is the same instant in samples
+    this.function = func
+    this.unit = unit
+    this.circuit = circuit
+  }
+  get time() { return this.t / config.sampleRate }
+  set time(seconds) { this.t = seconds * config.sampleRate }
+  run() {
+    const again = this.function.call(this.unit || this.circuit || null)
+    return again > 0 ? new Event(this.time + again, this.function, this.unit, this.circuit) : null
+  }
+}
+
+function insertByTime(list, event) {
+  for (let i = 0; i < list.length; i++)
+    if (event.t < list[i].t) { list.splice(i, 0, event); return }
+  list.push(event)
+}
+
 const timesUsed = new Map()
 
 class Unit {
@@ -180,6 +203,20 @@ class Unit {
 
   getOrBuildCircuit() { return this.circuit || new Circuit(this) }
 
+  addEvent(event) {
+    if (this.circuit) this.circuit.addEvent(event)
+    else insertByTime(this.events, event)
+  }
+  schedule(time /* seconds */, func) {
+    if (Array.isArray(time)) { for (const t of time) this.schedule(t, func); return }
+    this.addEvent(new Event(time, func, this))
+    return this
+  }
+  scheduleTrigger(t, val) {
+    if (!this.trigger) throw this.label + ': cannot call scheduleTrigger because trigger is undefined'
+    this.schedule(t, function () { this.trigger(val) })
+  }
+
   trigger() {
     for (const unit of this.inputUnits) unit.trigger()
     return this
@@ -206,9 +243,8 @@ class Circuit {
       this.tickIntervals.sort((a, b) => a - b)
     }
     if (unit.events) {
-      for (const e of unit.events) this.events.push(e)
-      this.events.sort((a, b) => a.t - b.t)
-      unit.events = null
+      for (const e of unit.events) this.addEvent(e)
+      unit.events = null // from now on the unit's events go straight to the circuit
     }
     if (unit.promises) {
       for (const p of unit.promises) this.promises.push(p)
@@ -219,6 +255,19 @@ class Circuit {
     unit.computeProcessIndex()
     this.computeOrders()
     return true
+  }
+
+  addEvent(event) {
+    event.circuit = this
+    insertByTime(this.events, event)
+  }
+
+  /* run every event due before `beforeT` (samples); callbacks may return a delay in seconds to be run again */
+  runEvents(beforeT) {
+    while (this.events[0] && this.events[0].t < beforeT) {
+      const followUp = this.events.shift().run()
+      if (followUp) this.addEvent(followUp)
+    }
   }
 
   computeOrders() {
@@ -450,7 +499,7 @@ class Gain extends Unit { // Gain.js:3-10 — (gain in dB); `in` stays 0 until s
   }
 }
 
-module.exports = { Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
+module.exports = { Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
   CircleBuffer, CircleBufferNode, CircleBufferReader, CircleBufferWriter, Repeater }

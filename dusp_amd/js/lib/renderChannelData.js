@@ -51,24 +51,61 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
   circuit.clock += Math.ceil(nSamples / chunkSize) * chunkSize
 }
 
-async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Array, engine = 0, stateWriteBack = true } = {}) {
-  const ex = extract(outlet)
-  const nSamples = sampleCount(duration, ex.sampleRate)
-  const channelData = []
-  channelData.sampleRate = ex.sampleRate
-  if (nSamples === 0) return channelData
-  const n = native()
+async function renderSegment(n, ex, nSamples, engine) {
   const prog = n.programBuild(contextFor(ex.sampleRate), ex.words, engine)
   try {
     const info = n.programInfo(prog)
     const pcm = await n.render(prog, 1, nSamples, null) // Float32Array [channel][sample]
-    for (let c = 0; c < info.nOutChannels; c++) {
-      const chan = pcm.subarray(c * nSamples, (c + 1) * nSamples)
-      channelData.push(TypedArray === Float32Array ? chan : TypedArray.from(chan))
-    }
-    if (stateWriteBack) writeBack(n, prog, ex.circuit, ex.chunkSize, nSamples)
+    writeBack(n, prog, ex.circuit, ex.chunkSize, nSamples)
+    return { pcm, nChannels: info.nOutChannels }
   } finally {
     n.programDestroy(prog)
+  }
+}
+
+async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Array, engine = 0 } = {}) {
+  const first = extract(outlet, { allowEvents: true })
+  const circuit = first.circuit
+  const chunk = first.chunkSize
+  const nSamples = sampleCount(duration, first.sampleRate)
+  const channelData = []
+  channelData.sampleRate = first.sampleRate
+  if (nSamples === 0) return channelData
+  const n = native()
+  const place = (pcm, nChannels, at, len) => {
+    for (let c = 0; c < nChannels; c++) {
+      while (channelData.length <= c) channelData.push(new TypedArray(nSamples)) // late channels start as zeros (:38-39)
+      const take = Math.min(len, nSamples - at)
+      if (take > 0) channelData[c].set(pcm.subarray(c * len, c * len + take), at)
+    }
+  }
+
+  if (!circuit.events || !circuit.events.length) {
+    const seg = await renderSegment(n, first, nSamples, engine)
+    if (TypedArray === Float32Array) { // hand the rendered buffer over without a copy
+      for (let c = 0; c < seg.nChannels; c++) channelData.push(seg.pcm.subarray(c * nSamples, (c + 1) * nSamples))
+    } else place(seg.pcm, seg.nChannels, 0, nSamples)
+    return channelData
+  }
+
+  /* Event-segmented rendering (SURVEY.md 8f-3).  The reference runs every event with t < clock + chunk at the
+   * start of the tick at `clock` (Circuit.js:23,57-65), i.e. events take effect on chunk boundaries.  So: run
+   * the due callbacks on the host objects, render up to the chunk in which the next event falls due from the
+   * objects' CURRENT state, write the state back, repeat.  Circuits that also carry delay lines are refused
+   * by the library (their rings live on the device and would not survive the re-extraction). */
+  const end = Math.ceil(nSamples / chunk) * chunk
+  let clock = 0
+  while (clock < end) {
+    circuit.runEvents(clock + chunk)
+    let next = end
+    if (circuit.events.length) {
+      const due = Math.floor(circuit.events[0].t / chunk) * chunk
+      next = Math.min(end, Math.max(clock + chunk, due))
+    }
+    const ex = extract(outlet, { allowEvents: true, allowClock: true })
+    const seg = await renderSegment(n, ex, next - clock, engine) // advances circuit.clock to `next`
+    place(seg.pcm, seg.nChannels, clock, next - clock)
+    clock = next
   }
   return channelData
 }

@@ -52,11 +52,11 @@ const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
 
 async function main() {
   fs.mkdirSync(OUT, { recursive: true })
-  const index = []
+  const index = [], eventIndex = []
   for (const c of cases) {
     if (ONLY && !ONLY.includes(c.name)) continue
     const target = c.build()
-    const ex = extract(target) // before rendering: captures the initial state
+    const ex = extract(target, { allowEvents: true }) // before rendering: captures the initial state
     const order = ex.circuit.units.map((u) => u.label + ':' + u.processIndex)
     const cd = await renderChannelData(target, c.duration)
     const n = cd[0].length
@@ -73,7 +73,7 @@ async function main() {
       n_samples: n, n_channels: cd.length, windows, sha256_full: h.digest('hex'),
       reference_unit_order: order.length <= 64 ? order : order.slice(0, 8).concat(['...' + order.length + ' units']) }
     fs.writeFileSync(path.join(OUT, c.name + '.json'), JSON.stringify(meta, null, 1) + '\n')
-    index.push(c.name)
+    ;(c.name.startsWith('ev_') ? eventIndex : index).push(c.name)
     console.log(c.name, 'n=' + n, 'ch=' + cd.length, 'units=' + order.length)
   }
   // wave tables: hashes of all five, plus the few entries the docs quote (SURVEY.md §8c)
@@ -87,6 +87,7 @@ async function main() {
     }
     fs.writeFileSync(path.join(OUT, S('wavetables') + '.json'), JSON.stringify({ sample_rate: SR, tables }, null, 1) + '\n')
     fs.writeFileSync(path.join(OUT, S('index') + '.json'), JSON.stringify(index, null, 1) + '\n')
+    if (eventIndex.length) fs.writeFileSync(path.join(OUT, S('index_events') + '.json'), JSON.stringify(eventIndex, null, 1) + '\n')
   }
 }
 main().catch((e) => { console.error('gen_golden failed:', e); process.exit(1) })

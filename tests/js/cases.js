@@ -131,5 +131,30 @@ module.exports = function goldenCases(L, SR) {
     add('map_pow_negative_base', () => quick.pow(new Osc(100), 0.5), 0.01) // NaN for negative bases -> `|| 0`
     add('map_fm_semitone', () => new Osc(new Multiply(new SemitoneToRatio(new Multiply(new Osc(4), 12)), 220)), 0.05) // vibrato in semitones
   }
+
+  // SURVEY.md §8f-3: scheduled events (host callbacks at chunk boundaries).  `ev_` cases are rendered only
+  // through the JS surface (tests/js/check_render.js): their descriptor alone does not carry the callbacks.
+  add('ev_retrigger', () => {
+    const r = new Ramp(2400, 1, 0)
+    r.scheduleTrigger(0.01)
+    r.scheduleTrigger(0.08)
+    return new Multiply(new Osc(440), r)
+  }, 0.15)
+  add('ev_freq_steps', () => {
+    const osc = new Osc(220)
+    osc.schedule([0.02, 0.05, 0.09], function () { this.F = this.F.constant * 1.5 })
+    return osc
+  }, 0.12)
+  add('ev_repeating', () => {
+    const r = new Ramp(600, 1, 0.25)
+    r.schedule(0.004, function () { this.trigger(); return 0.03 }) // a positive return value reschedules (Event.js:20-27)
+    return new Multiply(new Osc(330.5, 'triangle'), r)
+  }, 0.13)
+  add('ev_filter_sweep', () => {
+    const filt = new Filter(new Osc(100, 'saw'), 500)
+    filt.schedule(0.03, function () { this.F = 2500 })
+    filt.schedule(0.06, function () { this.F = 800 })
+    return filt
+  }, 0.1)
   return cases
 }
