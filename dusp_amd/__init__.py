@@ -6,8 +6,8 @@ ctypes binding of the HIP library (runtime.py).  Device side: dusp_amd/csrc/.
 """
 from . import config, descriptor, quick, runtime  # noqa: F401
 from .descriptor import DuspError  # noqa: F401
-from .graph import (Abs, Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, DecibelToScaler, Delay,  # noqa: F401
-                    Divide, Filter, FixedMultiply, Gain, HardClipAbove, HardClipBelow, Multiply, Osc, PolarityInvert, Pow,
+from .graph import (Abs, AllPass, Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, CombFilter, DecibelToScaler, Delay,  # noqa: F401
+                    Divide, Filter, FixedDelay, FixedMultiply, Gain, MonoDelay, MultiChannelOsc, ReadBackDelay, HardClipAbove, HardClipBelow, Multiply, Osc, PolarityInvert, Pow,
                     Ramp, Repeater, SecondsToSamples, SemitoneToRatio, Subtract, Sum, Unit)
 from .render import ChannelData, render_many, renderChannelData  # noqa: F401
 from .runtime import Context, DuspHipError, Program  # noqa: F401

@@ -314,6 +314,98 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[0] = T + (double)kChunk;
                 break;
             }
+            case OP_FIXED_DELAY:   // FixedDelay.js:13-19
+            case OP_COMB_FILTER:   // CombFilter.js:11-17
+            case OP_ALL_PASS: {    // AllPass.js:8-15
+                const Src x = make_src(op.in[0], a, i), fb = make_src(op.in[1], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const int64_t len = op.ring_len;
+                int64_t tB = (int64_t)st[0];
+                for (int t = 0; t < kChunk; ++t) {
+                    if (++tB >= len) tB = 0;  // (tBuffer + 1) % length
+                    float *slot = ring + (size_t)tB * NP;
+                    const float xin = x.at(t), delayOut = *slot;
+                    if (op.op == OP_FIXED_DELAY) {
+                        outp[(size_t)t * NP] = delayOut;
+                        *slot = xin;
+                    } else if (op.op == OP_COMB_FILTER) {
+                        outp[(size_t)t * NP] = delayOut;
+                        *slot = (float)((double)xin + (double)delayOut * (double)fb.at(t));
+                    } else {
+                        const double g = (double)fb.at(t);
+                        *slot = (float)((double)xin + (double)delayOut * g);
+                        outp[(size_t)t * NP] = (float)((double)delayOut - (double)xin * g);
+                    }
+                }
+                st[0] = (double)tB;
+                break;
+            }
+            case OP_MONO_DELAY: {  // MonoDelay.js:16-30: write first (ceil tap wraps), then read and clear
+                const Src x = make_src(op.in[0], a, i), dl = make_src(op.in[1], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const int64_t len = op.ring_len;
+                const double dlen = (double)len;
+                int64_t tBuffer = clock % len;
+                for (int t = 0; t < kChunk; ++t) {
+                    double tWrite = (double)tBuffer + (double)dl.at(t);
+                    if (!(tWrite >= 0.0 && tWrite < dlen))
+                        tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
+                    const double lo = floor(tWrite), frac = tWrite - trunc(tWrite);
+                    double hi = ceil(tWrite);
+                    if (hi >= dlen) hi -= dlen;  // Math.ceil(tWrite) % length
+                    const double xin = (double)x.at(t);
+                    if (lo >= 0.0 && lo < dlen) {
+                        float *p = ring + (size_t)(int64_t)lo * NP;
+                        *p = (float)((double)*p + xin * (1.0 - frac));
+                    }
+                    if (hi >= 0.0 && hi < dlen) {
+                        float *p = ring + (size_t)(int64_t)hi * NP;
+                        *p = (float)((double)*p + xin * frac);
+                    }
+                    outp[(size_t)t * NP] = ring[(size_t)tBuffer * NP];
+                    ring[(size_t)tBuffer * NP] = 0.f;
+                    if (++tBuffer == len) tBuffer = 0;
+                }
+                break;
+            }
+            case OP_READBACK_DELAY: {  // ReadBackDelay.js:24-44
+                const Src x = make_src(op.in[0], a, i), dl = make_src(op.in[1], a, i);
+                float *ring = a.rings + (size_t)op.ring_base * NP + i;
+                const double dlen = (double)op.ring_len;
+                const double T0 = st[0];
+                int64_t w = (int64_t)fmod(T0, dlen);
+                for (int t = 0; t < kChunk; ++t) {
+                    ring[(size_t)w * NP] = x.at(t);
+                    double r = (T0 + (double)t) - (double)dl.at(t) + dlen;
+                    r = (r >= 0.0 && r < dlen) ? r : fmod(r, dlen);
+                    // a fractional or negative index reads `undefined` -> NaN in the reference
+                    outp[(size_t)t * NP] = (r >= 0.0 && r < dlen && r == floor(r)) ? ring[(size_t)(int64_t)r * NP] : __builtin_nanf("");
+                    if (++w >= op.ring_len) w = 0;
+                }
+                st[0] = T0 + (double)kChunk;
+                break;
+            }
+            case OP_MULTI_OSC: {  // MultiChannelOsc.js:21-38: no `phase < 0` fix-up, so negative phases read NaN
+                const Src f = make_src(op.in[0], a, i);
+                const float *tbl = a.tables + (size_t)op.attr * a.table_stride;
+                double phase = or0(st[0]);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float fv[kBatch], r[kBatch];
+                    double ph[kBatch];
+                    f.load(t0, fv);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        double p = phase + (double)fv[k];
+                        if (fabs(p) >= sr) p = fmod(p, sr);
+                        ph[k] = phase = p;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) r[k] = osc_lookup(tbl, ph[k], sr);
+                    store_batch(outp, NP, t0, r);
+                }
+                st[0] = phase;
+                break;
+            }
             default: {  // stateless elementwise maps (map_ops.hpp)
                 const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
                 for (int t0 = 0; t0 < kChunk; t0 += kBatch) {

@@ -9,6 +9,8 @@ enum : int {
     // elementwise maps
     OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW,
     OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW,
+    // delay / filter family, per-channel oscillator
+    OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC,
     OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW
 };
 enum : int { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };   // descriptor inlet kinds

@@ -487,7 +487,15 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
         };
         const int n_ch = (u.op == dusp::OP_FILTER) ? u.n_out : 1;
         const int per = u.op == dusp::OP_DELAY ? 0 : u.slots_per_ch;  // Delay's slot is engine-internal, not unit state
-        if (u.op == dusp::OP_FILTER) {
+        // (FixedDelay / CombFilter / AllPass / ReadBackDelay: one word, the ring position; MonoDelay: none)
+        if (u.op == dusp::OP_MULTI_OSC) {  // [n, phase per channel]
+            words.push_back((double)u.n_out);
+            for (int c = 0; c < u.n_out; c++) {
+                double v;
+                HIP_TRY(ctx, rd(u.first_slot + c * per, v));
+                words.push_back(v);
+            }
+        } else if (u.op == dusp::OP_FILTER) {
             for (int k = 0; k < 7; k++) {
                 double v;
                 HIP_TRY(ctx, rd(u.first_slot + k, v));

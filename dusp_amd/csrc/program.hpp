@@ -204,6 +204,23 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         case OP_FIXED_MULTIPLY:
             if (!need(1, 1, 0)) return fail(err, where + "bad FixedMultiply record");
             break;
+        case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY: case OP_MONO_DELAY: {
+            int64_t len, tb = 0;
+            const size_t n_in = u.op == OP_FIXED_DELAY ? 1 : 2, n_st = u.op == OP_MONO_DELAY ? 0 : 1;
+            if (!need(n_in, 1, n_st) || !as_count(u.attrs[0], 1e9, len) || len < 1) return fail(err, where + "bad delay-family record");
+            if (n_st && u.op != OP_READBACK_DELAY && (!as_count(u.state[0], (double)len - 1, tb))) return fail(err, where + "bad ring position");
+            if (u.op == OP_READBACK_DELAY && !(u.state[0] >= 0 && u.state[0] < 9e15 && u.state[0] == std::floor(u.state[0])))
+                return fail(err, where + "bad ring position");
+            break;
+        }
+        case OP_MULTI_OSC: {
+            int64_t nph;
+            if (!need(1, 1, SIZE_MAX) || u.state.empty() || !as_count(u.state[0], 64, nph) || u.state.size() != (size_t)(1 + nph))
+                return fail(err, where + "bad MultiChannelOsc record");
+            if (!(u.attrs[0] >= 0 && u.attrs[0] < kNumTables && u.attrs[0] == std::floor(u.attrs[0])))
+                return fail(err, where + "waveform doesn't exist");
+            break;
+        }
         default:
             return fail(err, where + "unknown opcode " + std::to_string(u.op));
         }
@@ -226,6 +243,9 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_REPEATER: return std::max(1, nin(0));                         // Repeater.js:24-25
     case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: return std::max(nin(0), nin(1));
     case OP_FIXED_MULTIPLY: return 1;                                     // mono in / mono out
+    case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_MONO_DELAY: return 1;  // mono units
+    case OP_READBACK_DELAY: return std::max(1, std::max(nin(0), nin(1)));  // ReadBackDelay.js:27
+    case OP_MULTI_OSC: return std::max(1, nin(0));                         // MultiChannelOsc.js:22
     }
     if (u.op >= OP_MAP_FIRST && u.op <= OP_MAP_LAST) return std::max(1, nin(0));  // loop `c < this.in.length`
     return 1;
@@ -392,6 +412,22 @@ inline bool expand(Program &P, std::string &err) {
                 break;
             case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
                 op.in[0] = make_operand(g, u.inlets[0], c);
+                break;
+            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_MONO_DELAY: case OP_READBACK_DELAY: {
+                const bool mono = u.op != OP_READBACK_DELAY;
+                op.in[0] = make_operand(g, u.inlets[0], mono ? 0 : c);
+                if (u.inlets.size() > 1) op.in[1] = make_operand(g, u.inlets[1], mono ? 0 : c);
+                op.ring_len = (int64_t)u.attrs[0];
+                op.ring_base = ring_pos;
+                P.dev_rings.push_back({ring_pos, op.ring_len});
+                ring_pos += op.ring_len;
+                if (u.op != OP_MONO_DELAY) slot(u.state[0]);  // tBuffer (MonoDelay indexes with the circuit clock)
+                break;
+            }
+            case OP_MULTI_OSC:
+                op.attr = (int)u.attrs[0];
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                slot(c < (int)u.state[0] ? u.state[(size_t)(1 + c)] : 0.0);  // `this.phase[c] = this.phase[c] || 0`
                 break;
             }
             if (c == 0) u.slots_per_ch = (int)P.init_state.size() - u.first_slot;

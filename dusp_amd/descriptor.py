@@ -16,6 +16,7 @@ HEADER_WORDS = 12
 OP_OSC, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER = range(1, 10)
 (OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW, OP_SECONDS_TO_SAMPLES,
  OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW) = range(10, 23)  # elementwise maps
+OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC = range(23, 29)  # §8f-2
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
@@ -42,6 +43,12 @@ UNITS = {
     "DecibelToScaler": (OP_DECIBEL_TO_SCALER, ["in"]),
     "SemitoneToRatio": (OP_SEMITONE_TO_RATIO, ["in"]),
     "Pow": (OP_POW, ["a", "b"]),
+    "FixedDelay": (OP_FIXED_DELAY, ["in"]),
+    "CombFilter": (OP_COMB_FILTER, ["in", "feedbackGain"]),
+    "AllPass": (OP_ALL_PASS, ["in", "feedbackGain"]),
+    "MonoDelay": (OP_MONO_DELAY, ["in", "delay"]),
+    "ReadBackDelay": (OP_READBACK_DELAY, ["in", "delay"]),
+    "MultiChannelOsc": (OP_MULTI_OSC, ["f"]),
 }
 
 
@@ -125,6 +132,14 @@ def extract(target):
             attrs, state = [ring_id(unit.buffer), 1 if unit.preWipe else 0], [unit.t]
         elif op == OP_FIXED_MULTIPLY:
             attrs = [float(unit.sf)]  # a plain number on the unit, not an inlet (FixedMultiply.js:8,20)
+        elif op in (OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS):
+            attrs, state = [unit.delayTimeInSamples], [unit.tBuffer]
+        elif op == OP_MONO_DELAY:
+            attrs = [unit.maxDelay]
+        elif op == OP_READBACK_DELAY:
+            attrs, state = [unit.bufferLength], [unit.tBuffer]
+        elif op == OP_MULTI_OSC:
+            attrs, state = [WAVEFORMS[unit.waveform]], [len(unit.phase)] + [p or 0 for p in unit.phase]
         body += [op, len(inlet_names), len(attrs), len(state)]
         for name in inlet_names:
             inlet = unit.inlets[name]

@@ -133,26 +133,32 @@ class Unit:
         Unit._times_used[kind] = Unit._times_used.get(kind, 0) + 1
         self.label = "%s%d" % (kind, Unit._times_used[kind])
 
-    # `unit.F = 440` / `unit.F = otherUnit` and `unit.OUT`  (Unit.js:56-67, 82)
+    # `unit.F = 440` / `unit.F = otherUnit` and `unit.OUT`: the accessor is the port name upper-cased
+    # (Unit.js:56-67, 82), e.g. inlet "feedbackGain" -> unit.FEEDBACKGAIN
+    def _port(self, upper_name, table):
+        for name, port in table.items():
+            if name.upper() == upper_name:
+                return port
+        return None
+
     def __setattr__(self, name, value):
-        if name.isupper() and name.lower() in self.inlets:
-            inlet = self.inlets[name.lower()]
-            if value is None:
-                raise ValueError("Passed bad value to " + inlet.label)
-            if isinstance(value, (int, float, list, tuple, np.floating, np.integer)):
-                inlet.setConstant(value)
-            elif getattr(value, "isOutlet", False) or getattr(value, "isUnit", False):
-                inlet.connect(value)
-            return
+        if name.isupper():
+            inlet = self._port(name, self.inlets)
+            if inlet is not None:
+                if value is None:
+                    raise ValueError("Passed bad value to " + inlet.label)
+                if isinstance(value, (int, float, list, tuple, np.floating, np.integer)):
+                    inlet.setConstant(value)
+                elif getattr(value, "isOutlet", False) or getattr(value, "isUnit", False):
+                    inlet.connect(value)
+                return
         object.__setattr__(self, name, value)
 
     def __getattr__(self, name):
         if name.isupper():
-            low = name.lower()
-            if low in self.inlets:
-                return self.inlets[low]
-            if low in self.outlets:
-                return self.outlets[low]
+            port = self._port(name, self.inlets) or self._port(name, self.outlets)
+            if port is not None:
+                return port
         raise AttributeError(name)
 
     def addInlet(self, name, **opts):
@@ -563,3 +569,95 @@ class Gain(Unit):
         self.addInlet("gain", mono=True)
         self.addOutlet("out")
         self.GAIN = gain or 0
+
+
+# --------------------------------------------------------------------------- delay / filter family
+def _js_round(x):
+    return math.floor(x + 0.5)
+
+
+class FixedDelay(Unit):
+    """reference src/components/FixedDelay.js:4-33 — (delayTime in seconds); `in` stays 0 until set"""
+
+    def __init__(self, delayTime):
+        super().__init__()
+        self.addInlet("in", mono=True)
+        self.addOutlet("out", mono=True)
+        self.setSeconds(delayTime)
+        self.tBuffer = 0
+
+    def setDelayTime(self, tSamples):
+        if not tSamples or tSamples < 0.5:
+            raise ValueError("Cannot have fixed delay of length 0 samples")  # the reference's message
+        self.delayTimeInSamples = _js_round(tSamples)
+        self.delayTimeInSeconds = tSamples / self.sampleRate
+
+    def setSeconds(self, duration):
+        self.setDelayTime(duration * self.sampleRate)
+
+    def setFrequency(self, f):
+        self.setSeconds(1 / f)
+
+
+class CombFilter(FixedDelay):
+    """reference src/components/CombFilter.js:4-9"""
+
+    def __init__(self, delayTime, feedbackGain=None):
+        super().__init__(delayTime)
+        self.addInlet("feedbackGain", mono=True)
+        self.FEEDBACKGAIN = feedbackGain or 0
+
+
+class AllPass(CombFilter):
+    """reference src/components/AllPass.js:4-7"""
+
+
+class MonoDelay(Unit):
+    """reference src/components/MonoDelay.js:3-14 — delay in SAMPLES, fixed 5 s ring"""
+
+    def __init__(self, input=None, delay=None):
+        super().__init__()
+        self.addInlet("in", mono=True)
+        self.addInlet("delay", mono=True)
+        self.addOutlet("out", mono=True)
+        self.maxDelay = self.sampleRate * 5
+        self.IN = input or 0
+        self.DELAY = delay or 4410
+
+
+class ReadBackDelay(Unit):
+    """reference src/components/ReadBackDelay.js:4-17"""
+
+    def __init__(self, input=None, delay=None, bufferLength=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("delay")
+        self.addOutlet("out")
+        self.bufferLength = bufferLength or config.sampleRate
+        self.tBuffer = 0
+        self.IN = input or 0
+        self.DELAY = delay or 0
+
+
+class MultiChannelOsc(Unit):
+    """reference src/components/Osc/MultiChannelOsc.js:7-17 — one phase per channel of f"""
+
+    def __init__(self, f=None, waveform=None):
+        super().__init__()
+        self.addInlet("f")
+        self.addOutlet("out")
+        self.F = f or 440
+        self.phase = []
+        self.waveform = waveform or "sin"
+
+    @property
+    def waveform(self):
+        return self._waveform
+
+    @waveform.setter
+    def waveform(self, value):
+        from .wavetables import WAVEFORMS
+
+        if value not in WAVEFORMS:
+            raise ValueError("waveform doesn't exist: %s" % value)
+        object.__setattr__(self, "_waveform", value)

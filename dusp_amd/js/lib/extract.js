@@ -105,6 +105,22 @@ function extract(target, opts = {}) {
       case OP.FIXED_MULTIPLY:
         attrs = [Number(unit.sf)] // a plain JS number on the unit, not an inlet (FixedMultiply.js:8,20)
         break
+      case OP.FIXED_DELAY: case OP.COMB_FILTER: case OP.ALL_PASS: // ring = round(delayTime * sr) samples (FixedDelay.js:24-26)
+        attrs = [unit.delayTimeInSamples]; state = [unit.tBuffer]
+        break
+      case OP.MONO_DELAY:
+        attrs = [unit.maxDelay]
+        break
+      case OP.READBACK_DELAY:
+        attrs = [unit.bufferLength]; state = [unit.tBuffer]
+        break
+      case OP.MULTI_OSC: {
+        const w = WAVEFORMS[unit.waveform]
+        if (w === undefined) throw "waveform doesn't exist: " + unit.waveform
+        attrs = [w]
+        state = [unit.phase.length].concat(Array.from(unit.phase, (p) => p || 0))
+        break
+      }
     }
 
     body.push(spec.op, spec.inlets.length, attrs.length, state.length)

@@ -499,7 +499,73 @@ class Gain extends Unit { // Gain.js:3-10 — (gain in dB); `in` stays 0 until s
   }
 }
 
-module.exports = { Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
+/* ---- delay / filter family (SURVEY.md §8f-2) */
+class FixedDelay extends Unit { // FixedDelay.js:4-33 — (delayTime in seconds); `in` stays 0 until set
+  constructor(delayTime) {
+    super()
+    this.addInlet('in', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.setSeconds(delayTime)
+    this.tBuffer = 0
+  }
+  setDelayTime(tSamples) {
+    if (!tSamples || tSamples < 0.5) throw 'Cannot have fixed delay of length 0 samples' // the reference's message
+    this.delayTimeInSamples = Math.round(tSamples)
+    this.delayTimeInSeconds = tSamples / this.sampleRate
+  }
+  setSeconds(duration) { this.setDelayTime(duration * this.sampleRate) }
+  setFrequency(f) { this.setSeconds(1 / f) }
+}
+class CombFilter extends FixedDelay { // CombFilter.js:4-9
+  constructor(delayTime, feedbackGain) {
+    super(delayTime)
+    this.addInlet('feedbackGain', { mono: true })
+    this.FEEDBACKGAIN = feedbackGain || 0
+  }
+  set totalReverbTime(RVT) { this.FEEDBACKGAIN = Math.pow(0.001, this.delayTimeInSeconds / RVT) } // CombFilter.js:23-25
+}
+class AllPass extends CombFilter {} // AllPass.js:4-7
+class MonoDelay extends Unit { // MonoDelay.js:3-14 — delay in SAMPLES, fixed 5 s ring
+  constructor(input, delay) {
+    super()
+    this.addInlet('in', { mono: true })
+    this.addInlet('delay', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.maxDelay = this.sampleRate * 5
+    this.IN = input || 0
+    this.DELAY = delay || 4410
+  }
+}
+class ReadBackDelay extends Unit { // ReadBackDelay.js:4-17
+  constructor(input, delay, bufferLength) {
+    super()
+    this.addInlet('in')
+    this.addInlet('delay')
+    this.addOutlet('out')
+    this.bufferLength = bufferLength || config.sampleRate
+    this.tBuffer = 0
+    this.IN = input || 0
+    this.DELAY = delay || 0
+  }
+}
+class MultiChannelOsc extends Unit { // Osc/MultiChannelOsc.js:7-17 — one phase per channel of f
+  constructor(f, waveform) {
+    super()
+    this.addInlet('f')
+    this.addOutlet('out')
+    this.F = f || 440
+    this.phase = []
+    this.waveform = waveform || 'sin'
+  }
+  get waveform() { return this._waveform }
+  set waveform(w) {
+    if (WAVEFORMS[w] === undefined) throw "waveform doesn't exist: " + w
+    this._waveform = w
+  }
+  resetPhase() { for (const i in this.phase) this.phase[i] = 0 }
+}
+
+module.exports = { FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
   CircleBuffer, CircleBufferNode, CircleBufferReader, CircleBufferWriter, Repeater }

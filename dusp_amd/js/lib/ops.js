@@ -18,6 +18,8 @@ const OP = Object.freeze({
   // elementwise maps (SURVEY.md §8f-1)
   SUBTRACT: 10, DIVIDE: 11, POLARITY_INVERT: 12, ABS: 13, CLIP: 14, HARD_CLIP_ABOVE: 15, HARD_CLIP_BELOW: 16,
   SECONDS_TO_SAMPLES: 17, FIXED_MULTIPLY: 18, GAIN: 19, DECIBEL_TO_SCALER: 20, SEMITONE_TO_RATIO: 21, POW: 22,
+  // delay / filter family and the per-channel oscillator (SURVEY.md §8f-2)
+  FIXED_DELAY: 23, COMB_FILTER: 24, ALL_PASS: 25, MONO_DELAY: 26, READBACK_DELAY: 27, MULTI_OSC: 28,
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -50,6 +52,12 @@ const UNITS = Object.freeze({
   DecibelToScaler: { op: OP.DECIBEL_TO_SCALER, inlets: ['in'] },
   SemitoneToRatio: { op: OP.SEMITONE_TO_RATIO, inlets: ['in'] },
   Pow: { op: OP.POW, inlets: ['a', 'b'] },
+  FixedDelay: { op: OP.FIXED_DELAY, inlets: ['in'] },
+  CombFilter: { op: OP.COMB_FILTER, inlets: ['in', 'feedbackGain'] },
+  AllPass: { op: OP.ALL_PASS, inlets: ['in', 'feedbackGain'] },
+  MonoDelay: { op: OP.MONO_DELAY, inlets: ['in', 'delay'] },
+  ReadBackDelay: { op: OP.READBACK_DELAY, inlets: ['in', 'delay'] },
+  MultiChannelOsc: { op: OP.MULTI_OSC, inlets: ['f'] },
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, UNITS }

@@ -39,6 +39,9 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
     if (spec.op === OP.OSC) unit.phase = n.stateDownload(prog, 0, u)[0]
     else if (spec.op === OP.RAMP) { const s = n.stateDownload(prog, 0, u); unit.t = s[0]; unit.playing = s[1] !== 0 }
     else if (spec.op === OP.CB_READER || spec.op === OP.CB_WRITER) unit.t = n.stateDownload(prog, 0, u)[0]
+    else if (spec.op === OP.FIXED_DELAY || spec.op === OP.COMB_FILTER || spec.op === OP.ALL_PASS || spec.op === OP.READBACK_DELAY)
+      unit.tBuffer = n.stateDownload(prog, 0, u)[0]
+    else if (spec.op === OP.MULTI_OSC) { const s = n.stateDownload(prog, 0, u); for (let c = 0; c < s[0]; c++) unit.phase[c] = s[1 + c] }
     else if (spec.op === OP.FILTER) {
       const s = n.stateDownload(prog, 0, u)
       if (s[0]) unit.lastF = s[1]

@@ -23,7 +23,9 @@
 enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_WRITER, OP_REPEATER,
        /* elementwise maps */
        OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW,
-       OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW };
+       OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW,
+       /* delay / filter family, per-channel oscillator */
+       OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC };
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
 
 /* ---- SignalChunk (reference src/SignalChunk.js:1-11): channelData[c] = Float32Array(chunkSize).
@@ -112,6 +114,11 @@ typedef struct unit {
     double cb_t;
     /* FixedMultiply */
     double sf;
+    /* FixedDelay / CombFilter / AllPass / ReadBackDelay: ring length and write head; MultiChannelOsc: phases */
+    long fd_len;
+    double tBuffer;
+    int nphase;
+    double *phases;
 } unit_t;
 
 struct dusp_oracle {
@@ -337,6 +344,95 @@ static void tick_repeater(dusp_oracle *o, unit_t *u) {
     }
 }
 
+/* reference src/components/FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15 (mono in, mono out) */
+static void tick_fixed_delay(dusp_oracle *o, unit_t *u) {
+    const float *in = inlet_chunk(o, u, 0)->ch[0];
+    const float *fb = u->n_inlets > 1 ? inlet_chunk(o, u, 1)->ch[0] : NULL;
+    float *out = u->out.ch[0], *buf = u->buffers[0];
+    for (int t = 0; t < o->chunk; t++) {
+        u->tBuffer = fmod(u->tBuffer + 1, (double)u->fd_len);
+        const long tb = (long)u->tBuffer;
+        if (u->op == OP_FIXED_DELAY) {
+            out[t] = buf[tb];
+            buf[tb] = in[t];
+        } else if (u->op == OP_COMB_FILTER) {
+            out[t] = buf[tb];
+            buf[tb] = (float)((double)in[t] + (double)out[t] * (double)fb[t]);
+        } else {
+            const double delayOut = buf[tb];
+            buf[tb] = (float)((double)in[t] + delayOut * (double)fb[t]);
+            out[t] = (float)(delayOut - (double)in[t] * (double)fb[t]);
+        }
+    }
+}
+
+/* reference src/components/MonoDelay.js:16-30: writes first (the ceil tap WRAPS here, unlike Delay.js), then reads */
+static void tick_mono_delay(dusp_oracle *o, unit_t *u, long clock) {
+    const float *in = inlet_chunk(o, u, 0)->ch[0], *delay = inlet_chunk(o, u, 1)->ch[0];
+    float *out = u->out.ch[0], *buf = u->buffers[0];
+    const double len = (double)u->maxDelay;
+    for (int t = 0; t < o->chunk; t++) {
+        const long tBuffer = (clock + t) % u->maxDelay;
+        const double tWrite = fmod((double)tBuffer + (double)delay[t], len);
+        const double lo = floor(tWrite), hi = fmod(ceil(tWrite), len), frac = fmod(tWrite, 1.0);
+        if (lo >= 0 && lo < len) buf[(long)lo] = (float)((double)buf[(long)lo] + (double)in[t] * (1 - frac));
+        if (hi >= 0 && hi < len) buf[(long)hi] = (float)((double)buf[(long)hi] + (double)in[t] * frac); /* -0 indexes slot 0 */
+        out[t] = buf[tBuffer];
+        buf[tBuffer] = 0;
+    }
+}
+
+/* reference src/components/ReadBackDelay.js:24-44 (`delay > bufferLength` throws there; here it reads NaN) */
+static void tick_readback_delay(dusp_oracle *o, unit_t *u) {
+    chunk_t *in = inlet_chunk(o, u, 0), *dl = inlet_chunk(o, u, 1);
+    const double len = (double)u->fd_len;
+    const double t0 = u->tBuffer;
+    for (int c = 0; c < in->nch || c < dl->nch; c++) {
+        const float *input = in->ch[c % in->nch], *delay = dl->ch[c % dl->nch];
+        float *output = chunk_ensure(&u->out, c, o->chunk);
+        if (c >= u->nbuffers) {
+            u->buffers = (float **)realloc(u->buffers, (size_t)(c + 1) * sizeof(float *));
+            for (int i = u->nbuffers; i <= c; i++) u->buffers[i] = (float *)calloc((size_t)u->fd_len, sizeof(float));
+            u->nbuffers = c + 1;
+        }
+        float *buf = u->buffers[c];
+        for (int i = 0; i < o->chunk; i++) {
+            const double t = t0 + i;
+            buf[(long)fmod(t + len, len)] = input[i];
+            const double r = fmod(t - (double)delay[i] + len, len);
+            output[i] = (r >= 0 && r < len && r == floor(r)) ? buf[(long)r] : NAN; /* fractional / negative index: undefined */
+        }
+    }
+    u->tBuffer = t0 + o->chunk;
+}
+
+/* reference src/components/Osc/MultiChannelOsc.js:21-38: one phase per channel of f, and NO `phase < 0` fix-up */
+static void tick_multi_osc(dusp_oracle *o, unit_t *u) {
+    chunk_t *fch = inlet_chunk(o, u, 0);
+    const float *tbl = o->tables[u->waveform];
+    const double sr = o->sr;
+    for (int c = 0; c < fch->nch; c++) {
+        if (c >= u->nphase) {
+            u->phases = (double *)realloc(u->phases, (size_t)(c + 1) * sizeof(double));
+            for (int i = u->nphase; i <= c; i++) u->phases[i] = 0;
+            u->nphase = c + 1;
+        }
+        float *out = chunk_ensure(&u->out, c, o->chunk);
+        const float *f = fch->ch[c];
+        double phase = or0(u->phases[c]); /* `this.phase[c] = this.phase[c] || 0` */
+        for (int t = 0; t < o->chunk; t++) {
+            phase += (double)f[t];
+            phase = fmod(phase, sr);
+            const double fraction = fmod(phase, 1.0);
+            const double lo = floor(phase), hi = ceil(phase);
+            const double a = (lo >= 0 && lo <= sr) ? (double)tbl[(long)lo] : NAN;
+            const double b = (hi >= 0 && hi <= sr) ? (double)tbl[(long)hi] : NAN;
+            out[t] = (float)(a * (1 - fraction) + b * fraction);
+        }
+        u->phases[c] = phase;
+    }
+}
+
 /* Math.pow: like C pow except pow(+-1, +-Inf) and pow(x, NaN) are NaN (ECMA-262 Number::exponentiate) */
 static double js_pow(double x, double y) {
     if (y != y) return NAN;
@@ -407,6 +503,10 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_CB_READER: tick_cb_reader(o, u); break;
         case OP_CB_WRITER: tick_cb_writer(o, u); break;
         case OP_REPEATER: tick_repeater(o, u); break;
+        case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: tick_fixed_delay(o, u); break;
+        case OP_MONO_DELAY: tick_mono_delay(o, u, o->clock); break;
+        case OP_READBACK_DELAY: tick_readback_delay(o, u); break;
+        case OP_MULTI_OSC: tick_multi_osc(o, u); break;
         default: tick_map(o, u); break;
         }
     }
@@ -556,6 +656,31 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             if (u->n_inlets != 1 || n_attr != 1 || n_state) FAIL("unit %zu: bad FixedMultiply record", i);
             u->sf = a[0];
             break;
+        case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY:
+            if (u->n_inlets != (u->op == OP_FIXED_DELAY ? 1 : 2) || n_attr != 1 || n_state != 1 || !(a[0] >= 1 && a[0] < 1e9))
+                FAIL("unit %zu: bad delay-family record", i);
+            u->fd_len = (long)a[0];
+            u->tBuffer = s[0];
+            u->buffers = (float **)calloc(1, sizeof(float *));
+            u->buffers[0] = (float *)calloc((size_t)u->fd_len, sizeof(float));
+            u->nbuffers = 1;
+            break;
+        case OP_MONO_DELAY:
+            if (u->n_inlets != 2 || n_attr != 1 || n_state || !(a[0] >= 1 && a[0] < 1e9)) FAIL("unit %zu: bad MonoDelay record", i);
+            u->maxDelay = (long)a[0];
+            u->buffers = (float **)calloc(1, sizeof(float *));
+            u->buffers[0] = (float *)calloc((size_t)u->maxDelay, sizeof(float));
+            u->nbuffers = 1;
+            break;
+        case OP_MULTI_OSC: {
+            if (u->n_inlets != 1 || n_attr != 1 || n_state < 1 || n_state != (size_t)(1 + s[0])) FAIL("unit %zu: bad MultiChannelOsc record", i);
+            u->waveform = (int)a[0];
+            if (u->waveform < 0 || u->waveform > 4) FAIL("bad waveform");
+            u->nphase = (int)s[0];
+            u->phases = (double *)calloc((size_t)u->nphase + 1, sizeof(double));
+            for (int c = 0; c < u->nphase; c++) u->phases[c] = s[1 + c];
+            break;
+        }
         default: FAIL("unit %zu: unknown opcode %d", i, u->op);
         }
         chunk_init(&u->out, out_channels, o->chunk);
@@ -578,6 +703,7 @@ void dusp_oracle_destroy(dusp_oracle *o) {
         for (int b = 0; b < u->nbuffers; b++) free(u->buffers[b]);
         free(u->buffers);
         free(u->x1); free(u->x2); free(u->y1); free(u->y2);
+        free(u->phases);
         for (int c = 0; c < u->out.nch; c++) { /* a consumer Delay may have appended aliases */
             int dup = 0;
             for (int e = 0; e < c; e++) dup |= u->out.ch[e] == u->out.ch[c];
@@ -611,6 +737,10 @@ size_t dusp_oracle_unit_state(const dusp_oracle *o, size_t i, double *out, size_
     case OP_OSC: tmp[n++] = u->phase; break;
     case OP_RAMP: tmp[n++] = u->t; tmp[n++] = u->playing; break;
     case OP_CB_READER: case OP_CB_WRITER: tmp[n++] = u->cb_t; break;
+    case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY: tmp[n++] = u->tBuffer; break;
+    case OP_MULTI_OSC:
+        for (size_t k = 0; k < (size_t)u->nphase + 1 && k < cap; k++) out[k] = k ? u->phases[k - 1] : (double)u->nphase;
+        return (size_t)u->nphase + 1;
     case OP_FILTER: {
         const size_t total = 8 + 4 * (size_t)u->nstate;
         double head[8] = { (double)u->has_lastF, u->lastF, u->a0, u->a1, u->a2, u->b1, u->b2, (double)u->nstate };

@@ -43,7 +43,9 @@ const CircleBufferWriter = ref('components/CircleBufferWriter.js')
 const quick = ref('quick.js')
 const more = {}
 for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardClipAbove', 'HardClipBelow', 'SecondsToSamples',
-  'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow']) more[n] = ref('components/' + n + '.js')
+  'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow', 'FixedDelay', 'CombFilter', 'AllPass', 'MonoDelay',
+  'ReadBackDelay']) more[n] = ref('components/' + n + '.js')
+more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
 const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,

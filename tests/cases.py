@@ -3,8 +3,8 @@ graph classes (dusp_amd/graph.py).  Used to check that the host mirror produces
 the same descriptor — constants, state AND unit order — as the reference objects
 did, and as ready-made graphs for the GPU parity tests."""
 import dusp_amd as d
-from dusp_amd import (Abs, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, DecibelToScaler, Delay, Divide, Filter,
-                      FixedMultiply, Gain, HardClipAbove, HardClipBelow, Multiply, Osc, Pow, Ramp, Repeater,
+from dusp_amd import (Abs, AllPass, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, CombFilter, DecibelToScaler, Delay, Divide, Filter, FixedDelay,
+                      FixedMultiply, Gain, HardClipAbove, HardClipBelow, MonoDelay, MultiChannelOsc, Multiply, Osc, Pow, Ramp, ReadBackDelay, Repeater,
                       SecondsToSamples, SemitoneToRatio, Subtract, Sum, quick)
 
 
@@ -66,6 +66,23 @@ def _gain():
     return g
 
 
+def _with_in(unit, source):
+    unit.IN = source
+    return unit
+
+
+def _allpass_series():
+    a = _with_in(AllPass(0.0021, 0.6), Osc(220, "square"))
+    return _with_in(AllPass(0.0013, -0.45), a)
+
+
+def _allpass_loop():
+    s = Sum(Osc(180), 0)
+    a = _with_in(AllPass(0.0052, 0.5), s)
+    s.B = Multiply(a, 0.4)
+    return a
+
+
 def builders(sr):
     """name -> zero-argument builder; call d.configure(sr) first (done by build())."""
     voices = lambda n: [Osc(k * 10) for k in range(1, n + 1)]
@@ -113,6 +130,19 @@ def builders(sr):
         "map_pow": lambda: Pow(Sum(Osc(100), 1.5), Multiply(Osc(1.5), 2)),
         "map_pow_negative_base": lambda: quick.pow(Osc(100), 0.5),
         "map_fm_semitone": lambda: Osc(Multiply(SemitoneToRatio(Multiply(Osc(4), 12)), 220)),
+        # delay / filter family, per-channel oscillator
+        "fam_fixeddelay": lambda: _with_in(FixedDelay(0.0031), Osc(441)),
+        "fam_comb": lambda: _with_in(CombFilter(0.004, 0.7), Osc(150, "saw")),
+        "fam_comb_mod": lambda: _with_in(CombFilter(0.0007, Multiply(Osc(3), 0.9)), Osc(333.3)),
+        "fam_allpass_series": _allpass_series,
+        "fam_allpass_loop": _allpass_loop,
+        "fam_monodelay": lambda: MonoDelay(Osc(500), 123.5),
+        "fam_monodelay_mod": lambda: MonoDelay(Osc(300), Sum(Multiply(Osc(1.5), 30), 100)),
+        "fam_readback": lambda: ReadBackDelay(Multiply(Osc(400), [1, -1]), [100, 2000], 4096),
+        "fam_readback_frac": lambda: ReadBackDelay(Osc(400), 10.5, 1024),
+        "fam_multiosc": lambda: MultiChannelOsc([220, 330.5, 441.25]),
+        "fam_multiosc_fm": lambda: MultiChannelOsc(Sum(Multiply(Osc(5), [20, 40]), 300), "triangle"),
+        "fam_multiosc_negative": lambda: MultiChannelOsc(-100),
     }
     for tag, f in [("440p5", 440.5), ("0p1", 0.1), ("neg3", -3), ("47999p5", 47999.5), ("neg0p37", -0.37),
                    ("12345p678", 12345.678), ("tiny", 3e-5)]:

@@ -10,7 +10,7 @@
 module.exports = function goldenCases(L, SR) {
   const { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader, CircleBufferWriter, quick,
     Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
-    DecibelToScaler, SemitoneToRatio, Pow } = L
+    DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc } = L
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -130,6 +130,31 @@ module.exports = function goldenCases(L, SR) {
     add('map_pow', () => new Pow(new Sum(new Osc(100), 1.5), new Multiply(new Osc(1.5), 2)), 0.05)
     add('map_pow_negative_base', () => quick.pow(new Osc(100), 0.5), 0.01) // NaN for negative bases -> `|| 0`
     add('map_fm_semitone', () => new Osc(new Multiply(new SemitoneToRatio(new Multiply(new Osc(4), 12)), 220)), 0.05) // vibrato in semitones
+  }
+
+  // SURVEY.md §8f-2: delay / filter family and the per-channel oscillator
+  if (FixedDelay) {
+    add('fam_fixeddelay', () => { const d = new FixedDelay(0.0031); d.IN = new Osc(441); return d }, 0.05)
+    add('fam_comb', () => { const c = new CombFilter(0.004, 0.7); c.IN = new Osc(150, 'saw'); return c }, 0.1)
+    add('fam_comb_mod', () => { const c = new CombFilter(0.0007, new Multiply(new Osc(3), 0.9)); c.IN = new Osc(333.3); return c }, 0.1)
+    add('fam_allpass_series', () => {
+      const a = new AllPass(0.0021, 0.6); a.IN = new Osc(220, 'square')
+      const b = new AllPass(0.0013, -0.45); b.IN = a
+      return b
+    }, 0.1)
+    add('fam_allpass_loop', () => { // all-pass inside a feedback loop
+      const s = new Sum(new Osc(180), 0)
+      const a = new AllPass(0.0052, 0.5); a.IN = s
+      s.B = new Multiply(a, 0.4)
+      return a
+    }, 0.1)
+    add('fam_monodelay', () => new MonoDelay(new Osc(500), 123.5), 0.05)
+    add('fam_monodelay_mod', () => new MonoDelay(new Osc(300), new Sum(new Multiply(new Osc(1.5), 30), 100)), 0.1)
+    add('fam_readback', () => new ReadBackDelay(new Multiply(new Osc(400), [1, -1]), [100, 2000], 4096), 0.1)
+    add('fam_readback_frac', () => new ReadBackDelay(new Osc(400), 10.5, 1024), 0.01) // fractional index -> undefined -> NaN -> `|| 0`
+    add('fam_multiosc', () => new MultiChannelOsc([220, 330.5, 441.25]), 0.05)
+    add('fam_multiosc_fm', () => new MultiChannelOsc(new Sum(new Multiply(new Osc(5), [20, 40]), 300), 'triangle'), 0.05)
+    add('fam_multiosc_negative', () => new MultiChannelOsc(-100), 0.01) // no `phase < 0` fix-up in this unit: negative index -> NaN
   }
 
   // SURVEY.md §8f-3: scheduled events (host callbacks at chunk boundaries).  `ev_` cases are rendered only

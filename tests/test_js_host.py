@@ -29,7 +29,7 @@ def run_js(script, *args, ok_codes=(0,)):
 
 
 @needs_node
-@pytest.mark.parametrize("sr,count", [(48000, 65), (44100, 5)])
+@pytest.mark.parametrize("sr,count", [(48000, 77), (44100, 5)])
 def test_js_graph_mirror_extracts_the_reference_descriptors(sr, count):
     rep = run_js("check_descriptors.js", "--sampleRate=%d" % sr)
     assert rep["sampleRate"] == sr and rep["checked"] == count and rep["bad"] == 0 and rep["unifyOk"]
@@ -48,7 +48,7 @@ def test_addon_loads_and_fails_loudly_without_gpu():
 
 @needs_node
 @pytest.mark.gpu
-@pytest.mark.parametrize("sr,count", [(48000, 65), (44100, 5)])
+@pytest.mark.parametrize("sr,count", [(48000, 77), (44100, 5)])
 def test_js_render_channel_data_matches_reference_golden(sr, count):
     rep = run_js("check_render.js", "--sampleRate=%d" % sr)
     assert rep.get("fatal") is None, rep
