@@ -227,7 +227,11 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     if (engine == DUSP_ENGINE_LOOP && !loopable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
     if (engine == DUSP_ENGINE_AUTO)
-        engine = fusable ? DUSP_ENGINE_FUSED : wavable ? DUSP_ENGINE_WAVE : loopable ? DUSP_ENGINE_LOOP : DUSP_ENGINE_CHUNK;
+        engine = fusable ? DUSP_ENGINE_FUSED
+                 : (loopable && prog->loop_two_stage) ? DUSP_ENGINE_LOOP
+                 : wavable ? DUSP_ENGINE_WAVE
+                 : loopable ? DUSP_ENGINE_LOOP
+                           : DUSP_ENGINE_CHUNK;
     prog->engine = engine;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -278,7 +282,8 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
-    if (prog->engine == DUSP_ENGINE_WAVE) std::snprintf(info->shape, sizeof info->shape, "feed-forward, %d chunk buffers in LDS", prog->P.n_bufs);
+    if (prog->engine == DUSP_ENGINE_WAVE)
+        std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->P.n_bufs);
     return DUSP_OK;
 }
 
@@ -380,6 +385,14 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.table_stride = ctx->table_stride;
         w.vec4_ok = (n_samples % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
         w.lds_table_id = prog->wave.lds_table_id;
+        w.clock0 = (uint64_t)P.g.clock0;
+        w.has_filter = prog->wave.has_filter ? 1u : 0u;
+        w.ring_samples = (uint64_t)P.ring_samples;
+        if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); wave-engine layout [instance][slot]
+            HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
+            HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+        }
+        w.rings = prog->d_rings.p;
         const bool lds_ok = w.lds_table_id >= 0 && ctx->table_antisym[w.lds_table_id] && P.g.sample_rate % 2 == 0;
         HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
         HIP_TRY(ctx, dusp::launch_wave_engine(w, lds_ok, stream));

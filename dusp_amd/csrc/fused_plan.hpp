@@ -84,10 +84,18 @@ struct WaveArgs {
     uint32_t n_ops, n_out, n_inst, n_pad, n_bufs, n_groups, sample_rate, table_stride, vec4_ok;
     int32_t lds_table_id;
     uint32_t table_bytes, wave_bytes;
+    float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
+    uint64_t ring_samples, clock0;
+    uint32_t has_filter, pad3;
 };
 
+// LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
+inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_filter) {
+    return (n_bufs * 1024 + n_ops * 96 + (has_filter ? 3 * 256 * 8 : 0) + 15) & ~(size_t)15;
+}
+
 struct WavePlan {
-    bool ok = false;
+    bool ok = false, has_filter = false;
     int lds_table_id = -1;
     std::string why;
 };
@@ -331,10 +339,11 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         plan.ok = false;
         return false;
     };
-    if (!P.feed_forward) return no("feedback edge");
-    if (P.ring_samples) return no("rings");
+    if (!g.rings.empty()) return no("CircleBuffer rings");
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
-    if ((size_t)P.n_bufs * 1024 + P.ops.size() * 12 + 16 > 160 * 1024) return no("too many chunk buffers for LDS");
+    plan.has_filter = false;
+    for (const DevOp &op : P.ops) plan.has_filter = plan.has_filter || op.op == OP_FILTER;
+    if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_filter) > 160 * 1024) return no("too many chunk buffers for LDS");
     for (const DevOp &op : P.ops) {
         switch (op.op) {
         case OP_OSC: {
@@ -351,12 +360,21 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
                 return no("Ramp outside the closed-form regime");
             break;
         }
+        case OP_DELAY: {  // only a constant delay of at least one chunk reads and writes its ring in parallel
+            if (op.in[1].kind != SRC_CONST) return no("Delay with a connected / per-instance delay");
+            double dconst = (double)op.in[1].cval;
+            const double len = (double)op.ring_len;
+            if (dconst >= len) dconst = std::fmod(dconst, len);
+            if (!(std::floor(dconst) >= kChunk && std::floor(dconst) + kChunk <= len)) return no("Delay shorter than a chunk");
+            break;
+        }
+        case OP_FILTER:
         case OP_MULTIPLY:
         case OP_SUM:
         case OP_REPEATER: break;
         default:
             if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) break;  // stateless elementwise maps
-            return no("unit with a recurrence (Filter / Delay / CircleBuffer)");
+            return no("unit the wave engine does not run (short / modulated delay lines, CircleBuffers, comb family)");
         }
     }
     plan.ok = true;

@@ -1,6 +1,6 @@
-// wave_engine.hip — the "wave" engine: any FEED-FORWARD circuit of Osc / Ramp / Multiply / Sum /
-// Repeater units (arbitrary fan-out, connected oscillator frequencies = FM), one WAVEFRONT per
-// circuit instance, one LANE per SAMPLE.
+// wave_engine.hip — the "wave" engine: circuits of Osc / Ramp / Multiply / Sum / Repeater / the elementwise
+// maps (arbitrary fan-out, connected oscillator frequencies = FM) and, since v2, Filter and constant-delay
+// Delay units, with or without feedback edges: one WAVEFRONT per circuit instance, one LANE per SAMPLE.
 //
 // This is the north star's kernel shape in its general form: the wave walks the circuit's units in
 // the reference's process order (Circuit.js:34-37) once per 256-sample chunk, each unit reading and
@@ -19,6 +19,13 @@
 // once f is NaN/Inf the reference's phase is NaN for good.
 // Ramp is evaluated in closed form from the sample index (Ramp.js:25-40).
 //
+// Filter (Filter.js:27-51) splits like loop2_engine.hip: the feed-forward half (a0 x + a1 x1) + a2 x2 is
+// computed per lane (neighbour samples by DPP shuffle, coefficients per sample when the cutoff is modulated),
+// the output recurrence y = f32((P - b1 y1) - b2 y2) runs serially over the chunk's 256 samples out of LDS.
+// Delay (Delay.js:20-41) with a constant delay of at least one chunk reads and writes its ring
+// ([instance][slot] in HBM) fully in parallel.  Chunk buffers persist in LDS from chunk to chunk, so a unit
+// that reads a buffer whose producer ticks later sees the previous chunk — the reference's feedback semantics.
+//
 // Time is sequential per instance (the scan carry), so parallelism = instances: thousands of voices
 // fill the chip; a single circuit (BASELINE configs[1]) runs on one wave and is latency-bound
 // (~0.7 us per chunk) — still two orders of magnitude faster than ticking it on the host.
@@ -34,6 +41,31 @@ namespace {
 
 constexpr double kTwo36 = 68719476736.0;
 constexpr int kFracBits = 36;
+constexpr int kOpState = 12;  // doubles of LDS state per op per wave
+
+__device__ __forceinline__ double or0w(double v) { return (v != v || v == 0.0) ? 0.0 : v; }  // JS `v || 0`
+
+// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
+__device__ __forceinline__ void filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
+    const double PI = 3.141592653589793;
+    if (kind == 0) {
+        const double lamda = 1.0 / tan(PI * f / sr);
+        const double l2 = lamda * lamda;
+        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
+        k[1] = 2.0 * k[0];
+        k[2] = k[0];
+        k[3] = 2.0 * k[0] * (1.0 - l2);
+        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
+    } else {
+        const double lamda = tan(PI * f / sr);
+        const double l2 = lamda * lamda;
+        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
+        k[1] = 0.0;
+        k[2] = -k[0];
+        k[3] = 2.0 * k[0] * (l2 - 1.0);
+        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
+    }
+}
 
 struct V4 {
     float v[4];
@@ -79,8 +111,10 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     if (inst >= A.n_inst) return;  // whole waves only; no workgroup barrier follows
     char *mine = (char *)lds + A.table_bytes + (size_t)wave * A.wave_bytes;
     f32x4 *bufs = (f32x4 *)mine;                                            // [n_bufs][64] float4 = chunk buffers
-    unsigned long long *carry = (unsigned long long *)(mine + (size_t)A.n_bufs * 1024);  // [n_ops] phase carry (2^-36 units)
-    uint32_t *poison = (uint32_t *)(carry + A.n_ops);                        // [n_ops]
+    double *opstate = (double *)(mine + (size_t)A.n_bufs * 1024);           // [n_ops][kOpState] per-unit state
+    double *scratch = opstate + (size_t)A.n_ops * kOpState;                 // Filter: P[256], b1[256], b2[256]
+    // Osc: [0] phase carry (u64 bits, 2^-36 units), [1] poison flag.  Delay: [0] previous input sample.
+    // Filter: [0] has_lastF [1] lastF [2..6] a0 a1 a2 b1 b2 [7..10] x1 x2 y1 y2
 
     const uint32_t sr = A.sample_rate;
     const double srd = (double)sr;
@@ -89,11 +123,16 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // multiple of S that makes any |x| < 2^62 non-negative before the modulo
     const unsigned long long lift = S * ((1ull << 62) / S);
 
+    for (uint32_t b = 0; b < A.n_bufs; ++b) bufs[(size_t)b * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};  // outlets start as zeros
     if (lane == 0)
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
-            carry[u] = op.op == OP_OSC ? (unsigned long long)(A.init_state[op.state_slot] * kTwo36) : 0ull;
-            poison[u] = 0;
+            double *os = opstate + (size_t)u * kOpState;
+            for (int k = 0; k < kOpState; ++k) os[k] = 0.0;
+            if (op.op == OP_OSC) *(unsigned long long *)os = (unsigned long long)(A.init_state[op.state_slot] * kTwo36);
+            if (op.op == OP_DELAY) os[0] = A.init_state[op.state_slot];
+            if (op.op == OP_FILTER)
+                for (int k = 0; k < 11; ++k) os[k] = A.init_state[op.state_slot + k];
         }
     // (single wave: LDS accesses of one wave are issued in order; the fence keeps the compiler honest)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -106,6 +145,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             V4 out;
             switch (op.op) {
             case OP_OSC: {  // Osc.js:35-47
+                unsigned long long *carry = (unsigned long long *)(opstate + (size_t)u * kOpState);
+                uint32_t *poison = (uint32_t *)(carry + 1);
                 const V4 f = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 long long q[4];
                 bool bad = false;
@@ -122,17 +163,17 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 long long s0, before;
                 if (lane_constant) {  // equal increments: the prefix is a product, no scan needed
-                    before = (long long)carry[u] + q[0] * (long long)(lane * 4);
+                    before = (long long)*carry + q[0] * (long long)(lane * 4);
                     s0 = q[0];
                 } else {
                     const long long total = q[0] + q[1] + q[2] + q[3];
                     const long long incl = wave_inclusive_scan(total, lane);
-                    before = (long long)carry[u] + (incl - total);
+                    before = (long long)*carry + (incl - total);
                     s0 = q[0];
                 }
                 // poison: NaN/Inf increments make the reference's phase NaN from that sample on
                 const unsigned long long bad_lanes = __ballot(bad);
-                const bool poisoned_before = poison[u] != 0 || (bad_lanes & ((1ull << lane) - 1ull)) != 0;
+                const bool poisoned_before = *poison != 0 || (bad_lanes & ((1ull << lane) - 1ull)) != 0;
                 const float *gtab = A.tables + (size_t)op.attr * A.table_stride;
                 const bool in_lds = TBL == 1 && op.attr == A.lds_table_id;
                 // phase of this lane's first sample by one exact modulo; the next three by add + single wrap (|q| < S)
@@ -157,8 +198,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const unsigned long long lastP = __shfl(P, 63, 64);  // phase of the chunk's last sample
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) {
-                    carry[u] = lastP;
-                    if (bad_lanes) poison[u] = 1;
+                    *carry = lastP;
+                    if (bad_lanes) *poison = 1;
                 }
                 break;
             }
@@ -171,6 +212,101 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     const double tt = playing ? fmin(t0 + (double)(n0 + c + 1), duration) : t0;
                     out.v[c] = (float)(y0 + (tt / duration) * dy);
                 }
+                break;
+            }
+            case OP_FILTER: {  // Filter.js:27-51
+                double *fs = opstate + (size_t)u * kOpState;
+                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 fv = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const bool f_const = op.in[1].kind != SRC_BUF;  // wave-uniform
+                double k0[5];
+                if (f_const) {
+                    // `if(this.f[t] != this.lastF)`: with a constant f the coefficients change at most once
+                    const double ft = (double)fv.v[0];
+                    if (fs[0] == 0.0 || ft != fs[1]) filter_coefficients(op.attr, ft, srd, k0);
+                    else { k0[0] = fs[2]; k0[1] = fs[3]; k0[2] = fs[4]; k0[3] = fs[5]; k0[4] = fs[6]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { fs[0] = 1.0; fs[1] = ft; fs[2] = k0[0]; fs[3] = k0[1]; fs[4] = k0[2]; fs[5] = k0[3]; fs[6] = k0[4]; }
+                }
+                // feed-forward half, per lane: ((a0 x + a1 (x1||0)) + a2 (x2||0)) with x1, x2 = the two previous inputs
+                const float xl1 = __shfl_up(x.v[3], 1, 64), xl2 = __shfl_up(x.v[2], 1, 64);
+                double xm1 = lane == 0 ? fs[7] : (double)xl1, xm2 = lane == 0 ? fs[8] : (double)xl2;
+                double *P = scratch, *B1 = scratch + kChunk, *B2 = scratch + 2 * kChunk;
+                double klast[5] = {k0[0], k0[1], k0[2], k0[3], k0[4]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!f_const) {  // coefficients are a function of f[t] alone (they are refreshed whenever f changes)
+                        filter_coefficients(op.attr, (double)fv.v[c], srd, klast);
+                        B1[lane * 4 + c] = klast[3];
+                        B2[lane * 4 + c] = klast[4];
+                    }
+                    const double xin = (double)x.v[c];
+                    P[lane * 4 + c] = (klast[0] * xin + klast[1] * or0w(xm1)) + klast[2] * or0w(xm2);
+                    xm2 = or0w(xm1);
+                    xm1 = xin;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // output recurrence, serial over the chunk (every lane runs it; lane 0 stores): Filter.js:40-46
+                double y1 = fs[9], y2 = fs[10];
+                float *outf = (float *)(bufs + (size_t)op.out_buf * 64);
+#pragma unroll 8
+                for (int t = 0; t < kChunk; ++t) {
+                    const double b1 = f_const ? k0[3] : B1[t], b2 = f_const ? k0[4] : B2[t];
+                    const float y = (float)((P[t] - b1 * or0w(y1)) - b2 * or0w(y2));
+                    if (lane == 0) outf[t] = y;
+                    y2 = or0w(y1);
+                    y1 = (double)y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 63) {
+                    fs[7] = xm1;
+                    fs[8] = xm2;
+                    if (!f_const) { fs[0] = 1.0; fs[1] = (double)fv.v[3]; fs[2] = klast[0]; fs[3] = klast[1]; fs[4] = klast[2]; fs[5] = klast[3]; fs[6] = klast[4]; }
+                }
+                if (lane == 0) { fs[9] = y1; fs[10] = y2; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;  // the output chunk is already in LDS
+            }
+            case OP_DELAY: {  // Delay.js:20-41, constant delay D + phi with 256 <= D <= len - 256 (plan_wave checks)
+                double *ds = opstate + (size_t)u * kOpState;
+                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const int64_t len = op.ring_len;
+                double dconst = (double)op.in[1].cval;
+                if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
+                const double Dfl = floor(dconst), phi = dconst - Dfl;
+                const int64_t D = (int64_t)Dfl;
+                float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
+                const int64_t s0 = (int64_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+                float x_left = __shfl_up(x.v[3], 1, 64);
+                const double carried = ds[0];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int64_t s_ = s0 + lane * 4 + c;
+                    if (s_ >= len) s_ -= len;
+                    out.v[c] = ring[s_];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int64_t s_ = s0 + lane * 4 + c;
+                    if (s_ >= len) s_ -= len;
+                    int64_t lo = s_ + D;
+                    if (lo >= len) lo -= len;
+                    const double xin = (double)x.v[c];
+                    const double xprev = c == 0 ? (lane == 0 ? carried : (double)x_left) : (double)x.v[c - 1];
+                    float slot;
+                    if (phi != 0.0) {
+                        slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
+                        slot = (float)((double)slot + xin * (1.0 - phi));   // floor tap of sample n
+                    } else {
+                        slot = (float)(0.0 + xin * 1.0);
+                        slot = (float)((double)slot + xin * 0.0);
+                    }
+                    ring[lo] = slot;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 63) ds[0] = (double)x.v[3];
                 break;
             }
             case OP_MULTIPLY: {  // Multiply.js:23-34
@@ -209,12 +345,18 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     }
 
     // state write-back: what every unit holds after ceil(n_samples/256) ticks, in the chunk engine's slot layout
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         const uint64_t T_end = (uint64_t)A.n_groups * kChunk;
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
             double *st = A.state + (size_t)op.state_slot * A.n_pad + inst;
-            if (op.op == OP_OSC) st[0] = poison[u] ? __builtin_nan("") : (double)carry[u] * (1.0 / kTwo36);
+            const double *os = opstate + (size_t)u * kOpState;
+            if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
+            if (op.op == OP_DELAY) st[0] = os[0];
+            if (op.op == OP_FILTER)
+                for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];
             if (op.op == OP_RAMP) {
                 const double duration = op.d[0], t0 = A.init_state[op.state_slot];
                 const bool playing = A.init_state[op.state_slot + 1] != 0.0;
@@ -239,7 +381,7 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
-    A.wave_bytes = (uint32_t)(((size_t)A.n_bufs * 1024 + (size_t)A.n_ops * 12 + 15) & ~(size_t)15);
+    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_filter != 0);
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
     if (table_bytes && table_bytes + A.wave_bytes > budget) table_bytes = 0;  // buffers first; lookups fall back to L2
