@@ -387,6 +387,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.lds_table_id = prog->wave.lds_table_id;
         w.clock0 = (uint64_t)P.g.clock0;
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
+        w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
         w.ring_samples = (uint64_t)P.ring_samples;
         if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); wave-engine layout [instance][slot]
             HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));

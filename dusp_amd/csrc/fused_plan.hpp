@@ -86,16 +86,17 @@ struct WaveArgs {
     uint32_t table_bytes, wave_bytes;
     float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
     uint64_t ring_samples, clock0;
-    uint32_t has_filter, pad3;
+    uint32_t has_filter, has_modulated_filter;
 };
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
-inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_filter) {
-    return (n_bufs * 1024 + n_ops * 96 + (has_filter ? 3 * 256 * 8 : 0) + 15) & ~(size_t)15;
+// (the 6 KB scratch is only needed by Filters whose cutoff is connected: per-sample b1 / b2 and their own P)
+inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_modulated_filter) {
+    return (n_bufs * 1024 + n_ops * 96 + (has_modulated_filter ? 3 * 256 * 8 + 16 : 0) + 15) & ~(size_t)15;
 }
 
 struct WavePlan {
-    bool ok = false, has_filter = false;
+    bool ok = false, has_filter = false, has_modulated_filter = false;
     int lds_table_id = -1;
     std::string why;
 };
@@ -341,9 +342,13 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
     };
     if (!g.rings.empty()) return no("CircleBuffer rings");
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
-    plan.has_filter = false;
-    for (const DevOp &op : P.ops) plan.has_filter = plan.has_filter || op.op == OP_FILTER;
-    if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_filter) > 160 * 1024) return no("too many chunk buffers for LDS");
+    plan.has_filter = plan.has_modulated_filter = false;
+    for (const DevOp &op : P.ops) {
+        plan.has_filter = plan.has_filter || op.op == OP_FILTER;
+        plan.has_modulated_filter = plan.has_modulated_filter || (op.op == OP_FILTER && op.in[1].kind == SRC_BUF);
+    }
+    if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
+        return no("too many chunk buffers for LDS");
     for (const DevOp &op : P.ops) {
         switch (op.op) {
         case OP_OSC: {

@@ -107,9 +107,14 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t inst = blockIdx.x * WAVES + wave;
-    if (inst >= A.n_inst) return;  // whole waves only; no workgroup barrier follows
+    // a short last workgroup keeps its surplus waves alive (they take part in the Filter stage's barriers):
+    // they shadow the last real instance but never store to HBM
+    const bool live = blockIdx.x * WAVES + wave < A.n_inst;
+    const uint32_t inst = live ? blockIdx.x * WAVES + wave : A.n_inst - 1;
     char *mine = (char *)lds + A.table_bytes + (size_t)wave * A.wave_bytes;
+    // workgroup-shared hand-over tiles of the cooperative Filter stage: Pt[WAVES][258] f64, Yt[WAVES][260] f32
+    double *Pt = (double *)((char *)lds + A.table_bytes + (size_t)WAVES * A.wave_bytes);
+    float *Yt = (float *)(Pt + WAVES * 258);
     f32x4 *bufs = (f32x4 *)mine;                                            // [n_bufs][64] float4 = chunk buffers
     double *opstate = (double *)(mine + (size_t)A.n_bufs * 1024);           // [n_ops][kOpState] per-unit state
     double *scratch = opstate + (size_t)A.n_ops * kOpState;                 // Filter: P[256], b1[256], b2[256]
@@ -134,9 +139,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) os[k] = A.init_state[op.state_slot + k];
         }
-    // (single wave: LDS accesses of one wave are issued in order; the fence keeps the compiler honest)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     for (uint32_t g = 0; g < A.n_groups; ++g) {
         const uint64_t n0 = (uint64_t)g * kChunk + lane * 4;  // index of this lane's first sample
@@ -231,15 +234,50 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // feed-forward half, per lane: ((a0 x + a1 (x1||0)) + a2 (x2||0)) with x1, x2 = the two previous inputs
                 const float xl1 = __shfl_up(x.v[3], 1, 64), xl2 = __shfl_up(x.v[2], 1, 64);
                 double xm1 = lane == 0 ? fs[7] : (double)xl1, xm2 = lane == 0 ? fs[8] : (double)xl2;
-                double *P = scratch, *B1 = scratch + kChunk, *B2 = scratch + 2 * kChunk;
                 double klast[5] = {k0[0], k0[1], k0[2], k0[3], k0[4]};
+                if (f_const) {
+                    // ---- cooperative form: every wave of the workgroup (= WAVES instances) publishes its chunk's
+                    // feed-forward half, then ONE wave runs the output recurrence with lane = instance, so the
+                    // serial instruction stream is shared by WAVES instances instead of being repeated per wave.
+                    double *prow = Pt + wave * 258;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double xin = (double)x.v[c];
+                        prow[lane * 4 + c] = (k0[0] * xin + k0[1] * or0w(xm1)) + k0[2] * or0w(xm2);
+                        xm2 = or0w(xm1);
+                        xm1 = xin;
+                    }
+                    if (lane == 63) { fs[7] = xm1; fs[8] = xm2; }
+                    __syncthreads();
+                    if (wave == 0 && lane < WAVES) {
+                        double *os = (double *)((char *)lds + A.table_bytes + (size_t)lane * A.wave_bytes + (size_t)A.n_bufs * 1024) +
+                                     (size_t)u * kOpState;  // instance `lane`'s state of this Filter
+                        const double b1 = os[5], b2 = os[6];
+                        double y1 = os[9], y2 = os[10];
+                        const double *pr = Pt + lane * 258;
+                        float *yr = Yt + lane * 260;
+#pragma unroll 8
+                        for (int t = 0; t < kChunk; ++t) {
+                            const float y = (float)((pr[t] - b1 * or0w(y1)) - b2 * or0w(y2));  // Filter.js:40-46
+                            yr[t] = y;
+                            y2 = or0w(y1);
+                            y1 = (double)y;
+                        }
+                        os[9] = y1;
+                        os[10] = y2;
+                    }
+                    __syncthreads();
+                    const f32x4 yv = *(const f32x4 *)(Yt + wave * 260 + lane * 4);
+                    out.v[0] = yv[0]; out.v[1] = yv[1]; out.v[2] = yv[2]; out.v[3] = yv[3];
+                    break;
+                }
+                // ---- modulated cutoff: coefficients per sample, recurrence per wave out of its own scratch
+                double *P = scratch, *B1 = scratch + kChunk, *B2 = scratch + 2 * kChunk;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (!f_const) {  // coefficients are a function of f[t] alone (they are refreshed whenever f changes)
-                        filter_coefficients(op.attr, (double)fv.v[c], srd, klast);
-                        B1[lane * 4 + c] = klast[3];
-                        B2[lane * 4 + c] = klast[4];
-                    }
+                    filter_coefficients(op.attr, (double)fv.v[c], srd, klast);  // a function of f[t] alone
+                    B1[lane * 4 + c] = klast[3];
+                    B2[lane * 4 + c] = klast[4];
                     const double xin = (double)x.v[c];
                     P[lane * 4 + c] = (klast[0] * xin + klast[1] * or0w(xm1)) + klast[2] * or0w(xm2);
                     xm2 = or0w(xm1);
@@ -247,13 +285,11 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // output recurrence, serial over the chunk (every lane runs it; lane 0 stores): Filter.js:40-46
                 double y1 = fs[9], y2 = fs[10];
                 float *outf = (float *)(bufs + (size_t)op.out_buf * 64);
 #pragma unroll 8
                 for (int t = 0; t < kChunk; ++t) {
-                    const double b1 = f_const ? k0[3] : B1[t], b2 = f_const ? k0[4] : B2[t];
-                    const float y = (float)((P[t] - b1 * or0w(y1)) - b2 * or0w(y2));
+                    const float y = (float)((P[t] - B1[t] * or0w(y1)) - B2[t] * or0w(y2));
                     if (lane == 0) outf[t] = y;
                     y2 = or0w(y1);
                     y1 = (double)y;
@@ -262,7 +298,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (lane == 63) {
                     fs[7] = xm1;
                     fs[8] = xm2;
-                    if (!f_const) { fs[0] = 1.0; fs[1] = (double)fv.v[3]; fs[2] = klast[0]; fs[3] = klast[1]; fs[4] = klast[2]; fs[5] = klast[3]; fs[6] = klast[4]; }
+                    fs[0] = 1.0; fs[1] = (double)fv.v[3]; fs[2] = klast[0]; fs[3] = klast[1]; fs[4] = klast[2]; fs[5] = klast[3]; fs[6] = klast[4];
                 }
                 if (lane == 0) { fs[9] = y1; fs[10] = y2; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -303,7 +339,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                         slot = (float)(0.0 + xin * 1.0);
                         slot = (float)((double)slot + xin * 0.0);
                     }
-                    ring[lo] = slot;
+                    if (live) ring[lo] = slot;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 63) ds[0] = (double)x.v[3];
@@ -339,6 +375,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const f32x4 x = bufs[(size_t)A.out_bufs[oc] * 64 + lane];
             float v[4] = {fix_out<false>(x[0]), fix_out<false>(x[1]), fix_out<false>(x[2]), fix_out<false>(x[3])};
             float *row = A.out + ((size_t)inst * A.n_out + oc) * A.n_samples + n0;
+            if (!live) continue;
             if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, v, n0, A.n_samples);
             else store4<false>(row, v, n0, A.n_samples);
         }
@@ -347,7 +384,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // state write-back: what every unit holds after ceil(n_samples/256) ticks, in the chunk engine's slot layout
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    if (lane == 0 && live) {
         const uint64_t T_end = (uint64_t)A.n_groups * kChunk;
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
@@ -381,20 +418,22 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
-    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_filter != 0);
+    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_modulated_filter != 0);
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
-    if (table_bytes && table_bytes + A.wave_bytes > budget) table_bytes = 0;  // buffers first; lookups fall back to L2
-    if (A.wave_bytes > budget) return hipErrorInvalidValue;                   // plan_wave() guards this
+    const size_t one_wave = A.wave_bytes + (A.has_filter ? 258 * 8 + 260 * 4 : 0);
+    if (table_bytes && table_bytes + one_wave > budget) table_bytes = 0;  // buffers first; lookups fall back to L2
+    if (one_wave > budget) return hipErrorInvalidValue;                   // plan_wave() guards this
     A.table_bytes = (uint32_t)table_bytes;
     if (!table_bytes) A.lds_table_id = -1;
     // waves per workgroup: as many as LDS holds next to the table image (they share it and hide each other's
     // scan / lookup latency), but no more than needed to give every CU a workgroup
-    const int fit = (int)((budget - table_bytes) / A.wave_bytes);
+    const size_t shared_per_wave = A.has_filter ? 258 * 8 + 260 * 4 : 0;  // Pt / Yt rows of the cooperative Filter stage
+    const int fit = (int)((budget - table_bytes) / (A.wave_bytes + shared_per_wave));
     const unsigned want = (A.n_inst + 255) / 256;  // instances per CU on a 256-CU part
     int waves = 1;
     while (waves < 16 && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
-    const size_t lds_bytes = table_bytes + (size_t)waves * A.wave_bytes;
+    const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
 #define DUSP_W(T, W) launch_wave_one<T, W>(A, lds_bytes, stream)
     if (table_bytes) {
         switch (waves) {
