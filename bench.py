@@ -170,7 +170,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 phase/lerp -> f32 PCM", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2] per-voice: %d voices/GPU x Multiply(Osc(10k), Ramp(T,1,0) triggered), "
                                    "%gs @%d Hz, every voice's PCM written" % (n_voices, args.seconds, sr),
                        "voices_per_gpu": n_voices, "n_samples": n_samples, "engine": prog.engine, "shape": prog.shape,

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profile_$TAG
 mkdir -p $O $R/profiles
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0"
+BENCH="python3 $R/bench.py --cpu-seconds 0"   # default --steps / --warmup = the judged command minus the CPU leg
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1 || echo "stats pass failed"
 for P in "WRITE_SIZE" "FETCH_SIZE" \
@@ -18,4 +18,6 @@ for P in "WRITE_SIZE" "FETCH_SIZE" \
   N=$(echo $P | cut -d" " -f1)
   timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $O/pmc_$N -- $BENCH > $O/pmc_$N.log 2>&1 || echo "pmc pass $N failed"
 done
+# the other BASELINE configs (wave / sumchain / loop2 kernels): kernel-trace only
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/configs -- python3 $R/tools/configs_bench.py --rounds 2 > $O/configs.log 2>&1 || echo "configs pass failed"
 python3 $R/tools/profile_summary.py $O $R/profiles $TAG

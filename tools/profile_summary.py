@@ -11,7 +11,7 @@ import sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 lines = ["# rocprofv3 summary (%s)" % tag, "",
-         "Command: `python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0` (1 GPU, 1024 voices x 60 s @ 48 kHz).", ""]
+         "Command: `python3 bench.py --cpu-seconds 0` (default --steps 10 --warmup 3) (1 GPU, 1024 voices x 60 s @ 48 kHz).", ""]
 kernel_ms = None
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % tag))
@@ -58,5 +58,28 @@ if "SQ_INSTS_VALU" in counters:
 if "SQ_LDS_BANK_CONFLICT" in counters and counters.get("SQ_LDS_IDX_ACTIVE"):
     lines += ["- LDS bank-conflict cycles / LDS active cycles: %.1f %%" % (100 * counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"])]
 lines += ["", "Dispatch: %s" % json.dumps(meta), ""]
+for f in glob.glob(os.path.join(src, "configs", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "%s_configs_kernel_stats.csv" % tag))
+    lines += ["## other BASELINE configs: `python3 tools/configs_bench.py --rounds 2` under --kernel-trace --stats", "",
+              "| kernel | calls | avg ms | min ms | max ms |", "|---|---|---|---|---|"]
+    for r in csv.DictReader(open(f)):
+        if "dusp_" in r["Name"]:
+            lines.append("| `%s` | %s | %.4f | %.4f | %.4f |" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                              float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6))
+    lines.append("")
+    log = os.path.join(src, "configs.log")
+    if os.path.exists(log):
+        lines += ["```"] + [l.rstrip() for l in open(log) if l.startswith("cfg")] + ["```", ""]
+slog = os.path.join(src, "stats.log")
+if os.path.exists(slog):
+    for l in open(slog):
+        if l.startswith("{") and '"metric"' in l:
+            open(os.path.join(dst, "%s_bench_line_profiled.json" % tag), "w").write(l)
+            j = json.loads(l)
+            lines += ["## bench.py's own line from the --kernel-trace pass (HIP events inside bench.py)", "",
+                      "- kernel_ms (HIP events, timed steps only) = %.4f; rocprofv3 AverageNs over all launches incl. warm-up = %.4f ms"
+                      % (j["roofline"]["kernel_ms"], kernel_ms or float("nan")),
+                      "- roofline.frac in that pass = %.4f (clock state varies between processes on the same box; see %s_bench_line.json for the unprofiled run of the same call)"
+                      % (j["roofline"]["frac"], tag), ""]
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines))
 print("\n".join(lines))
