@@ -406,6 +406,57 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[0] = phase;
                 break;
             }
+            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: {
+                Src src[kMaxIn];
+#pragma unroll
+                for (int k = 0; k < kMaxIn; ++k) src[k] = make_src(op.in[k < op.n_in ? k : 0], a, i);
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float v[kMaxIn][kBatch], r[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kMaxIn; ++k)
+                        if (k < op.n_in) src[k].load(t0, v[k]);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const float w[kMaxIn] = {v[0][k], v[1][k], v[2][k], v[3][k], v[4][k]};
+                        r[k] = map_wide(op.op, op.attr, op.n_in, w, op.d[0]);
+                    }
+                    store_batch(outp, NP, t0, r);
+                }
+                break;
+            }
+            case OP_TIMER: {  // Timer.js:36-41: a running f64 sum of 1/sampleRate, rounded to f32 per sample
+                double tt = st[0];
+                const double period = op.d[0];
+                for (int t = 0; t < kChunk; ++t) {
+                    tt += period;
+                    outp[(size_t)t * NP] = (float)tt;
+                }
+                st[0] = tt;
+                break;
+            }
+            case OP_SAMPLE_RATE_REDUX: {  // SampleRateRedux.js:21-38
+                const Src x = make_src(op.in[0], a, i), amount = make_src(op.in[1], a, i);
+                double since = st[0];
+                float held = (float)st[NP];
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float xv[kBatch], av[kBatch], r[kBatch];
+                    x.load(t0, xv);
+                    amount.load(t0, av);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        since += 1.0;
+                        if (since > (double)av[k]) {
+                            held = xv[k];
+                            since = 0.0;
+                        }
+                        r[k] = held;
+                    }
+                    store_batch(outp, NP, t0, r);
+                }
+                st[0] = since;
+                st[NP] = (double)held;
+                break;
+            }
             default: {  // stateless elementwise maps (map_ops.hpp)
                 const Src x = make_src(op.in[0], a, i), y = make_src(op.in[1], a, i);
                 for (int t0 = 0; t0 < kChunk; t0 += kBatch) {

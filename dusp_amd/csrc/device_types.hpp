@@ -11,8 +11,14 @@ enum : int {
     OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW,
     // delay / filter family, per-channel oscillator
     OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC,
-    OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW
+    // rest of the elementwise sweep.  ConcatChannels / PickChannel exist in descriptors only: the
+    // host compiler turns them into per-channel copies (OP_REPEATER device ops).
+    OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
+    OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
+    OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW,    // stateless maps of at most two operands (map_apply)
+    OP_WIDE_FIRST = OP_PAN, OP_WIDE_LAST = OP_VECTOR_MAGNITUDE  // stateless maps of up to kMaxIn operands (map_wide)
 };
+constexpr int kMaxIn = 5;  // Rescale has five inlets
 enum : int { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };   // descriptor inlet kinds
 enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand kinds
 constexpr int kNumTables = 5;
@@ -32,9 +38,9 @@ struct DevOperand {
 // One mono operation: a (unit, output channel) pair of the circuit.
 struct DevOp {
     int32_t op, unit, out_buf, state_slot;
-    int32_t attr, pad0;      // Osc: table id; Filter: kind; CircleBuffer node: bit0 wipe, bit1 no-input
-    DevOperand in[2];
-    double d[3];             // Ramp: duration, y0, y1; FixedMultiply: sf; SecondsToSamples: sample rate
+    int32_t attr, n_in;      // Osc: table id; Filter: kind; CircleBuffer node: bit0 wipe, bit1 no-input; Pan: output channel
+    DevOperand in[kMaxIn];   // n_in operands are meaningful (VectorMagnitude: one per input channel)
+    double d[3];             // Ramp: duration, y0, y1; FixedMultiply: sf; SecondsToSamples: sample rate; Pan: compensation dB; Timer: period
     int64_t ring_base, ring_len;  // Delay / CircleBuffer nodes: ring location (samples, per instance)
 };
 

@@ -502,7 +502,18 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
         const int n_ch = (u.op == dusp::OP_FILTER) ? u.n_out : 1;
         const int per = u.op == dusp::OP_DELAY ? 0 : u.slots_per_ch;  // Delay's slot is engine-internal, not unit state
         // (FixedDelay / CombFilter / AllPass / ReadBackDelay: one word, the ring position; MonoDelay: none)
-        if (u.op == dusp::OP_MULTI_OSC) {  // [n, phase per channel]
+        if (u.op == dusp::OP_SAMPLE_RATE_REDUX) {  // [timeSinceLastUpdate, n, held value per channel]; `val` is `[0]` until the first update
+            double since;
+            HIP_TRY(ctx, rd(u.first_slot, since));
+            const int n_val = std::isinf(since) ? 1 : u.n_out;
+            words.push_back(since);
+            words.push_back((double)n_val);
+            for (int c = 0; c < n_val; c++) {
+                double v;
+                HIP_TRY(ctx, rd(u.first_slot + c * per + 1, v));
+                words.push_back(v);
+            }
+        } else if (u.op == dusp::OP_MULTI_OSC) {  // [n, phase per channel]
             words.push_back((double)u.n_out);
             for (int c = 0; c < u.n_out; c++) {
                 double v;

@@ -378,8 +378,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         case OP_SUM:
         case OP_REPEATER: break;
         default:
-            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) break;  // stateless elementwise maps
-            return no("unit the wave engine does not run (short / modulated delay lines, CircleBuffers, comb family)");
+            if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
+            return no("unit the wave engine does not run (short / modulated delay lines, CircleBuffers, comb family, Timer, SampleRateRedux)");
         }
     }
     plan.ok = true;

@@ -34,5 +34,30 @@ __device__ __forceinline__ float map_apply(int op, float x, float y, double d0) 
     return x;
 }
 
+// Stateless maps with more operands or an output-channel attribute: Pan, MidiToFrequency, Rescale, CrossFader,
+// VectorMagnitude.  v[k] = operand k of this sample (unused operands are whatever the caller loaded).
+__device__ __forceinline__ float map_wide(int op, int attr, int n_in, const float (&v)[kMaxIn], double d0) {
+    switch (op) {
+    case OP_PAN: {                                                             // Pan.js:19-29
+        const double in = (double)v[0], pan = (double)v[1];
+        const double compensation = js_pow(10.0, ((1.0 - fabs(pan)) * d0) / 20.0);
+        return (float)(in * (attr ? 1.0 + pan : 1.0 - pan) / 2.0 * compensation);
+    }
+    case OP_MIDI_TO_FREQUENCY: return (float)(js_pow(2.0, ((double)v[0] - 69.0) / 12.0) * 440.0);  // MidiToFrequency.js:20
+    case OP_RESCALE:                                                           // Rescale.js:34-35
+        return (float)(((double)v[0] - (double)v[1]) / ((double)v[2] - (double)v[1]) * ((double)v[4] - (double)v[3]) + (double)v[3]);
+    case OP_CROSS_FADER:                                                       // CrossFader.js:28
+        return (float)((1.0 - (double)v[2]) * (double)v[0] + (double)v[2] * (double)v[1]);
+    case OP_VECTOR_MAGNITUDE: {                                                // VectorMagnitude.js:20-26
+        double square_sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < kMaxIn; ++c)
+            if (c < n_in) square_sum += (double)v[c] * (double)v[c];
+        return (float)sqrt(square_sum);
+    }
+    }
+    return v[0];
+}
+
 }  // namespace
 }  // namespace dusp

@@ -123,7 +123,7 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         const std::string where = "unit " + std::to_string(i) + ": ";
         if (p + 4 > nw) return fail(err, where + "truncated record");
         int64_t op, n_in, n_attr, n_state;
-        if (!as_count(d[p], 64, op) || !as_count(d[p + 1], 2, n_in) || !as_count(d[p + 2], 64, n_attr) ||
+        if (!as_count(d[p], 64, op) || !as_count(d[p + 1], kMaxIn, n_in) || !as_count(d[p + 2], 64, n_attr) ||
             !as_count(d[p + 3], 1 << 12, n_state))
             return fail(err, where + "bad record header");
         p += 4;
@@ -221,6 +221,39 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
                 return fail(err, where + "waveform doesn't exist");
             break;
         }
+        case OP_PAN:
+            if (!need(2, 1, 0)) return fail(err, where + "bad Pan record");
+            break;
+        case OP_MIDI_TO_FREQUENCY: case OP_VECTOR_MAGNITUDE:
+            if (!need(1, 0, 0)) return fail(err, where + "bad unary map record");
+            break;
+        case OP_RESCALE:
+            if (!need(5, 0, 0)) return fail(err, where + "bad Rescale record");
+            break;
+        case OP_CROSS_FADER:
+            if (!need(3, 0, 0)) return fail(err, where + "bad CrossFader record");
+            break;
+        case OP_TIMER:
+            if (!need(0, 1, 1)) return fail(err, where + "bad Timer record");
+            break;
+        case OP_SAMPLE_RATE_REDUX: {
+            int64_t nval;
+            if (!need(2, 0, SIZE_MAX) || u.state.size() < 2 || !as_count(u.state[1], 64, nval) || u.state.size() != (size_t)(2 + nval))
+                return fail(err, where + "bad SampleRateRedux record");
+            break;
+        }
+        case OP_CONCAT_CHANNELS:
+            if (!need(2, 0, 0)) return fail(err, where + "bad ConcatChannels record");
+            break;
+        case OP_PICK_CHANNEL:
+            if (!need(2, 0, 0)) return fail(err, where + "bad PickChannel record");
+            // `this.in[this.c[t] % this.in.length][t]` (PickChannel.js:20): the index has to be known when the program
+            // is built, and has to be a channel number — anything else makes the reference throw mid-render
+            if (u.inlets[1].kind != IN_CONST)
+                return fail(err, where + "PickChannel with a signal-rate or per-instance channel index is not supported on the GPU path");
+            if (!(u.inlets[1].vals[0] >= 0 && u.inlets[1].vals[0] < 9e15 && u.inlets[1].vals[0] == std::floor(u.inlets[1].vals[0])))
+                return fail(err, where + "PickChannel index is not a channel number (the reference would throw a TypeError)");
+            break;
         default:
             return fail(err, where + "unknown opcode " + std::to_string(u.op));
         }
@@ -246,6 +279,13 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_MONO_DELAY: return 1;  // mono units
     case OP_READBACK_DELAY: return std::max(1, std::max(nin(0), nin(1)));  // ReadBackDelay.js:27
     case OP_MULTI_OSC: return std::max(1, nin(0));                         // MultiChannelOsc.js:22
+    case OP_PAN: return 2;                                                 // Pan.js:8
+    case OP_MIDI_TO_FREQUENCY: return 1;                                   // only channel 0 is ever stored (MidiToFrequency.js:18)
+    case OP_RESCALE: return std::max(1, nin(0));                           // Rescale.js:26
+    case OP_CROSS_FADER: return std::max(1, std::max(nin(0), nin(1)));     // CrossFader.js:22
+    case OP_VECTOR_MAGNITUDE: case OP_TIMER: case OP_PICK_CHANNEL: return 1;  // mono outlets
+    case OP_SAMPLE_RATE_REDUX: return std::max(1, nin(0));                 // SampleRateRedux.js:23-24
+    case OP_CONCAT_CHANNELS: return nin(0) + nin(1);                       // ConcatChannels.js:18
     }
     if (u.op >= OP_MAP_FIRST && u.op <= OP_MAP_LAST) return std::max(1, nin(0));  // loop `c < this.in.length`
     return 1;
@@ -276,6 +316,9 @@ inline bool infer_channels(Graph &g, std::string &err) {
             return fail(err, "Delay with more delay channels than input channels is not supported "
                              "(the reference aliases its input chunk, Delay.js:23)");
         if (u.op == OP_FILTER && u.inlets[1].n_channels(g.units) < 1) return fail(err, "Filter without f");
+        if (u.op == OP_VECTOR_MAGNITUDE && u.inlets[0].n_channels(g.units) > kMaxIn)
+            return fail(err, "VectorMagnitude of more than " + std::to_string(kMaxIn) + " channels is not supported on the GPU path");
+        if (u.op == OP_CONCAT_CHANNELS && u.n_out > 64) return fail(err, "ConcatChannels: too many channels");
     }
     if (g.units[(size_t)g.out_unit].n_out < 1) return fail(err, "the rendered unit has no data outlet");
     return true;
@@ -429,6 +472,55 @@ inline bool expand(Program &P, std::string &err) {
                 op.in[0] = make_operand(g, u.inlets[0], c);
                 slot(c < (int)u.state[0] ? u.state[(size_t)(1 + c)] : 0.0);  // `this.phase[c] = this.phase[c] || 0`
                 break;
+            case OP_PAN:  // mono inlets (Pan.js:6-7); one device op per output channel
+                op.attr = c;
+                op.n_in = 2;
+                op.in[0] = make_operand(g, u.inlets[0], 0);
+                op.in[1] = make_operand(g, u.inlets[1], 0);
+                op.d[0] = u.attrs[0];
+                break;
+            case OP_MIDI_TO_FREQUENCY:
+                op.n_in = 1;
+                op.in[0] = make_operand(g, u.inlets[0], 0);
+                break;
+            case OP_RESCALE:  // every inlet but `in` broadcasts by modulo (Rescale.js:29-32)
+                op.n_in = 5;
+                for (int k = 0; k < 5; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+                break;
+            case OP_CROSS_FADER:  // `this.a[c] || zeroChannel` (CrossFader.js:23-24); dial is mono
+                op.n_in = 3;
+                for (int k = 0; k < 2; k++) {
+                    if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+                    else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
+                }
+                op.in[2] = make_operand(g, u.inlets[2], 0);
+                break;
+            case OP_VECTOR_MAGNITUDE:
+                op.n_in = u.inlets[0].n_channels(g.units);
+                for (int k = 0; k < op.n_in; k++) op.in[k] = make_operand(g, u.inlets[0], k);
+                break;
+            case OP_TIMER:
+                op.d[0] = u.attrs[0];
+                slot(u.state[0]);
+                break;
+            case OP_SAMPLE_RATE_REDUX:  // every channel keeps its own copy of the (shared) counter next to its held value
+                op.in[0] = make_operand(g, u.inlets[0], c);
+                op.in[1] = make_operand(g, u.inlets[1], 0);  // ammount is mono (SampleRateRedux.js:6)
+                slot(u.state[0]);
+                slot(c < (int)u.state[1] ? u.state[(size_t)(2 + c)] : 0.0);  // unwritten output channels read 0
+                break;
+            case OP_CONCAT_CHANNELS: {  // a plain copy of one input channel (ConcatChannels.js:19-30)
+                const int na = u.inlets[0].n_channels(g.units);
+                op.op = OP_REPEATER;
+                op.in[0] = c < na ? make_operand(g, u.inlets[0], c) : make_operand(g, u.inlets[1], c - na);
+                break;
+            }
+            case OP_PICK_CHANNEL: {  // constant index (checked by parse): a copy of channel c % n (PickChannel.js:20)
+                const int n = u.inlets[0].n_channels(g.units);
+                op.op = OP_REPEATER;
+                op.in[0] = make_operand(g, u.inlets[0], (int)std::fmod(u.inlets[1].vals[0], (double)n));
+                break;
+            }
             }
             if (c == 0) u.slots_per_ch = (int)P.init_state.size() - u.first_slot;
             P.ops.push_back(op);

@@ -361,6 +361,18 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 break;
             }
+            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: {
+                V4 w[kMaxIn];
+#pragma unroll
+                for (int k = 0; k < kMaxIn; ++k)
+                    if (k < op.n_in) w[k] = load_operand(op.in[k], bufs, lane, A.params, A.n_inst, inst);
+                    else w[k] = w[0];
+                for (int c = 0; c < 4; ++c) {
+                    const float v[kMaxIn] = {w[0].v[c], w[1].v[c], w[2].v[c], w[3].v[c], w[4].v[c]};
+                    out.v[c] = map_wide(op.op, op.attr, op.n_in, v, op.d[0]);
+                }
+                break;
+            }
             default: {  // stateless elementwise maps (map_ops.hpp)
                 const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 const V4 y = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);

@@ -17,6 +17,8 @@ OP_OSC, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_W
 (OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW, OP_SECONDS_TO_SAMPLES,
  OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW) = range(10, 23)  # elementwise maps
 OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC = range(23, 29)  # §8f-2
+(OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
+ OP_CONCAT_CHANNELS, OP_PICK_CHANNEL) = range(29, 38)  # rest of §8f-1
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
@@ -49,7 +51,21 @@ UNITS = {
     "MonoDelay": (OP_MONO_DELAY, ["in", "delay"]),
     "ReadBackDelay": (OP_READBACK_DELAY, ["in", "delay"]),
     "MultiChannelOsc": (OP_MULTI_OSC, ["f"]),
+    "Pan": (OP_PAN, ["in", "pan"]),
+    "MidiToFrequency": (OP_MIDI_TO_FREQUENCY, ["midi"]),
+    "Rescale": (OP_RESCALE, ["in", "inLower", "inUpper", "outLower", "outUpper"]),
+    "CrossFader": (OP_CROSS_FADER, ["a", "b", "dial"]),
+    "VectorMagnitude": (OP_VECTOR_MAGNITUDE, ["in"]),
+    "Timer": (OP_TIMER, []),
+    "SampleRateRedux": (OP_SAMPLE_RATE_REDUX, ["in", "ammount"]),
+    "ConcatChannels": (OP_CONCAT_CHANNELS, ["a", "b"]),
+    "PickChannel": (OP_PICK_CHANNEL, ["in", "c"]),
 }
+DATA_OUTLET = {"MidiToFrequency": "frequency"}  # every other unit's data outlet is "out" (MidiToFrequency.js:6)
+
+
+def data_outlet_name(unit):
+    return DATA_OUTLET.get(type(unit).__name__, "out")
 
 
 class DuspError(Exception):
@@ -140,6 +156,12 @@ def extract(target):
             attrs, state = [unit.bufferLength], [unit.tBuffer]
         elif op == OP_MULTI_OSC:
             attrs, state = [WAVEFORMS[unit.waveform]], [len(unit.phase)] + [p or 0 for p in unit.phase]
+        elif op == OP_PAN:
+            attrs = [float(unit.compensationDB)]  # a plain property (Pan.js:12)
+        elif op == OP_TIMER:
+            attrs, state = [unit.samplePeriod], [unit.t]
+        elif op == OP_SAMPLE_RATE_REDUX:
+            state = [unit.timeSinceLastUpdate, len(unit.val)] + list(unit.val)
         body += [op, len(inlet_names), len(attrs), len(state)]
         for name in inlet_names:
             inlet = unit.inlets[name]
@@ -147,8 +169,8 @@ def extract(target):
                 src_unit = inlet.outlet.unit
                 if src_unit not in units:
                     raise DuspError("dusp-hip: inlet %s is fed from outside the circuit" % inlet.label)
-                if inlet.outlet.name != "out":
-                    raise DuspError('dusp-hip: only "out" outlets carry data on the GPU path (%s)' % inlet.outlet.label)
+                if inlet.outlet.name != data_outlet_name(src_unit):
+                    raise DuspError('dusp-hip: only the data outlet ("out") of a unit can feed an inlet on the GPU path (%s)' % inlet.outlet.label)
                 body += [IN_CONNECT, 3, units.index(src_unit), 0, 0]
             else:
                 vals = list(inlet.values)
@@ -156,7 +178,7 @@ def extract(target):
                 body += [IN_CONST, len(vals)] + vals
         body += attrs + state
 
-    if outlet.name != "out":
+    if outlet.name != data_outlet_name(out_unit):
         raise DuspError('dusp-hip: only "out" outlets can be rendered on the GPU path')
     ring_words = []
     for r in rings:

@@ -661,3 +661,120 @@ class MultiChannelOsc(Unit):
         if value not in WAVEFORMS:
             raise ValueError("waveform doesn't exist: %s" % value)
         object.__setattr__(self, "_waveform", value)
+
+
+# --------------------------------------------------------------------------- rest of the elementwise sweep
+class Pan(Unit):
+    """reference src/components/Pan.js:3-13 — mono in, stereo out"""
+
+    def __init__(self, input=None, pan=None):
+        super().__init__()
+        self.addInlet("in", mono=True)
+        self.addInlet("pan", mono=True)
+        self.addOutlet("out", numberOfChannels=2)
+        self.PAN = pan or 0
+        self.IN = input or 0
+        self.compensationDB = 1.5
+
+
+class MidiToFrequency(Unit):
+    """reference src/components/MidiToFrequency.js:3-9 — the data outlet is called "frequency" """
+
+    def __init__(self, midi=None):
+        super().__init__()
+        self.addInlet("midi")
+        self.addOutlet("frequency")
+        self.MIDI = midi or 69
+
+
+class Rescale(Unit):
+    """reference src/components/Rescale.js:3-17 — `in` is not a constructor argument"""
+
+    isRescale = True
+
+    def __init__(self, inLower=None, inUpper=None, outLower=None, outUpper=None):
+        super().__init__()
+        for name in ("in", "inLower", "inUpper", "outLower", "outUpper"):
+            self.addInlet(name)
+        self.addOutlet("out")
+        self.IN = 0
+        self.INLOWER = inLower or -1
+        self.INUPPER = inUpper or 1
+        self.OUTLOWER = outLower or 0
+        self.OUTUPPER = outUpper or 1
+
+
+class CrossFader(Unit):
+    """reference src/components/CrossFader.js:3-14 — dial 0: all A, 1: all B"""
+
+    def __init__(self, a=None, b=None, dial=None):
+        super().__init__()
+        self.addInlet("a")
+        self.addInlet("b")
+        self.addInlet("dial", mono=True)
+        self.addOutlet("out")
+        self.A = a or 0
+        self.B = b or 0
+        self.DIAL = dial or 0
+
+
+class VectorMagnitude(Unit):
+    """reference src/components/vector/VectorMagnitude.js:5-11 (no constructor argument)"""
+
+    def __init__(self):
+        super().__init__()
+        self.addInlet("in")
+        self.addOutlet("out", mono=True)
+        self.IN = [0, 0]
+
+
+class Timer(Unit):
+    """reference src/components/Timer.js:26-32,43-45"""
+
+    def __init__(self):
+        super().__init__()
+        self.addOutlet("out", mono=True)
+        self.t = 0
+        self.samplePeriod = 1 / self.sampleRate
+
+    def trigger(self):
+        self.t = 0
+        return self
+
+
+class SampleRateRedux(Unit):
+    """reference src/components/SampleRateRedux.js:3-16 — sample & hold every `ammount` samples"""
+
+    def __init__(self, input=None, ammount=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("ammount", mono=True)
+        self.addOutlet("out")
+        self.val = [0]
+        self.timeSinceLastUpdate = float("inf")
+        self.IN = input or 0
+        self.AMMOUNT = ammount or 0
+
+
+class ConcatChannels(Unit):
+    """reference src/components/ConcatChannels.js:3-11"""
+
+    def __init__(self, a=None, b=None):
+        super().__init__()
+        self.addInlet("a")
+        self.addInlet("b")
+        self.addOutlet("out")
+        self.A = a or 0
+        self.B = b or 0
+
+
+class PickChannel(Unit):
+    """reference src/components/PickChannel.js:3-11"""
+
+    def __init__(self, input=None, c=None):
+        super().__init__()
+        self.addInlet("in")
+        self.addInlet("c", mono=True)
+        self.addOutlet("out", mono=True)
+        self.IN = input or 0
+        self.C = c or 0

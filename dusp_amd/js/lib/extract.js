@@ -38,6 +38,11 @@ function inletConstants(inlet) {
   return Array.isArray(k) ? k.map(Math.fround) : [Math.fround(k || 0)]
 }
 
+function dataOutletName(unit) { // "out" everywhere except MidiToFrequency's "frequency" (MidiToFrequency.js:6)
+  const spec = UNITS[unit.constructor && unit.constructor.name]
+  return (spec && spec.outlet) || 'out'
+}
+
 function extract(target, opts = {}) {
   const outlet = toOutlet(target)
   const outUnit = outlet.unit
@@ -121,6 +126,15 @@ function extract(target, opts = {}) {
         state = [unit.phase.length].concat(Array.from(unit.phase, (p) => p || 0))
         break
       }
+      case OP.PAN:
+        attrs = [Number(unit.compensationDB)] // a plain property (Pan.js:12)
+        break
+      case OP.TIMER:
+        attrs = [unit.samplePeriod]; state = [unit.t]
+        break
+      case OP.SAMPLE_RATE_REDUX: // val = the held sample per channel, `[0]` before the first update (SampleRateRedux.js:9-10)
+        state = [unit.timeSinceLastUpdate, unit.val.length].concat(Array.from(unit.val))
+        break
     }
 
     body.push(spec.op, spec.inlets.length, attrs.length, state.length)
@@ -130,8 +144,8 @@ function extract(target, opts = {}) {
       if (inlet.connected) {
         const src = units.indexOf(inlet.outlet.unit)
         if (src < 0) throw 'dusp-hip: inlet ' + inlet.label + ' is fed from outside the circuit'
-        if (inlet.outlet.name !== 'out')
-          throw 'dusp-hip: only "out" outlets carry data on the GPU path (' + inlet.outlet.label + ')'
+        if (inlet.outlet.name !== dataOutletName(inlet.outlet.unit))
+          throw 'dusp-hip: only the data outlet ("out") of a unit can feed an inlet on the GPU path (' + inlet.outlet.label + ')'
         body.push(INLET.CONNECT, 3, src, 0, 0)
       } else {
         const vals = inletConstants(inlet)
@@ -143,7 +157,7 @@ function extract(target, opts = {}) {
   }
 
   const outIndex = units.indexOf(outUnit)
-  if (outlet.name !== 'out') throw 'dusp-hip: only "out" outlets can be rendered on the GPU path'
+  if (outlet.name !== dataOutletName(outUnit)) throw 'dusp-hip: only "out" outlets can be rendered on the GPU path'
 
   const ringWords = []
   for (const r of rings) ringWords.push(r.numberOfChannels, r.lengthInSamples)

@@ -565,7 +565,103 @@ class MultiChannelOsc extends Unit { // Osc/MultiChannelOsc.js:7-17 — one phas
   resetPhase() { for (const i in this.phase) this.phase[i] = 0 }
 }
 
-module.exports = { FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
+/* ---- rest of the elementwise sweep (SURVEY.md §8f-1) */
+class Pan extends Unit { // Pan.js:3-13 — mono in, stereo out, constant-power-ish compensation
+  constructor(input, pan) {
+    super()
+    this.addInlet('in', { mono: true })
+    this.addInlet('pan', { mono: true })
+    this.addOutlet('out', { numberOfChannels: 2 })
+    this.PAN = pan || 0
+    this.IN = input || 0
+    this.compensationDB = 1.5
+  }
+}
+class MidiToFrequency extends Unit { // MidiToFrequency.js:3-9 — the data outlet is called "frequency"
+  constructor(midi) {
+    super()
+    this.addInlet('midi')
+    this.addOutlet('frequency')
+    this.MIDI = midi || 69
+  }
+}
+class Rescale extends Unit { // Rescale.js:3-17 — `in` is not a constructor argument
+  constructor(inLower, inUpper, outLower, outUpper) {
+    super()
+    for (const n of ['in', 'inLower', 'inUpper', 'outLower', 'outUpper']) this.addInlet(n)
+    this.addOutlet('out')
+    this.IN = 0
+    this.INLOWER = inLower || -1
+    this.INUPPER = inUpper || 1
+    this.OUTLOWER = outLower || 0
+    this.OUTUPPER = outUpper || 1
+  }
+  get isRescale() { return true }
+}
+class CrossFader extends Unit { // CrossFader.js:3-14 — dial 0: all A, 1: all B
+  constructor(a, b, dial) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addInlet('dial', { mono: true })
+    this.addOutlet('out')
+    this.A = a || 0
+    this.B = b || 0
+    this.DIAL = dial || 0
+  }
+}
+class VectorMagnitude extends Unit { // vector/VectorMagnitude.js:5-11 — no constructor argument
+  constructor() {
+    super()
+    this.addInlet('in')
+    this.addOutlet('out', { mono: true })
+    this.IN = [0, 0]
+  }
+}
+class Timer extends Unit { // Timer.js:26-32,43-45
+  constructor() {
+    super()
+    this.addOutlet('out', { mono: true })
+    this.t = 0
+    this.samplePeriod = 1 / this.sampleRate
+  }
+  trigger() { this.t = 0 }
+}
+class SampleRateRedux extends Unit { // SampleRateRedux.js:3-16 — sample & hold every `ammount` samples
+  constructor(input, ammount) {
+    super()
+    this.addInlet('in')
+    this.addInlet('ammount', { mono: true })
+    this.addOutlet('out')
+    this.val = [0]
+    this.timeSinceLastUpdate = Infinity
+    this.IN = input || 0
+    this.AMMOUNT = ammount || 0
+  }
+}
+class ConcatChannels extends Unit { // ConcatChannels.js:3-11
+  constructor(a, b) {
+    super()
+    this.addInlet('a')
+    this.addInlet('b')
+    this.addOutlet('out')
+    this.A = a || 0
+    this.B = b || 0
+  }
+}
+class PickChannel extends Unit { // PickChannel.js:3-11
+  constructor(input, c) {
+    super()
+    this.addInlet('in')
+    this.addInlet('c', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.IN = input || 0
+    this.C = c || 0
+  }
+}
+
+module.exports = { Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+  FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,
   CircleBuffer, CircleBufferNode, CircleBufferReader, CircleBufferWriter, Repeater }

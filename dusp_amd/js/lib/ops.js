@@ -20,6 +20,9 @@ const OP = Object.freeze({
   SECONDS_TO_SAMPLES: 17, FIXED_MULTIPLY: 18, GAIN: 19, DECIBEL_TO_SCALER: 20, SEMITONE_TO_RATIO: 21, POW: 22,
   // delay / filter family and the per-channel oscillator (SURVEY.md §8f-2)
   FIXED_DELAY: 23, COMB_FILTER: 24, ALL_PASS: 25, MONO_DELAY: 26, READBACK_DELAY: 27, MULTI_OSC: 28,
+  // rest of the elementwise sweep (SURVEY.md §8f-1): multi-inlet maps, channel plumbing, two small stateful units
+  PAN: 29, MIDI_TO_FREQUENCY: 30, RESCALE: 31, CROSS_FADER: 32, VECTOR_MAGNITUDE: 33, TIMER: 34, SAMPLE_RATE_REDUX: 35,
+  CONCAT_CHANNELS: 36, PICK_CHANNEL: 37,
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -28,7 +31,7 @@ const WAVEFORMS = Object.freeze({ sin: 0, sine: 0, saw: 1, square: 2, triangle: 
 const WAVEFORM_NAMES = Object.freeze(['sin', 'saw', 'square', 'triangle', '8bit'])
 const FILTER_KINDS = Object.freeze({ LP: 0, HP: 1 })
 
-/* constructor name -> { op, inlets (data inlets, in descriptor order) } */
+/* constructor name -> { op, inlets (data inlets, in descriptor order), outlet (name of the data outlet, default "out") } */
 const UNITS = Object.freeze({
   Osc: { op: OP.OSC, inlets: ['f'] },
   Ramp: { op: OP.RAMP, inlets: [] },
@@ -58,6 +61,15 @@ const UNITS = Object.freeze({
   MonoDelay: { op: OP.MONO_DELAY, inlets: ['in', 'delay'] },
   ReadBackDelay: { op: OP.READBACK_DELAY, inlets: ['in', 'delay'] },
   MultiChannelOsc: { op: OP.MULTI_OSC, inlets: ['f'] },
+  Pan: { op: OP.PAN, inlets: ['in', 'pan'] },
+  MidiToFrequency: { op: OP.MIDI_TO_FREQUENCY, inlets: ['midi'], outlet: 'frequency' },
+  Rescale: { op: OP.RESCALE, inlets: ['in', 'inLower', 'inUpper', 'outLower', 'outUpper'] },
+  CrossFader: { op: OP.CROSS_FADER, inlets: ['a', 'b', 'dial'] },
+  VectorMagnitude: { op: OP.VECTOR_MAGNITUDE, inlets: ['in'] },
+  Timer: { op: OP.TIMER, inlets: [] },
+  SampleRateRedux: { op: OP.SAMPLE_RATE_REDUX, inlets: ['in', 'ammount'] },
+  ConcatChannels: { op: OP.CONCAT_CHANNELS, inlets: ['a', 'b'] },
+  PickChannel: { op: OP.PICK_CHANNEL, inlets: ['in', 'c'] },
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, UNITS }

@@ -1,7 +1,7 @@
 'use strict'
 /* Operator helpers with the reference's folding rules (src/quick.js:15-110): numbers fold, signals
- * build a unit.  Helpers whose unit the GPU path does not execute yet fold numbers and refuse signals. */
-const { Sum, Multiply, Subtract, Divide, PolarityInvert, SemitoneToRatio, Pow, HardClipAbove, HardClipBelow } = require('./graph')
+ * build a unit. */
+const { ConcatChannels, Sum, Multiply, Subtract, Divide, PolarityInvert, SemitoneToRatio, Pow, HardClipAbove, HardClipBelow } = require('./graph')
 
 const isNum = (x) => typeof x === 'number'
 const isSignal = (x) => x && (x.isUnitOrPatch || x.isOutlet)
@@ -31,7 +31,4 @@ exports.clip = function (input, th) {
   if (isSignal(input) || isSignal(th)) throw 'dusp-hip: quick.clip on signals is broken in the reference (Clip is not imported); build a Clip unit directly'
   return Math.abs(input) < Math.abs(th) ? th : input // sic: the reference's number branch (quick.js:106-109)
 }
-exports.concat = function (a, b) {
-  if (isSignal(a) || isSignal(b)) throw 'dusp-hip: quick.concat on signals needs ConcatChannels, which the GPU path does not execute yet'
-  return [].concat(a, b)
-}
+exports.concat = (a, b) => (isSignal(a) || isSignal(b) ? new ConcatChannels(a, b) : [].concat(a, b)) // quick.js:68-73

@@ -7,7 +7,8 @@
  *
  * After the render the circuit is consumed exactly as the reference leaves it: circuit.clock has
  * advanced by the ticked chunks and every unit's state fields (Osc.phase, Ramp.t/playing, Filter
- * history and coefficients, CircleBuffer node t) hold the post-render values (state write-back).
+ * history and coefficients, CircleBuffer node t, Timer.t, SampleRateRedux.val) hold the post-render values
+ * (state write-back).
  */
 const native = require('./native')
 const { extract, unify } = require('./extract')
@@ -41,7 +42,12 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
     else if (spec.op === OP.CB_READER || spec.op === OP.CB_WRITER) unit.t = n.stateDownload(prog, 0, u)[0]
     else if (spec.op === OP.FIXED_DELAY || spec.op === OP.COMB_FILTER || spec.op === OP.ALL_PASS || spec.op === OP.READBACK_DELAY)
       unit.tBuffer = n.stateDownload(prog, 0, u)[0]
-    else if (spec.op === OP.MULTI_OSC) { const s = n.stateDownload(prog, 0, u); for (let c = 0; c < s[0]; c++) unit.phase[c] = s[1 + c] }
+    else if (spec.op === OP.TIMER) unit.t = n.stateDownload(prog, 0, u)[0]
+    else if (spec.op === OP.SAMPLE_RATE_REDUX) {
+      const s = n.stateDownload(prog, 0, u)
+      unit.timeSinceLastUpdate = s[0]
+      unit.val = Array.from(s.subarray ? s.subarray(2, 2 + s[1]) : s.slice(2, 2 + s[1]))
+    } else if (spec.op === OP.MULTI_OSC) { const s = n.stateDownload(prog, 0, u); for (let c = 0; c < s[0]; c++) unit.phase[c] = s[1 + c] }
     else if (spec.op === OP.FILTER) {
       const s = n.stateDownload(prog, 0, u)
       if (s[0]) unit.lastF = s[1]

@@ -1,9 +1,8 @@
 """Operator helpers (reference src/quick.js:15-110): fold when both operands are
-numbers, otherwise build the unit.  Only the helpers whose units the GPU path
-executes build anything; the rest fold numbers and refuse signals (quick.concat needs ConcatChannels)."""
+numbers, otherwise build the unit."""
 import numbers
 
-from .graph import Divide, HardClipAbove, HardClipBelow, Multiply, PolarityInvert, Pow, SemitoneToRatio, Subtract, Sum
+from .graph import ConcatChannels, Divide, HardClipAbove, HardClipBelow, Multiply, PolarityInvert, Pow, SemitoneToRatio, Subtract, Sum
 
 
 def _num(x):
@@ -65,3 +64,10 @@ def clipBelow(input, threshold):
     if _is_signal(input) or _is_signal(threshold):
         return HardClipBelow(input, threshold)
     return threshold if input < threshold else input
+
+
+def concat(a, b):  # quick.js:68-73
+    if _is_signal(a) or _is_signal(b):
+        return ConcatChannels(a, b)
+    as_list = lambda x: list(x) if isinstance(x, (list, tuple)) else [x]
+    return as_list(a) + as_list(b)

@@ -25,7 +25,11 @@ enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READ
        OP_SUBTRACT, OP_DIVIDE, OP_POLARITY_INVERT, OP_ABS, OP_CLIP, OP_HARD_CLIP_ABOVE, OP_HARD_CLIP_BELOW,
        OP_SECONDS_TO_SAMPLES, OP_FIXED_MULTIPLY, OP_GAIN, OP_DECIBEL_TO_SCALER, OP_SEMITONE_TO_RATIO, OP_POW,
        /* delay / filter family, per-channel oscillator */
-       OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC };
+       OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC,
+       /* rest of the elementwise sweep */
+       OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
+       OP_CONCAT_CHANNELS, OP_PICK_CHANNEL };
+#define MAX_INLETS 5
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
 
 /* ---- SignalChunk (reference src/SignalChunk.js:1-11): channelData[c] = Float32Array(chunkSize).
@@ -93,7 +97,7 @@ typedef struct {
 
 typedef struct unit {
     int op, n_inlets;
-    inlet_t in[2];
+    inlet_t in[MAX_INLETS];
     chunk_t out;
     /* Osc */
     int waveform;
@@ -119,6 +123,10 @@ typedef struct unit {
     double tBuffer;
     int nphase;
     double *phases;
+    /* Pan: compensationDB; Timer: t, samplePeriod; SampleRateRedux: val[], timeSinceLastUpdate */
+    double comp_db, timer_t, sample_period, tslu;
+    int nval;
+    float *val;
 } unit_t;
 
 struct dusp_oracle {
@@ -488,6 +496,108 @@ static void tick_map(dusp_oracle *o, unit_t *u) {
     }
 }
 
+
+/* reference src/components/Pan.js:19-29 — mono in / pan, two output channels */
+static void tick_pan(dusp_oracle *o, unit_t *u) {
+    const float *in = inlet_chunk(o, u, 0)->ch[0], *pan = inlet_chunk(o, u, 1)->ch[0];
+    for (int t = 0; t < o->chunk; t++) {
+        const double compensation = js_pow(10, ((1 - fabs((double)pan[t])) * u->comp_db) / 20);
+        u->out.ch[0][t] = (float)((double)in[t] * (1 - (double)pan[t]) / 2 * compensation);
+        u->out.ch[1][t] = (float)((double)in[t] * (1 + (double)pan[t]) / 2 * compensation);
+    }
+}
+
+/* reference src/components/MidiToFrequency.js:15-22: `this.frequency[c] || new Float32Array(..)` never stores the new
+ * array, so only channel 0 of the outlet ever exists; the other midi channels are computed into garbage. */
+static void tick_midi_to_frequency(dusp_oracle *o, unit_t *u) {
+    const float *m = inlet_chunk(o, u, 0)->ch[0];
+    for (int t = 0; t < o->chunk; t++) u->out.ch[0][t] = (float)(js_pow(2, ((double)m[t] - 69) / 12) * 440);
+}
+
+/* reference src/components/Rescale.js:25-38 */
+static void tick_rescale(dusp_oracle *o, unit_t *u) {
+    chunk_t *in = inlet_chunk(o, u, 0), *il = inlet_chunk(o, u, 1), *iu = inlet_chunk(o, u, 2), *ol = inlet_chunk(o, u, 3),
+            *ou = inlet_chunk(o, u, 4);
+    for (int c = 0; c < in->nch; c++) {
+        float *oc = chunk_ensure(&u->out, c, o->chunk);
+        const float *x = in->ch[c], *a = il->ch[c % il->nch], *b = iu->ch[c % iu->nch], *p = ol->ch[c % ol->nch],
+                    *q = ou->ch[c % ou->nch];
+        for (int t = 0; t < o->chunk; t++)
+            oc[t] = (float)(((double)x[t] - (double)a[t]) / ((double)b[t] - (double)a[t]) * ((double)q[t] - (double)p[t]) + (double)p[t]);
+    }
+}
+
+/* reference src/components/CrossFader.js:21-30: a missing channel of a / b is silence */
+static void tick_cross_fader(dusp_oracle *o, unit_t *u) {
+    static float zero[4096];
+    chunk_t *a = inlet_chunk(o, u, 0), *b = inlet_chunk(o, u, 1);
+    const float *dial = inlet_chunk(o, u, 2)->ch[0];
+    for (int c = 0; c < a->nch || c < b->nch; c++) {
+        const float *ac = c < a->nch ? a->ch[c] : zero, *bc = c < b->nch ? b->ch[c] : zero;
+        float *oc = chunk_ensure(&u->out, c, o->chunk);
+        for (int t = 0; t < o->chunk; t++) oc[t] = (float)((1 - (double)dial[t]) * (double)ac[t] + (double)dial[t] * (double)bc[t]);
+    }
+}
+
+/* reference src/components/vector/VectorMagnitude.js:17-29 */
+static void tick_vector_magnitude(dusp_oracle *o, unit_t *u) {
+    chunk_t *in = inlet_chunk(o, u, 0);
+    for (int t = 0; t < o->chunk; t++) {
+        double squareSum = 0;
+        for (int c = 0; c < in->nch; c++) {
+            const double x = in->ch[c][t];
+            squareSum += x * x;
+        }
+        u->out.ch[0][t] = (float)sqrt(squareSum);
+    }
+}
+
+/* reference src/components/Timer.js:36-41 */
+static void tick_timer(dusp_oracle *o, unit_t *u) {
+    for (int t = 0; t < o->chunk; t++) {
+        u->timer_t += u->sample_period;
+        u->out.ch[0][t] = (float)u->timer_t;
+    }
+}
+
+/* reference src/components/SampleRateRedux.js:21-38: `val` has one entry before the first update, then one per input
+ * channel; output channels beyond val.length are not written that sample */
+static void tick_sample_rate_redux(dusp_oracle *o, unit_t *u) {
+    chunk_t *in = inlet_chunk(o, u, 0);
+    const float *amount = inlet_chunk(o, u, 1)->ch[0];
+    while (u->out.nch < in->nch) chunk_ensure(&u->out, u->out.nch, o->chunk);
+    for (int t = 0; t < o->chunk; t++) {
+        u->tslu += 1;
+        if (u->tslu > (double)amount[t]) {
+            if (u->nval < in->nch) u->val = (float *)realloc(u->val, (size_t)in->nch * sizeof(float));
+            u->nval = in->nch;
+            for (int c = 0; c < in->nch; c++) u->val[c] = in->ch[c][t];
+            u->tslu = 0;
+        }
+        for (int c = 0; c < u->nval && c < u->out.nch; c++) u->out.ch[c][t] = u->val[c];
+    }
+}
+
+/* reference src/components/ConcatChannels.js:17-31 */
+static void tick_concat_channels(dusp_oracle *o, unit_t *u) {
+    chunk_t *a = inlet_chunk(o, u, 0), *b = inlet_chunk(o, u, 1);
+    for (int c = 0; c < a->nch + b->nch; c++) {
+        float *oc = chunk_ensure(&u->out, c, o->chunk);
+        memcpy(oc, c < a->nch ? a->ch[c] : b->ch[c - a->nch], (size_t)o->chunk * sizeof(float));
+    }
+}
+
+/* reference src/components/PickChannel.js:17-22: `this.in[this.c[t] % this.in.length][t]`; an index that is not one
+ * of 0..n-1 (fractional, negative, NaN) makes the reference throw a TypeError mid-render — NaN here */
+static void tick_pick_channel(dusp_oracle *o, unit_t *u) {
+    chunk_t *in = inlet_chunk(o, u, 0);
+    const float *c = inlet_chunk(o, u, 1)->ch[0];
+    for (int t = 0; t < o->chunk; t++) {
+        const double k = fmod((double)c[t], (double)in->nch);
+        u->out.ch[0][t] = (k >= 0 && k < in->nch && k == floor(k)) ? in->ch[(int)k][t] : NAN;
+    }
+}
+
 /* reference src/Circuit.js:19-41 (tick) with src/Unit.js:111-119; every unit's
  * tickInterval equals the chunk size here, so gcdTickInterval == chunk. */
 static void circuit_tick(dusp_oracle *o) {
@@ -507,6 +617,15 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_MONO_DELAY: tick_mono_delay(o, u, o->clock); break;
         case OP_READBACK_DELAY: tick_readback_delay(o, u); break;
         case OP_MULTI_OSC: tick_multi_osc(o, u); break;
+        case OP_PAN: tick_pan(o, u); break;
+        case OP_MIDI_TO_FREQUENCY: tick_midi_to_frequency(o, u); break;
+        case OP_RESCALE: tick_rescale(o, u); break;
+        case OP_CROSS_FADER: tick_cross_fader(o, u); break;
+        case OP_VECTOR_MAGNITUDE: tick_vector_magnitude(o, u); break;
+        case OP_TIMER: tick_timer(o, u); break;
+        case OP_SAMPLE_RATE_REDUX: tick_sample_rate_redux(o, u); break;
+        case OP_CONCAT_CHANNELS: tick_concat_channels(o, u); break;
+        case OP_PICK_CHANNEL: tick_pick_channel(o, u); break;
         default: tick_map(o, u); break;
         }
     }
@@ -567,7 +686,7 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
         u->n_inlets = (int)d[p + 1];
         const size_t n_attr = (size_t)d[p + 2], n_state = (size_t)d[p + 3];
         p += 4;
-        if (u->n_inlets < 0 || u->n_inlets > 2) FAIL("unit %zu: bad inlet count", i);
+        if (u->n_inlets < 0 || u->n_inlets > MAX_INLETS) FAIL("unit %zu: bad inlet count", i);
         for (int k = 0; k < u->n_inlets; k++) {
             if (p + 2 > nw) FAIL("truncated inlet");
             const int kind = (int)d[p];
@@ -681,6 +800,35 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             for (int c = 0; c < u->nphase; c++) u->phases[c] = s[1 + c];
             break;
         }
+        case OP_PAN:
+            if (u->n_inlets != 2 || n_attr != 1 || n_state) FAIL("unit %zu: bad Pan record", i);
+            u->comp_db = a[0];
+            out_channels = 2; /* Pan.js:8 */
+            break;
+        case OP_MIDI_TO_FREQUENCY: case OP_VECTOR_MAGNITUDE:
+            if (u->n_inlets != 1 || n_attr || n_state) FAIL("unit %zu: bad unary record", i);
+            break;
+        case OP_RESCALE:
+            if (u->n_inlets != 5 || n_attr || n_state) FAIL("unit %zu: bad Rescale record", i);
+            break;
+        case OP_CROSS_FADER:
+            if (u->n_inlets != 3 || n_attr || n_state) FAIL("unit %zu: bad CrossFader record", i);
+            break;
+        case OP_TIMER:
+            if (u->n_inlets != 0 || n_attr != 1 || n_state != 1) FAIL("unit %zu: bad Timer record", i);
+            u->sample_period = a[0];
+            u->timer_t = s[0];
+            break;
+        case OP_SAMPLE_RATE_REDUX:
+            if (u->n_inlets != 2 || n_attr || n_state < 2 || n_state != (size_t)(2 + s[1])) FAIL("unit %zu: bad SampleRateRedux record", i);
+            u->tslu = s[0];
+            u->nval = (int)s[1];
+            u->val = (float *)calloc((size_t)u->nval + 1, sizeof(float));
+            for (int c = 0; c < u->nval; c++) u->val[c] = (float)s[2 + c];
+            break;
+        case OP_CONCAT_CHANNELS: case OP_PICK_CHANNEL:
+            if (u->n_inlets != 2 || n_attr || n_state) FAIL("unit %zu: bad channel-plumbing record", i);
+            break;
         default: FAIL("unit %zu: unknown opcode %d", i, u->op);
         }
         chunk_init(&u->out, out_channels, o->chunk);
@@ -738,6 +886,10 @@ size_t dusp_oracle_unit_state(const dusp_oracle *o, size_t i, double *out, size_
     case OP_RAMP: tmp[n++] = u->t; tmp[n++] = u->playing; break;
     case OP_CB_READER: case OP_CB_WRITER: tmp[n++] = u->cb_t; break;
     case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY: tmp[n++] = u->tBuffer; break;
+    case OP_TIMER: tmp[n++] = u->timer_t; break;
+    case OP_SAMPLE_RATE_REDUX:
+        for (size_t k = 0; k < (size_t)u->nval + 2 && k < cap; k++) out[k] = k == 0 ? u->tslu : k == 1 ? (double)u->nval : (double)u->val[k - 2];
+        return (size_t)u->nval + 2;
     case OP_MULTI_OSC:
         for (size_t k = 0; k < (size_t)u->nphase + 1 && k < cap; k++) out[k] = k ? u->phases[k - 1] : (double)u->nphase;
         return (size_t)u->nphase + 1;

@@ -44,7 +44,8 @@ const quick = ref('quick.js')
 const more = {}
 for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardClipAbove', 'HardClipBelow', 'SecondsToSamples',
   'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow', 'FixedDelay', 'CombFilter', 'AllPass', 'MonoDelay',
-  'ReadBackDelay']) more[n] = ref('components/' + n + '.js')
+  'ReadBackDelay', 'Pan', 'MidiToFrequency', 'Rescale', 'CrossFader', 'VectorMagnitude', 'Timer', 'SampleRateRedux',
+  'ConcatChannels', 'PickChannel']) more[n] = ref('components/' + n + '.js')
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
 const waveTables = ref('components/Osc/waveTables.js')
 

@@ -5,7 +5,8 @@ did, and as ready-made graphs for the GPU parity tests."""
 import dusp_amd as d
 from dusp_amd import (Abs, AllPass, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, CombFilter, DecibelToScaler, Delay, Divide, Filter, FixedDelay,
                       FixedMultiply, Gain, HardClipAbove, HardClipBelow, MonoDelay, MultiChannelOsc, Multiply, Osc, Pow, Ramp, ReadBackDelay, Repeater,
-                      SecondsToSamples, SemitoneToRatio, Subtract, Sum, quick)
+                      SecondsToSamples, SemitoneToRatio, Subtract, Sum, quick,
+                      ConcatChannels, CrossFader, MidiToFrequency, Pan, PickChannel, Rescale, SampleRateRedux, Timer, VectorMagnitude)
 
 
 def _loop(f_osc, delay, max_delay, cutoff, gain):
@@ -83,6 +84,12 @@ def _allpass_loop():
     return a
 
 
+def _srr_nan():
+    r = SampleRateRedux(Osc(300), 5)
+    r.AMMOUNT = float("nan")
+    return r
+
+
 def builders(sr):
     """name -> zero-argument builder; call d.configure(sr) first (done by build())."""
     voices = lambda n: [Osc(k * 10) for k in range(1, n + 1)]
@@ -143,6 +150,30 @@ def builders(sr):
         "fam_multiosc": lambda: MultiChannelOsc([220, 330.5, 441.25]),
         "fam_multiosc_fm": lambda: MultiChannelOsc(Sum(Multiply(Osc(5), [20, 40]), 300), "triangle"),
         "fam_multiosc_negative": lambda: MultiChannelOsc(-100),
+        # SURVEY.md 8f-1, the rest of the sweep
+        "rest_pan": lambda: Pan(Osc(440), Osc(2)),
+        "rest_pan_const": lambda: Pan(Osc(300.5, "saw"), -0.3),
+        "rest_pan_filter": lambda: Filter(Pan(Osc(200, "square"), 0.25), 1500),
+        "rest_midi_fm": lambda: Osc(MidiToFrequency(Sum(Multiply(Osc(3), 12), 60))),
+        "rest_midi_multi": lambda: MidiToFrequency([60, 72]),
+        "rest_rescale_fm": lambda: Osc(_with_in(Rescale(-1, 1, 200, 800), Osc(5))),
+        "rest_rescale_2ch": lambda: _with_in(Rescale(Multiply(Osc(1), 0.5), 2, [0, 10], [1, 20]), Multiply(Osc(100), [1, 0.5])),
+        "rest_rescale_default": lambda: _with_in(Rescale(), Osc(441, "triangle")),
+        "rest_crossfader": lambda: CrossFader(Osc(220), Multiply(Osc(330, "square"), [1, 0.5]), Sum(Multiply(Osc(4), 0.5), 0.5)),
+        "rest_crossfader_const": lambda: CrossFader(Osc(100), 0.5, 0.25),
+        "rest_vecmag": lambda: _with_in(VectorMagnitude(), Multiply(Osc(50), [1, 0.5, -2])),
+        "rest_vecmag_2d": lambda: _with_in(VectorMagnitude(), ConcatChannels(Osc(100), Osc(100.5, "triangle"))),
+        "rest_vecmag_default": lambda: VectorMagnitude(),
+        "rest_timer": lambda: Timer(),
+        "rest_timer_fm": lambda: Osc(Multiply(Timer(), 4000)),
+        "rest_srr": lambda: SampleRateRedux(Osc(440), 10),
+        "rest_srr_mod": lambda: SampleRateRedux(Multiply(Osc(300), [1, -1]), Sum(Multiply(Osc(2), 20), 20.5)),
+        "rest_srr_nan": _srr_nan,
+        "rest_srr_nan_later": lambda: SampleRateRedux(Osc(300), Divide(Osc(100), Osc(100))),
+        "rest_concat": lambda: ConcatChannels(Multiply(Osc(100), [1, 0.5]), Osc(200)),
+        "rest_concat_quick": lambda: quick.concat(Osc(50), 0.25),
+        "rest_pick": lambda: PickChannel(Multiply(Osc(100), [1, 0.5, 0.25]), 4),
+        "rest_pick_default": lambda: PickChannel(Multiply(Osc(60), [0.75, 0.5])),
     }
     for tag, f in [("440p5", 440.5), ("0p1", 0.1), ("neg3", -3), ("47999p5", 47999.5), ("neg0p37", -0.37),
                    ("12345p678", 12345.678), ("tiny", 3e-5)]:

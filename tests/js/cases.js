@@ -10,7 +10,8 @@
 module.exports = function goldenCases(L, SR) {
   const { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader, CircleBufferWriter, quick,
     Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
-    DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc } = L
+    DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc,
+    Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel } = L
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -157,6 +158,35 @@ module.exports = function goldenCases(L, SR) {
     add('fam_multiosc_negative', () => new MultiChannelOsc(-100), 0.01) // no `phase < 0` fix-up in this unit: negative index -> NaN
   }
 
+  // SURVEY.md §8f-1, the rest of the sweep: multi-inlet maps, channel plumbing, Timer, SampleRateRedux
+  if (Pan) {
+    const withIn = (u, x) => { u.IN = x; return u }
+    add('rest_pan', () => new Pan(new Osc(440), new Osc(2)), 0.05) // stereo out, pan sweeping -1..1
+    add('rest_pan_const', () => new Pan(new Osc(300.5, 'saw'), -0.3), 0.01)
+    add('rest_pan_filter', () => new Filter(new Pan(new Osc(200, 'square'), 0.25), 1500), 0.02) // 2 channels through a Filter
+    add('rest_midi_fm', () => new Osc(new MidiToFrequency(new Sum(new Multiply(new Osc(3), 12), 60))), 0.05) // "frequency" outlet feeding an inlet
+    add('rest_midi_multi', () => new MidiToFrequency([60, 72]), 0.01) // only channel 0 is ever stored (MidiToFrequency.js:18)
+    add('rest_rescale_fm', () => new Osc(withIn(new Rescale(-1, 1, 200, 800), new Osc(5))), 0.05)
+    add('rest_rescale_2ch', () => withIn(new Rescale(new Multiply(new Osc(1), 0.5), 2, [0, 10], [1, 20]), new Multiply(new Osc(100), [1, 0.5])), 0.02)
+    add('rest_rescale_default', () => withIn(new Rescale(), new Osc(441, 'triangle')), 0.01)
+    add('rest_crossfader', () => new CrossFader(new Osc(220), new Multiply(new Osc(330, 'square'), [1, 0.5]),
+      new Sum(new Multiply(new Osc(4), 0.5), 0.5)), 0.05) // b has a channel a lacks: silence, not a modulo broadcast
+    add('rest_crossfader_const', () => new CrossFader(new Osc(100), 0.5, 0.25), 0.01)
+    add('rest_vecmag', () => withIn(new VectorMagnitude(), new Multiply(new Osc(50), [1, 0.5, -2])), 0.02)
+    add('rest_vecmag_2d', () => withIn(new VectorMagnitude(), new ConcatChannels(new Osc(100), new Osc(100.5, 'triangle'))), 0.02)
+    add('rest_vecmag_default', () => new VectorMagnitude(), 0.01)
+    add('rest_timer', () => new Timer(), 0.05)
+    add('rest_timer_fm', () => new Osc(new Multiply(new Timer(), 4000)), 0.05)
+    add('rest_srr', () => new SampleRateRedux(new Osc(440), 10), 0.02)
+    add('rest_srr_mod', () => new SampleRateRedux(new Multiply(new Osc(300), [1, -1]), new Sum(new Multiply(new Osc(2), 20), 20.5)), 0.1)
+    add('rest_srr_nan', () => { const r = new SampleRateRedux(new Osc(300), 5); r.AMMOUNT = NaN; return r }, 0.01) // `x > NaN` is false: nothing is ever sampled
+    add('rest_srr_nan_later', () => new SampleRateRedux(new Osc(300), new Divide(new Osc(100), new Osc(100))), 0.02) // 0/0 once per 480 samples
+    add('rest_concat', () => new ConcatChannels(new Multiply(new Osc(100), [1, 0.5]), new Osc(200)), 0.01) // 2 + 1 channels
+    add('rest_concat_quick', () => quick.concat(new Osc(50), 0.25), 0.01)
+    add('rest_pick', () => new PickChannel(new Multiply(new Osc(100), [1, 0.5, 0.25]), 4), 0.01) // 4 % 3 = channel 1
+    add('rest_pick_default', () => new PickChannel(new Multiply(new Osc(60), [0.75, 0.5])), 0.01)
+  }
+
   // SURVEY.md §8f-3: scheduled events (host callbacks at chunk boundaries).  `ev_` cases are rendered only
   // through the JS surface (tests/js/check_render.js): their descriptor alone does not carry the callbacks.
   add('ev_retrigger', () => {
@@ -181,5 +211,11 @@ module.exports = function goldenCases(L, SR) {
     filt.schedule(0.06, function () { this.F = 800 })
     return filt
   }, 0.1)
+  if (Timer)
+    add('ev_timer_trigger', () => {
+      const tm = new Timer()
+      tm.scheduleTrigger(0.02)
+      return new Osc(new Multiply(tm, 20000))
+    }, 0.05)
   return cases
 }

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5  # north_star: "within 1e-5 relative float tolerance" (of full scale)
 # device tan() in the Filter coefficients, device pow() in Gain / DecibelToScaler / SemitoneToRatio / Pow
-USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow", "map_fm_semitone")
+# ... and in Pan's compensation gain / MidiToFrequency
+USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow", "map_fm_semitone", "rest_pan", "rest_midi")
 
 
 # |f| < 2^-13: the reference's own f64 phase accumulation rounds there (SURVEY.md §8a note ii), so the wave
@@ -38,6 +39,8 @@ ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": r
 EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
                    "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
                    "loop_220": "loop", "loop_110p5_short": "loop", "loop_frac_delay": "loop", "loop_220_sr44100": "loop", "delay_mod": "chunk", "delay_2ch": "chunk", "circlebuffer_taps": "chunk", "fam_comb": "chunk",
+                   "rest_crossfader": "wave", "rest_rescale_2ch": "wave", "rest_vecmag": "wave", "rest_concat": "wave", "rest_pick": "wave",
+                   "rest_timer_fm": "chunk", "rest_srr_mod": "chunk",
                    "filter_2ch": "wave", "filter_lp_mod": "wave", "filter_hp": "wave", "delay_default": "wave", "delay_wrap": "wave"}
 
 
@@ -60,7 +63,8 @@ def test_render_matches_reference_golden(name, engine, oracle):
     prog.close()
 
 
-@pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum"])
+@pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum",
+                                  "rest_timer_fm", "rest_srr_mod", "rest_srr_nan", "rest_srr", "rest_vecmag_2d"])
 @pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
@@ -88,7 +92,8 @@ def test_malformed_descriptors_are_rejected_not_crashed():
     ctx = render.context(48000)
     poison = [np.nan, np.inf, -1.0, 0.5, 1e18, -1e18, 3.0, 65536.0, 2.0 ** 40]
     built = rejected = 0
-    for name in ("cfg2_sweep", "loop_220", "circlebuffer_2ch", "filter_2ch", "summany_8", "map_db_semitone"):
+    for name in ("cfg2_sweep", "loop_220", "circlebuffer_2ch", "filter_2ch", "summany_8", "map_db_semitone", "rest_rescale_2ch",
+                 "rest_srr_mod", "rest_pick", "rest_vecmag"):
         g = Golden(name)
         trials = [g.desc[:k] for k in range(0, g.desc.size, 3)]
         for _ in range(150):
