@@ -424,6 +424,77 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 }
                 break;
             }
+            case OP_SHAPE: {  // Shape/index.js:28-59
+                const Src duration = make_src(op.in[0], a, i), mn = make_src(op.in[1], a, i), mx = make_src(op.in[2], a, i);
+                const float *data = a.tables + (size_t)(op.attr & 255) * a.table_stride;
+                const bool left_shape = (op.attr & 256) != 0, right_shape = (op.attr & 512) != 0;
+                const double left = left_shape ? (double)data[0] : op.d[0];
+                const double right = right_shape ? (double)data[a.sample_rate] : op.d[1];
+                double tt = st[0];
+                const bool playing = st[NP] != 0.0;
+                bool finished = st[2 * NP] != 0.0;
+                for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
+                    float dv[kBatch], lo[kBatch], hi[kBatch], r[kBatch];
+                    duration.load(t0, dv);
+                    mn.load(t0, lo);
+                    mx.load(t0, hi);
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const double l = (double)lo[k], h = (double)hi[k];
+                        if (playing) tt += 1.0 / (double)dv[k];
+                        if (tt <= 0.0) {
+                            r[k] = (float)(left * (h - l) + l);
+                        } else if (tt > sr) {
+                            finished = true;
+                            r[k] = (float)(right * (h - l) + l);
+                        } else if (tt == tt) {
+                            const double fl = floor(tt), frac = tt - fl;  // t % 1 for t > 0
+                            const double hi_tap = (double)data[(int)ceil(tt)], lo_tap = (double)data[(int)fl];
+                            r[k] = (float)(l + (h - l) * (hi_tap * frac + lo_tap * (1.0 - frac)));
+                        } else
+                            r[k] = __builtin_nanf("");  // t is NaN: table[NaN] is undefined
+                    }
+                    store_batch(outp, NP, t0, r);
+                }
+                st[0] = tt;
+                st[2 * NP] = finished ? 1.0 : 0.0;
+                break;
+            }
+            case OP_AHD: {  // AHD.js:35-76
+                const Src attack = make_src(op.in[0], a, i), hold = make_src(op.in[1], a, i), decay = make_src(op.in[2], a, i);
+                const double period = op.d[0];
+                int stage = (int)st[0];
+                bool playing = st[NP] != 0.0;
+                double tt = st[2 * NP];
+                for (int t = 0; t < kChunk; ++t) {
+                    float y = outp[(size_t)t * NP];  // an unknown `state` leaves the sample as it was
+                    if (stage == 1) {
+                        y = (float)tt;
+                        if (playing) {
+                            tt += period / (double)attack.at(t);
+                            if (tt >= 1.0) { ++stage; tt -= 1.0; }
+                        }
+                    } else if (stage == 2) {
+                        y = 1.f;
+                        if (playing) {
+                            tt += period / (double)hold.at(t);
+                            if (tt >= 1.0) { ++stage; tt -= 1.0; }
+                        }
+                    } else if (stage == 3) {
+                        y = (float)(1.0 - tt);
+                        if (playing) {
+                            tt += period / (double)decay.at(t);
+                            if (tt >= 1.0) { stage = 0; playing = false; }  // stop()
+                        }
+                    } else if (stage == 0)
+                        y = 0.f;
+                    outp[(size_t)t * NP] = y;
+                }
+                st[0] = (double)stage;
+                st[NP] = playing ? 1.0 : 0.0;
+                st[2 * NP] = tt;
+                break;
+            }
             case OP_TIMER: {  // Timer.js:36-41: a running f64 sum of 1/sampleRate, rounded to f32 per sample
                 double tt = st[0];
                 const double period = op.d[0];

@@ -15,13 +15,15 @@ enum : int {
     // host compiler turns them into per-channel copies (OP_REPEATER device ops).
     OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
     OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
+    OP_SHAPE, OP_AHD,  // envelopes
     OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW,    // stateless maps of at most two operands (map_apply)
     OP_WIDE_FIRST = OP_PAN, OP_WIDE_LAST = OP_VECTOR_MAGNITUDE  // stateless maps of up to kMaxIn operands (map_wide)
 };
 constexpr int kMaxIn = 5;  // Rescale has five inlets
 enum : int { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };   // descriptor inlet kinds
 enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand kinds
-constexpr int kNumTables = 5;
+constexpr int kNumTables = 9;      // 0-4 oscillator wave tables, 5-8 Shape tables (decay, attack, semiSine, decaySquared)
+constexpr int kFirstShapeTable = 5;
 constexpr int kChunk = 256;
 
 #if defined(__HIPCC__)

@@ -290,7 +290,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
 static int check_tables(dusp_program *prog) {
     dusp_ctx *ctx = prog->ctx;
     for (const auto &u : prog->P.g.units)
-        if (u.op == dusp::OP_OSC) {
+        if (u.op == dusp::OP_OSC || u.op == dusp::OP_MULTI_OSC || u.op == dusp::OP_SHAPE) {
             const int w = (int)u.attrs[0];
             if (!ctx->d_tables || !ctx->table_set[w])
                 CTX_FAIL(ctx, DUSP_ERR_STATE, "render: wave table " + std::to_string(w) + " has not been uploaded (dusp_table_upload)");

@@ -242,6 +242,14 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
                 return fail(err, where + "bad SampleRateRedux record");
             break;
         }
+        case OP_SHAPE:
+            if (!need(3, 5, 3)) return fail(err, where + "bad Shape record");
+            if (!(u.attrs[0] >= kFirstShapeTable && u.attrs[0] < kNumTables && u.attrs[0] == std::floor(u.attrs[0])))
+                return fail(err, where + "shape table doesn't exist");
+            break;
+        case OP_AHD:
+            if (!need(3, 1, 3)) return fail(err, where + "bad AHD record");
+            break;
         case OP_CONCAT_CHANNELS:
             if (!need(2, 0, 0)) return fail(err, where + "bad ConcatChannels record");
             break;
@@ -283,7 +291,7 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_MIDI_TO_FREQUENCY: return 1;                                   // only channel 0 is ever stored (MidiToFrequency.js:18)
     case OP_RESCALE: return std::max(1, nin(0));                           // Rescale.js:26
     case OP_CROSS_FADER: return std::max(1, std::max(nin(0), nin(1)));     // CrossFader.js:22
-    case OP_VECTOR_MAGNITUDE: case OP_TIMER: case OP_PICK_CHANNEL: return 1;  // mono outlets
+    case OP_VECTOR_MAGNITUDE: case OP_TIMER: case OP_PICK_CHANNEL: case OP_SHAPE: case OP_AHD: return 1;  // mono outlets
     case OP_SAMPLE_RATE_REDUX: return std::max(1, nin(0));                 // SampleRateRedux.js:23-24
     case OP_CONCAT_CHANNELS: return nin(0) + nin(1);                       // ConcatChannels.js:18
     }
@@ -502,6 +510,24 @@ inline bool expand(Program &P, std::string &err) {
             case OP_TIMER:
                 op.d[0] = u.attrs[0];
                 slot(u.state[0]);
+                break;
+            case OP_SHAPE:  // mono inlets duration / min / max; attr: table id | left-is-shape << 8 | right-is-shape << 9
+                op.n_in = 3;
+                for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
+                op.attr = (int)u.attrs[0] | (u.attrs[1] != 0 ? 256 : 0) | (u.attrs[3] != 0 ? 512 : 0);
+                op.d[0] = u.attrs[2];  // leftEdge as a number
+                op.d[1] = u.attrs[4];  // rightEdge as a number
+                slot(u.state[0]);                    // t
+                slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
+                slot(u.state[2] != 0 ? 1.0 : 0.0);   // finished
+                break;
+            case OP_AHD:
+                op.n_in = 3;
+                for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
+                op.d[0] = u.attrs[0];  // samplePeriod
+                slot(u.state[0]);                    // state (0 off, 1 attack, 2 hold, 3 decay)
+                slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
+                slot(u.state[2]);                    // t
                 break;
             case OP_SAMPLE_RATE_REDUX:  // every channel keeps its own copy of the (shared) counter next to its held value
                 op.in[0] = make_operand(g, u.inlets[0], c);

@@ -19,6 +19,7 @@ OP_OSC, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READER, OP_CB_W
 OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC = range(23, 29)  # §8f-2
 (OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
  OP_CONCAT_CHANNELS, OP_PICK_CHANNEL) = range(29, 38)  # rest of §8f-1
+OP_SHAPE, OP_AHD = 38, 39  # envelopes (§8f-3)
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
@@ -60,6 +61,8 @@ UNITS = {
     "SampleRateRedux": (OP_SAMPLE_RATE_REDUX, ["in", "ammount"]),
     "ConcatChannels": (OP_CONCAT_CHANNELS, ["a", "b"]),
     "PickChannel": (OP_PICK_CHANNEL, ["in", "c"]),
+    "Shape": (OP_SHAPE, ["duration", "min", "max"]),
+    "AHD": (OP_AHD, ["attack", "hold", "decay"]),
 }
 DATA_OUTLET = {"MidiToFrequency": "frequency"}  # every other unit's data outlet is "out" (MidiToFrequency.js:6)
 
@@ -156,6 +159,21 @@ def extract(target):
             attrs, state = [unit.bufferLength], [unit.tBuffer]
         elif op == OP_MULTI_OSC:
             attrs, state = [WAVEFORMS[unit.waveform]], [len(unit.phase)] + [p or 0 for p in unit.phase]
+        elif op == OP_SHAPE:
+            from .wavetables import SHAPES
+
+            def edge(e):  # the string "shape" (= the table's end value) or a plain number (Shape/index.js:35-49)
+                if isinstance(e, str):
+                    if e != "shape":
+                        raise DuspError('dusp-hip: Shape edge must be "shape" or a number (%s)' % unit.label)
+                    return [1, 0]
+                return [0, float(e)]
+            if getattr(unit, "_finish", None) or getattr(unit, "onFinish", None):
+                raise DuspError("dusp-hip: finish callbacks cannot run on the GPU path (%s)" % unit.label)
+            attrs = [SHAPES[unit.shape]] + edge(unit.leftEdge) + edge(unit.rightEdge)
+            state = [unit.t, 1 if unit.playing else 0, 1 if unit.finished else 0]
+        elif op == OP_AHD:
+            attrs, state = [1 / outlet.sampleRate], [unit.state, 1 if unit.playing else 0, unit.t]
         elif op == OP_PAN:
             attrs = [float(unit.compensationDB)]  # a plain property (Pan.js:12)
         elif op == OP_TIMER:

@@ -778,3 +778,71 @@ class PickChannel(Unit):
         self.addOutlet("out", mono=True)
         self.IN = input or 0
         self.C = c or 0
+
+
+# --------------------------------------------------------------------------- envelopes
+class Shape(Unit):
+    """reference src/components/Shape/index.js:7-23,107-122 — a table read once over `duration` seconds after trigger()"""
+
+    def __init__(self, shape=None, durationInSeconds=None, min=None, max=None):  # noqa: A002 - the reference's names
+        super().__init__()
+        self.addInlet("duration", mono=True)
+        self.addInlet("min", mono=True)
+        self.addInlet("max", mono=True)
+        self.addOutlet("out", mono=True)
+        self.t = 0
+        self.playing = False
+        self.finished = False
+        self.leftEdge = 0
+        self.rightEdge = "shape"
+        self.shape = shape or "decay"
+        self.DURATION = durationInSeconds or 1
+        self.MIN = min or 0
+        self.MAX = max or 1
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @shape.setter
+    def shape(self, value):
+        from .wavetables import SHAPES
+
+        if value not in SHAPES:
+            raise ValueError("%s:\n\tinvalid shape function: %s" % (self.label, value))
+        object.__setattr__(self, "_shape", value)
+
+    def trigger(self):
+        self.playing = True
+        self.t = 0
+        return self
+
+    def stop(self):
+        self.playing = False
+
+
+class AHD(Unit):
+    """reference src/components/AHD.js:6-34 — attack / hold / decay times in seconds"""
+
+    def __init__(self, attack=None, hold=None, decay=None):
+        super().__init__()
+        self.addInlet("attack", mono=True)
+        self.addInlet("hold", mono=True)
+        self.addInlet("decay", mono=True)
+        self.addOutlet("out", mono=True)
+        self.ATTACK = attack or 0
+        self.HOLD = hold or 0
+        self.DECAY = decay or 0
+        self.state = 0
+        self.playing = False
+        self.t = 0
+
+    def trigger(self):
+        self.state = 1
+        self.playing = True
+        return self
+
+    def stop(self):
+        self.state = 0
+        self.playing = False
+        return self

@@ -15,7 +15,7 @@
  * holds, i.e. the reference's own computeProcessIndex + stable sort result.
  */
 
-const { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, FILTER_KINDS, UNITS } = require('./ops')
+const { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, FILTER_KINDS, SHAPES, UNITS } = require('./ops')
 
 function toOutlet(x) {
   // same checks and messages as reference src/renderChannelData.js:12-17
@@ -131,6 +131,22 @@ function extract(target, opts = {}) {
         break
       case OP.TIMER:
         attrs = [unit.samplePeriod]; state = [unit.t]
+        break
+      case OP.SHAPE: { // edges: the string "shape" (= the table's end value) or a plain number (Shape/index.js:35-49)
+        const table = SHAPES[unit.shape]
+        if (table === undefined) throw 'dusp-hip: shape function not supported on the GPU path: ' + unit.shape
+        const edge = (e) => {
+          if (e === 'shape') return [1, 0]
+          if (typeof e === 'number') return [0, e]
+          throw 'dusp-hip: Shape edge must be "shape" or a number (' + unit.label + ')'
+        }
+        if (unit._finish || unit.onFinish) throw 'dusp-hip: finish callbacks cannot run on the GPU path (' + unit.label + ')'
+        attrs = [table, ...edge(unit.leftEdge), ...edge(unit.rightEdge)]
+        state = [unit.t, unit.playing ? 1 : 0, unit.finished ? 1 : 0]
+        break
+      }
+      case OP.AHD: // samplePeriod is a module constant of the reference (AHD.js:4)
+        attrs = [1 / sampleRate]; state = [unit.state, unit.playing ? 1 : 0, unit.t]
         break
       case OP.SAMPLE_RATE_REDUX: // val = the held sample per channel, `[0]` before the first update (SampleRateRedux.js:9-10)
         state = [unit.timeSinceLastUpdate, unit.val.length].concat(Array.from(unit.val))

@@ -15,7 +15,7 @@
  * The same objects also work with the real `dusp` package's graphs: extract.js is duck-typed.
  */
 const config = require('./config')
-const { WAVEFORMS } = require('./ops')
+const { WAVEFORMS, SHAPES } = require('./ops')
 
 class Port {
   constructor(unit, name, opts = {}) {
@@ -660,7 +660,51 @@ class PickChannel extends Unit { // PickChannel.js:3-11
   }
 }
 
-module.exports = { Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+/* ---- envelopes (SURVEY.md §8f-3) */
+class Shape extends Unit { // Shape/index.js:7-23,107-122 — a table read once over `duration` seconds after trigger()
+  constructor(shape, durationInSeconds, min, max) {
+    super()
+    this.addInlet('duration', { mono: true })
+    this.addInlet('min', { mono: true })
+    this.addInlet('max', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.t = 0
+    this.playing = false
+    this.finished = false
+    this.leftEdge = 0
+    this.rightEdge = 'shape'
+    this.shape = shape || 'decay'
+    this.DURATION = durationInSeconds || 1
+    this.MIN = min || 0
+    this.MAX = max || 1
+  }
+  get shape() { return this._shape }
+  set shape(shape) {
+    if (SHAPES[shape] === undefined) throw this.label + ':\n\tinvalid shape function: ' + shape
+    this._shape = shape
+  }
+  trigger() { this.playing = true; this.t = 0; return this }
+  stop() { this.playing = false }
+}
+class AHD extends Unit { // AHD.js:6-34 — attack / hold / decay times in seconds
+  constructor(attack, hold, decay) {
+    super()
+    this.addInlet('attack', { mono: true })
+    this.addInlet('hold', { mono: true })
+    this.addInlet('decay', { mono: true })
+    this.addOutlet('out', { mono: true })
+    this.ATTACK = attack || 0
+    this.HOLD = hold || 0
+    this.DECAY = decay || 0
+    this.state = 0
+    this.playing = false
+    this.t = 0
+  }
+  trigger() { this.state = 1; this.playing = true; return this }
+  stop() { this.state = 0; this.playing = false; return this }
+}
+
+module.exports = { Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
   FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,

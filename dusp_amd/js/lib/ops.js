@@ -23,6 +23,8 @@ const OP = Object.freeze({
   // rest of the elementwise sweep (SURVEY.md §8f-1): multi-inlet maps, channel plumbing, two small stateful units
   PAN: 29, MIDI_TO_FREQUENCY: 30, RESCALE: 31, CROSS_FADER: 32, VECTOR_MAGNITUDE: 33, TIMER: 34, SAMPLE_RATE_REDUX: 35,
   CONCAT_CHANNELS: 36, PICK_CHANNEL: 37,
+  // envelopes driven by trigger() events (SURVEY.md §8f-3)
+  SHAPE: 38, AHD: 39,
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -30,6 +32,8 @@ const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
 const WAVEFORMS = Object.freeze({ sin: 0, sine: 0, saw: 1, square: 2, triangle: 3, '8bit': 4 })
 const WAVEFORM_NAMES = Object.freeze(['sin', 'saw', 'square', 'triangle', '8bit'])
 const FILTER_KINDS = Object.freeze({ LP: 0, HP: 1 })
+/* Shape's lookup tables (reference src/components/Shape/shapeTables.js:21-38) share the table space of the wave tables */
+const SHAPES = Object.freeze({ decay: 5, attack: 6, semiSine: 7, decaySquared: 8 })
 
 /* constructor name -> { op, inlets (data inlets, in descriptor order), outlet (name of the data outlet, default "out") } */
 const UNITS = Object.freeze({
@@ -70,6 +74,8 @@ const UNITS = Object.freeze({
   SampleRateRedux: { op: OP.SAMPLE_RATE_REDUX, inlets: ['in', 'ammount'] },
   ConcatChannels: { op: OP.CONCAT_CHANNELS, inlets: ['a', 'b'] },
   PickChannel: { op: OP.PICK_CHANNEL, inlets: ['in', 'c'] },
+  Shape: { op: OP.SHAPE, inlets: ['duration', 'min', 'max'] },
+  AHD: { op: OP.AHD, inlets: ['attack', 'hold', 'decay'] },
 })
 
-module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, UNITS }
+module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, SHAPES, UNITS }

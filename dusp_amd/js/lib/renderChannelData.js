@@ -43,6 +43,13 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
     else if (spec.op === OP.FIXED_DELAY || spec.op === OP.COMB_FILTER || spec.op === OP.ALL_PASS || spec.op === OP.READBACK_DELAY)
       unit.tBuffer = n.stateDownload(prog, 0, u)[0]
     else if (spec.op === OP.TIMER) unit.t = n.stateDownload(prog, 0, u)[0]
+    else if (spec.op === OP.SHAPE) {
+      const s = n.stateDownload(prog, 0, u)
+      unit.t = s[0]; unit.playing = s[1] !== 0; unit.finished = s[2] !== 0
+    } else if (spec.op === OP.AHD) {
+      const s = n.stateDownload(prog, 0, u)
+      unit.state = s[0]; unit.playing = s[1] !== 0; unit.t = s[2]
+    }
     else if (spec.op === OP.SAMPLE_RATE_REDUX) {
       const s = n.stateDownload(prog, 0, u)
       unit.timeSinceLastUpdate = s[0]

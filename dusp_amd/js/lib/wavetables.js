@@ -1,5 +1,5 @@
 'use strict'
-/* Oscillator wave tables, computed on the host exactly as the reference computes them
+/* Oscillator wave tables (ids 0-4) and Shape tables (ids 5-8: decay, attack, semiSine, decaySquared), computed on the host exactly as the reference computes them
  * (src/components/Osc/waveTables.js:5-40) and handed to the device as data.  Under Node these are
  * V8's own Math.sin values, i.e. bit-identical to what `dusp` itself would hold. */
 const cache = new Map()
@@ -25,7 +25,10 @@ function makeTables(sampleRate) {
   }
   triangle[sampleRate] = 0
   const eightBit = sin.map((s) => Math.round(s * 128) / 128)
-  const tables = [sin, saw, square, triangle, eightBit]
+  // Shape's tables (src/components/Shape/shapeTables.js:3-38): func(x / sampleRate) for x = 0..sampleRate
+  const shape = (func) => { const t = new Float32Array(n); for (let x = 0; x < n; x++) t[x] = func(x / sampleRate); return t }
+  const tables = [sin, saw, square, triangle, eightBit,
+    shape((x) => 1 - x), shape((x) => x), shape((x) => Math.sin(Math.PI * x)), shape((x) => (1 - x) * (1 - x))]
   cache.set(sampleRate, tables)
   return tables
 }

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .wavetables import make_table
+from .wavetables import N_TABLES, make_table
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdusp_hip.so")
@@ -96,8 +96,9 @@ class Context:
         return rc
 
     def upload_tables(self, sample_rate, tables=None):
-        """Compute (or take) the five wave tables for this sample rate and hand them to the device."""
-        for tid in range(5):
+        """Compute (or take) the wave tables (ids 0-4) and Shape tables (ids 5-8) for this sample rate and hand
+        them to the device."""
+        for tid in range(N_TABLES):
             try:
                 t = tables[tid] if tables is not None else make_table(tid, sample_rate)
             except ValueError:

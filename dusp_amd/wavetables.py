@@ -10,7 +10,9 @@ import math
 import numpy as np
 
 WAVEFORMS = {"sin": 0, "sine": 0, "saw": 1, "square": 2, "triangle": 3, "8bit": 4}
-TABLE_NAMES = ["sin", "saw", "square", "triangle", "8bit"]
+TABLE_NAMES = ["sin", "saw", "square", "triangle", "8bit", "decay", "attack", "semiSine", "decaySquared"]
+SHAPES = {"decay": 5, "attack": 6, "semiSine": 7, "decaySquared": 8}  # Shape's tables share the table space (ids 5-8)
+N_TABLES = 9
 
 
 def _js_round(x):
@@ -43,6 +45,9 @@ def make_table(table_id, sample_rate):
         out[2 * q:3 * q] = -first
         out[3 * q:4 * q] = (-1 + first.astype(np.float64)).astype(np.float32)
         out[sample_rate] = 0
+    elif 5 <= table_id <= 8:  # Shape tables: func(x / sampleRate), x = 0..sampleRate (Shape/shapeTables.js:3-38)
+        func = {5: lambda x: 1 - x, 6: lambda x: x, 7: lambda x: math.sin(math.pi * x), 8: lambda x: (1 - x) * (1 - x)}[table_id]
+        out[:] = [func(x / sample_rate) for x in range(n)]
     else:
         raise ValueError("no such wave table: %r" % (table_id,))
     return out

@@ -28,7 +28,10 @@ enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READ
        OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, OP_MULTI_OSC,
        /* rest of the elementwise sweep */
        OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
-       OP_CONCAT_CHANNELS, OP_PICK_CHANNEL };
+       OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
+       /* envelopes */
+       OP_SHAPE, OP_AHD };
+#define N_TABLES 9 /* 0-4 oscillator wave tables, 5-8 Shape tables */
 #define MAX_INLETS 5
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
 
@@ -123,6 +126,9 @@ typedef struct unit {
     double tBuffer;
     int nphase;
     double *phases;
+    /* Shape: table, edges, t (shares `t`, `playing` with Ramp), finished; AHD: stage, t, playing, samplePeriod */
+    int shape_table, left_is_shape, right_is_shape, finished, ahd_state;
+    double left_edge, right_edge;
     /* Pan: compensationDB; Timer: t, samplePeriod; SampleRateRedux: val[], timeSinceLastUpdate */
     double comp_db, timer_t, sample_period, tslu;
     int nval;
@@ -136,7 +142,7 @@ struct dusp_oracle {
     ring_t *rings;
     size_t out_unit;
     long clock;
-    float *tables[5];
+    float *tables[N_TABLES];
 };
 
 /* ---- wave tables (reference src/components/Osc/waveTables.js:5-40) */
@@ -148,6 +154,13 @@ static double js_round(double x) { /* Math.round: ties toward +inf, keeps -0 */
 int dusp_oracle_wavetable(int id, int sr, float *out) {
     const double PHI = 2 * 3.141592653589793; /* waveTables.js:3 */
     const int n = sr + 1;
+    if (id >= 5 && id <= 8) { /* Shape tables: func(x / sampleRate), x = 0..sampleRate (Shape/shapeTables.js:3-38) */
+        for (int x = 0; x < n; x++) {
+            const double v = (double)x / sr;
+            out[x] = (float)(id == 5 ? 1 - v : id == 6 ? v : id == 7 ? sin(3.141592653589793 * v) : (1 - v) * (1 - v));
+        }
+        return 0;
+    }
     switch (id) {
     case 0: /* sine :5-8 — note the period is the table LENGTH sr+1 */
     case 4: /* 8bit :28-31 is derived from the f32 sine table */
@@ -598,6 +611,61 @@ static void tick_pick_channel(dusp_oracle *o, unit_t *u) {
     }
 }
 
+/* reference src/components/Shape/index.js:28-59 */
+static void tick_shape(dusp_oracle *o, unit_t *u) {
+    const float *duration = inlet_chunk(o, u, 0)->ch[0], *mn = inlet_chunk(o, u, 1)->ch[0], *mx = inlet_chunk(o, u, 2)->ch[0];
+    const float *data = o->tables[u->shape_table];
+    const double sr = o->sr;
+    float *out = u->out.ch[0];
+    for (int t = 0; t < o->chunk; t++) {
+        const double lo = mn[t], hi = mx[t];
+        if (u->playing) u->t += 1 / (double)duration[t];
+        if (u->t <= 0) {
+            out[t] = (float)((u->left_is_shape ? (double)data[0] : u->left_edge) * (hi - lo) + lo);
+        } else if (u->t > sr) {
+            u->finished = 1; /* finish(): UnitOrPatch.js:77-84; hooks are refused by the extractor */
+            out[t] = (float)((u->right_is_shape ? (double)data[o->sr] : u->right_edge) * (hi - lo) + lo);
+        } else if (u->t == u->t) {
+            const double frac = fmod(u->t, 1);
+            out[t] = (float)(lo + (hi - lo) * ((double)data[(long)ceil(u->t)] * frac + (double)data[(long)floor(u->t)] * (1 - frac)));
+        } else
+            out[t] = NAN; /* t is NaN (duration NaN): table[NaN] is undefined */
+    }
+}
+
+/* reference src/components/AHD.js:35-76 */
+static void tick_ahd(dusp_oracle *o, unit_t *u) {
+    const float *attack = inlet_chunk(o, u, 0)->ch[0], *hold = inlet_chunk(o, u, 1)->ch[0], *decay = inlet_chunk(o, u, 2)->ch[0];
+    float *out = u->out.ch[0];
+    for (int t = 0; t < o->chunk; t++) {
+        switch (u->ahd_state) {
+        case 1:
+            out[t] = (float)u->t;
+            if (u->playing) {
+                u->t += u->sample_period / (double)attack[t];
+                if (u->t >= 1) { u->ahd_state++; u->t--; }
+            }
+            break;
+        case 2:
+            out[t] = 1;
+            if (u->playing) {
+                u->t += u->sample_period / (double)hold[t];
+                if (u->t >= 1) { u->ahd_state++; u->t--; }
+            }
+            break;
+        case 3:
+            out[t] = (float)(1 - u->t);
+            if (u->playing) {
+                u->t += u->sample_period / (double)decay[t];
+                if (u->t >= 1) { u->ahd_state = 0; u->playing = 0; } /* stop() */
+            }
+            break;
+        case 0: out[t] = 0; break;
+        default: break; /* any other `state`: the sample keeps its previous value */
+        }
+    }
+}
+
 /* reference src/Circuit.js:19-41 (tick) with src/Unit.js:111-119; every unit's
  * tickInterval equals the chunk size here, so gcdTickInterval == chunk. */
 static void circuit_tick(dusp_oracle *o) {
@@ -626,6 +694,8 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_SAMPLE_RATE_REDUX: tick_sample_rate_redux(o, u); break;
         case OP_CONCAT_CHANNELS: tick_concat_channels(o, u); break;
         case OP_PICK_CHANNEL: tick_pick_channel(o, u); break;
+        case OP_SHAPE: tick_shape(o, u); break;
+        case OP_AHD: tick_ahd(o, u); break;
         default: tick_map(o, u); break;
         }
     }
@@ -674,7 +744,7 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
         for (int c = 0; c < o->rings[r].nch; c++)
             o->rings[r].data[c] = (float *)calloc((size_t)o->rings[r].len, sizeof(float));
     }
-    for (int w = 0; w < 5; w++) {
+    for (int w = 0; w < N_TABLES; w++) {
         o->tables[w] = (float *)malloc((size_t)(o->sr + 1) * sizeof(float));
         if (dusp_oracle_wavetable(w, o->sr, o->tables[w])) memset(o->tables[w], 0, (size_t)(o->sr + 1) * sizeof(float));
     }
@@ -829,6 +899,18 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
         case OP_CONCAT_CHANNELS: case OP_PICK_CHANNEL:
             if (u->n_inlets != 2 || n_attr || n_state) FAIL("unit %zu: bad channel-plumbing record", i);
             break;
+        case OP_SHAPE:
+            if (u->n_inlets != 3 || n_attr != 5 || n_state != 3 || !(a[0] >= 5 && a[0] <= 8)) FAIL("unit %zu: bad Shape record", i);
+            u->shape_table = (int)a[0];
+            u->left_is_shape = a[1] != 0; u->left_edge = a[2];
+            u->right_is_shape = a[3] != 0; u->right_edge = a[4];
+            u->t = s[0]; u->playing = s[1] != 0; u->finished = s[2] != 0;
+            break;
+        case OP_AHD:
+            if (u->n_inlets != 3 || n_attr != 1 || n_state != 3) FAIL("unit %zu: bad AHD record", i);
+            u->sample_period = a[0];
+            u->ahd_state = (int)s[0]; u->playing = s[1] != 0; u->t = s[2];
+            break;
         default: FAIL("unit %zu: unknown opcode %d", i, u->op);
         }
         chunk_init(&u->out, out_channels, o->chunk);
@@ -870,7 +952,7 @@ void dusp_oracle_destroy(dusp_oracle *o) {
         }
     }
     free(o->units);
-    for (int w = 0; w < 5; w++) free(o->tables[w]);
+    for (int w = 0; w < N_TABLES; w++) free(o->tables[w]);
     free(o);
 }
 
@@ -887,6 +969,8 @@ size_t dusp_oracle_unit_state(const dusp_oracle *o, size_t i, double *out, size_
     case OP_CB_READER: case OP_CB_WRITER: tmp[n++] = u->cb_t; break;
     case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY: tmp[n++] = u->tBuffer; break;
     case OP_TIMER: tmp[n++] = u->timer_t; break;
+    case OP_SHAPE: tmp[n++] = u->t; tmp[n++] = u->playing; tmp[n++] = u->finished; break;
+    case OP_AHD: tmp[n++] = u->ahd_state; tmp[n++] = u->playing; tmp[n++] = u->t; break;
     case OP_SAMPLE_RATE_REDUX:
         for (size_t k = 0; k < (size_t)u->nval + 2 && k < cap; k++) out[k] = k == 0 ? u->tslu : k == 1 ? (double)u->nval : (double)u->val[k - 2];
         return (size_t)u->nval + 2;

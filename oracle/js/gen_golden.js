@@ -47,6 +47,9 @@ for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardCli
   'ReadBackDelay', 'Pan', 'MidiToFrequency', 'Rescale', 'CrossFader', 'VectorMagnitude', 'Timer', 'SampleRateRedux',
   'ConcatChannels', 'PickChannel']) more[n] = ref('components/' + n + '.js')
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
+more.Shape = ref('components/Shape')
+more.AHD = ref('components/AHD.js')
+const shapeTables = ref('components/Shape/shapeTables.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
 const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
@@ -84,6 +87,12 @@ async function main() {
     const tables = {}
     for (const w of ['sin', 'saw', 'square', 'triangle', '8bit']) {
       const t = waveTables[w]
+      tables[w] = { length: t.length,
+        sha256: crypto.createHash('sha256').update(Buffer.from(t.buffer, t.byteOffset, t.byteLength)).digest('hex'),
+        head: Array.from(t.slice(0, 4)), tail: Array.from(t.slice(t.length - 2)) }
+    }
+    for (const w of ['decay', 'attack', 'semiSine', 'decaySquared']) { // Shape's tables (shapeTables.js:21-38)
+      const t = shapeTables[w].data
       tables[w] = { length: t.length,
         sha256: crypto.createHash('sha256').update(Buffer.from(t.buffer, t.byteOffset, t.byteLength)).digest('hex'),
         head: Array.from(t.slice(0, 4)), tail: Array.from(t.slice(t.length - 2)) }

@@ -6,7 +6,7 @@ import dusp_amd as d
 from dusp_amd import (Abs, AllPass, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, CombFilter, DecibelToScaler, Delay, Divide, Filter, FixedDelay,
                       FixedMultiply, Gain, HardClipAbove, HardClipBelow, MonoDelay, MultiChannelOsc, Multiply, Osc, Pow, Ramp, ReadBackDelay, Repeater,
                       SecondsToSamples, SemitoneToRatio, Subtract, Sum, quick,
-                      ConcatChannels, CrossFader, MidiToFrequency, Pan, PickChannel, Rescale, SampleRateRedux, Timer, VectorMagnitude)
+                      AHD, ConcatChannels, CrossFader, MidiToFrequency, Pan, PickChannel, Rescale, SampleRateRedux, Shape, Timer, VectorMagnitude)
 
 
 def _loop(f_osc, delay, max_delay, cutoff, gain):
@@ -82,6 +82,19 @@ def _allpass_loop():
     a = _with_in(AllPass(0.0052, 0.5), s)
     s.B = Multiply(a, 0.4)
     return a
+
+
+def _shape_edges():
+    s = Shape("attack", 0.004, 0.5, 2)
+    s.leftEdge = "shape"
+    s.rightEdge = 0.5
+    return s.trigger()
+
+
+def _shape_left_number():
+    s = Shape("decay", 0.01, -1, 1)
+    s.leftEdge = 0.25
+    return s
 
 
 def _srr_nan():
@@ -174,6 +187,19 @@ def builders(sr):
         "rest_concat_quick": lambda: quick.concat(Osc(50), 0.25),
         "rest_pick": lambda: PickChannel(Multiply(Osc(100), [1, 0.5, 0.25]), 4),
         "rest_pick_default": lambda: PickChannel(Multiply(Osc(60), [0.75, 0.5])),
+        # envelopes
+        "env_shape_decay": lambda: Shape("decay", 0.02).trigger(),
+        "env_shape_idle": lambda: Shape("attack", 0.01, 0.25, 0.75),
+        "env_shape_semisine_amp": lambda: Multiply(Osc(440), Shape("semiSine", 0.03).trigger()),
+        "env_shape_decaysq_range": lambda: Shape("decaySquared", 0.013, -1, 2).trigger(),
+        "env_shape_edges": _shape_edges,
+        "env_shape_left_number": _shape_left_number,
+        "env_shape_mod": lambda: Shape("decay", Sum(Multiply(Osc(20), 0.01), 0.02), Multiply(Osc(3), 0.5), 1).trigger(),
+        "env_ahd": lambda: AHD(0.01, 0.02, 0.03).trigger(),
+        "env_ahd_idle": lambda: AHD(0.01, 0.02, 0.03),
+        "env_ahd_zero_hold": lambda: AHD(0.005, 0, 0.005).trigger(),
+        "env_ahd_amp": lambda: Multiply(Osc(330), AHD(0.002, 0.01, 0.02).trigger()),
+        "env_ahd_mod": lambda: AHD(Sum(Multiply(Osc(50), 0.002), 0.004), 0.002, Sum(Multiply(Osc(30), 0.01), 0.02)).trigger(),
     }
     for tag, f in [("440p5", 440.5), ("0p1", 0.1), ("neg3", -3), ("47999p5", 47999.5), ("neg0p37", -0.37),
                    ("12345p678", 12345.678), ("tiny", 3e-5)]:

@@ -11,7 +11,8 @@ module.exports = function goldenCases(L, SR) {
   const { Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer, CircleBufferReader, CircleBufferWriter, quick,
     Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
     DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc,
-    Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel } = L
+    Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+    Shape, AHD } = L
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -187,6 +188,22 @@ module.exports = function goldenCases(L, SR) {
     add('rest_pick_default', () => new PickChannel(new Multiply(new Osc(60), [0.75, 0.5])), 0.01)
   }
 
+  // SURVEY.md §8f-3: envelopes (idle until trigger(); the ev_ cases below trigger them from scheduled events)
+  if (Shape) {
+    add('env_shape_decay', () => new Shape('decay', 0.02).trigger(), 0.05)
+    add('env_shape_idle', () => new Shape('attack', 0.01, 0.25, 0.75), 0.01) // never triggered: leftEdge 0 -> min
+    add('env_shape_semisine_amp', () => new Multiply(new Osc(440), new Shape('semiSine', 0.03).trigger()), 0.05)
+    add('env_shape_decaysq_range', () => new Shape('decaySquared', 0.013, -1, 2).trigger(), 0.03)
+    add('env_shape_edges', () => { const s = new Shape('attack', 0.004, 0.5, 2); s.leftEdge = 'shape'; s.rightEdge = 0.5; return s.trigger() }, 0.01)
+    add('env_shape_left_number', () => { const s = new Shape('decay', 0.01, -1, 1); s.leftEdge = 0.25; return s }, 0.01)
+    add('env_shape_mod', () => new Shape('decay', new Sum(new Multiply(new Osc(20), 0.01), 0.02), new Multiply(new Osc(3), 0.5), 1).trigger(), 0.1)
+    add('env_ahd', () => new AHD(0.01, 0.02, 0.03).trigger(), 0.08)
+    add('env_ahd_idle', () => new AHD(0.01, 0.02, 0.03), 0.01)
+    add('env_ahd_zero_hold', () => new AHD(0.005, 0, 0.005).trigger(), 0.02) // `hold || 0` = 0 s: samplePeriod / 0 = Infinity
+    add('env_ahd_amp', () => new Multiply(new Osc(330), new AHD(0.002, 0.01, 0.02).trigger()), 0.05)
+    add('env_ahd_mod', () => new AHD(new Sum(new Multiply(new Osc(50), 0.002), 0.004), 0.002, new Sum(new Multiply(new Osc(30), 0.01), 0.02)).trigger(), 0.08)
+  }
+
   // SURVEY.md §8f-3: scheduled events (host callbacks at chunk boundaries).  `ev_` cases are rendered only
   // through the JS surface (tests/js/check_render.js): their descriptor alone does not carry the callbacks.
   add('ev_retrigger', () => {
@@ -211,6 +228,18 @@ module.exports = function goldenCases(L, SR) {
     filt.schedule(0.06, function () { this.F = 800 })
     return filt
   }, 0.1)
+  if (Shape) {
+    add('ev_shape_retrigger', () => {
+      const s = new Shape('decaySquared', 0.02)
+      s.scheduleTrigger([0.01, 0.06])
+      return new Multiply(new Osc(440), s)
+    }, 0.1)
+    add('ev_ahd_retrigger', () => { // trigger() does not reset t: the second attack starts from where stop() left it (AHD.js:23-27)
+      const e = new AHD(0.004, 0.003, 0.006)
+      e.scheduleTrigger([0.005, 0.04])
+      return e
+    }, 0.07)
+  }
   if (Timer)
     add('ev_timer_trigger', () => {
       const tm = new Timer()

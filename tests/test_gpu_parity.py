@@ -64,7 +64,8 @@ def test_render_matches_reference_golden(name, engine, oracle):
 
 
 @pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum",
-                                  "rest_timer_fm", "rest_srr_mod", "rest_srr_nan", "rest_srr", "rest_vecmag_2d"])
+                                  "rest_timer_fm", "rest_srr_mod", "rest_srr_nan", "rest_srr", "rest_vecmag_2d",
+                                  "env_shape_mod", "env_shape_edges", "env_ahd_mod", "env_ahd_zero_hold", "env_ahd"])
 @pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
@@ -93,7 +94,7 @@ def test_malformed_descriptors_are_rejected_not_crashed():
     poison = [np.nan, np.inf, -1.0, 0.5, 1e18, -1e18, 3.0, 65536.0, 2.0 ** 40]
     built = rejected = 0
     for name in ("cfg2_sweep", "loop_220", "circlebuffer_2ch", "filter_2ch", "summany_8", "map_db_semitone", "rest_rescale_2ch",
-                 "rest_srr_mod", "rest_pick", "rest_vecmag"):
+                 "rest_srr_mod", "rest_pick", "rest_vecmag", "env_shape_mod", "env_ahd_amp"):
         g = Golden(name)
         trials = [g.desc[:k] for k in range(0, g.desc.size, 3)]
         for _ in range(150):

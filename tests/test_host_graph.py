@@ -19,6 +19,24 @@ def test_python_graph_extracts_to_the_reference_descriptor(name):
     assert same.all(), "first differing word: %d" % int(np.argmin(same))
 
 
+@pytest.mark.parametrize("sr,fname", [(48000, "wavetables.json"), (44100, "wavetables_sr44100.json")])
+def test_host_tables_are_the_references(sr, fname):
+    """The tables the Python host uploads (wave tables 0-4, Shape tables 5-8) hash to what the reference held."""
+    import hashlib
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from dusp_amd.wavetables import N_TABLES, TABLE_NAMES, make_table
+    with open(os.path.join(GOLDEN, fname)) as f:
+        meta = json.load(f)["tables"]
+    assert len(TABLE_NAMES) == N_TABLES == 9
+    for tid, w in enumerate(TABLE_NAMES):
+        t = make_table(tid, sr)
+        assert t.dtype == np.float32 and t.size == meta[w]["length"]
+        assert hashlib.sha256(t.tobytes()).hexdigest() == meta[w]["sha256"], w
+
+
 def test_feedback_loop_order_is_the_references():
     # SURVEY.md Appendix A: observed on the reference for the G6 loop
     f = cases.build("loop_220", 48000)

@@ -26,7 +26,7 @@ def test_oracle_matches_reference_bit_for_bit(oracle, name):
 def test_oracle_wavetables_match_reference(oracle, sr, fname):
     with open(os.path.join(GOLDEN, fname)) as f:
         meta = json.load(f)
-    for tid, w in enumerate(["sin", "saw", "square", "triangle", "8bit"]):
+    for tid, w in enumerate(["sin", "saw", "square", "triangle", "8bit", "decay", "attack", "semiSine", "decaySquared"]):
         t = oracle.wavetable(tid, sr)
         assert t.size == meta["tables"][w]["length"] == sr + 1
         assert hashlib.sha256(t.tobytes()).hexdigest() == meta["tables"][w]["sha256"], w
