@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 double dconst = (double)dl.c;
                 if (dconst >= dlen) dconst = fmod(dconst, dlen);
                 const double Dfl = floor(dconst);
-                const bool fast_lane = !dl.is_buf && dconst >= (double)kBatch && Dfl <= dlen - (double)kBatch;
+                const bool fast_lane = !dl.is_buf && dconst >= (double)kBatch && Dfl <= dlen - (double)kBatch &&
+                                       !(a.flags & kChunkFlagResumable);  // (leaves stale slots and a pending tap behind)
                 if (__all(fast_lane)) {
                     const int64_t D = (int64_t)Dfl;
                     const double phi = dconst - Dfl;

@@ -58,7 +58,8 @@ struct ChunkArgs {
     float *out;             // [n_inst][n_out][n_samples]
     uint64_t n_samples;
     int64_t clock0;
-    uint32_t n_ops, n_out, n_inst, n_pad, n_chunks, sample_rate, table_stride, pad;
+    uint32_t n_ops, n_out, n_inst, n_pad, n_chunks, sample_rate, table_stride, flags;
 };
+constexpr uint32_t kChunkFlagResumable = 1;  // segments will follow: Delay keeps to the reference's read-modify-write ring protocol
 
 }  // namespace dusp

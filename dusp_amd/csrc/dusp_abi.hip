@@ -84,6 +84,12 @@ struct dusp_program {
     std::vector<double> h_sum_end;
     uint32_t last_n_inst = 0, last_n_pad = 0;
     bool rendered = false;
+    // event-segmented rendering (dusp_program_continue)
+    int requested_engine = DUSP_ENGINE_AUTO;
+    bool resumable = false;      // built with DUSP_ENGINE_RESUMABLE
+    bool persistent = false;     // rings / feedback edges: device memory carries over between segments (CHUNK engine only)
+    bool keep_memory = false;    // the next render continues: do not clear chunk buffers and rings
+    int64_t next_clock = 0;      // circuit clock the last render stopped at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -189,23 +195,12 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     return DUSP_OK;
 }
 
-int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out) {
-    if (!ctx) return DUSP_ERR_ARG;
-    if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
-    *out = nullptr;
-    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE && engine != DUSP_ENGINE_LOOP)
-        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
-    std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
-    if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
-    prog->ctx = ctx;
-    std::string err;
-    if (!dusp::compile(desc, n_words, prog->P, err)) {
-        const bool unsupported = err.find("not supported") != std::string::npos || err.find("only ") != std::string::npos;
-        CTX_FAIL(ctx, unsupported ? DUSP_ERR_UNSUPPORTED : DUSP_ERR_ARG, "dusp_program_build: " + err);
-    }
-    if (ctx->table_len && ctx->table_len != (uint32_t)prog->P.g.sample_rate + 1)
-        CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_build: uploaded wave tables do not match the program's sample rate");
-
+// Engine selection + upload of the program constants; shared by build and continue.
+static int finish_build(dusp_program *prog) {
+    dusp_ctx *ctx = prog->ctx;
+    int engine = prog->requested_engine;
+    prog->fused = dusp::FusedPlan();
+    prog->wave = dusp::WavePlan();
     const bool fusable = dusp::plan_fused(prog->P, prog->fused);
     const bool wavable = dusp::plan_wave(prog->P, prog->wave);
     if (engine == DUSP_ENGINE_FUSED && !fusable)
@@ -214,6 +209,7 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: the wave engine cannot run this graph (" + prog->wave.why + ")");
     std::string loop_why;
     const bool loopable = dusp::plan_loop(prog->P, prog->loop, loop_why);
+    prog->loop_two_stage = false;
     if (loopable) {
         const dusp::DevOperand &dl = prog->loop.delay.in[1];
         const double len = (double)prog->loop.delay.ring_len;
@@ -226,6 +222,14 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     }
     if (engine == DUSP_ENGINE_LOOP && !loopable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
+    // A circuit with rings or a feedback edge carries device memory from one segment to the next; only the chunk
+    // engine keeps all of it (rings, every outlet's previous chunk) in HBM in a layout a later launch can pick up.
+    prog->persistent = prog->P.ring_samples != 0 || !prog->P.feed_forward;
+    if (prog->resumable && prog->persistent) {
+        if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK)
+            CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: a resumable program with delay lines / feedback only runs on DUSP_ENGINE_CHUNK");
+        engine = DUSP_ENGINE_CHUNK;
+    }
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
                  : (loopable && prog->loop_two_stage) ? DUSP_ENGINE_LOOP
@@ -244,9 +248,69 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
         HIP_TRY(ctx, prog->d_init.ensure(P.init_state.size()));
         HIP_TRY(ctx, hipMemcpy(prog->d_init.p, P.init_state.data(), P.init_state.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    return DUSP_OK;
+}
+
+static int compile_status(dusp_ctx *ctx, const char *who, const std::string &err) {
+    const bool unsupported = err.find("not supported") != std::string::npos || err.find("only ") != std::string::npos;
+    CTX_FAIL(ctx, unsupported ? DUSP_ERR_UNSUPPORTED : DUSP_ERR_ARG, std::string(who) + ": " + err);
+}
+
+int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
+    *out = nullptr;
+    const bool resumable = (engine & DUSP_ENGINE_RESUMABLE) != 0;
+    engine &= ~DUSP_ENGINE_RESUMABLE;
+    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE && engine != DUSP_ENGINE_LOOP)
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
+    std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
+    if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
+    prog->ctx = ctx;
+    prog->requested_engine = engine;
+    prog->resumable = resumable;
+    std::string err;
+    if (!dusp::compile(desc, n_words, prog->P, err, /*continuation=*/false)) return compile_status(ctx, "dusp_program_build", err);
+    if (ctx->table_len && ctx->table_len != (uint32_t)prog->P.g.sample_rate + 1)
+        CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_build: uploaded wave tables do not match the program's sample rate");
+    if (int rc = finish_build(prog.get())) return rc;
     HIP_TRY(ctx, hipEventCreate(&prog->ev0));
     HIP_TRY(ctx, hipEventCreate(&prog->ev1));
     *out = prog.release();
+    return DUSP_OK;
+}
+
+int dusp_program_continue(dusp_program *prog, const double *desc, size_t n_words) {
+    if (!prog) return DUSP_ERR_ARG;
+    dusp_ctx *ctx = prog->ctx;
+    if (!prog->rendered) CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: nothing has been rendered yet");
+    dusp::Program next;
+    std::string err;
+    if (!dusp::compile(desc, n_words, next, err, /*continuation=*/true)) return compile_status(ctx, "dusp_program_continue", err);
+    const dusp::Program &P = prog->P;
+    // same circuit: same units, wiring, channel counts, buffers, state slots and rings — only constants and state may differ
+    bool same = next.g.units.size() == P.g.units.size() && next.ops.size() == P.ops.size() && next.n_bufs == P.n_bufs &&
+                next.ring_samples == P.ring_samples && next.out_bufs == P.out_bufs && next.g.n_params == P.g.n_params &&
+                next.g.sample_rate == P.g.sample_rate && next.init_state.size() == P.init_state.size() &&
+                next.dev_rings.size() == P.dev_rings.size();
+    for (size_t k = 0; same && k < P.g.units.size(); k++) same = next.g.units[k].op == P.g.units[k].op && next.g.units[k].n_out == P.g.units[k].n_out;
+    for (size_t k = 0; same && k < P.ops.size(); k++) {
+        const dusp::DevOp &a = P.ops[k], &b = next.ops[k];
+        same = a.op == b.op && a.unit == b.unit && a.out_buf == b.out_buf && a.state_slot == b.state_slot && a.ring_base == b.ring_base &&
+               a.ring_len == b.ring_len && a.n_in == b.n_in;
+        for (int j = 0; same && j < dusp::kMaxIn; j++)  // connections must stay connections to the same buffer
+            same = (a.in[j].kind == dusp::SRC_BUF) == (b.in[j].kind == dusp::SRC_BUF) && (a.in[j].kind != dusp::SRC_BUF || a.in[j].idx == b.in[j].idx);
+    }
+    if (!same) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_continue: the descriptor does not describe the circuit this program was built from");
+    if (next.g.clock0 != prog->next_clock)
+        CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: descriptor clock " + std::to_string(next.g.clock0) + " does not follow the rendered clock " +
+                                          std::to_string(prog->next_clock));
+    const bool persistent = next.ring_samples != 0 || !next.feed_forward;
+    if (persistent && !(prog->resumable && prog->engine == DUSP_ENGINE_CHUNK))
+        CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: a circuit with delay lines / feedback has to be built with DUSP_ENGINE_RESUMABLE");
+    prog->P = std::move(next);
+    if (int rc = finish_build(prog)) return rc;
+    prog->keep_memory = persistent;
     return DUSP_OK;
 }
 
@@ -359,6 +423,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         }
         prog->last_n_inst = n_inst;
         prog->rendered = true;
+        prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
         return DUSP_OK;
     }
 
@@ -401,14 +466,20 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         prog->last_n_inst = n_inst;
         prog->last_n_pad = n_pad;
         prog->rendered = true;
+        prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
         return DUSP_OK;
     }
-    HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
-    HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
-    HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
-    // outlets' chunks and all rings start as zeros (SignalChunk.js:7, Delay.js:14, CircleBuffer.js:12)
-    HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad * sizeof(float), stream));
-    if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+    if (prog->keep_memory) {  // continuing: chunk buffers and rings hold what the previous segment left
+        if (n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
+    } else {
+        HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
+        HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+        HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
+        // outlets' chunks and all rings start as zeros (SignalChunk.js:7, Delay.js:14, CircleBuffer.js:12)
+        HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad * sizeof(float), stream));
+        if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+    }
+    prog->keep_memory = false;
     HIP_TRY(ctx, dusp::launch_state_init(prog->d_state.p, prog->d_init.p, (uint32_t)n_slots, n_pad, stream));
 
     dusp::ChunkArgs a{};
@@ -429,6 +500,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     a.n_chunks = n_chunks;
     a.sample_rate = (uint32_t)P.g.sample_rate;
     a.table_stride = ctx->table_stride;
+    a.flags = (prog->resumable && prog->persistent) ? dusp::kChunkFlagResumable : 0u;
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
     if (prog->engine == DUSP_ENGINE_LOOP) {
         const int w = prog->loop.osc.attr;
@@ -442,6 +514,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;
+    prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
     return DUSP_OK;
 }
 

@@ -559,13 +559,14 @@ inline bool expand(Program &P, std::string &err) {
     return true;
 }
 
-inline bool compile(const double *d, size_t nw, Program &P, std::string &err) {
+inline bool compile(const double *d, size_t nw, Program &P, std::string &err, bool continuation = false) {
     if (!(parse(d, nw, P.g, err) && infer_channels(P.g, err) && expand(P, err))) return false;
-    // A non-zero start clock is a continuation (event-segmented rendering).  Unit state travels in the
-    // descriptor, ring contents do not: refuse continuations of circuits that own delay lines.
-    if (P.g.clock0 != 0 && P.ring_samples != 0)
-        return fail(err, "continuing a circuit with Delay / CircleBuffer rings is not supported "
-                         "(scheduled events and delay lines cannot be combined on the GPU path yet)");
+    // A non-zero start clock means the circuit has been ticked before.  Unit state travels in the descriptor;
+    // ring contents and the previous chunk behind a feedback edge do not, so a FRESH program can only start
+    // such a circuit at clock 0 (dusp_program_continue carries them over on the device instead).
+    if (!continuation && P.g.clock0 != 0 && (P.ring_samples != 0 || !P.feed_forward))
+        return fail(err, "a circuit with delay lines or feedback that has already been ticked is not supported by "
+                         "dusp_program_build (continue the program it was rendered with: dusp_program_continue)");
     return true;
 }
 

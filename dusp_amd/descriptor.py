@@ -259,3 +259,46 @@ def unify(extractions):
 
 def single(extraction):
     return Unified(extraction.words, None, 0, 1, extraction)
+
+
+def state_sites(words):
+    """[(first_word, n_words)] of every unit's state block inside a descriptor (layout: DESIGN.md §3)."""
+    words = np.asarray(words, dtype=np.float64)
+    n_units, n_rings = int(words[4]), int(words[5])
+    p = HEADER_WORDS + 2 * n_rings
+    sites = []
+    for _ in range(n_units):
+        n_in, n_attr, n_state = int(words[p + 1]), int(words[p + 2]), int(words[p + 3])
+        p += 4
+        for _ in range(n_in):
+            p += 2 + int(words[p + 1])
+        p += n_attr
+        sites.append((p, n_state))
+        p += n_state
+    return sites
+
+
+def continued(words, clock, states):
+    """Descriptor of the same circuit `clock` samples later: the start clock and every unit's state words are
+    replaced (states[u] = what Program.state(u) returned after the previous segment; a state block may have
+    grown, e.g. a Filter's per-channel history).  This is what a host does between two segments of an
+    event-segmented render before calling dusp_program_continue."""
+    words = np.asarray(words, dtype=np.float64)
+    parts, at = [], 0
+    for (first, n), st in zip(state_sites(words), states):
+        st = np.asarray(st, dtype=np.float64)
+        parts += [words[at:first], st]
+        at = first + n
+    parts.append(words[at:])
+    out = np.concatenate(parts)
+    out[9] = clock
+    # record headers: n_state of every unit
+    p = HEADER_WORDS + 2 * int(out[5])
+    for st in states:
+        out[p + 3] = len(st)
+        n_in, n_attr = int(out[p + 1]), int(out[p + 2])
+        p += 4
+        for _ in range(n_in):
+            p += 2 + int(out[p + 1])
+        p += n_attr + len(st)
+    return out

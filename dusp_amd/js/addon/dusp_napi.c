@@ -195,6 +195,33 @@ static napi_value fn_program_build(napi_env env, napi_callback_info info) {
     return ext;
 }
 
+/* programContinue(prog, words): dusp_program_continue — re-arm a rendered program from a later extraction of
+ * the same circuit (event-segmented rendering). */
+static napi_value fn_program_continue(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    prog_box *pb = as_prog(env, argv[0]);
+    if (!pb) return NULL;
+    void *data;
+    size_t len;
+    if (!typed_array(env, argv[1], napi_float64_array, &data, &len)) {
+        throw_string(env, "dusp-hip: programContinue expects a Float64Array of descriptor words");
+        return NULL;
+    }
+    pthread_mutex_lock(&g_lock);
+    int rc = dusp_program_continue(pb->prog, (const double *)data, len);
+    char msg[512];
+    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->ctx));
+    pthread_mutex_unlock(&g_lock);
+    if (rc != DUSP_OK) {
+        throw_string(env, msg);
+        return NULL;
+    }
+    napi_value undef;
+    NAPI_OK(napi_get_undefined(env, &undef));
+    return undef;
+}
+
 static napi_value fn_program_destroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
@@ -375,7 +402,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"version", fn_version},          {"abiVersion", fn_abi_version},     {"ctxCreate", fn_ctx_create},
         {"ctxDestroy", fn_ctx_destroy},   {"tableUpload", fn_table_upload},   {"programBuild", fn_program_build},
         {"programDestroy", fn_program_destroy}, {"programInfo", fn_program_info}, {"stateDownload", fn_state_download},
-        {"render", fn_render},
+        {"render", fn_render},            {"programContinue", fn_program_continue},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -67,17 +67,7 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
   circuit.clock += Math.ceil(nSamples / chunkSize) * chunkSize
 }
 
-async function renderSegment(n, ex, nSamples, engine) {
-  const prog = n.programBuild(contextFor(ex.sampleRate), ex.words, engine)
-  try {
-    const info = n.programInfo(prog)
-    const pcm = await n.render(prog, 1, nSamples, null) // Float32Array [channel][sample]
-    writeBack(n, prog, ex.circuit, ex.chunkSize, nSamples)
-    return { pcm, nChannels: info.nOutChannels }
-  } finally {
-    n.programDestroy(prog)
-  }
-}
+const RESUMABLE = 0x100 // DUSP_ENGINE_RESUMABLE (include/dusp_hip.h)
 
 async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Array, engine = 0 } = {}) {
   const first = extract(outlet, { allowEvents: true })
@@ -95,33 +85,40 @@ async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Arr
       if (take > 0) channelData[c].set(pcm.subarray(c * len, c * len + take), at)
     }
   }
-
-  if (!circuit.events || !circuit.events.length) {
-    const seg = await renderSegment(n, first, nSamples, engine)
-    if (TypedArray === Float32Array) { // hand the rendered buffer over without a copy
-      for (let c = 0; c < seg.nChannels; c++) channelData.push(seg.pcm.subarray(c * nSamples, (c + 1) * nSamples))
-    } else place(seg.pcm, seg.nChannels, 0, nSamples)
-    return channelData
-  }
+  const hasEvents = !!(circuit.events && circuit.events.length)
 
   /* Event-segmented rendering (SURVEY.md 8f-3).  The reference runs every event with t < clock + chunk at the
    * start of the tick at `clock` (Circuit.js:23,57-65), i.e. events take effect on chunk boundaries.  So: run
-   * the due callbacks on the host objects, render up to the chunk in which the next event falls due from the
-   * objects' CURRENT state, write the state back, repeat.  Circuits that also carry delay lines are refused
-   * by the library (their rings live on the device and would not survive the re-extraction). */
-  const end = Math.ceil(nSamples / chunk) * chunk
-  let clock = 0
-  while (clock < end) {
-    circuit.runEvents(clock + chunk)
-    let next = end
-    if (circuit.events.length) {
-      const due = Math.floor(circuit.events[0].t / chunk) * chunk
-      next = Math.min(end, Math.max(clock + chunk, due))
+   * the due callbacks on the host objects, render up to the chunk in which the next event falls due, write the
+   * unit state back, re-extract and CONTINUE the same device program (dusp_program_continue: unit state and
+   * constants come from the objects, delay lines / CircleBuffers / feedback chunks stay resident on the device). */
+  let prog = null
+  try {
+    const end = Math.ceil(nSamples / chunk) * chunk
+    let clock = 0
+    while (clock < end) {
+      let next = end
+      if (hasEvents) {
+        circuit.runEvents(clock + chunk)
+        if (circuit.events.length) {
+          const due = Math.floor(circuit.events[0].t / chunk) * chunk
+          next = Math.min(end, Math.max(clock + chunk, due))
+        }
+      }
+      const ex = clock === 0 && !hasEvents ? first : extract(outlet, { allowEvents: true, allowClock: true })
+      if (!prog) prog = n.programBuild(contextFor(ex.sampleRate), ex.words, hasEvents ? engine | RESUMABLE : engine)
+      else n.programContinue(prog, ex.words)
+      const len = Math.min(next, nSamples) - clock // the last segment may end inside a chunk
+      const pcm = await n.render(prog, 1, len, null) // Float32Array [channel][sample]
+      writeBack(n, prog, circuit, chunk, len) // advances circuit.clock to `next`
+      const nChannels = n.programInfo(prog).nOutChannels
+      if (!hasEvents && TypedArray === Float32Array) { // single segment: hand the rendered buffer over without a copy
+        for (let c = 0; c < nChannels; c++) channelData.push(pcm.subarray(c * nSamples, (c + 1) * nSamples))
+      } else place(pcm, nChannels, clock, len)
+      clock = next
     }
-    const ex = extract(outlet, { allowEvents: true, allowClock: true })
-    const seg = await renderSegment(n, ex, next - clock, engine) // advances circuit.clock to `next`
-    place(seg.pcm, seg.nChannels, clock, next - clock)
-    clock = next
+  } finally {
+    if (prog) n.programDestroy(prog)
   }
   return channelData
 }

@@ -14,11 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdusp_hip.so")
 
 ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED, ENGINE_WAVE, ENGINE_LOOP = 0, 1, 2, 3, 4
+ENGINE_RESUMABLE = 0x100  # OR into the engine: the program will be continued (Program.continue_with)
 ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave", ENGINE_LOOP: "loop"}
 
 EXPORTS = [
     "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",
-    "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_info_get",
+    "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_state_download", "dusp_last_kernel_ms", "dusp_fill_device",
 ]
 
@@ -66,6 +67,7 @@ def load():
     L.dusp_program_build.argtypes = [vp, vp, sz, ci, ctypes.POINTER(vp)]
     L.dusp_program_destroy.argtypes = [vp]
     L.dusp_program_destroy.restype = None
+    L.dusp_program_continue.argtypes = [vp, vp, sz]
     L.dusp_program_info_get.argtypes = [vp, ctypes.POINTER(ProgramInfo)]
     L.dusp_render_device.argtypes = [vp, sz, sz, vp, vp, vp]
     L.dusp_render_host.argtypes = [vp, sz, sz, vp, vp]
@@ -133,8 +135,11 @@ class Program:
         h = ctypes.c_void_p()
         ctx._check(self._L.dusp_program_build(ctx._h, words.ctypes.data, words.size, engine, ctypes.byref(h)))
         self._h = h
+        self._read_info()
+
+    def _read_info(self):
         info = ProgramInfo()
-        ctx._check(self._L.dusp_program_info_get(self._h, ctypes.byref(info)))
+        self.ctx._check(self._L.dusp_program_info_get(self._h, ctypes.byref(info)))
         self.sample_rate = info.sample_rate
         self.n_units = info.n_units
         self.n_out_channels = info.n_out_channels
@@ -142,6 +147,13 @@ class Program:
         self.engine = ENGINE_NAMES.get(info.engine, str(info.engine))
         self.shape = info.shape.decode()
         self.n_device_ops = info.n_device_ops
+
+    def continue_with(self, words):
+        """dusp_program_continue: re-arm this rendered program from a later extraction of the same circuit
+        (unit state and constants from `words`, delay lines / feedback chunks stay on the device)."""
+        words = np.ascontiguousarray(words, dtype=np.float64)
+        self.ctx._check(self._L.dusp_program_continue(self._h, words.ctypes.data, words.size))
+        self._read_info()
 
     def render(self, n_samples, n_instances=1, params=None):
         """Host round trip: float32 [n_instances, n_out_channels, n_samples]."""

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 1
+#define DUSP_ABI_VERSION 2
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -49,18 +49,26 @@ typedef enum {
 
 /* Engine that executes a program (chosen at build time from the graph's shape):
  *   CHUNK — universal engine: one lane per instance, units ticked chunk by chunk
- *           exactly in circuit order (feedback, filters, delays, CircleBuffers).
+ *           exactly in circuit order (every opcode: feedback, filters, delay lines, CircleBuffers,
+ *           envelopes).
  *   FUSED — time-parallel fused kernels for recognised voice shapes (Osc, Osc x Ramp,
  *           Osc x gain, Sum.many chains): one lane per sample, time split across waves,
  *           16-byte coalesced PCM stores.
- *   WAVE  — any feed-forward graph of Osc / Ramp / Multiply / Sum / Repeater (incl. FM):
- *           one wavefront per instance, per-unit chunk buffers in LDS, wavefront-wide
- *           phase accumulation.
- *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum): the chunk
- *           engine's mapping and memory layout with the five units evaluated per sample in registers.
- * AUTO picks FUSED, else WAVE, else LOOP, else CHUNK. */
+ *   WAVE  — one wavefront per instance, chunk buffers in LDS, wavefront-wide phase accumulation:
+ *           graphs of Osc / Ramp / Multiply / Sum / Repeater / the stateless maps (incl. FM), Filters,
+ *           constant Delays of at least one chunk, feedback edges; no CircleBuffers.
+ *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
+ *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
+ *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
+ * AUTO picks FUSED, else LOOP (two-stage), else WAVE, else LOOP, else CHUNK.
+ *
+ * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
+ * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose
+ * circuit owns delay lines / CircleBuffers or has a feedback edge then run on the CHUNK engine and keep
+ * their rings and chunk buffers resident between segments. */
 typedef enum {
-    DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3, DUSP_ENGINE_LOOP = 4
+    DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3, DUSP_ENGINE_LOOP = 4,
+    DUSP_ENGINE_RESUMABLE = 0x100
 } dusp_engine;
 
 typedef struct {
@@ -87,10 +95,11 @@ const char *dusp_last_error(const dusp_ctx *ctx);
 int dusp_ctx_create(int device, dusp_ctx **out);
 void dusp_ctx_destroy(dusp_ctx *ctx);
 
-/* Upload one wave table (replaces src/components/Osc/waveTables.js:5-40: the
- * host computes the tables exactly as the reference does and hands them over as
- * data).  table_id: 0 sin, 1 saw, 2 square, 3 triangle, 4 8bit.  n must equal
- * sample_rate + 1 of every program later built on this context. */
+/* Upload one lookup table (replaces src/components/Osc/waveTables.js:5-40 and
+ * src/components/Shape/shapeTables.js:3-38: the host computes the tables exactly as the
+ * reference does and hands them over as data).  table_id: 0 sin, 1 saw, 2 square,
+ * 3 triangle, 4 8bit (oscillators); 5 decay, 6 attack, 7 semiSine, 8 decaySquared (Shape).
+ * n must equal sample_rate + 1 of every program later built on this context. */
 int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n);
 
 /* Compile a descriptor into a device program (replaces `new Circuit(unit)` +
@@ -99,6 +108,17 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
  * normally; tests force CHUNK to cross-check the engines. */
 int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out);
 void dusp_program_destroy(dusp_program *prog);
+
+/* Continue a rendered program from a LATER extraction of the same circuit (replaces what
+ * src/Circuit.js:23,57-65 does between two ticks: host callbacks — scheduled events — have run
+ * on the unit objects, changing state fields or inlet constants).  `desc` must describe the same
+ * structure (units, connections, channel counts, rings) and carry the clock the previous render
+ * stopped at; unit state and constants are taken from it, ring contents and (for feedback graphs)
+ * the previous chunk of every outlet stay as the device left them.  The next dusp_render_* call
+ * renders the next segment.  Needs a program built with DUSP_ENGINE_RESUMABLE unless the circuit is
+ * feed-forward and owns no rings; the instance count of the following render must not change. */
+int dusp_program_continue(dusp_program *prog, const double *desc, size_t n_words);
+
 int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info);
 
 /* Render n_instances independent instances of the program for n_samples samples
@@ -124,7 +144,8 @@ int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
 /* State write-back (SURVEY.md §5 "checkpoint/resume"): after a render, copy the
  * state of `unit` for `instance` into out[] in the layout of the descriptor's
  * state words for that unit's opcode (Osc: phase; Ramp: t, playing; Filter:
- * has_lastF,lastF,a0,a1,a2,b1,b2,nch,(x1,x2,y1,y2)*nch; CircleBuffer nodes: t).
+ * has_lastF,lastF,a0,a1,a2,b1,b2,nch,(x1,x2,y1,y2)*nch; CircleBuffer nodes: t; Timer: t;
+ * Shape: t,playing,finished; AHD: state,playing,t; SampleRateRedux: timeSinceLastUpdate,n,val*n).
  * Returns the number of words (>= 0) or a negative dusp_status. */
 int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double *out, size_t cap);
 

@@ -228,6 +228,55 @@ module.exports = function goldenCases(L, SR) {
     filt.schedule(0.06, function () { this.F = 800 })
     return filt
   }, 0.1)
+  // events on circuits that carry device memory from segment to segment: delay lines, CircleBuffers, feedback chunks
+  add('ev_delay_retrigger', () => {
+    const r = new Ramp(1200, 1, 0)
+    r.scheduleTrigger([0.004, 0.03, 0.055])
+    return new Delay(new Multiply(new Osc(660), r), 300.5, 2048)
+  }, 0.08)
+  add('ev_delay_time_change', () => {
+    const d = new Delay(new Osc(500), 100, 4096)
+    d.schedule(0.02, function () { this.DELAY = 1000.25 })
+    d.schedule(0.05, function () { this.DELAY = 17 })
+    return d
+  }, 0.08)
+  add('ev_loop_gain', () => { // configs[3]'s feedback voice with the feedback gain changed on the fly
+    const sum = new Sum(new Osc(220), 0)
+    const f = new Filter(new Delay(sum, 480, 4096), 2000)
+    const fb = new Multiply(f, 0.5)
+    sum.B = fb
+    fb.schedule(0.03, function () { this.B = 0.9 })
+    fb.schedule(0.07, function () { this.B = 0.1 })
+    return f
+  }, 0.1)
+  add('ev_feedback_no_delay', () => { // a bare feedback edge: only the previous CHUNK of the loop carries over
+    const sum = new Sum(new Osc(330), 0)
+    const m = new Multiply(sum, 0.5)
+    sum.B = m
+    m.schedule([0.011, 0.033], function () { this.B = this.B.constant * -1.5 })
+    return sum
+  }, 0.05)
+  add('ev_circlebuffer', () => {
+    const buffer = new CircleBuffer(1, 0.05)
+    const writer = new CircleBufferWriter(buffer)
+    writer.preWipe = true
+    const osc = new Osc(330)
+    writer.IN = osc
+    const tap = new CircleBufferReader(buffer, 0.01)
+    tap.chain(writer)
+    osc.schedule(0.02, function () { this.F = 495 })
+    tap.schedule(0.04, function () { this.OFFSET = 0.003 })
+    return tap
+  }, 0.07)
+  if (CombFilter)
+    add('ev_comb', () => {
+      const c = new CombFilter(0.004, 0.7)
+      const r = new Ramp(800, 1, 0)
+      c.IN = new Multiply(new Osc(150, 'saw'), r)
+      r.scheduleTrigger([0.0, 0.05])
+      c.schedule(0.03, function () { this.FEEDBACKGAIN = -0.5 })
+      return c
+    }, 0.1)
   if (Shape) {
     add('ev_shape_retrigger', () => {
       const s = new Shape('decaySquared', 0.02)

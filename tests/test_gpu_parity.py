@@ -86,6 +86,57 @@ def test_state_write_back_matches_oracle(name, engine, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("name", ALL_GOLDEN)
+def test_segmented_render_equals_one_shot(name):
+    """dusp_program_continue: render every golden case in three segments — state written back into the descriptor
+    between them, delay lines / CircleBuffers / feedback chunks staying on the device — and require the PCM of
+    the one-shot render, bit for bit (same engine family: segment boundaries must not be observable)."""
+    from dusp_amd import descriptor
+    g = Golden(name)
+    n = g.n_samples
+    if n < 3 * 256 + 1:
+        pytest.skip("shorter than three segments")
+    ctx = render.context(g.sample_rate)
+    whole = ctx.build(g.desc, runtime.ENGINE_CHUNK)
+    want = whole.render(n)[0]
+    whole.close()
+    cuts = [0, 256, 256 * (1 + (n // 256) // 2), n]
+    prog = ctx.build(g.desc, runtime.ENGINE_RESUMABLE)
+    parts, words = [], g.desc
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a:
+            words = descriptor.continued(words, a, [prog.state(u) for u in range(prog.n_units)])
+            prog.continue_with(words)
+        parts.append(prog.render(b - a)[0])
+    got = np.concatenate(parts, axis=1)
+    prog.close()
+    assert np.array_equal(got, want), "first mismatch at sample %d" % int(np.argmax((got != want).any(axis=0)))
+
+
+def test_continue_refuses_a_different_circuit_and_a_wrong_clock():
+    from dusp_amd import descriptor
+    ctx = render.context(48000)
+    g = Golden("loop_220")
+    prog = ctx.build(g.desc, runtime.ENGINE_RESUMABLE)
+    with pytest.raises(runtime.DuspHipError, match="nothing has been rendered"):
+        prog.continue_with(g.desc)
+    prog.render(512)
+    states = [prog.state(u) for u in range(prog.n_units)]
+    with pytest.raises(runtime.DuspHipError, match="does not follow the rendered clock"):
+        prog.continue_with(descriptor.continued(g.desc, 256, states))
+    with pytest.raises(runtime.DuspHipError, match="does not describe the circuit"):
+        prog.continue_with(Golden("fam_comb").desc)
+    prog.continue_with(descriptor.continued(g.desc, 512, states))
+    prog.close()
+    plain = ctx.build(g.desc)  # not resumable: a circuit with a delay line cannot be continued
+    plain.render(512)
+    with pytest.raises(runtime.DuspHipError, match="DUSP_ENGINE_RESUMABLE"):
+        plain.continue_with(descriptor.continued(g.desc, 512, states))
+    plain.close()
+    with pytest.raises(runtime.DuspHipError, match="already been ticked"):
+        ctx.build(descriptor.continued(g.desc, 512, states))  # a fresh program cannot know the ring contents
+
+
 def test_malformed_descriptors_are_rejected_not_crashed():
     """Truncations and single-word corruptions of real descriptors: program_build must either accept the
     program or fail with a status + message — never crash, hang or read out of bounds."""

@@ -53,8 +53,8 @@ def test_js_graph_mirror_extracts_the_reference_descriptors(sr):
 @needs_node
 def test_addon_loads_and_fails_loudly_without_gpu():
     rep = run_js("check_addon.js", "--sampleRate=48000")
-    assert rep["abi"] == 1 and "gfx950" in rep["version"]
-    assert set(rep["exports"]) >= {"ctxCreate", "tableUpload", "programBuild", "render", "stateDownload"}
+    assert rep["abi"] == 2 and "gfx950" in rep["version"]
+    assert set(rep["exports"]) >= {"ctxCreate", "tableUpload", "programBuild", "programContinue", "render", "stateDownload"}
     assert rep["nullRejects"] == "renderAudioBuffer expects an outlet"  # the reference's own string
     if not rep["gpu"]:
         assert rep["ctxErrorIsString"] is True
