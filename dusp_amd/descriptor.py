@@ -96,17 +96,20 @@ def to_outlet(x):
     return x
 
 
-def extract(target):
+def extract(target, allow_events=False, allow_clock=False):
+    """Flatten the circuit of `target` as it stands NOW.  allow_events / allow_clock are for the event-segmented
+    render loop (render.py), which extracts once per segment."""
     from .wavetables import WAVEFORMS
 
     outlet = to_outlet(target)
     out_unit = outlet.unit
     circuit = out_unit.circuit if out_unit.circuit is not None else out_unit.getOrBuildCircuit()
-    if circuit.events:
-        raise DuspError("dusp-hip: circuits with scheduled events are not supported on the GPU path")
+    if circuit.events and not allow_events:
+        raise DuspError("dusp-hip: this circuit has scheduled events; extract() flattens a single segment "
+                        "(renderChannelData segments them)")
     if getattr(circuit, "promises", None):
         raise DuspError("dusp-hip: circuits with pending promises are not supported on the GPU path")
-    if circuit.clock:
+    if circuit.clock and not allow_clock:
         raise DuspError("dusp-hip: circuit has already been ticked (clock=%s); render a fresh circuit" % circuit.clock)
 
     units = circuit.units

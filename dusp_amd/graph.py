@@ -111,6 +111,37 @@ class Inlet(_Port):
                 modified.computeOrders()
 
 
+class Event:
+    """A host callback at a point in time (reference src/Event.js:3-30): `time` in seconds, `t` the same instant in
+    samples.  The callback receives the unit (the reference binds it as `this`); a positive return value
+    reschedules it that many seconds later."""
+
+    def __init__(self, time, func, unit=None, circuit=None):
+        self.t = time * config.sampleRate
+        self.function = func
+        self.unit = unit
+        self.circuit = circuit
+
+    @property
+    def time(self):
+        return self.t / config.sampleRate
+
+    def run(self):
+        subject = self.unit if self.unit is not None else self.circuit
+        again = self.function(subject)
+        if isinstance(again, (int, float)) and not isinstance(again, bool) and again > 0:
+            return Event(self.time + again, self.function, self.unit, self.circuit)
+        return None
+
+
+def _insert_by_time(events, event):  # after every event that is not later (Circuit.js:49-55)
+    for i, other in enumerate(events):
+        if event.t < other.t:
+            events.insert(i, event)
+            return
+    events.append(event)
+
+
 class Unit:
     """reference src/Unit.js"""
 
@@ -238,6 +269,26 @@ class Unit:
             unit.trigger()
         return self
 
+    # ---- scheduled events (reference src/UnitOrPatch.js:9-33, src/Unit.js addEvent)
+    def addEvent(self, event):
+        if self.circuit is not None:
+            self.circuit.addEvent(event)
+        else:
+            _insert_by_time(self.events, event)
+
+    def schedule(self, time, func):
+        """Run func(unit) at `time` seconds (a list schedules every entry); it takes effect at the start of the
+        chunk that contains it (Circuit.js:23,57-65)."""
+        if isinstance(time, (list, tuple)):
+            for t in time:
+                self.schedule(t, func)
+            return None
+        self.addEvent(Event(time, func, self))
+        return self
+
+    def scheduleTrigger(self, t, val=None):
+        self.schedule(t, (lambda unit: unit.trigger()) if val is None else (lambda unit: unit.trigger(val)))
+
 
 class Circuit:
     """reference src/Circuit.js (construction + ordering only; ticking happens on the GPU)."""
@@ -262,9 +313,9 @@ class Circuit:
         if unit.tickInterval not in self.tickIntervals:
             self.tickIntervals = sorted(self.tickIntervals + [unit.tickInterval])
         if unit.events:
-            self.events.extend(unit.events)
-            self.events.sort(key=lambda e: e.t)
-        unit.events = None
+            for e in unit.events:
+                self.addEvent(e)
+        unit.events = None  # from now on the unit's events go straight to the circuit
         for other in unit.inputUnits:
             self.add(other)
         for other in unit.outputUnits:
@@ -272,6 +323,17 @@ class Circuit:
         unit.computeProcessIndex()
         self.computeOrders()
         return True
+
+    def addEvent(self, event):
+        event.circuit = self
+        _insert_by_time(self.events, event)
+
+    def runEvents(self, beforeT):
+        """Run every event due before `beforeT` samples (Circuit.js:57-65)."""
+        while self.events and self.events[0].t < beforeT:
+            follow_up = self.events.pop(0).run()
+            if follow_up is not None:
+                self.addEvent(follow_up)
 
     def computeOrders(self):
         """Stable sort by process index.  While a flood fill is in flight some

@@ -213,6 +213,107 @@ def builders(sr):
     return b
 
 
+def event_builders(sr):
+    """The `ev_` cases of tests/js/cases.js: graphs with scheduled host callbacks (callbacks take the unit)."""
+    def retrigger():
+        r = Ramp(2400, 1, 0)
+        r.scheduleTrigger(0.01)
+        r.scheduleTrigger(0.08)
+        return Multiply(Osc(440), r)
+
+    def freq_steps():
+        osc = Osc(220)
+        osc.schedule([0.02, 0.05, 0.09], lambda u: setattr(u, "F", u.F.constant * 1.5))
+        return osc
+
+    def repeating():
+        r = Ramp(600, 1, 0.25)
+
+        def again(u):
+            u.trigger()
+            return 0.03  # a positive return value reschedules (Event.js:20-27)
+        r.schedule(0.004, again)
+        return Multiply(Osc(330.5, "triangle"), r)
+
+    def filter_sweep():
+        filt = Filter(Osc(100, "saw"), 500)
+        filt.schedule(0.03, lambda u: setattr(u, "F", 2500))
+        filt.schedule(0.06, lambda u: setattr(u, "F", 800))
+        return filt
+
+    def delay_retrigger():
+        r = Ramp(1200, 1, 0)
+        r.scheduleTrigger([0.004, 0.03, 0.055])
+        return Delay(Multiply(Osc(660), r), 300.5, 2048)
+
+    def delay_time_change():
+        dl = Delay(Osc(500), 100, 4096)
+        dl.schedule(0.02, lambda u: setattr(u, "DELAY", 1000.25))
+        dl.schedule(0.05, lambda u: setattr(u, "DELAY", 17))
+        return dl
+
+    def loop_gain():
+        s = Sum(Osc(220), 0)
+        f = Filter(Delay(s, 480, 4096), 2000)
+        fb = Multiply(f, 0.5)
+        s.B = fb
+        fb.schedule(0.03, lambda u: setattr(u, "B", 0.9))
+        fb.schedule(0.07, lambda u: setattr(u, "B", 0.1))
+        return f
+
+    def feedback_no_delay():
+        s = Sum(Osc(330), 0)
+        m = Multiply(s, 0.5)
+        s.B = m
+        m.schedule([0.011, 0.033], lambda u: setattr(u, "B", u.B.constant * -1.5))
+        return s
+
+    def circlebuffer():
+        buffer = CircleBuffer(1, 0.05)
+        writer = CircleBufferWriter(buffer)
+        writer.preWipe = True
+        osc = Osc(330)
+        writer.IN = osc
+        tap = CircleBufferReader(buffer, 0.01)
+        tap.chain(writer)
+        osc.schedule(0.02, lambda u: setattr(u, "F", 495))
+        tap.schedule(0.04, lambda u: setattr(u, "OFFSET", 0.003))
+        return tap
+
+    def comb():
+        c = CombFilter(0.004, 0.7)
+        r = Ramp(800, 1, 0)
+        c.IN = Multiply(Osc(150, "saw"), r)
+        r.scheduleTrigger([0.0, 0.05])
+        c.schedule(0.03, lambda u: setattr(u, "FEEDBACKGAIN", -0.5))
+        return c
+
+    def shape_retrigger():
+        sh = Shape("decaySquared", 0.02)
+        sh.scheduleTrigger([0.01, 0.06])
+        return Multiply(Osc(440), sh)
+
+    def ahd_retrigger():
+        e = AHD(0.004, 0.003, 0.006)
+        e.scheduleTrigger([0.005, 0.04])
+        return e
+
+    def timer_trigger():
+        tm = Timer()
+        tm.scheduleTrigger(0.02)
+        return Osc(Multiply(tm, 20000))
+
+    return {"ev_retrigger": retrigger, "ev_freq_steps": freq_steps, "ev_repeating": repeating, "ev_filter_sweep": filter_sweep,
+            "ev_delay_retrigger": delay_retrigger, "ev_delay_time_change": delay_time_change, "ev_loop_gain": loop_gain,
+            "ev_feedback_no_delay": feedback_no_delay, "ev_circlebuffer": circlebuffer, "ev_comb": comb,
+            "ev_shape_retrigger": shape_retrigger, "ev_ahd_retrigger": ahd_retrigger, "ev_timer_trigger": timer_trigger}
+
+
+def build_event_case(name, sr):
+    d.configure(sr)
+    return event_builders(sr)[name]()
+
+
 def build(name, sr):
     """Build the graph of golden case `name` (48 kHz names carry no suffix)."""
     d.configure(sr)
