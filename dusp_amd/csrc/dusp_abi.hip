@@ -19,6 +19,7 @@ namespace dusp {
 hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
+hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
 hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, hipStream_t stream);
 hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
@@ -518,7 +519,30 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     return DUSP_OK;
 }
 
+static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out, bool interleaved);
+
 int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out) {
+    return render_host(prog, n_instances, n_samples, h_params, h_out, false);
+}
+
+int dusp_render_host_interleaved(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out) {
+    return render_host(prog, n_instances, n_samples, h_params, h_out, true);
+}
+
+int dusp_interleave_device(dusp_ctx *ctx, const float *d_planar, size_t n_instances, size_t n_channels, size_t n_samples, float *d_interleaved,
+                           void *stream_) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (!d_planar || !d_interleaved) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_interleave_device: NULL buffer");
+    if (n_channels < 1 || n_channels > 64 || n_instances < 1 || n_samples < 1 || n_samples > (1ull << 31) ||
+        (n_samples + 127) / 128 * n_instances > 0x7fffffffull)
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_interleave_device: need 1..64 channels and at most 2^31 tiles of 128 frames");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, dusp::launch_interleave(d_planar, d_interleaved, (uint32_t)n_instances, (uint32_t)n_channels, n_samples,
+                                         stream_ ? (hipStream_t)stream_ : ctx->stream));
+    return DUSP_OK;
+}
+
+static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out, bool interleaved) {
     if (!prog) return DUSP_ERR_ARG;
     dusp_ctx *ctx = prog->ctx;
     if (!h_out) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: h_out is NULL");
@@ -526,7 +550,7 @@ int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples, c
     if (n_par && !h_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but h_params is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_out = n_instances * prog->P.out_bufs.size() * n_samples;
-    float *d_out = nullptr, *d_par = nullptr;
+    float *d_out = nullptr, *d_par = nullptr, *d_frames = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d_out, std::max<size_t>(1, n_out) * sizeof(float)));
     int rc = DUSP_OK;
     hipError_t e = hipSuccess;
@@ -536,13 +560,19 @@ int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples, c
     }
     if (e == hipSuccess) {
         rc = dusp_render_device(prog, n_instances, n_samples, d_par, d_out, ctx->stream);
-        if (rc == DUSP_OK) {
-            e = hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        const size_t n_ch = prog->P.out_bufs.size();
+        if (rc == DUSP_OK && interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
+            e = hipMalloc((void **)&d_frames, n_out * sizeof(float));
+            if (e == hipSuccess) rc = dusp_interleave_device(ctx, d_out, n_instances, n_ch, n_samples, d_frames, ctx->stream);
+        }
+        if (rc == DUSP_OK && e == hipSuccess) {
+            e = hipMemcpyAsync(h_out, d_frames ? d_frames : d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
     }
     (void)hipFree(d_out);
     if (d_par) (void)hipFree(d_par);
+    if (d_frames) (void)hipFree(d_frames);
     if (rc != DUSP_OK) return rc;
     if (e != hipSuccess) CTX_FAIL(ctx, DUSP_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e));
     return DUSP_OK;

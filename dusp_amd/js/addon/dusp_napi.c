@@ -297,6 +297,7 @@ typedef struct {
     size_t n_instances, n_samples, n_floats;
     float *params;
     float *out;
+    int interleaved; /* frames [instance][sample][channel] instead of planar [instance][channel][sample] */
     int rc;
     char err[512];
 } render_job;
@@ -305,7 +306,8 @@ static void render_execute(napi_env env, void *data) {
     (void)env;
     render_job *j = (render_job *)data;
     pthread_mutex_lock(&g_lock);
-    j->rc = dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
+    j->rc = j->interleaved ? dusp_render_host_interleaved(j->prog, j->n_instances, j->n_samples, j->params, j->out)
+                           : dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
     if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->ctx));
     pthread_mutex_unlock(&g_lock);
 }
@@ -341,9 +343,16 @@ static void render_complete(napi_env env, napi_status status, void *data) {
     free(j);
 }
 
+/* render(prog, nInstances, nSamples, params | null [, interleaved]) -> Promise<Float32Array> */
 static napi_value fn_render(napi_env env, napi_callback_info info) {
-    napi_value argv[4];
-    if (!get_args(env, info, 4, argv)) return NULL;
+    napi_value argv[5];
+    size_t argc = 5;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 4) {
+        throw_string(env, "dusp-hip: wrong number of arguments");
+        return NULL;
+    }
+    bool interleaved = false;
+    if (argc >= 5) napi_get_value_bool(env, argv[4], &interleaved);
     prog_box *pb = as_prog(env, argv[0]);
     if (!pb) return NULL;
     double n_inst = 0, n_samples = 0;
@@ -361,6 +370,7 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
     j->n_instances = (size_t)n_inst;
     j->n_samples = (size_t)n_samples;
     j->n_floats = j->n_instances * pi.n_out_channels * j->n_samples;
+    j->interleaved = interleaved ? 1 : 0;
     napi_valuetype vt;
     napi_typeof(env, argv[3], &vt);
     if (vt != napi_null && vt != napi_undefined) {

@@ -8,6 +8,12 @@ module.exports = {
   renderChannelData,
   renderMany: renderChannelData.renderMany,
   quick: require('./lib/quick'),
+  unDusp: require('./lib/unDusp'),
+  RenderStream: require('./lib/RenderStream'),
+  SegmentRenderer: renderChannelData.SegmentRenderer,
+  encodeWav: require('./lib/wav').encodeWav,
+  decodeWav: require('./lib/wav').decodeWav,
+  parse: require('./lib/parse'),
   config: require('./lib/config'),
   extract: require('./lib/extract').extract,
   unify: require('./lib/extract').unify,

@@ -47,6 +47,11 @@ class Inlet extends Port {
     this.signalChunk = { channelData: [new Float32Array(1)] }
   }
   get isInlet() { return true }
+  set(val) { // Inlet.js:26-31
+    if (val && (val.isUnit || val.isOutlet || val.isPatch)) this.connect(val)
+    else this.setConstant(val)
+  }
+  get() { return this.connected ? this.outlet : this.constant }
 
   disconnect() {
     if (!this.outlet) return
@@ -123,6 +128,7 @@ class Unit {
     this.clock = 0
     this.tickInterval = config.standardChunkSize
     this.processIndex = undefined
+    this.finished = false
     this.nChains = 0
     this.sampleRate = config.sampleRate
     const kind = this.constructor.name
@@ -216,6 +222,12 @@ class Unit {
     if (!this.trigger) throw this.label + ': cannot call scheduleTrigger because trigger is undefined'
     this.schedule(t, function () { this.trigger(val) })
   }
+  finish() { // UnitOrPatch.js:77-84
+    this.finished = true
+    if (this._finish) this._finish()
+    if (this.onFinish) this.onFinish()
+  }
+  scheduleFinish(t) { this.schedule(t, () => { this.finish() }) } // UnitOrPatch.js:85-90
 
   trigger() {
     for (const unit of this.inputUnits) unit.trigger()

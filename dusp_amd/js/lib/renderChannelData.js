@@ -69,58 +69,85 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
 
 const RESUMABLE = 0x100 // DUSP_ENGINE_RESUMABLE (include/dusp_hip.h)
 
-async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Array, engine = 0 } = {}) {
-  const first = extract(outlet, { allowEvents: true })
-  const circuit = first.circuit
-  const chunk = first.chunkSize
-  const nSamples = sampleCount(duration, first.sampleRate)
-  const channelData = []
-  channelData.sampleRate = first.sampleRate
-  if (nSamples === 0) return channelData
-  const n = native()
-  const place = (pcm, nChannels, at, len) => {
-    for (let c = 0; c < nChannels; c++) {
-      while (channelData.length <= c) channelData.push(new TypedArray(nSamples)) // late channels start as zeros (:38-39)
-      const take = Math.min(len, nSamples - at)
-      if (take > 0) channelData[c].set(pcm.subarray(c * len, c * len + take), at)
-    }
+/* Renders a circuit piecewise, in time order.  Every call continues where the previous one stopped:
+ *
+ * Event-segmented rendering (SURVEY.md 8f-3).  The reference runs every event with t < clock + chunk at the start
+ * of the tick at `clock` (Circuit.js:23,57-65), i.e. events take effect on chunk boundaries.  So: run the due
+ * callbacks on the host objects, render up to the chunk in which the next event falls due, write the unit state
+ * back, re-extract and CONTINUE the same device program (dusp_program_continue: unit state and constants come from
+ * the objects, delay lines / CircleBuffers / feedback chunks stay resident on the device). */
+class SegmentRenderer {
+  constructor(outlet, { engine = 0, resumable = false } = {}) {
+    this.outlet = outlet
+    this.first = extract(outlet, { allowEvents: true })
+    this.circuit = this.first.circuit
+    this.chunk = this.first.chunkSize
+    this.sampleRate = this.first.sampleRate
+    this.hasEvents = !!(this.circuit.events && this.circuit.events.length)
+    this.engine = resumable || this.hasEvents ? engine | RESUMABLE : engine
+    this.native = native()
+    this.prog = null
+    this.clock = 0
   }
-  const hasEvents = !!(circuit.events && circuit.events.length)
 
-  /* Event-segmented rendering (SURVEY.md 8f-3).  The reference runs every event with t < clock + chunk at the
-   * start of the tick at `clock` (Circuit.js:23,57-65), i.e. events take effect on chunk boundaries.  So: run
-   * the due callbacks on the host objects, render up to the chunk in which the next event falls due, write the
-   * unit state back, re-extract and CONTINUE the same device program (dusp_program_continue: unit state and
-   * constants come from the objects, delay lines / CircleBuffers / feedback chunks stay resident on the device). */
-  let prog = null
-  try {
-    const end = Math.ceil(nSamples / chunk) * chunk
-    let clock = 0
-    while (clock < end) {
+  /* the next nSamples samples (a whole number of chunks, except in the last call of a render) ->
+   * { pcm: Float32Array [channel][nSamples], nChannels } */
+  async next(nSamples) {
+    const n = this.native, chunk = this.chunk
+    const start = this.clock
+    const end = start + Math.ceil(nSamples / chunk) * chunk
+    const pieces = []
+    while (this.clock < end) {
       let next = end
-      if (hasEvents) {
-        circuit.runEvents(clock + chunk)
-        if (circuit.events.length) {
-          const due = Math.floor(circuit.events[0].t / chunk) * chunk
-          next = Math.min(end, Math.max(clock + chunk, due))
+      if (this.circuit.events && this.circuit.events.length) {
+        this.circuit.runEvents(this.clock + chunk)
+        if (this.circuit.events.length) {
+          const due = Math.floor(this.circuit.events[0].t / chunk) * chunk
+          next = Math.min(end, Math.max(this.clock + chunk, due))
         }
       }
-      const ex = clock === 0 && !hasEvents ? first : extract(outlet, { allowEvents: true, allowClock: true })
-      if (!prog) prog = n.programBuild(contextFor(ex.sampleRate), ex.words, hasEvents ? engine | RESUMABLE : engine)
-      else n.programContinue(prog, ex.words)
-      const len = Math.min(next, nSamples) - clock // the last segment may end inside a chunk
-      const pcm = await n.render(prog, 1, len, null) // Float32Array [channel][sample]
-      writeBack(n, prog, circuit, chunk, len) // advances circuit.clock to `next`
-      const nChannels = n.programInfo(prog).nOutChannels
-      if (!hasEvents && TypedArray === Float32Array) { // single segment: hand the rendered buffer over without a copy
-        for (let c = 0; c < nChannels; c++) channelData.push(pcm.subarray(c * nSamples, (c + 1) * nSamples))
-      } else place(pcm, nChannels, clock, len)
-      clock = next
+      const ex = !this.prog && !this.hasEvents ? this.first : extract(this.outlet, { allowEvents: true, allowClock: true })
+      if (!this.prog) this.prog = n.programBuild(contextFor(ex.sampleRate), ex.words, this.engine)
+      else n.programContinue(this.prog, ex.words)
+      const len = Math.min(next, start + nSamples) - this.clock // the last segment may end inside a chunk
+      const pcm = await n.render(this.prog, 1, len, null) // Float32Array [channel][len]
+      writeBack(n, this.prog, this.circuit, chunk, len) // advances circuit.clock to `next`
+      pieces.push({ pcm, len, nChannels: n.programInfo(this.prog).nOutChannels })
+      this.clock = next
     }
-  } finally {
-    if (prog) n.programDestroy(prog)
+    const nChannels = Math.max(...pieces.map((p) => p.nChannels))
+    if (pieces.length === 1) return { pcm: pieces[0].pcm, nChannels }
+    const pcm = new Float32Array(nChannels * nSamples) // late channels start as zeros (renderChannelData.js:38-39)
+    let at = 0
+    for (const p of pieces) {
+      for (let c = 0; c < p.nChannels; c++) pcm.set(p.pcm.subarray(c * p.len, (c + 1) * p.len), c * nSamples + at)
+      at += p.len
+    }
+    return { pcm, nChannels }
   }
-  return channelData
+
+  close() {
+    if (this.prog) this.native.programDestroy(this.prog)
+    this.prog = null
+  }
+}
+
+async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Array, engine = 0 } = {}) {
+  const renderer = new SegmentRenderer(outlet, { engine })
+  try {
+    const nSamples = sampleCount(duration, renderer.sampleRate)
+    const channelData = []
+    channelData.sampleRate = renderer.sampleRate
+    if (nSamples === 0) return channelData
+    const { pcm, nChannels } = await renderer.next(nSamples)
+    for (let c = 0; c < nChannels; c++) {
+      const channel = pcm.subarray(c * nSamples, (c + 1) * nSamples) // Float32Array: handed over without a copy
+      channelData.push(TypedArray === Float32Array ? channel : TypedArray.from(channel))
+    }
+    return channelData
+  } finally {
+    renderer.close()
+  }
 }
 
 /* N structurally identical circuits (voices, a parameter sweep) as ONE GPU program:
@@ -153,3 +180,4 @@ async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
 module.exports = renderChannelData
 module.exports.renderChannelData = renderChannelData
 module.exports.renderMany = renderMany
+module.exports.SegmentRenderer = SegmentRenderer

@@ -20,7 +20,8 @@ ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave
 EXPORTS = [
     "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
-    "dusp_render_device", "dusp_render_host", "dusp_state_download", "dusp_last_kernel_ms", "dusp_fill_device",
+    "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
+    "dusp_last_kernel_ms", "dusp_fill_device",
 ]
 
 
@@ -71,6 +72,8 @@ def load():
     L.dusp_program_info_get.argtypes = [vp, ctypes.POINTER(ProgramInfo)]
     L.dusp_render_device.argtypes = [vp, sz, sz, vp, vp, vp]
     L.dusp_render_host.argtypes = [vp, sz, sz, vp, vp]
+    L.dusp_render_host_interleaved.argtypes = [vp, sz, sz, vp, vp]
+    L.dusp_interleave_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
     L.dusp_state_download.argtypes = [vp, sz, sz, vp, sz]
     L.dusp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dusp_fill_device.argtypes = [vp, vp, sz, ctypes.c_float, vp]
@@ -111,6 +114,10 @@ class Context:
 
     def build(self, words, engine=ENGINE_AUTO):
         return Program(self, words, engine)
+
+    def interleave(self, d_planar, n_instances, n_channels, n_samples, d_out, stream=None):
+        """Device pointers: planar f32 [instance][channel][sample] -> frames f32 [instance][sample][channel]."""
+        self._check(self._L.dusp_interleave_device(self._h, d_planar, n_instances, n_channels, n_samples, d_out, stream))
 
     def fill(self, d_ptr, n_floats, value=0.0, stream=None):
         self._check(self._L.dusp_fill_device(self._h, d_ptr, n_floats, value, stream))
@@ -155,16 +162,19 @@ class Program:
         self.ctx._check(self._L.dusp_program_continue(self._h, words.ctypes.data, words.size))
         self._read_info()
 
-    def render(self, n_samples, n_instances=1, params=None):
-        """Host round trip: float32 [n_instances, n_out_channels, n_samples]."""
-        out = np.empty((n_instances, self.n_out_channels, n_samples), dtype=np.float32)
+    def render(self, n_samples, n_instances=1, params=None, interleaved=False):
+        """Host round trip: float32 [n_instances, n_out_channels, n_samples], or — interleaved — frames
+        [n_instances, n_samples, n_out_channels] (the RenderStream / WAV layout, transposed on the device)."""
+        shape = (n_instances, n_samples, self.n_out_channels) if interleaved else (n_instances, self.n_out_channels, n_samples)
+        out = np.empty(shape, dtype=np.float32)
         pp = None
         if self.n_params:
             params = np.ascontiguousarray(params, dtype=np.float32)
             if params.shape != (self.n_params, n_instances):
                 raise ValueError("params must have shape (n_params=%d, n_instances=%d)" % (self.n_params, n_instances))
             pp = params.ctypes.data
-        self.ctx._check(self._L.dusp_render_host(self._h, n_instances, n_samples, pp, out.ctypes.data))
+        call = self._L.dusp_render_host_interleaved if interleaved else self._L.dusp_render_host
+        self.ctx._check(call(self._h, n_instances, n_samples, pp, out.ctypes.data))
         return out
 
     def render_device(self, n_samples, n_instances, d_params, d_out, stream=None):

@@ -141,6 +141,17 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
 int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
                      const float *h_params, float *h_out);
 
+/* Wire format (replaces the per-chunk loop of src/RenderStream.js:36-57 as the thing that produces frames):
+ * planar PCM f32 [n_instances][n_channels][n_samples], as the render calls write it, to interleaved frames
+ * f32 [n_instances][n_samples][n_channels] — `buffer[t * numberOfChannels + c]`, 32-bit little-endian floats
+ * (src/RenderStream.js:54,63-68; also the layout of a WAV data chunk).  Device pointers, asynchronous; the two
+ * buffers must not overlap. */
+int dusp_interleave_device(dusp_ctx *ctx, const float *d_planar, size_t n_instances, size_t n_channels, size_t n_samples,
+                           float *d_interleaved, void *stream);
+
+/* dusp_render_host, delivering interleaved frames: h_out is f32 [n_instances][n_samples][n_out_channels]. */
+int dusp_render_host_interleaved(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out);
+
 /* State write-back (SURVEY.md §5 "checkpoint/resume"): after a render, copy the
  * state of `unit` for `instance` into out[] in the layout of the descriptor's
  * state words for that unit's opcode (Osc: phase; Ramp: t, playing; Filter:

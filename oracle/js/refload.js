@@ -19,6 +19,7 @@ const BUNDLE = REF + '/demos/browser-dusp-demo-2.bundle.js'
 const BARE = ['compute-gcd', 'promise', 'audio-buffer']
 
 let installed = false
+let bundleRequireFn = null
 function install() {
   if (installed) return
   let text = fs.readFileSync(BUNDLE, 'utf8')
@@ -26,6 +27,7 @@ function install() {
   if (!tail) throw new Error('unrecognised browserify bundle tail in ' + BUNDLE)
   text = text.slice(0, tail.index) + '},{},[])'
   const bundleRequire = (0, eval)(text) // browserify prelude returns its require-by-id
+  bundleRequireFn = bundleRequire
   const ids = {}
   for (const name of BARE) {
     const m = text.match(new RegExp('"' + name + '":(\\d+)'))
@@ -43,4 +45,10 @@ function install() {
 
 function ref(path) { install(); return require(REF + '/src/' + path) }
 
-module.exports = { ref, REF }
+/* A module of the reference's bundle by its browserify id.  The bundle is the only place the reference's string
+ * front-end still exists (src/parseDSP is an empty submodule): ids 110-137 are the parser, 171 is unDusp, 170
+ * renderChannelData, 99 config.  The bundle is a SEPARATE instance of the library (its own config, classes and
+ * wave tables), so set bundle(99).sampleRate before touching anything else in it. */
+function bundle(id) { install(); return bundleRequireFn(id) }
+
+module.exports = { ref, bundle, REF }

@@ -231,3 +231,27 @@ def test_loop_kernels_agree_bit_for_bit(monkeypatch):
             assert np.array_equal(pcm, results[0][0])
             for s_a, s_b in zip(states, results[0][1]):
                 assert np.array_equal(s_a, s_b, equal_nan=True)
+
+
+@pytest.mark.parametrize("n_inst,n_ch,n", [(1, 2, 2400), (3, 3, 1000), (5, 8, 257), (2, 33, 513), (1, 64, 4096), (7, 1, 300), (1, 2, 2_880_000)])
+def test_interleave_device_is_a_transpose(n_inst, n_ch, n):
+    """dusp_interleave_device: planar [instance][channel][sample] -> frames [instance][sample][channel], bit for bit,
+    for channel counts on both sides of the tile-size switch, ragged tails and a full-length stereo render."""
+    import torch
+    ctx = render.context(48000)
+    g = torch.Generator(device="cpu").manual_seed(n_ch * 1000 + n)
+    planar = torch.randn((n_inst, n_ch, n), generator=g, dtype=torch.float32).cuda()
+    frames = torch.full((n_inst, n, n_ch), float("nan"), dtype=torch.float32, device="cuda")
+    ctx.interleave(planar.data_ptr(), n_inst, n_ch, n, frames.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(frames, planar.transpose(1, 2).contiguous())
+
+
+def test_render_host_interleaved_matches_planar():
+    from conftest import Golden
+    g = Golden("rest_pan")
+    prog = render.context(48000).build(g.desc)
+    planar = prog.render(g.n_samples, 1)
+    frames = prog.render(g.n_samples, 1, interleaved=True)
+    assert frames.shape == (1, g.n_samples, 2) and np.array_equal(frames[0].T, planar[0])
+    prog.close()

@@ -51,6 +51,53 @@ def test_js_graph_mirror_extracts_the_reference_descriptors(sr):
 
 
 @needs_node
+def test_string_front_end_matches_the_reference_parser_and_constructors():
+    """dusp_amd/js/lib/parse.js + unDusp.js against trees / descriptors captured from the reference's own parser
+    (the copy inside its browserify bundle; oracle/js/gen_golden_strings.js): 800+ strings incl. two fuzzers."""
+    rep = run_js("check_strings.js", "--sampleRate=48000")
+    assert rep["trees"] >= 800 and not rep["treeMismatches"], rep["treeMismatches"][:3]
+    assert rep["graphs"] >= 30 and not rep["graphMismatches"], rep["graphMismatches"]
+    assert rep["rejected"] == 3
+
+
+@needs_node
+@pytest.mark.gpu
+def test_strings_render_like_the_reference():
+    rep = run_js("check_strings.js", "--sampleRate=48000", "--render")
+    assert rep.get("fatal") is None, rep
+    assert not rep["renderFailures"] and not rep["graphMismatches"], rep
+    assert rep["rendered"] == rep["graphs"] - rep["rejected"] >= 27
+
+
+@needs_node
+@pytest.mark.gpu
+def test_render_stream_frames_and_wav():
+    """RenderStream (interleaved f32 LE frames, auto-normalising, block-wise continuation of one device program)
+    against frames captured from the reference's RenderStream; WAV encode/decode; device-side interleave."""
+    rep = run_js("check_stream.js", "--sampleRate=48000")
+    assert rep.get("fatal") is None, rep
+    assert rep["checked"] == 10 and not rep["failed"], rep["failed"]
+    assert rep["wavFloatExact"] and rep["wavPcm16Close"] and rep["deviceFramesMatch"]
+
+
+@needs_node
+def test_wav_header_layout():
+    out = subprocess.run([NODE, "-e", """
+const {encodeWav, decodeWav} = require('./dusp_amd/js/lib/wav')
+const cd = [Float32Array.from([0, 0.5, -1, 1.5]), Float32Array.from([1, -0.25, 0, -2])]; cd.sampleRate = 48000
+const f = encodeWav(cd), p = encodeWav(cd, {bitDepth: 16})
+console.log(JSON.stringify({flen: f.length, plen: p.length, riff: f.toString('ascii', 0, 4) + f.toString('ascii', 8, 16), ftag: f.readUInt16LE(20),
+  ptag: p.readUInt16LE(20), rate: f.readUInt32LE(24), align: f.readUInt16LE(32), frames: Array.from(decodeWav(f).channelData[1]),
+  pcm: [p.readInt16LE(44), p.readInt16LE(46), p.readInt16LE(52), p.readInt16LE(56), p.readInt16LE(58)]}))
+"""], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout
+    rep = json.loads(out)
+    assert rep["riff"] == "RIFFWAVEfmt " and rep["ftag"] == 3 and rep["ptag"] == 1 and rep["rate"] == 48000 and rep["align"] == 8
+    assert rep["flen"] == 12 + 8 + 18 + 12 + 8 + 32 and rep["plen"] == 44 + 16
+    assert rep["frames"] == [1, -0.25, 0, -2]
+    assert rep["pcm"] == [0, 32767, -32767, 32767, -32767]  # clamped to full scale
+
+
+@needs_node
 def test_addon_loads_and_fails_loudly_without_gpu():
     rep = run_js("check_addon.js", "--sampleRate=48000")
     assert rep["abi"] == 2 and "gfx950" in rep["version"]
