@@ -21,7 +21,7 @@ hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
-hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, hipStream_t stream);
+hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, hipStream_t stream);
 hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
@@ -506,7 +506,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     if (prog->engine == DUSP_ENGINE_LOOP) {
         const int w = prog->loop.osc.attr;
         if (prog->loop_two_stage)
-            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, stream));
+            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, stream));
         else
             HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
     } else

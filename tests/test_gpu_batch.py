@@ -205,8 +205,8 @@ def test_config4_sweep_shard_full_size(oracle):
 
 
 def test_loop_kernels_agree_bit_for_bit(monkeypatch):
-    """The two-stage feedback-voice kernel (delay >= one chunk), the one-stage loop kernel and the generic
-    chunk engine execute the same operations in the same order per sample: identical PCM and state."""
+    """The two-stage feedback-voice kernels (delay >= one chunk; wide and narrow variant), the one-stage loop kernel
+    and the generic chunk engine execute the same operations in the same order per sample: identical PCM and state."""
     d.configure(48000)
     def loop(k, delay):
         s = d.Sum(d.Osc(110 + k / 64), 0)
@@ -218,8 +218,11 @@ def test_loop_kernels_agree_bit_for_bit(monkeypatch):
         n = 256 * 9 + 17
         ctx = render.context(48000)
         results = []
-        for engine, knob in ((runtime.ENGINE_LOOP, "1"), (runtime.ENGINE_LOOP, "0"), (runtime.ENGINE_CHUNK, "1")):
+        # two-stage wide (32 instances / workgroup, table in LDS), two-stage narrow, one-stage, generic chunk engine
+        for engine, knob, wide in ((runtime.ENGINE_LOOP, "1", "1"), (runtime.ENGINE_LOOP, "1", "0"), (runtime.ENGINE_LOOP, "0", "1"),
+                                   (runtime.ENGINE_CHUNK, "1", "1")):
             monkeypatch.setenv("DUSP_LOOP2", knob)
+            monkeypatch.setenv("DUSP_LOOP_WIDE", wide)
             prog = ctx.build(uni.words, engine)
             if engine == runtime.ENGINE_LOOP:
                 assert ("two-stage" in prog.shape) == (knob == "1")
