@@ -288,7 +288,10 @@ __device__ __forceinline__ void lds_barrier() {
 struct WideCarry {             // per-instance state stage A carries from chunk to chunk (LDS)
     unsigned long long phase;  // Osc phase of the previous chunk's last sample, 2^-36 units
     long long q;               // Osc increment f, 2^-36 units
+    unsigned long long qm;     // q mod S (non-negative): sample-to-sample steps need one wrap test only
     double xprev;              // Sum output at the previous chunk's last sample (Delay's ceil tap)
+    double phi;                // fractional part of the delay
+    uint32_t D, pad2;          // integer part of the delay (256 <= D, D + 256 <= len)
     double a0, a1, a2;         // feed-forward biquad coefficients (published by stage B's lane at start)
     float xd[2][2];            // [chunk parity][0: x[-1], 1: x[-2]]: the delayed signal's last two samples of the chunk before
     float gain, delay_f;
@@ -337,9 +340,17 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
         if (fabs(fd) >= srd) fd = fmod(fd, srd);
         c.q = (long long)(fd * kTwo36L);
         c.xprev = a.state[(size_t)L.delay.state_slot * NP + i];
+        c.qm = c.q < 0 ? (unsigned long long)(c.q + (long long)S) : (unsigned long long)c.q;
         c.gain = lane_const(L.mul.in[L.mul_gain_operand], i);
         c.delay_f = lane_const(L.delay.in[1], i);
-        c.pad = 0;
+        {
+            double dconst = (double)c.delay_f;  // Delay.js:30: tWrite = (tBuffer + delay) % len
+            if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
+            const double Dfl = floor(dconst);
+            c.phi = dconst - Dfl;
+            c.D = (uint32_t)Dfl;
+        }
+        c.pad = c.pad2 = 0;
         // Filter.js:34-37 with a constant f: coefficients are (re)computed at the first sample iff f != lastF
         const bool has_lastF = st[0] != 0.0;
         const double ft = (double)lane_const(L.filter.in[1], i);
@@ -402,27 +413,39 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
         }
     };
 
-    int64_t s0 = a.clock0 % len;  // ring slot of the chunk's first sample
+    uint32_t s0 = (uint32_t)(a.clock0 % len);  // ring slot of the chunk's first sample (ring lengths are below 2^31)
+    const uint32_t len32 = (uint32_t)len;
+    auto uniform32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uniform64 = [&](unsigned long long v) { return ((unsigned long long)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v); };
     // The Delay's ring reads of a chunk are issued one chunk ahead (right after the previous stage A, whose ring
-    // writes — the latest this chunk can depend on, because D >= 256 — are ordered before them by the barrier), so
-    // their HBM / MALL latency hides behind stage B instead of sitting at the head of stage A.
-    float ahead[kWI / kWWaves][4];
-    auto fetch_ring = [&](int64_t first_slot) {
+    // writes — the latest this chunk can depend on, because D >= 256 — precede them), so their HBM / MALL latency
+    // hides behind stage B instead of sitting at the head of stage A.  A lane's four slots are one 16-byte access
+    // when the ring geometry keeps them contiguous and aligned (configs[3]: len 4096, D 480).
+    f32x4 ahead[kWI / kWWaves];
+    auto fetch_ring = [&](uint32_t first_slot) {
 #pragma unroll
         for (int jj = 0; jj < kWI / kWWaves; ++jj) {
             const uint32_t inst = min(inst0 + wave + jj * kWWaves, a.n_inst - 1);
             const float *ring = a.rings + (size_t)inst * (size_t)len;
+            uint32_t s_ = first_slot + lane * 4;
+            if ((len32 & 3u) == 0 && (first_slot & 3u) == 0) {
+                if (s_ >= len32) s_ -= len32;
+                ahead[jj] = *(const f32x4 *)(ring + s_);
+            } else {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                int64_t s_ = first_slot + lane * 4 + cc;
-                if (s_ >= len) s_ -= len;
-                ahead[jj][cc] = ring[s_];
+                for (int cc = 0; cc < 4; ++cc) {
+                    uint32_t sc = s_ + cc;
+                    if (sc >= len32) sc -= len32;
+                    ahead[jj][cc] = ring[sc];
+                }
             }
         }
     };
     fetch_ring(s0);
     for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
         // ------------------------------------------------------------------ stage A (and the previous chunk's copy-out)
+        // Per-instance constants are wave-uniform: pulled into scalar registers so that the address and wrap
+        // arithmetic built on them runs on the scalar unit and the branches on them do not touch the exec mask.
 #pragma unroll
         for (int jj = 0; jj < kWI / kWWaves; ++jj) {
             const uint32_t j = wave + jj * kWWaves;
@@ -437,55 +460,71 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
                 if ((a.n_samples & 3) == 0 && n0 + 4 <= a.n_samples) store4<true>(row, v, n0, a.n_samples);
                 else store4<false>(row, v, n0, a.n_samples);
             }
-            const WideCarry c = carry[j];
+            const WideCarry &cr = carry[j];
+            const unsigned long long phase0 = uniform64(cr.phase), qm = uniform64(cr.qm);
+            const long long q = (long long)uniform64((unsigned long long)cr.q);
+            const float gain = __uint_as_float(uniform32(__float_as_uint(cr.gain)));
+            const uint32_t D = uniform32(cr.D);
+            const double phi = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(cr.phi)));
+            const double xprev_chunk = __longlong_as_double((long long)uniform64((unsigned long long)__double_as_longlong(cr.xprev)));
+            const bool bad = uniform32((uint32_t)cr.bad) != 0;
             float *ring = a.rings + (size_t)inst * (size_t)len;
             // Osc (Osc.js:35-47): exact fixed-point phase of this lane's 4 samples
-            unsigned long long P = mod_u64_lifted((unsigned long long)((long long)c.phase + c.q * (long long)(lane * 4 + 1)) + lift, S, inv_S);
+            unsigned long long P = mod_u64_lifted((unsigned long long)((long long)phase0 + q * (long long)(lane * 4 + 1)) + lift, S, inv_S);
             float x[4];  // Sum output
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 if (cc > 0) {
-                    long long Pn = (long long)P + c.q;
-                    if (Pn < 0) Pn += (long long)S;
-                    if (Pn >= (long long)S) Pn -= (long long)S;
-                    P = (unsigned long long)Pn;
+                    P += qm;  // P, qm < S: one wrap test
+                    if (P >= S) P -= S;
                 }
                 const uint32_t idx = (uint32_t)(P >> 36);
-                const double fraction = (double)(P & ((1ull << 36) - 1ull)) * (1.0 / kTwo36L);
+                // fraction = (P mod 2^36) / 2^36, exactly: 4 high bits and 32 low bits are converted separately
+                const double fraction =
+                    ldexp(fma((double)((uint32_t)(P >> 32) & 15u), 4294967296.0, (double)(uint32_t)P), -36);
                 float ta, tb;
                 T.pair(idx, ta, tb);
-                const float osc = c.bad ? __builtin_nanf("") : (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
-                const float fb = L.mul_gain_operand ? fbv[cc] * c.gain : c.gain * fbv[cc];  // Multiply.js:31
-                x[cc] = L.sum_osc_operand ? fb + osc : osc + fb;                              // Sum.js:42
+                const float osc = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+                const float fb = L.mul_gain_operand ? fbv[cc] * gain : gain * fbv[cc];  // Multiply.js:31
+                x[cc] = L.sum_osc_operand ? fb + osc : osc + fb;                          // Sum.js:42
             }
+            if (bad)  // f is NaN / Inf: the reference's phase is NaN for good and every table read undefined
+                for (int cc = 0; cc < 4; ++cc) x[cc] = __builtin_nanf("");
             const unsigned long long lastP = __shfl(P, 63, 64);
-            // Delay (Delay.js:27-39), constant delay D + phi with D >= 256
-            double dconst = (double)c.delay_f;
-            if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
-            const double Dfl = floor(dconst), phi = dconst - Dfl;
-            const int64_t D = (int64_t)Dfl;
-            const float delayed[4] = {ahead[jj][0], ahead[jj][1], ahead[jj][2], ahead[jj][3]};
+            // Delay (Delay.js:27-39), constant delay D + phi with D >= 256: every slot gets the ceil tap of sample
+            // n-1 and the floor tap of sample n, with the reference's two `+=` roundings, and is written once
+            const f32x4 delayed = ahead[jj];
             float x_left = __shfl_up(x[3], 1, 64);  // Sum output of sample 4l-1
-            if (lane == 0) x_left = (float)c.xprev;
+            if (lane == 0) x_left = (float)xprev_chunk;
+            uint32_t lo0 = s0 + lane * 4 + D;  // slot of this lane's first write (< 3 len)
+            if (lo0 >= len32) lo0 -= len32;
+            if (lo0 >= len32) lo0 -= len32;
+            float slot[4];
+            if (phi == 0.0) {  // floor(tWrite) == ceil(tWrite): (0 + x*1) + x*0 — x itself, with -0 -> +0 and Inf -> NaN
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                int64_t s_ = s0 + lane * 4 + cc;
-                if (s_ >= len) s_ -= len;
-                int64_t lo = s_ + D;
-                if (lo >= len) lo -= len;
-                const double xin = (double)x[cc];
-                const double xprev = cc == 0 ? (lane == 0 ? c.xprev : (double)x_left) : (double)x[cc - 1];
-                float slot;
-                if (phi != 0.0) {
-                    slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
-                    slot = (float)((double)slot + xin * (1.0 - phi));   // floor tap of sample n
-                } else {
-                    slot = (float)(0.0 + xin * 1.0);
-                    slot = (float)((double)slot + xin * 0.0);
+                for (int cc = 0; cc < 4; ++cc) slot[cc] = fabsf(x[cc]) < __builtin_inff() ? x[cc] + 0.f : __builtin_nanf("");
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    uint32_t lo = lo0 + cc;
+                    if (lo >= len32) lo -= len32;
+                    const double xin = (double)x[cc];
+                    const double xprev = (double)(cc == 0 ? x_left : x[cc - 1]);
+                    const float ceil_tap = (float)(0.0 + xprev * phi);  // of sample n-1; dropped at slot 0 (no wrap, Delay.js:38)
+                    slot[cc] = (float)((double)(lo != 0 ? ceil_tap : 0.f) + xin * (1.0 - phi));  // floor tap of sample n
                 }
-                ring[lo] = slot;
             }
-            *cell = f32x4{delayed[0], delayed[1], delayed[2], delayed[3]};  // the Filter's input takes the row over
+            if ((len32 & 3u) == 0 && ((s0 + D) & 3u) == 0) {
+                *(f32x4 *)(ring + lo0) = f32x4{slot[0], slot[1], slot[2], slot[3]};
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    uint32_t lo = lo0 + cc;
+                    if (lo >= len32) lo -= len32;
+                    ring[lo] = slot[cc];
+                }
+            }
+            *cell = delayed;  // the Filter's input takes the row over
             if (lane == 63) {
                 carry[j].phase = lastP;
                 carry[j].xprev = (double)x[3];
@@ -555,8 +594,8 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
             for (int half = 0; half < 2; ++half) {
                 const int cur = sb + half;
                 if (cur == 2 && ck + 1 < a.n_chunks) {  // next chunk's ring reads: stage A's stores have long landed by now
-                    int64_t nxt = s0 + kChunk;
-                    if (nxt >= len) nxt -= len;
+                    uint32_t nxt = s0 + kChunk;
+                    if (nxt >= len32) nxt -= len32;
                     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's ring stores precede its ring loads
                     fetch_ring(nxt);
                 }
@@ -579,7 +618,7 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
             }
         }
         s0 += kChunk;
-        if (s0 >= len) s0 -= len;
+        if (s0 >= len32) s0 -= len32;
     }
     // ---- copy-out of the last chunk
     for (uint32_t j = wave; j < kWI && a.n_chunks > 0; j += kWWaves) {
