@@ -266,8 +266,11 @@ __global__ void __launch_bounds__(256) dusp_loop2_kernel(ChunkArgs a, LoopShape 
 // P values into registers while it works through the current one (an LDS read costs ~100 cycles and there is
 // nothing else on that wave to hide it behind).  All barriers in the chunk loop order LDS traffic only, so ring /
 // PCM stores and the next chunk's ring prefetch stay in flight across them.
-// Measured on configs[3] (8192 loops x 10 s): 25.3 ms, of which ~47 % is stage A's instruction issue (Osc lerp and
-// Delay taps in f64, 64-bit phase arithmetic) and ~48 % the recurrence; the narrow kernel above takes 33 ms.
+// Stage A keeps its per-instance constants in scalar registers (readfirstlane), indexes the ring in 32 bits with
+// 16-byte accesses when the geometry allows, and short-cuts the taps of an integer delay.
+// Measured on configs[3] (8192 loops x 10 s): 20.2 ms — roughly half stage A's instruction issue (~390 instructions
+// per instance-chunk per wave: Osc lerp and Delay taps in f64, 64-bit phase arithmetic) and half the recurrence
+// (~35-48 cycles per sample on one wave); the narrow kernel above takes 33 ms.
 namespace {
 constexpr int kWI = 32;        // instances per workgroup
 constexpr int kWWaves = 8;     // waves per workgroup (2 per SIMD: 256 VGPRs each, so stage B keeps a sub-block's 32 P values in registers)

@@ -43,6 +43,15 @@ constexpr double kTwo36 = 68719476736.0;
 constexpr int kFracBits = 36;
 constexpr int kOpState = 12;  // doubles of LDS state per op per wave
 
+// Barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue, i.e. waits for every PCM /
+// ring store in flight to be acknowledged.  Inside the chunk loop no wave reads GLOBAL data another wave wrote (an
+// instance — its ring rows, its PCM rows — belongs to one wave), so only the LDS tiles need the fence.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double or0w(double v) { return (v != v || v == 0.0) ? 0.0 : v; }  // JS `v || 0`
 
 // Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
@@ -248,25 +257,56 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                         xm1 = xin;
                     }
                     if (lane == 63) { fs[7] = xm1; fs[8] = xm2; }
-                    __syncthreads();
+                    lds_barrier();
                     if (wave == 0 && lane < WAVES) {
                         double *os = (double *)((char *)lds + A.table_bytes + (size_t)lane * A.wave_bytes + (size_t)A.n_bufs * 1024) +
                                      (size_t)u * kOpState;  // instance `lane`'s state of this Filter
                         const double b1 = os[5], b2 = os[6];
                         double y1 = os[9], y2 = os[10];
                         const double *pr = Pt + lane * 258;
-                        float *yr = Yt + lane * 260;
-#pragma unroll 8
-                        for (int t = 0; t < kChunk; ++t) {
-                            const float y = (float)((pr[t] - b1 * or0w(y1)) - b2 * or0w(y2));  // Filter.js:40-46
-                            yr[t] = y;
-                            y2 = or0w(y1);
-                            y1 = (double)y;
+                        f32x4 *yr = (f32x4 *)(Yt + lane * 260);
+                        // A wave issues one instruction per ~4-6 cycles whatever its lane count, so the serial stage costs
+                        // (instructions per sample) x 256: the P values of a 16-sample block are pulled into registers
+                        // first (an LDS read left on the chain costs ~100 cycles), and the `|| 0` selects of Filter.js:42-46
+                        // are speculated away — without them a NaN never leaves the recurrence, so testing the block's
+                        // last outputs finds one anywhere in it (the block is then redone exactly), and a -0 in place of
+                        // +0 can only flip the sign of a later zero (see loop2_engine.hip).
+                        for (int t0 = 0; t0 < kChunk; t0 += 16) {
+                            double pv[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) pv[k] = pr[t0 + k];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const double y1_in = y1, y2_in = y2;
+                            double u1 = or0w(y1), u2 = or0w(y2);
+                            f32x4 y4[4];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                const float y = (float)((pv[k] - b1 * u1) - b2 * u2);
+                                y4[k >> 2][k & 3] = y;
+                                u2 = u1;
+                                u1 = (double)y;
+                            }
+                            if (u1 == u1 && u2 == u2) {
+                                y1 = u1;
+                                y2 = u2;  // = y2 || 0 up to the sign of a zero
+                            } else {
+                                y1 = y1_in;
+                                y2 = y2_in;
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) {
+                                    const float y = (float)((pv[k] - b1 * or0w(y1)) - b2 * or0w(y2));  // Filter.js:40-46
+                                    y4[k >> 2][k & 3] = y;
+                                    y2 = or0w(y1);
+                                    y1 = (double)y;
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) yr[(t0 >> 2) + k] = y4[k];
                         }
                         os[9] = y1;
                         os[10] = y2;
                     }
-                    __syncthreads();
+                    lds_barrier();
                     const f32x4 yv = *(const f32x4 *)(Yt + wave * 260 + lane * 4);
                     out.v[0] = yv[0]; out.v[1] = yv[1]; out.v[2] = yv[2]; out.v[3] = yv[3];
                     break;
