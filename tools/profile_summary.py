@@ -13,7 +13,13 @@ os.makedirs(dst, exist_ok=True)
 lines = ["# rocprofv3 summary (%s)" % tag, "",
          "Command: `python3 bench.py --cpu-seconds 0` (default --steps 10 --warmup 3) (1 GPU, 1024 voices x 60 s @ 48 kHz).", ""]
 kernel_ms = None
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: keep the most recent capture of a pass."""
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return found[-1:]
+
+
+for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % tag))
     lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(f)):
@@ -24,7 +30,7 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     lines.append("")
 counters = collections.OrderedDict()
 meta = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+for f in [g for d in sorted(glob.glob(os.path.join(src, "pmc_*"))) for g in newest(os.path.join(d, "*", "*_counter_collection.csv"))]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "dusp_fused_kernel" in r["Kernel_Name"] or "dusp_chunk_kernel" in r["Kernel_Name"]:
@@ -58,7 +64,7 @@ if "SQ_INSTS_VALU" in counters:
 if "SQ_LDS_BANK_CONFLICT" in counters and counters.get("SQ_LDS_IDX_ACTIVE"):
     lines += ["- LDS bank-conflict cycles / LDS active cycles: %.1f %%" % (100 * counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"])]
 lines += ["", "Dispatch: %s" % json.dumps(meta), ""]
-for f in glob.glob(os.path.join(src, "configs", "*", "*_kernel_stats.csv")):
+for f in newest(os.path.join(src, "configs", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "%s_configs_kernel_stats.csv" % tag))
     lines += ["## other BASELINE configs: `python3 tools/configs_bench.py --rounds 2` under --kernel-trace --stats", "",
               "| kernel | calls | avg ms | min ms | max ms |", "|---|---|---|---|---|"]
