@@ -78,6 +78,7 @@ struct dusp_program {
     // per-render workspaces (grown on demand)
     DevBuf<float> d_scratch, d_rings;
     DevBuf<double> d_state;
+    DevBuf<unsigned long long> d_seg;  // WAVE, time-split: segment phase totals + start phases
     DevBuf<double> d_fused_state;  // FUSED: [n_state_words][n_inst] end-of-render state
     DevBuf<dusp::OscRec> d_recs;   // FUSED: per-voice oscillator records
     DevBuf<dusp::SumVoice> d_sum_voices;  // FUSED sum chain: per-oscillator records
@@ -204,6 +205,8 @@ static int finish_build(dusp_program *prog) {
     prog->wave = dusp::WavePlan();
     const bool fusable = dusp::plan_fused(prog->P, prog->fused);
     const bool wavable = dusp::plan_wave(prog->P, prog->wave);
+    for (size_t k = 0; k < prog->wave.osc_level.size() && k < prog->P.ops.size(); k++)  // FM depth, for time-split rendering
+        if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
     if (engine == DUSP_ENGINE_FUSED && !fusable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
     if (engine == DUSP_ENGINE_WAVE && !wavable)
@@ -460,6 +463,27 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
             HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
         }
         w.rings = prog->d_rings.p;
+        // Few instances, long render: cut time into segments so that the whole chip works on it (wave_engine.hip).
+        w.n_seg = 1;
+        w.seg_groups = n_chunks;
+        w.max_osc_level = prog->wave.max_osc_level;
+        if (prog->wave.splittable) {
+            const char *knob = getenv("DUSP_WAVE_SEGMENTS");  // 0 / 1: off; n: force n segments
+            const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
+            uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
+            if (knob) n_seg = (uint64_t)std::max(0, atoi(knob));
+            n_seg = std::max<uint64_t>(1, std::min<uint64_t>(n_seg, n_chunks));
+            if (n_seg > 1) {
+                w.seg_groups = (uint32_t)((n_chunks + n_seg - 1) / n_seg);
+                w.n_seg = (uint32_t)((n_chunks + w.seg_groups - 1) / w.seg_groups);  // no empty segments
+            }
+            if (w.n_seg > 1) {
+                const size_t per = (size_t)w.n_ops * n_inst * w.n_seg;
+                HIP_TRY(ctx, prog->d_seg.ensure(2 * per));
+                w.seg_sum = prog->d_seg.p;
+                w.seg_start = prog->d_seg.p + per;
+            }
+        }
         const bool lds_ok = w.lds_table_id >= 0 && ctx->table_antisym[w.lds_table_id] && P.g.sample_rate % 2 == 0;
         HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
         HIP_TRY(ctx, dusp::launch_wave_engine(w, lds_ok, stream));

@@ -87,6 +87,14 @@ struct WaveArgs {
     float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
     uint64_t ring_samples, clock0;
     uint32_t has_filter, has_modulated_filter;
+    // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
+    // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
+    // in 2^-36 units (bit 63 = poisoned by a NaN / Inf increment).
+    uint32_t n_seg, seg_groups;
+    uint32_t pass_mode;   // 0: render; 1: only accumulate the phase totals of the oscillators of level pass_level
+    uint32_t pass_level;
+    unsigned long long *seg_sum, *seg_start;
+    int32_t max_osc_level, pad4;
 };
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
@@ -97,6 +105,9 @@ inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_modulated_fil
 
 struct WavePlan {
     bool ok = false, has_filter = false, has_modulated_filter = false;
+    bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
+    int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
+    std::vector<int> osc_level;  // per device op (-1: not an Osc)
     int lds_table_id = -1;
     std::string why;
 };
@@ -381,6 +392,26 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
             return no("unit the wave engine does not run (short / modulated delay lines, CircleBuffers, comb family, Timer, SampleRateRedux)");
         }
+    }
+    // Time-split rendering: without Filters / Delays / feedback the only state that crosses a chunk boundary is each
+    // oscillator's phase, and that is a modular SUM of its increments — segments can be rendered independently once
+    // every segment's phase total is known.  An oscillator whose increments come from other oscillators (FM) needs
+    // theirs resolved first: level = depth of oscillators stacked in the f input.
+    plan.splittable = P.feed_forward && !plan.has_filter && P.ring_samples == 0;
+    plan.osc_level.assign(P.ops.size(), -1);
+    std::vector<int> buf_depth((size_t)std::max(1, P.n_bufs), 0);
+    for (size_t k = 0; k < P.ops.size(); k++) {
+        const DevOp &op = P.ops[k];
+        if (op.op == OP_DELAY) plan.splittable = false;
+        int dep = 0;
+        for (int j = 0; j < kMaxIn; j++)
+            if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs) dep = std::max(dep, buf_depth[(size_t)op.in[j].idx]);
+        if (op.op == OP_OSC) {
+            plan.osc_level[k] = dep;
+            plan.max_osc_level = std::max(plan.max_osc_level, dep);
+            dep += 1;
+        }
+        if (op.out_buf >= 0) buf_depth[(size_t)op.out_buf] = dep;
     }
     plan.ok = true;
     return true;

@@ -118,8 +118,14 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     const uint32_t wave = threadIdx.x >> 6;
     // a short last workgroup keeps its surplus waves alive (they take part in the Filter stage's barriers):
     // they shadow the last real instance but never store to HBM
-    const bool live = blockIdx.x * WAVES + wave < A.n_inst;
-    const uint32_t inst = live ? blockIdx.x * WAVES + wave : A.n_inst - 1;
+    // time-split mode: a "virtual instance" is one segment of an instance (n_seg == 1: the instance itself)
+    const uint32_t n_virtual = A.n_inst * A.n_seg;
+    const bool live = blockIdx.x * WAVES + wave < n_virtual;
+    const uint32_t vinst = live ? blockIdx.x * WAVES + wave : n_virtual - 1;
+    const uint32_t inst = vinst / A.n_seg, seg = vinst - inst * A.n_seg;
+    const uint32_t g_begin = seg * A.seg_groups;
+    const uint32_t g_end = A.n_seg == 1 ? A.n_groups : (g_begin + A.seg_groups < A.n_groups ? g_begin + A.seg_groups : A.n_groups);
+    const bool rendering = A.pass_mode == 0;
     char *mine = (char *)lds + A.table_bytes + (size_t)wave * A.wave_bytes;
     // workgroup-shared hand-over tiles of the cooperative Filter stage: Pt[WAVES][258] f64, Yt[WAVES][260] f32
     double *Pt = (double *)((char *)lds + A.table_bytes + (size_t)WAVES * A.wave_bytes);
@@ -143,14 +149,21 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const DevOp &op = A.ops[u];
             double *os = opstate + (size_t)u * kOpState;
             for (int k = 0; k < kOpState; ++k) os[k] = 0.0;
-            if (op.op == OP_OSC) *(unsigned long long *)os = (unsigned long long)(A.init_state[op.state_slot] * kTwo36);
+            if (op.op == OP_OSC) {
+                if (A.n_seg == 1) *(unsigned long long *)os = (unsigned long long)(A.init_state[op.state_slot] * kTwo36);
+                else if (rendering || (uint32_t)op.d[0] < A.pass_level) {  // start phase known from the earlier passes
+                    const unsigned long long v = A.seg_start[((size_t)u * A.n_inst + inst) * A.n_seg + seg];
+                    *(unsigned long long *)os = v & ~(1ull << 63);
+                    ((uint32_t *)(os + 1))[0] = (uint32_t)(v >> 63);
+                }  // else: accumulate from 0 — the segment's phase total
+            }
             if (op.op == OP_DELAY) os[0] = A.init_state[op.state_slot];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) os[k] = A.init_state[op.state_slot + k];
         }
     __syncthreads();
 
-    for (uint32_t g = 0; g < A.n_groups; ++g) {
+    for (uint32_t g = g_begin; g < g_end; ++g) {
         const uint64_t n0 = (uint64_t)g * kChunk + lane * 4;  // index of this lane's first sample
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
@@ -427,7 +440,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const f32x4 x = bufs[(size_t)A.out_bufs[oc] * 64 + lane];
             float v[4] = {fix_out<false>(x[0]), fix_out<false>(x[1]), fix_out<false>(x[2]), fix_out<false>(x[3])};
             float *row = A.out + ((size_t)inst * A.n_out + oc) * A.n_samples + n0;
-            if (!live) continue;
+            if (!live || !rendering) continue;
             if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, v, n0, A.n_samples);
             else store4<false>(row, v, n0, A.n_samples);
         }
@@ -436,7 +449,16 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // state write-back: what every unit holds after ceil(n_samples/256) ticks, in the chunk engine's slot layout
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && live) {
+    if (lane == 0 && live && !rendering) {  // phase totals of this pass's oscillators over this segment
+        for (uint32_t u = 0; u < A.n_ops; ++u) {
+            const DevOp &op = A.ops[u];
+            if (op.op != OP_OSC || (uint32_t)op.d[0] != A.pass_level) continue;
+            const double *os = opstate + (size_t)u * kOpState;
+            A.seg_sum[((size_t)u * A.n_inst + inst) * A.n_seg + seg] =
+                *(const unsigned long long *)os | ((unsigned long long)(((const uint32_t *)(os + 1))[0] != 0) << 63);
+        }
+    }
+    if (lane == 0 && live && rendering && seg == A.n_seg - 1) {
         const uint64_t T_end = (uint64_t)A.n_groups * kChunk;
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
@@ -456,6 +478,26 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     }
 }
 
+// Start phase of every segment from the segments' phase totals: a serial modular prefix per (oscillator, instance) —
+// n_seg additions, one thread each.  A poisoned segment poisons everything after it.
+__global__ void dusp_wave_prefix_kernel(WaveArgs A) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_ops * A.n_inst) return;
+    const uint32_t u = k / A.n_inst, inst = k - u * A.n_inst;
+    const DevOp &op = A.ops[u];
+    if (op.op != OP_OSC || (uint32_t)op.d[0] != A.pass_level) return;
+    const unsigned long long S = (unsigned long long)A.sample_rate << kFracBits;
+    unsigned long long phase = (unsigned long long)(A.init_state[op.state_slot] * kTwo36), poison = 0;
+    const size_t base = ((size_t)u * A.n_inst + inst) * A.n_seg;
+    for (uint32_t s = 0; s < A.n_seg; ++s) {
+        A.seg_start[base + s] = phase | poison;
+        const unsigned long long v = A.seg_sum[base + s];
+        phase += v & ~(1ull << 63);  // both below S
+        if (phase >= S) phase -= S;
+        poison |= v & (1ull << 63);
+    }
+}
+
 template <int TBL, int WAVES>
 static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream_t stream) {
     auto kernel = dusp_wave_kernel<TBL, WAVES>;
@@ -463,7 +505,16 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const unsigned grid = (A.n_inst + WAVES - 1) / WAVES;
+    const unsigned grid = (A.n_inst * A.n_seg + WAVES - 1) / WAVES;
+    if (A.n_seg > 1) {  // one accumulate pass + prefix per FM level, then the render pass
+        WaveArgs pass = A;
+        pass.pass_mode = 1;
+        for (int level = 0; level <= A.max_osc_level; ++level) {
+            pass.pass_level = (uint32_t)level;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, pass);
+            hipLaunchKernelGGL(dusp_wave_prefix_kernel, dim3((A.n_ops * A.n_inst + 63) / 64), dim3(64), 0, stream, pass);
+        }
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, A);
     return hipGetLastError();
 }
@@ -482,7 +533,7 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     // scan / lookup latency), but no more than needed to give every CU a workgroup
     const size_t shared_per_wave = A.has_filter ? 258 * 8 + 260 * 4 : 0;  // Pt / Yt rows of the cooperative Filter stage
     const int fit = (int)((budget - table_bytes) / (A.wave_bytes + shared_per_wave));
-    const unsigned want = (A.n_inst + 255) / 256;  // instances per CU on a 256-CU part
+    const unsigned want = (A.n_inst * A.n_seg + 255) / 256;  // (virtual) instances per CU on a 256-CU part
     int waves = 1;
     while (waves < 16 && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);

@@ -113,6 +113,30 @@ def test_segmented_render_equals_one_shot(name):
     assert np.array_equal(got, want), "first mismatch at sample %d" % int(np.argmax((got != want).any(axis=0)))
 
 
+@pytest.mark.parametrize("n_seg", [2, 5, 64])
+@pytest.mark.parametrize("name", ALL_GOLDEN)
+def test_time_split_wave_render_equals_unsplit(name, n_seg, monkeypatch):
+    """Wave engine, time-split mode (few instances, long render): every instance is cut into segments rendered by
+    separate wavefronts after one accumulate + prefix pass per FM level.  Oscillator phases are exact modular sums,
+    so PCM and written-back state must equal the unsplit render bit for bit, whatever the number of segments."""
+    g = Golden(name)
+    ctx = render.context(g.sample_rate)
+    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", "1")
+    try:
+        prog = ctx.build(g.desc, runtime.ENGINE_WAVE)
+    except runtime.DuspHipError:
+        pytest.skip("not a wave-engine graph")
+    want = prog.render(g.n_samples)[0]
+    want_state = [prog.state(u) for u in range(prog.n_units)]
+    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", str(n_seg))
+    got = prog.render(g.n_samples)[0]
+    got_state = [prog.state(u) for u in range(prog.n_units)]
+    prog.close()
+    assert np.array_equal(got, want), "first mismatch at sample %d" % int(np.argmax((got != want).any(axis=0)))
+    for a, b in zip(got_state, want_state):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_continue_refuses_a_different_circuit_and_a_wrong_clock():
     from dusp_amd import descriptor
     ctx = render.context(48000)
