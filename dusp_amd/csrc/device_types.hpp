@@ -16,6 +16,7 @@ enum : int {
     OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
     OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
     OP_SHAPE, OP_AHD,  // envelopes
+    OP_HOST_ONLY,      // a unit that produces no signal and acts through host callbacks (Retriggerer): keeps its place in the unit list
     OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW,    // stateless maps of at most two operands (map_apply)
     OP_WIDE_FIRST = OP_PAN, OP_WIDE_LAST = OP_VECTOR_MAGNITUDE  // stateless maps of up to kMaxIn operands (map_wide)
 };

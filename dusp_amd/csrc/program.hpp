@@ -250,6 +250,9 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         case OP_AHD:
             if (!need(3, 1, 3)) return fail(err, where + "bad AHD record");
             break;
+        case OP_HOST_ONLY:
+            if (!need(0, 0, 0)) return fail(err, where + "bad host-only record");
+            break;
         case OP_CONCAT_CHANNELS:
             if (!need(2, 0, 0)) return fail(err, where + "bad ConcatChannels record");
             break;
@@ -280,7 +283,7 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_FILTER: return std::max(1, nin(0));                           // Filter.js:31-32
     case OP_DELAY: return std::max(1, std::max(nin(0), nin(1)));          // Delay.js:21
     case OP_CB_READER: return std::max(1, g.rings[(size_t)u.attrs[0]].nch);  // CircleBufferNode.js:19-22
-    case OP_CB_WRITER: return 0;                                          // no data outlet
+    case OP_CB_WRITER: case OP_HOST_ONLY: return 0;                       // no data outlet
     case OP_REPEATER: return std::max(1, nin(0));                         // Repeater.js:24-25
     case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: return std::max(nin(0), nin(1));
     case OP_FIXED_MULTIPLY: return 1;                                     // mono in / mono out
@@ -300,14 +303,14 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
 }
 
 inline bool infer_channels(Graph &g, std::string &err) {
-    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER) ? 0 : 1;  // outlets start with one channel (Piglet.js:13)
+    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;  // outlets start with one channel (Piglet.js:13)
     std::vector<int> first_pass;
     for (int pass = 0; pass < 66; pass++) {
         bool changed = false;
         for (auto &u : g.units) {
             for (auto &in : u.inlets)
                 if (in.kind == IN_CONNECT && g.units[(size_t)in.src_unit].n_out == 0)
-                    return fail(err, "a unit without a data outlet (CircleBufferWriter) feeds an inlet");
+                    return fail(err, "a unit without a data outlet (CircleBufferWriter, Retriggerer) feeds an inlet");
             int n = unit_channels(g, u);
             if (n != u.n_out) { u.n_out = n; changed = true; }
         }

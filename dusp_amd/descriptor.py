@@ -20,6 +20,7 @@ OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, O
 (OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
  OP_CONCAT_CHANNELS, OP_PICK_CHANNEL) = range(29, 38)  # rest of §8f-1
 OP_SHAPE, OP_AHD = 38, 39  # envelopes (§8f-3)
+OP_HOST_ONLY = 40  # no signal: the unit acts through host callbacks between segments (Retriggerer)
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 

@@ -132,6 +132,11 @@ function extract(target, opts = {}) {
       case OP.TIMER:
         attrs = [unit.samplePeriod]; state = [unit.t]
         break
+      case OP.HOST_ONLY:
+        if (unit.rateConstant) unit.rateConstant() // throws for a connected rate
+        else if (unit.inlets.rate && unit.inlets.rate.connected)
+          throw 'dusp-hip: Retriggerer with a signal-rate `rate` is not supported on the GPU path (' + unit.label + ')'
+        break
       case OP.SHAPE: { // edges: the string "shape" (= the table's end value) or a plain number (Shape/index.js:35-49)
         const table = SHAPES[unit.shape]
         if (table === undefined) throw 'dusp-hip: shape function not supported on the GPU path: ' + unit.shape

@@ -716,7 +716,52 @@ class AHD extends Unit { // AHD.js:6-34 — attack / hold / decay times in secon
   stop() { this.state = 0; this.playing = false; return this }
 }
 
-module.exports = { Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+/* ---- host-ticked units */
+class Retriggerer extends Unit { // Retriggerer.js:3-43 — calls target.trigger() every sampleRate / rate samples
+  constructor(target, rate) {
+    super()
+    this.addInlet('rate', { mono: true })
+    if (target) this.target = target
+    this.t = 0
+    this.RATE = rate || 1
+  }
+  get target() { return this._target }
+  set target(target) {
+    if (target) {
+      this._target = target
+      this.chainBefore(target) // ticks before its target, so a trigger takes effect in the same chunk
+    }
+  }
+  /* The unit produces no signal: its _tick only runs an accumulator and calls trigger() (Retriggerer.js:13-24), and
+   * because it is ordered before its target the trigger acts at the START of the chunk in which the accumulator
+   * crosses the sample rate.  The GPU path therefore ticks it on the host, chunk by chunk, and treats a firing chunk
+   * as a segment boundary.  Needs a constant rate (the signal would have to be read back from the device). */
+  get isHostTicked() { return true }
+  rateConstant() {
+    if (this.RATE.connected) throw 'dusp-hip: Retriggerer with a signal-rate `rate` is not supported on the GPU path (' + this.label + ')'
+    return this.RATE.signalChunk.channelData[0][0]
+  }
+  hostTick(chunkSize, commit = true) { // one chunk; returns true when it fired (and, committing, triggers the target)
+    const rate = this.rateConstant()
+    let t = this.t, fired = false
+    for (let k = 0; k < chunkSize; k++) {
+      t += rate
+      if (t >= this.sampleRate) { fired = true; if (commit && this._target && this._target.trigger) this._target.trigger(); t -= this.sampleRate }
+    }
+    if (commit) this.t = t
+    return fired
+  }
+  quietChunks(chunkSize, limit) { // how many of the next `limit` chunks pass without firing (state untouched)
+    const rate = this.rateConstant()
+    let t = this.t
+    for (let c = 0; c < limit; c++)
+      for (let k = 0; k < chunkSize; k++) { t += rate; if (t >= this.sampleRate) return c }
+    return limit
+  }
+  skipQuiet(chunkSize, chunks) { const rate = this.rateConstant(); for (let k = 0; k < chunks * chunkSize; k++) this.t += rate }
+}
+
+module.exports = { Retriggerer, Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
   FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,

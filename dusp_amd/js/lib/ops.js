@@ -25,6 +25,7 @@ const OP = Object.freeze({
   CONCAT_CHANNELS: 36, PICK_CHANNEL: 37,
   // envelopes driven by trigger() events (SURVEY.md §8f-3)
   SHAPE: 38, AHD: 39,
+  HOST_ONLY: 40, // no signal: the unit acts through host callbacks between segments (Retriggerer)
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -76,6 +77,7 @@ const UNITS = Object.freeze({
   PickChannel: { op: OP.PICK_CHANNEL, inlets: ['in', 'c'] },
   Shape: { op: OP.SHAPE, inlets: ['duration', 'min', 'max'] },
   AHD: { op: OP.AHD, inlets: ['attack', 'hold', 'decay'] },
+  Retriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, SHAPES, UNITS }

@@ -83,7 +83,11 @@ class SegmentRenderer {
     this.circuit = this.first.circuit
     this.chunk = this.first.chunkSize
     this.sampleRate = this.first.sampleRate
-    this.hasEvents = !!(this.circuit.events && this.circuit.events.length)
+    // units that act through host callbacks between chunks (Retriggerer): ticked here, firing = segment boundary
+    this.tickers = this.circuit.units.filter((u) => UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick)
+    for (const u of this.tickers)
+      if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
+    this.hasEvents = !!(this.circuit.events && this.circuit.events.length) || this.tickers.length > 0
     this.engine = resumable || this.hasEvents ? engine | RESUMABLE : engine
     this.native = native()
     this.prog = null
@@ -105,6 +109,14 @@ class SegmentRenderer {
           const due = Math.floor(this.circuit.events[0].t / chunk) * chunk
           next = Math.min(end, Math.max(this.clock + chunk, due))
         }
+      }
+      if (this.tickers.length) { // this chunk's host ticks (after the events, as in Circuit.tick), then run up to the next firing
+        for (const u of this.tickers) u.hostTick(chunk)
+        const room = (next - this.clock) / chunk - 1
+        let quiet = room
+        for (const u of this.tickers) quiet = Math.min(quiet, u.quietChunks(chunk, quiet))
+        for (const u of this.tickers) u.skipQuiet(chunk, quiet)
+        next = this.clock + (1 + quiet) * chunk
       }
       const ex = !this.prog && !this.hasEvents ? this.first : extract(this.outlet, { allowEvents: true, allowClock: true })
       if (!this.prog) this.prog = n.programBuild(contextFor(ex.sampleRate), ex.words, this.engine)

@@ -6,8 +6,8 @@
  * way it threads (and loses) the `#id` index: only an object's named attributes share the index of the object they
  * belong to — positional arguments and the two sides of an operator each start from scratch, so "#id" references
  * resolve inside "[Multiply a:[Osc #x 3] b:#x]" but not in "[Osc #x 3] * #x" (the reference throws there, and so
- * does this).  Operators whose units cannot run on the GPU path (`!`, `~!`: Retriggerer / SporadicRetriggerer tick
- * host callbacks at signal rate; `then`: rewires the graph from a finish callback) are refused with a "dusp-hip:" string.
+ * does this).  `!` builds a Retriggerer, which this package ticks on the host between segments.  `~!`
+ * (SporadicRetriggerer: random) and `then` (rewires the graph from a finish callback) are refused with a "dusp-hip:" string.
  */
 const graph = require('./graph')
 const quick = require('./quick')
@@ -125,7 +125,12 @@ function constructOperation(node, index) {
       unit.scheduleFinish(b)
       return unit
     }
-    case 'then': case '!': case '~!':
+    case '!': // regular retrigger (constructOperation.js:69-75)
+      if (!a.stop || !a.trigger) throw "invalid use of '!' operator"
+      a.trigger()
+      new graph.Retriggerer(a, b)
+      return a
+    case 'then': case '~!':
       throw 'dusp-hip: operator ' + node.operator + ' is not supported on the GPU path'
     default: throw 'Unknown operator: ' + node.operator
   }

@@ -30,7 +30,8 @@ enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READ
        OP_PAN, OP_MIDI_TO_FREQUENCY, OP_RESCALE, OP_CROSS_FADER, OP_VECTOR_MAGNITUDE, OP_TIMER, OP_SAMPLE_RATE_REDUX,
        OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
        /* envelopes */
-       OP_SHAPE, OP_AHD };
+       OP_SHAPE, OP_AHD,
+       OP_HOST_ONLY /* no signal: acts through host callbacks (Retriggerer); ticking it is a no-op */ };
 #define N_TABLES 9 /* 0-4 oscillator wave tables, 5-8 Shape tables */
 #define MAX_INLETS 5
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
@@ -694,6 +695,7 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_SAMPLE_RATE_REDUX: tick_sample_rate_redux(o, u); break;
         case OP_CONCAT_CHANNELS: tick_concat_channels(o, u); break;
         case OP_PICK_CHANNEL: tick_pick_channel(o, u); break;
+        case OP_HOST_ONLY: break;
         case OP_SHAPE: tick_shape(o, u); break;
         case OP_AHD: tick_ahd(o, u); break;
         default: tick_map(o, u); break;
@@ -898,6 +900,10 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             break;
         case OP_CONCAT_CHANNELS: case OP_PICK_CHANNEL:
             if (u->n_inlets != 2 || n_attr || n_state) FAIL("unit %zu: bad channel-plumbing record", i);
+            break;
+        case OP_HOST_ONLY:
+            if (u->n_inlets || n_attr || n_state) FAIL("unit %zu: bad host-only record", i);
+            out_channels = 0;
             break;
         case OP_SHAPE:
             if (u->n_inlets != 3 || n_attr != 5 || n_state != 3 || !(a[0] >= 5 && a[0] <= 8)) FAIL("unit %zu: bad Shape record", i);

@@ -45,7 +45,7 @@ const more = {}
 for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardClipAbove', 'HardClipBelow', 'SecondsToSamples',
   'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow', 'FixedDelay', 'CombFilter', 'AllPass', 'MonoDelay',
   'ReadBackDelay', 'Pan', 'MidiToFrequency', 'Rescale', 'CrossFader', 'VectorMagnitude', 'Timer', 'SampleRateRedux',
-  'ConcatChannels', 'PickChannel']) more[n] = ref('components/' + n + '.js')
+  'ConcatChannels', 'PickChannel', 'Retriggerer']) more[n] = ref('components/' + n + '.js')
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
 more.Shape = ref('components/Shape')
 more.AHD = ref('components/AHD.js')
@@ -58,7 +58,7 @@ const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
 
 async function main() {
   fs.mkdirSync(OUT, { recursive: true })
-  const index = [], eventIndex = []
+  const index = [], eventIndex = [], hostIndex = []
   for (const c of cases) {
     if (ONLY && !ONLY.includes(c.name)) continue
     const target = c.build()
@@ -79,7 +79,7 @@ async function main() {
       n_samples: n, n_channels: cd.length, windows, sha256_full: h.digest('hex'),
       reference_unit_order: order.length <= 64 ? order : order.slice(0, 8).concat(['...' + order.length + ' units']) }
     fs.writeFileSync(path.join(OUT, c.name + '.json'), JSON.stringify(meta, null, 1) + '\n')
-    ;(c.name.startsWith('ev_') ? eventIndex : index).push(c.name)
+    ;(c.name.startsWith('ev_') ? eventIndex : c.name.startsWith('rt_') ? hostIndex : index).push(c.name)
     console.log(c.name, 'n=' + n, 'ch=' + cd.length, 'units=' + order.length)
   }
   // wave tables: hashes of all five, plus the few entries the docs quote (SURVEY.md §8c)
@@ -100,6 +100,7 @@ async function main() {
     fs.writeFileSync(path.join(OUT, S('wavetables') + '.json'), JSON.stringify({ sample_rate: SR, tables }, null, 1) + '\n')
     fs.writeFileSync(path.join(OUT, S('index') + '.json'), JSON.stringify(index, null, 1) + '\n')
     if (eventIndex.length) fs.writeFileSync(path.join(OUT, S('index_events') + '.json'), JSON.stringify(eventIndex, null, 1) + '\n')
+    if (hostIndex.length) fs.writeFileSync(path.join(OUT, S('index_host') + '.json'), JSON.stringify(hostIndex, null, 1) + '\n')
   }
 }
 main().catch((e) => { console.error('gen_golden failed:', e); process.exit(1) })

@@ -12,7 +12,7 @@ module.exports = function goldenCases(L, SR) {
     Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
     DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc,
     Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
-    Shape, AHD } = L
+    Shape, AHD, Retriggerer } = L
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -288,6 +288,37 @@ module.exports = function goldenCases(L, SR) {
       e.scheduleTrigger([0.005, 0.04])
       return e
     }, 0.07)
+  }
+  // Retriggerer: a unit without a signal that calls target.trigger() every sampleRate / rate samples; ticked on the host
+  // (`rt_` cases, like `ev_` ones, are rendered through the JS surface only)
+  if (Retriggerer) {
+    add('rt_ramp', () => {
+      const r = new Ramp(2400, 1, 0).trigger()
+      new Retriggerer(r, 8)
+      return new Multiply(new Osc(440), r)
+    }, 0.5)
+    add('rt_shape_fast', () => { // fires every 960 samples: segments of three or four chunks
+      const s = new Shape('decay', 0.01).trigger()
+      new Retriggerer(s, 50)
+      return new Multiply(new Osc(330.5, 'saw'), s)
+    }, 0.2)
+    add('rt_faster_than_chunks', () => { // 400 Hz: more than one crossing per chunk, still one trigger per chunk boundary
+      const s = new Shape('decaySquared', 0.002).trigger()
+      new Retriggerer(s, 400)
+      return s
+    }, 0.05)
+    add('rt_two_targets_and_event', () => {
+      const a = new Ramp(3000, 1, 0).trigger(), b = new AHD(0.002, 0.004, 0.01).trigger()
+      const ra = new Retriggerer(a, 10)
+      new Retriggerer(b, 23.5)
+      ra.schedule(0.15, function () { this.RATE = 30 }) // the rate changes on the fly
+      return new Sum(new Multiply(new Osc(220), a), new Multiply(new Osc(331), b))
+    }, 0.3)
+    add('rt_delay_line', () => { // retriggered bursts into a delay line: the ring has to survive the segment boundaries
+      const r = new Ramp(600, 1, 0).trigger()
+      new Retriggerer(r, 12)
+      return new Delay(new Multiply(new Osc(700), r), 1000.5, 4096)
+    }, 0.3)
   }
   if (Timer)
     add('ev_timer_trigger', () => {

@@ -41,6 +41,7 @@ const graphs = [
   { name: 'for_finish', text: 'O330 for 0.02', duration: 0.03, events: true },
   { name: 'delay_attribute', text: '[Delay in:O500 delay:300.5]', duration: 0.03 },
   { name: 'semitone', text: '[Osc f:[SemitoneToRatio in:O4 * 12] * 220]', duration: 0.05 },
+  { name: 'retrigger', text: '(D0.02 ! 20) * O440', duration: 0.2, events: true }, // `!`: Retriggerer, ticked on the host
   { name: 'number_only', text: '2 * 3 + 4', duration: 0.01 }, // not a graph: unDusp returns 10 and renderChannelData rejects it
   { name: 'unknown', text: '[Foo 1]', duration: 0.01 },
   { name: 'garbage', text: ']] nothing [[', duration: 0.01 },

@@ -34,7 +34,7 @@ def golden_count(sr):
     """event-free + event cases generated from the reference at this sample rate (tests/golden/index*.json)"""
     sfx = "" if sr == 48000 else "_sr%d" % sr
     n = 0
-    for stem in ("index", "index_events"):
+    for stem in ("index", "index_events", "index_host"):
         f = os.path.join(GOLDEN, stem + sfx + ".json")
         if os.path.exists(f):
             n += len(json.load(open(f)))
@@ -56,7 +56,7 @@ def test_string_front_end_matches_the_reference_parser_and_constructors():
     (the copy inside its browserify bundle; oracle/js/gen_golden_strings.js): 800+ strings incl. two fuzzers."""
     rep = run_js("check_strings.js", "--sampleRate=48000")
     assert rep["trees"] >= 800 and not rep["treeMismatches"], rep["treeMismatches"][:3]
-    assert rep["graphs"] >= 30 and not rep["graphMismatches"], rep["graphMismatches"]
+    assert rep["graphs"] >= 31 and not rep["graphMismatches"], rep["graphMismatches"]
     assert rep["rejected"] == 3
 
 
@@ -66,7 +66,7 @@ def test_strings_render_like_the_reference():
     rep = run_js("check_strings.js", "--sampleRate=48000", "--render")
     assert rep.get("fatal") is None, rep
     assert not rep["renderFailures"] and not rep["graphMismatches"], rep
-    assert rep["rendered"] == rep["graphs"] - rep["rejected"] >= 27
+    assert rep["rendered"] == rep["graphs"] - rep["rejected"] >= 28
 
 
 @needs_node
