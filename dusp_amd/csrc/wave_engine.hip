@@ -157,7 +157,11 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     ((uint32_t *)(os + 1))[0] = (uint32_t)(v >> 63);
                 }  // else: accumulate from 0 — the segment's phase total
             }
-            if (op.op == OP_DELAY) os[0] = A.init_state[op.state_slot];
+            if (op.op == OP_DELAY || op.op == OP_TIMER) os[0] = A.init_state[op.state_slot];
+            if (op.op == OP_SHAPE || op.op == OP_AHD)
+                for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
+            if (op.op == OP_SAMPLE_RATE_REDUX)
+                for (int k = 0; k < 2; ++k) os[k] = A.init_state[op.state_slot + k];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) os[k] = A.init_state[op.state_slot + k];
         }
@@ -410,6 +414,135 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 for (int c = 0; c < 4; ++c) out.v[c] = x.v[c] + y.v[c];
                 break;
             }
+            // ---- units whose state evolves sample by sample with its own roundings: the sequential part runs on lane 0
+            // out of the wave's LDS scratch (a few instructions per sample), everything else stays lane-parallel
+            case OP_SHAPE: {  // Shape/index.js:28-59
+                double *ss = opstate + (size_t)u * kOpState;  // [0] t [1] playing [2] finished
+                const V4 dur = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 mn = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const V4 mx = load_operand(op.in[2], bufs, lane, A.params, A.n_inst, inst);
+                const float *data = A.tables + (size_t)(op.attr & 255) * A.table_stride;
+                const double left = (op.attr & 256) ? (double)data[0] : op.d[0];
+                const double right = (op.attr & 512) ? (double)data[sr] : op.d[1];
+                double tt[4];
+                if (ss[1] != 0.0) {  // playing: t += 1 / duration[t], a running f64 sum
+                    double *T = scratch;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) T[lane * 4 + c] = 1.0 / (double)dur.v[c];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        double t = ss[0];
+#pragma unroll 8
+                        for (int k = 0; k < kChunk; ++k) {
+                            t += T[k];
+                            T[k] = t;
+                        }
+                        ss[0] = t;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tt[c] = T[lane * 4 + c];
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tt[c] = ss[0];
+                }
+                bool over = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double l = (double)mn.v[c], h = (double)mx.v[c], t = tt[c];
+                    if (t <= 0.0) out.v[c] = (float)(left * (h - l) + l);
+                    else if (t > srd) { over = true; out.v[c] = (float)(right * (h - l) + l); }
+                    else if (t == t) {
+                        const double fl = floor(t), frac = t - fl;
+                        out.v[c] = (float)(l + (h - l) * ((double)data[(int)ceil(t)] * frac + (double)data[(int)fl] * (1.0 - frac)));
+                    } else out.v[c] = __builtin_nanf("");
+                }
+                if (__ballot(over) && lane == 0) ss[2] = 1.0;  // finish() (UnitOrPatch.js:77-84)
+                break;
+            }
+            case OP_TIMER: {  // Timer.js:36-41
+                double *ss = opstate + (size_t)u * kOpState;
+                float *Y = (float *)scratch;
+                if (lane == 0) {
+                    double t = ss[0];
+                    const double period = op.d[0];
+#pragma unroll 8
+                    for (int k = 0; k < kChunk; ++k) {
+                        t += period;
+                        Y[k] = (float)t;
+                    }
+                    ss[0] = t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 y = ((const f32x4 *)Y)[lane];
+                out.v[0] = y[0]; out.v[1] = y[1]; out.v[2] = y[2]; out.v[3] = y[3];
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
+            case OP_AHD: case OP_SAMPLE_RATE_REDUX: {  // AHD.js:35-76, SampleRateRedux.js:21-38
+                double *ss = opstate + (size_t)u * kOpState;
+                float *Y = (float *)scratch;  // [256] output, then up to three operand rows
+                // operands as plain rows: a connected inlet is the producer's chunk buffer, a constant fills a scratch row
+                const float *rows[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const DevOperand &o = op.in[k];
+                    if (o.kind == SRC_BUF) rows[k] = (const float *)(bufs + (size_t)o.idx * 64);
+                    else {
+                        float *r = Y + (k + 1) * kChunk;
+                        const float cst = o.kind == SRC_PARAM ? A.params[(size_t)o.idx * A.n_inst + inst] : o.cval;
+                        ((f32x4 *)r)[lane] = f32x4{cst, cst, cst, cst};
+                        rows[k] = r;
+                    }
+                }
+                ((f32x4 *)Y)[lane] = bufs[(size_t)op.out_buf * 64 + lane];  // AHD: an unknown `state` leaves samples as they were
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    if (op.op == OP_AHD) {
+                        int stage = (int)ss[0];
+                        bool playing = ss[1] != 0.0;
+                        double t = ss[2];
+                        const double period = op.d[0];
+                        for (int k = 0; k < kChunk; ++k) {
+                            if (stage == 1) {
+                                Y[k] = (float)t;
+                                if (playing) { t += period / (double)rows[0][k]; if (t >= 1.0) { ++stage; t -= 1.0; } }
+                            } else if (stage == 2) {
+                                Y[k] = 1.f;
+                                if (playing) { t += period / (double)rows[1][k]; if (t >= 1.0) { ++stage; t -= 1.0; } }
+                            } else if (stage == 3) {
+                                Y[k] = (float)(1.0 - t);
+                                if (playing) { t += period / (double)rows[2][k]; if (t >= 1.0) { stage = 0; playing = false; } }
+                            } else if (stage == 0)
+                                Y[k] = 0.f;
+                        }
+                        ss[0] = (double)stage;
+                        ss[1] = playing ? 1.0 : 0.0;
+                        ss[2] = t;
+                    } else {
+                        double since = ss[0];
+                        float held = (float)ss[1];
+                        for (int k = 0; k < kChunk; ++k) {
+                            since += 1.0;
+                            if (since > (double)rows[1][k]) { held = rows[0][k]; since = 0.0; }
+                            Y[k] = held;
+                        }
+                        ss[0] = since;
+                        ss[1] = (double)held;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 y = ((const f32x4 *)Y)[lane];
+                out.v[0] = y[0]; out.v[1] = y[1]; out.v[2] = y[2]; out.v[3] = y[3];
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
             case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 break;
@@ -465,9 +598,13 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             double *st = A.state + (size_t)op.state_slot * A.n_pad + inst;
             const double *os = opstate + (size_t)u * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
-            if (op.op == OP_DELAY) st[0] = os[0];
+            if (op.op == OP_DELAY || op.op == OP_TIMER) st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];
+            if (op.op == OP_SHAPE || op.op == OP_AHD)
+                for (int k = 0; k < 3; ++k) st[(size_t)k * A.n_pad] = os[k];
+            if (op.op == OP_SAMPLE_RATE_REDUX)
+                for (int k = 0; k < 2; ++k) st[(size_t)k * A.n_pad] = os[k];
             if (op.op == OP_RAMP) {
                 const double duration = op.d[0], t0 = A.init_state[op.state_slot];
                 const bool playing = A.init_state[op.state_slot + 1] != 0.0;
