@@ -87,6 +87,10 @@ struct dusp_program {
     uint32_t last_n_inst = 0, last_n_pad = 0;
     bool rendered = false;
     // event-segmented rendering (dusp_program_continue)
+    // host-side conveniences for segment-by-segment rendering (many short renders + state downloads per second)
+    std::vector<double> h_state;   // copy of d_state / d_fused_state, fetched once per render on the first state download
+    bool h_state_valid = false;
+    DevBuf<float> d_host_out, d_host_par, d_host_frames;  // dusp_render_host staging, grown on demand
     int requested_engine = DUSP_ENGINE_AUTO;
     bool resumable = false;      // built with DUSP_ENGINE_RESUMABLE
     bool persistent = false;     // rings / feedback edges: device memory carries over between segments (CHUNK engine only)
@@ -326,6 +330,9 @@ void dusp_program_destroy(dusp_program *prog) {
     prog->d_out_bufs.release();
     prog->d_init.release();
     prog->d_scratch.release();
+    prog->d_host_out.release();
+    prog->d_host_par.release();
+    prog->d_host_frames.release();
     prog->d_rings.release();
     prog->d_state.release();
     prog->d_fused_state.release();
@@ -427,6 +434,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         }
         prog->last_n_inst = n_inst;
         prog->rendered = true;
+        prog->h_state_valid = false;
         prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
         return DUSP_OK;
     }
@@ -491,6 +499,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         prog->last_n_inst = n_inst;
         prog->last_n_pad = n_pad;
         prog->rendered = true;
+        prog->h_state_valid = false;
         prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
         return DUSP_OK;
     }
@@ -539,6 +548,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;
+    prog->h_state_valid = false;
     prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
     return DUSP_OK;
 }
@@ -574,29 +584,29 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
     if (n_par && !h_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but h_params is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_out = n_instances * prog->P.out_bufs.size() * n_samples;
-    float *d_out = nullptr, *d_par = nullptr, *d_frames = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&d_out, std::max<size_t>(1, n_out) * sizeof(float)));
+    // staging buffers live with the program (grown on demand): a segmented render calls this hundreds of times a second
+    HIP_TRY(ctx, prog->d_host_out.ensure(std::max<size_t>(1, n_out)));
+    float *d_out = prog->d_host_out.p, *d_par = nullptr, *d_frames = nullptr;
     int rc = DUSP_OK;
     hipError_t e = hipSuccess;
     if (n_par) {
-        e = hipMalloc((void **)&d_par, n_par * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        HIP_TRY(ctx, prog->d_host_par.ensure(n_par));
+        d_par = prog->d_host_par.p;
+        e = hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     }
     if (e == hipSuccess) {
         rc = dusp_render_device(prog, n_instances, n_samples, d_par, d_out, ctx->stream);
         const size_t n_ch = prog->P.out_bufs.size();
         if (rc == DUSP_OK && interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
-            e = hipMalloc((void **)&d_frames, n_out * sizeof(float));
-            if (e == hipSuccess) rc = dusp_interleave_device(ctx, d_out, n_instances, n_ch, n_samples, d_frames, ctx->stream);
+            HIP_TRY(ctx, prog->d_host_frames.ensure(n_out));
+            d_frames = prog->d_host_frames.p;
+            rc = dusp_interleave_device(ctx, d_out, n_instances, n_ch, n_samples, d_frames, ctx->stream);
         }
-        if (rc == DUSP_OK && e == hipSuccess) {
+        if (rc == DUSP_OK) {
             e = hipMemcpyAsync(h_out, d_frames ? d_frames : d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         }
     }
-    (void)hipFree(d_out);
-    if (d_par) (void)hipFree(d_par);
-    if (d_frames) (void)hipFree(d_frames);
     if (rc != DUSP_OK) return rc;
     if (e != hipSuccess) CTX_FAIL(ctx, DUSP_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e));
     return DUSP_OK;
@@ -614,17 +624,23 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
     const dusp::UnitDesc &u = g.units[unit];
     std::vector<double> words;
     auto or0 = [](double v) { return (v != v || v == 0) ? 0.0 : v; };
-    if (prog->engine == DUSP_ENGINE_FUSED) {
+    // one device-to-host copy of the whole state array per render, however many units are read back afterwards
+    const bool fused = prog->engine == DUSP_ENGINE_FUSED;
+    const size_t stride = fused ? prog->last_n_inst : prog->last_n_pad;
+    if (!prog->h_state_valid) {
+        const size_t rows = fused ? (size_t)std::max(1, prog->fused.n_state_words) : std::max<size_t>(1, prog->P.init_state.size());
+        prog->h_state.resize(rows * stride);
+        HIP_TRY(ctx, hipMemcpy(prog->h_state.data(), fused ? prog->d_fused_state.p : prog->d_state.p, rows * stride * sizeof(double),
+                               hipMemcpyDeviceToHost));
+        prog->h_state_valid = true;
+    }
+    if (fused) {
         const int first = prog->fused.unit_state_first[unit], n = prog->fused.unit_state_count[unit];
-        for (int k = 0; k < n; k++) {
-            double v = 0;
-            HIP_TRY(ctx, hipMemcpy(&v, prog->d_fused_state.p + (size_t)(first + k) * prog->last_n_inst + instance,
-                                   sizeof(double), hipMemcpyDeviceToHost));
-            words.push_back(v);
-        }
+        for (int k = 0; k < n; k++) words.push_back(prog->h_state[(size_t)(first + k) * stride + instance]);
     } else {
         auto rd = [&](int slot, double &v) {
-            return hipMemcpy(&v, prog->d_state.p + (size_t)slot * prog->last_n_pad + instance, sizeof(double), hipMemcpyDeviceToHost);
+            v = prog->h_state[(size_t)slot * stride + instance];
+            return hipSuccess;
         };
         const int n_ch = (u.op == dusp::OP_FILTER) ? u.n_out : 1;
         const int per = u.op == dusp::OP_DELAY ? 0 : u.slots_per_ch;  // Delay's slot is engine-internal, not unit state
