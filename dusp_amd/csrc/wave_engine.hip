@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     ((uint32_t *)(os + 1))[0] = (uint32_t)(v >> 63);
                 }  // else: accumulate from 0 — the segment's phase total
             }
-            if (op.op == OP_DELAY || op.op == OP_TIMER) os[0] = A.init_state[op.state_slot];
+            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS)
+                os[0] = A.init_state[op.state_slot];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
                 for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
             if (op.op == OP_SAMPLE_RATE_REDUX)
@@ -543,6 +544,69 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 break;
             }
+            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: {  // FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15
+                // A private ring of L slots read and rewritten one slot per sample: sample t depends on sample t - L only,
+                // so a chunk is L (at most 64) independent samples at a time.  The slots the chunk touches — min(L, 256)
+                // of them — are staged in LDS, walked in rounds, and written back.
+                double *ss = opstate + (size_t)u * kOpState;  // [0] tBuffer
+                float *Y = (float *)scratch, *R = Y + kChunk;
+                const float *rows[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const DevOperand &o = op.in[k];
+                    if (o.kind == SRC_BUF) rows[k] = (const float *)(bufs + (size_t)o.idx * 64);
+                    else {
+                        float *r = Y + (k + 2) * kChunk;
+                        const float cst = o.kind == SRC_PARAM ? A.params[(size_t)o.idx * A.n_inst + inst] : o.cval;
+                        ((f32x4 *)r)[lane] = f32x4{cst, cst, cst, cst};
+                        rows[k] = r;
+                    }
+                }
+                const uint32_t L = (uint32_t)op.ring_len;
+                const uint32_t first = ((uint32_t)ss[0] + 1u) % L;  // slot of the chunk's first sample: (tBuffer + 1) % length
+                const uint32_t window = L < (uint32_t)kChunk ? L : (uint32_t)kChunk;
+                float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
+                for (uint32_t p = lane; p < window; p += 64) {
+                    uint32_t s_ = first + p;
+                    if (s_ >= L) s_ -= L;
+                    R[p] = ring[s_];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t step = L < 64u ? L : 64u;
+                uint32_t p = lane;  // (base + lane) mod L, kept incrementally
+                for (uint32_t base = 0; base < (uint32_t)kChunk; base += step) {
+                    const uint32_t t = base + lane;
+                    if (lane < step && t < (uint32_t)kChunk) {
+                        const float xin = rows[0][t], was = R[p];
+                        float now, y;
+                        if (op.op == OP_FIXED_DELAY) { y = was; now = xin; }
+                        else if (op.op == OP_COMB_FILTER) { y = was; now = (float)((double)xin + (double)was * (double)rows[1][t]); }
+                        else {
+                            const double g = (double)rows[1][t];
+                            now = (float)((double)xin + (double)was * g);
+                            y = (float)((double)was - (double)xin * g);
+                        }
+                        R[p] = now;
+                        Y[t] = y;
+                    }
+                    p += step;
+                    if (p >= L) p -= L;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (live)
+                    for (uint32_t q = lane; q < window; q += 64) {
+                        uint32_t s_ = first + q;
+                        if (s_ >= L) s_ -= L;
+                        ring[s_] = R[q];
+                    }
+                if (lane == 0) ss[0] = (double)(((uint32_t)ss[0] + (uint32_t)kChunk) % L);
+                const f32x4 y4 = ((const f32x4 *)Y)[lane];
+                out.v[0] = y4[0]; out.v[1] = y4[1]; out.v[2] = y4[2]; out.v[3] = y4[3];
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
             case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 break;
@@ -598,7 +662,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             double *st = A.state + (size_t)op.state_slot * A.n_pad + inst;
             const double *os = opstate + (size_t)u * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
-            if (op.op == OP_DELAY || op.op == OP_TIMER) st[0] = os[0];
+            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS)
+                st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
