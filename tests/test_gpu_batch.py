@@ -258,3 +258,26 @@ def test_render_host_interleaved_matches_planar():
     frames = prog.render(g.n_samples, 1, interleaved=True)
     assert frames.shape == (1, g.n_samples, 2) and np.array_equal(frames[0].T, planar[0])
     prog.close()
+
+
+def test_time_split_with_many_instances_and_parameters(monkeypatch):
+    """Time-split wave rendering of a BATCH: per-instance parameters feed both FM levels; every (instance, segment)
+    pair gets its own wavefront and the per-instance prefix of phase totals.  Must equal the unsplit render."""
+    d.configure(48000)
+    def voice(k):
+        return d.Multiply(d.Osc(d.Sum(d.Multiply(d.Osc(3.5 + k), 40 + 3 * k), 220.25 + 10 * k)), d.Ramp(5000, 1, 0.25).trigger())
+    uni = descriptor.unify([descriptor.extract(voice(k)) for k in range(7)])
+    assert uni.n_params >= 3
+    n = 256 * 37 + 100
+    ctx = render.context(48000)
+    prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
+    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", "1")
+    want = prog.render(n, uni.n_instances, uni.params)
+    want_state = [prog.state(u, instance=5) for u in range(prog.n_units)]
+    for segs in ("3", "11", "38"):
+        monkeypatch.setenv("DUSP_WAVE_SEGMENTS", segs)
+        got = prog.render(n, uni.n_instances, uni.params)
+        assert np.array_equal(got, want), segs
+        for a, b in zip([prog.state(u, instance=5) for u in range(prog.n_units)], want_state):
+            assert np.array_equal(a, b, equal_nan=True)
+    prog.close()
