@@ -351,7 +351,13 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         plan.ok = false;
         return false;
     };
-    if (!g.rings.empty()) return no("CircleBuffer rings");
+    // CircleBuffer nodes: with a lane-constant offset a node touches 256 consecutive slots per chunk (lane-parallel);
+    // a modulated offset can make two samples of one chunk meet in one slot, and a ring shorter than a chunk wraps onto itself
+    for (const DevOp &op : P.ops)
+        if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) {
+            if (op.in[0].kind == SRC_BUF) return no("CircleBuffer node with a signal-rate offset");
+            if (op.ring_len < kChunk || op.ring_len >= (1ll << 31)) return no("CircleBuffer shorter than a chunk");
+        }
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
     plan.has_filter = plan.has_modulated_filter = false;
     for (const DevOp &op : P.ops) {
@@ -392,12 +398,13 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         case OP_SUM:
         case OP_REPEATER: break;
         case OP_SHAPE: case OP_AHD: case OP_TIMER: case OP_SAMPLE_RATE_REDUX: break;  // serial stage on one lane, rest lane-parallel
+        case OP_CB_READER: case OP_CB_WRITER: break;                                     // checked above
         case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:                     // lane-parallel in rounds of the ring length
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
             break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
-            return no("unit the wave engine does not run (short / modulated delay lines, CircleBuffers, MonoDelay, ReadBackDelay, MultiChannelOsc)");
+            return no("unit the wave engine does not run (short / modulated delay lines, MonoDelay, ReadBackDelay, MultiChannelOsc)");
         }
     }
     // Time-split rendering: without Filters / Delays / feedback the only state that crosses a chunk boundary is each

@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     ((uint32_t *)(os + 1))[0] = (uint32_t)(v >> 63);
                 }  // else: accumulate from 0 — the segment's phase total
             }
-            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS)
+            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER)
                 os[0] = A.init_state[op.state_slot];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
                 for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
@@ -607,6 +608,43 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 break;
             }
+            case OP_CB_READER: case OP_CB_WRITER: {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
+                // Lane-constant offset: the node's 256 accesses of a chunk are 256 consecutive slots of the ring
+                // (index = floor((T + t -+ sr*offset) % len), negatives wrapped), one per sample, lane-parallel.  Several
+                // nodes share a ring and tick one after another, so each node waits for the wave's earlier ring traffic.
+                double *ss = opstate + (size_t)u * kOpState;  // [0] the node's private sample counter
+                const float off = op.in[0].kind == SRC_PARAM ? A.params[(size_t)op.in[0].idx * A.n_inst + inst] : op.in[0].cval;
+                const double origin = op.op == OP_CB_READER ? ss[0] - srd * (double)off : ss[0] + srd * (double)off;
+                const bool ok = fabs(origin) < 9.0e15;  // NaN / Inf offsets read `undefined` and write nowhere
+                const int64_t len = op.ring_len;
+                int64_t base = 0;
+                if (ok) {
+                    base = (int64_t)fmod(floor(origin), (double)len);
+                    if (base < 0) base += len;
+                }
+                float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                V4 x;
+                if (op.op == OP_CB_WRITER && !(op.attr & 2)) x = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int64_t idx = base + lane * 4 + c;
+                    if (idx >= len) idx -= len;
+                    if (op.op == OP_CB_READER) {
+                        out.v[c] = ok ? ring[idx] : __builtin_nanf("");
+                        if (ok && (op.attr & 1) && live) ring[idx] = 0.f;  // postWipe
+                    } else if (ok && live) {
+                        float v = (op.attr & 1) ? 0.f : ring[idx];           // preWipe
+                        if (!(op.attr & 2)) v = v + x.v[c];                  // mix
+                        if ((op.attr & 1) || !(op.attr & 2)) ring[idx] = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) ss[0] += (double)kChunk;
+                if (op.op == OP_CB_WRITER) continue;  // no outlet
+                break;
+            }
             case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 break;
@@ -662,7 +700,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             double *st = A.state + (size_t)op.state_slot * A.n_pad + inst;
             const double *os = opstate + (size_t)u * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
-            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS)
+            if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER)
                 st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];

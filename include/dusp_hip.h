@@ -57,7 +57,8 @@ typedef enum {
  *   WAVE  — one wavefront per instance, chunk buffers in LDS, wavefront-wide phase accumulation:
  *           graphs of Osc / Ramp / Multiply / Sum / Repeater / the stateless maps (incl. FM), Filters,
  *           constant Delays of at least one chunk, the comb family, envelopes, Timer, feedback edges;
- *           few instances and a long render are split in time when the graph allows it.  No CircleBuffers.
+ *           CircleBuffer nodes with constant offsets; few instances and a long render are split in time when
+ *           the graph allows it.
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.

@@ -281,3 +281,36 @@ def test_time_split_with_many_instances_and_parameters(monkeypatch):
         for a, b in zip([prog.state(u, instance=5) for u in range(prog.n_units)], want_state):
             assert np.array_equal(a, b, equal_nan=True)
     prog.close()
+
+
+def test_circlebuffer_batch_wave_equals_chunk():
+    """CircleBuffer taps with PER-INSTANCE offsets and a feedback writer, 70 instances (ragged last workgroup):
+    the wave engine (lane-parallel ring windows) against the chunk engine (the reference's schedule)."""
+    d.configure(48000)
+    def taps(k):  # the MultiTapDelay topology of the `circlebuffer_taps` golden, offsets and pitch per instance
+        buf = d.CircleBuffer(1, 0.05)
+        w = d.CircleBufferWriter(buf)
+        w.preWipe = True
+        w.IN = d.Osc(200 + 3.5 * k)
+        tap = d.CircleBufferReader(buf, 0.01 + 0.0001 * k)
+        tap.chain(w)
+        fb_tap = d.CircleBufferReader(buf, 0.02)
+        fb_tap.chain(w)
+        fb = d.CircleBufferWriter(buf, 0.005 + 0.00005 * k)
+        fb.IN = d.quick.multiply(fb_tap, 0.5)
+        fb.chain(w)
+        return d.Sum(tap, fb_tap)
+    uni = descriptor.unify([descriptor.extract(taps(k)) for k in range(70)])
+    assert uni.n_params >= 3
+    n = 256 * 30 + 77
+    ctx = render.context(48000)
+    out = []
+    for engine in (runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK):
+        prog = ctx.build(uni.words, engine)
+        pcm = prog.render(n, uni.n_instances, uni.params)
+        out.append((pcm, [prog.state(u, instance=69) for u in range(prog.n_units)]))
+        prog.close()
+    assert np.abs(out[0][0]).max() > 0.5
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b, equal_nan=True)
