@@ -19,6 +19,8 @@ namespace dusp {
 hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
 hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
+hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uint64_t ring_samples, const float *saved_bufs, float *chunk_scratch,
+                                uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
 hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, hipStream_t stream);
@@ -95,6 +97,9 @@ struct dusp_program {
     bool resumable = false;      // built with DUSP_ENGINE_RESUMABLE
     bool persistent = false;     // rings / feedback edges: device memory carries over between segments (CHUNK engine only)
     bool keep_memory = false;    // the next render continues: do not clear chunk buffers and rings
+    bool delay_changed = false;     // a continuation changed a Delay's constant: the wave engine's write-once ring protocol no longer applies
+    bool migrate_to_chunk = false;  // ... and first moves the wave engine's rings / saved buffers into the chunk layout
+    DevBuf<float> d_saved_bufs, d_rings_wave;  // wave engine, resumable: outlets' last chunk; rings parked during a migration
     int64_t next_clock = 0;      // circuit clock the last render stopped at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -232,11 +237,18 @@ static int finish_build(dusp_program *prog) {
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
     // A circuit with rings or a feedback edge carries device memory from one segment to the next; only the chunk
     // engine keeps all of it (rings, every outlet's previous chunk) in HBM in a layout a later launch can pick up.
+    // A circuit with rings or a feedback edge carries device memory from one segment to the next.  The chunk engine keeps
+    // all of it in HBM; the wave engine parks its LDS chunk buffers in HBM between launches.  An engine, once chosen, is
+    // kept for the whole chain (ring layouts differ) — except that a wave program that stops being plannable migrates to
+    // the chunk engine.
     prog->persistent = prog->P.ring_samples != 0 || !prog->P.feed_forward;
     if (prog->resumable && prog->persistent) {
-        if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK)
-            CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: a resumable program with delay lines / feedback only runs on DUSP_ENGINE_CHUNK");
-        engine = DUSP_ENGINE_CHUNK;
+        if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_WAVE)
+            CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: a resumable program with delay lines / feedback runs on DUSP_ENGINE_WAVE or DUSP_ENGINE_CHUNK");
+        if (prog->rendered)  // continuing: stay, or fall back to the chunk engine
+            engine = (prog->engine == DUSP_ENGINE_WAVE && wavable && !prog->delay_changed) ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
+        else if (engine == DUSP_ENGINE_AUTO)
+            engine = wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
     }
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
@@ -314,11 +326,20 @@ int dusp_program_continue(dusp_program *prog, const double *desc, size_t n_words
         CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: descriptor clock " + std::to_string(next.g.clock0) + " does not follow the rendered clock " +
                                           std::to_string(prog->next_clock));
     const bool persistent = next.ring_samples != 0 || !next.feed_forward;
-    if (persistent && !(prog->resumable && prog->engine == DUSP_ENGINE_CHUNK))
+    if (persistent && !(prog->resumable && (prog->engine == DUSP_ENGINE_CHUNK || prog->engine == DUSP_ENGINE_WAVE)))
         CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: a circuit with delay lines / feedback has to be built with DUSP_ENGINE_RESUMABLE");
+    const int engine_before = prog->engine;
+    // The wave engine writes every Delay slot once, with its final value; after a change of the delay new taps can land on
+    // slots that already hold data, which only the chunk engine's read-modify-write protocol accumulates like the reference.
+    for (size_t k = 0; k < P.ops.size(); k++)
+        if (P.ops[k].op == dusp::OP_DELAY) {
+            const dusp::DevOperand &a = P.ops[k].in[1], &b = next.ops[k].in[1];
+            if (a.kind != b.kind || a.idx != b.idx || std::memcmp(&a.cval, &b.cval, sizeof(float)) != 0) prog->delay_changed = true;
+        }
     prog->P = std::move(next);
     if (int rc = finish_build(prog)) return rc;
     prog->keep_memory = persistent;
+    if (persistent && engine_before == DUSP_ENGINE_WAVE && prog->engine == DUSP_ENGINE_CHUNK) prog->migrate_to_chunk = true;
     return DUSP_OK;
 }
 
@@ -331,6 +352,8 @@ void dusp_program_destroy(dusp_program *prog) {
     prog->d_init.release();
     prog->d_scratch.release();
     prog->d_host_out.release();
+    prog->d_saved_bufs.release();
+    prog->d_rings_wave.release();
     prog->d_host_par.release();
     prog->d_host_frames.release();
     prog->d_rings.release();
@@ -466,11 +489,20 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
         w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
         w.ring_samples = (uint64_t)P.ring_samples;
-        if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); wave-engine layout [instance][slot]
+        const bool resume = prog->keep_memory;
+        if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
+        if (P.ring_samples && !resume) {  // Delay rings start as zeros (Delay.js:14); wave-engine layout [instance][slot]
             HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
             HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
         }
         w.rings = prog->d_rings.p;
+        w.resume = resume ? 1u : 0u;
+        w.save_bufs = (prog->resumable && prog->persistent) ? 1u : 0u;
+        if (w.save_bufs) {
+            HIP_TRY(ctx, prog->d_saved_bufs.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_inst));
+            w.saved_bufs = prog->d_saved_bufs.p;
+        }
+        prog->keep_memory = false;
         // Few instances, long render: cut time into segments so that the whole chip works on it (wave_engine.hip).
         w.n_seg = 1;
         w.seg_groups = n_chunks;
@@ -505,6 +537,17 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     }
     if (prog->keep_memory) {  // continuing: chunk buffers and rings hold what the previous segment left
         if (n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
+        if (prog->migrate_to_chunk) {  // the chain ran on the wave engine so far: move its memory into this engine's layout
+            std::swap(prog->d_rings_wave.p, prog->d_rings.p);
+            std::swap(prog->d_rings_wave.cap, prog->d_rings.cap);
+            HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
+            HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
+            HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad * sizeof(float), stream));
+            if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+            HIP_TRY(ctx, dusp::launch_wave_to_chunk(prog->d_rings_wave.p, prog->d_rings.p, (uint64_t)P.ring_samples, prog->d_saved_bufs.p, prog->d_scratch.p,
+                                                    (uint32_t)P.n_bufs, n_inst, n_pad, stream));
+            prog->migrate_to_chunk = false;
+        }
     } else {
         HIP_TRY(ctx, prog->d_scratch.ensure((size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad));
         HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));

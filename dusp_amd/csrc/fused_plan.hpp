@@ -95,6 +95,10 @@ struct WaveArgs {
     uint32_t pass_level;
     unsigned long long *seg_sum, *seg_start;
     int32_t max_osc_level, pad4;
+    // continuation (dusp_program_continue): chunk buffers survive between launches in saved_bufs [n_inst][n_bufs][256]
+    // (a feedback edge reads its producer's PREVIOUS chunk); resume = this launch continues one
+    float *saved_bufs;
+    uint32_t save_bufs, resume;
 };
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)

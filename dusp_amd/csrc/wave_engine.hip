@@ -143,7 +143,11 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // multiple of S that makes any |x| < 2^62 non-negative before the modulo
     const unsigned long long lift = S * ((1ull << 62) / S);
 
-    for (uint32_t b = 0; b < A.n_bufs; ++b) bufs[(size_t)b * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};  // outlets start as zeros
+    if (A.resume)  // a continued render: every outlet's last chunk comes back (feedback edges read it)
+        for (uint32_t b = 0; b < A.n_bufs; ++b)
+            bufs[(size_t)b * 64 + lane] = ((const f32x4 *)(A.saved_bufs + ((size_t)inst * A.n_bufs + b) * kChunk))[lane];
+    else
+        for (uint32_t b = 0; b < A.n_bufs; ++b) bufs[(size_t)b * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};  // outlets start as zeros
     if (lane == 0)
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
@@ -160,6 +164,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
                 op.op == OP_CB_READER || op.op == OP_CB_WRITER)
                 os[0] = A.init_state[op.state_slot];
+            // Delay's carried input sample is engine-internal (no descriptor carries it): a continued render takes it
+            // from where the previous launch left it
+            if (op.op == OP_DELAY && A.resume) os[0] = A.state[(size_t)op.state_slot * A.n_pad + inst];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
                 for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
             if (op.op == OP_SAMPLE_RATE_REDUX)
@@ -376,11 +383,16 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const int64_t s0 = (int64_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
                 float x_left = __shfl_up(x.v[3], 1, 64);
                 const double carried = ds[0];
+                // In a chain of continued renders the ring is kept in exactly the state the reference's ring has at a
+                // chunk boundary — slots zeroed once read (Delay.js:29), the last sample's ceil tap in place — so that the
+                // chain can move to the chunk engine's read-modify-write protocol whenever an event changes the delay.
+                const bool exact_ring = A.save_bufs != 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     int64_t s_ = s0 + lane * 4 + c;
                     if (s_ >= len) s_ -= len;
                     out.v[c] = ring[s_];
+                    if (exact_ring && live) ring[s_] = 0.f;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -399,6 +411,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                         slot = (float)((double)slot + xin * 0.0);
                     }
                     if (live) ring[lo] = slot;
+                    if (exact_ring && live && c == 3 && lane == 63 && g + 1 == g_end && phi != 0.0 && lo + 1 < len)
+                        ring[lo + 1] = (float)(0.0 + xin * phi);  // the launch's last ceil tap, which the next launch would fold in
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 63) ds[0] = (double)x.v[3];
@@ -684,6 +698,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // state write-back: what every unit holds after ceil(n_samples/256) ticks, in the chunk engine's slot layout
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (A.save_bufs && live && rendering)
+        for (uint32_t b = 0; b < A.n_bufs; ++b)
+            ((f32x4 *)(A.saved_bufs + ((size_t)inst * A.n_bufs + b) * kChunk))[lane] = bufs[(size_t)b * 64 + lane];
     if (lane == 0 && live && !rendering) {  // phase totals of this pass's oscillators over this segment
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
@@ -737,6 +754,30 @@ __global__ void dusp_wave_prefix_kernel(WaveArgs A) {
         if (phase >= S) phase -= S;
         poison |= v & (1ull << 63);
     }
+}
+
+// A continued program that can no longer run on this engine (an event changed a constant, e.g. a Delay below one
+// chunk) moves to the chunk engine: rings [instance][slot] -> [slot][instance], saved chunk buffers
+// [instance][buffer][t] -> [buffer][t][instance].  Unit state already lives in the shared slot layout.
+__global__ void dusp_wave_to_chunk_kernel(const float *wave_rings, float *chunk_rings, uint64_t ring_samples, const float *saved_bufs,
+                                          float *chunk_scratch, uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad) {
+    const uint64_t total_r = ring_samples * n_inst, total_b = (uint64_t)n_bufs * kChunk * n_inst;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total_r + total_b; k += (uint64_t)gridDim.x * blockDim.x) {
+        if (k < total_r) {
+            const uint64_t inst = k / ring_samples, slot = k - inst * ring_samples;
+            chunk_rings[slot * n_pad + inst] = wave_rings[k];
+        } else {
+            const uint64_t j = k - total_r, inst = j / ((uint64_t)n_bufs * kChunk), bt = j - inst * (uint64_t)n_bufs * kChunk;
+            chunk_scratch[bt * n_pad + inst] = saved_bufs[j];
+        }
+    }
+}
+
+hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uint64_t ring_samples, const float *saved_bufs, float *chunk_scratch,
+                                uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(dusp_wave_to_chunk_kernel, dim3(1024), dim3(256), 0, stream, wave_rings, chunk_rings, ring_samples, saved_bufs,
+                       chunk_scratch, n_bufs, n_inst, n_pad);
+    return hipGetLastError();
 }
 
 template <int TBL, int WAVES>

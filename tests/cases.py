@@ -252,6 +252,20 @@ def event_builders(sr):
         dl.schedule(0.05, lambda u: setattr(u, "DELAY", 17))
         return dl
 
+    def delay_long_to_short():
+        dl = Delay(Osc(500), 1000.25, 4096)
+        dl.schedule(0.02, lambda u: setattr(u, "DELAY", 300))
+        dl.schedule(0.05, lambda u: setattr(u, "DELAY", 17.5))
+        return dl
+
+    def loop_delay_change():
+        s = Sum(Osc(220), 0)
+        dl = Delay(s, 480, 4096)
+        f = Filter(dl, 2000)
+        s.B = Multiply(f, 0.6)
+        dl.schedule(0.04, lambda u: setattr(u, "DELAY", 700.5))
+        return f
+
     def loop_gain():
         s = Sum(Osc(220), 0)
         f = Filter(Delay(s, 480, 4096), 2000)
@@ -304,7 +318,7 @@ def event_builders(sr):
         return Osc(Multiply(tm, 20000))
 
     return {"ev_retrigger": retrigger, "ev_freq_steps": freq_steps, "ev_repeating": repeating, "ev_filter_sweep": filter_sweep,
-            "ev_delay_retrigger": delay_retrigger, "ev_delay_time_change": delay_time_change, "ev_loop_gain": loop_gain,
+            "ev_delay_retrigger": delay_retrigger, "ev_delay_long_to_short": delay_long_to_short, "ev_loop_delay_change": loop_delay_change, "ev_delay_time_change": delay_time_change, "ev_loop_gain": loop_gain,
             "ev_feedback_no_delay": feedback_no_delay, "ev_circlebuffer": circlebuffer, "ev_comb": comb,
             "ev_shape_retrigger": shape_retrigger, "ev_ahd_retrigger": ahd_retrigger, "ev_timer_trigger": timer_trigger}
 

@@ -240,6 +240,20 @@ module.exports = function goldenCases(L, SR) {
     d.schedule(0.05, function () { this.DELAY = 17 })
     return d
   }, 0.08)
+  add('ev_delay_long_to_short', () => { // starts on the wave engine's write-once ring protocol, then the delay changes: the chain
+    const d = new Delay(new Osc(500), 1000.25, 4096) // has to move to the read-modify-write protocol with the ring intact
+    d.schedule(0.02, function () { this.DELAY = 300 })
+    d.schedule(0.05, function () { this.DELAY = 17.5 })
+    return d
+  }, 0.08)
+  add('ev_loop_delay_change', () => { // the same inside a feedback loop (the outlets' previous chunks move along)
+    const sum = new Sum(new Osc(220), 0)
+    const dl = new Delay(sum, 480, 4096)
+    const f = new Filter(dl, 2000)
+    sum.B = new Multiply(f, 0.6)
+    dl.schedule(0.04, function () { this.DELAY = 700.5 })
+    return f
+  }, 0.1)
   add('ev_loop_gain', () => { // configs[3]'s feedback voice with the feedback gain changed on the fly
     const sum = new Sum(new Osc(220), 0)
     const f = new Filter(new Delay(sum, 480, 4096), 2000)

@@ -7,7 +7,7 @@ const lib = require('../../dusp_amd/js')
 const SR = lib.config.sampleRate
 const GOLDEN = path.join(__dirname, '..', 'golden')
 const cases = require('./cases')(lib, SR)
-const USES_DEVICE_TAN = /^(loop_|filter_|map_gain|map_db_semitone|map_pow|map_fm_semitone|rest_pan|rest_midi|ev_filter)/ // device tan() / pow()
+const USES_DEVICE_TAN = /^(loop_|filter_|map_gain|map_db_semitone|map_pow|map_fm_semitone|rest_pan|rest_midi|ev_filter|ev_loop|rt_|str_)/ // device tan() / pow()
 
 async function main() {
   const report = { sampleRate: SR, checked: 0, exact: 0, withinTol: 0, failed: [] }

@@ -16,7 +16,7 @@ from dusp_amd import descriptor
 with open(os.path.join(GOLDEN, "index_events.json")) as f:
     EVENT_CASES = json.load(f)
 
-USES_DEVICE_TAN = ("ev_filter_sweep", "ev_loop_gain")  # Filter coefficients: device tan()
+USES_DEVICE_TAN = ("ev_filter_sweep", "ev_loop_gain", "ev_loop_delay_change")  # Filter coefficients: device tan()
 
 
 def test_every_reference_event_case_has_a_python_twin():

@@ -87,7 +87,7 @@ def test_state_write_back_matches_oracle(name, engine, oracle):
 
 
 @pytest.mark.parametrize("name", ALL_GOLDEN)
-def test_segmented_render_equals_one_shot(name):
+def test_segmented_render_equals_one_shot(name, oracle):
     """dusp_program_continue: render every golden case in three segments — state written back into the descriptor
     between them, delay lines / CircleBuffers / feedback chunks staying on the device — and require the PCM of
     the one-shot render, bit for bit (same engine family: segment boundaries must not be observable)."""
@@ -97,8 +97,9 @@ def test_segmented_render_equals_one_shot(name):
     if n < 3 * 256 + 1:
         pytest.skip("shorter than three segments")
     ctx = render.context(g.sample_rate)
-    whole = ctx.build(g.desc, runtime.ENGINE_CHUNK)
+    whole = ctx.build(g.desc, runtime.ENGINE_RESUMABLE)  # same engine choice as the segmented chain (wave where it can, else chunk)
     want = whole.render(n)[0]
+    engine = whole.engine
     whole.close()
     cuts = [0, 256, 256 * (1 + (n // 256) // 2), n]
     prog = ctx.build(g.desc, runtime.ENGINE_RESUMABLE)
@@ -110,6 +111,7 @@ def test_segmented_render_equals_one_shot(name):
         parts.append(prog.render(b - a)[0])
     got = np.concatenate(parts, axis=1)
     prog.close()
+    check(name, want, oracle.render(g.desc, n), engine)  # ... and the chain's engine renders this case correctly in the first place
     assert np.array_equal(got, want), "first mismatch at sample %d" % int(np.argmax((got != want).any(axis=0)))
 
 
