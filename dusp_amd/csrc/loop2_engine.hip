@@ -271,6 +271,11 @@ __global__ void __launch_bounds__(256) dusp_loop2_kernel(ChunkArgs a, LoopShape 
 // Measured on configs[3] (8192 loops x 10 s): 20.2 ms — roughly half stage A's instruction issue (~390 instructions
 // per instance-chunk per wave: Osc lerp and Delay taps in f64, 64-bit phase arithmetic) and half the recurrence
 // (~35-48 cycles per sample on one wave); the narrow kernel above takes 33 ms.
+// Tried and dropped: pipelining the recurrence against stage A of the NEXT chunk at sub-block granularity (stage A of
+// sub-block j of chunk c+1 needs only sub-block j of chunk c).  It was bit-exact but no faster (21.7 ms): the CU executes
+// ~17 500 vector instructions per chunk (stage A ~12 500, feed-forward ~3 000, recurrence ~2 000) at one instruction per
+// ~4.5 cycles per SIMD, i.e. ~20 000 cycles however they are arranged — the kernel is bound by total instruction
+// issue, not by the recurrence's latency.  What would help is a leaner stage A (~98 instructions per sample now).
 namespace {
 constexpr int kWI = 32;        // instances per workgroup
 constexpr int kWWaves = 8;     // waves per workgroup (2 per SIMD: 256 VGPRs each, so stage B keeps a sub-block's 32 P values in registers)
