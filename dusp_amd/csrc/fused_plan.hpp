@@ -369,7 +369,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         // per-wave scratch (3 x 256 doubles): a Filter with a connected cutoff, or a unit with a serial stage
         plan.has_modulated_filter = plan.has_modulated_filter || (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) || op.op == OP_SHAPE ||
                                     op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX || op.op == OP_FIXED_DELAY ||
-                                    op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS;
+                                    op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC;
     }
     if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");
@@ -403,12 +403,13 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         case OP_REPEATER: break;
         case OP_SHAPE: case OP_AHD: case OP_TIMER: case OP_SAMPLE_RATE_REDUX: break;  // serial stage on one lane, rest lane-parallel
         case OP_CB_READER: case OP_CB_WRITER: break;                                     // checked above
+        case OP_MULTI_OSC: break;                                                        // phases on the serial lane, lookups lane-parallel
         case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:                     // lane-parallel in rounds of the ring length
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
             break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
-            return no("unit the wave engine does not run (short / modulated delay lines, MonoDelay, ReadBackDelay, MultiChannelOsc)");
+            return no("unit the wave engine does not run (short / modulated delay lines, MonoDelay, ReadBackDelay)");
         }
     }
     // Time-split rendering: without Filters / Delays / feedback the only state that crosses a chunk boundary is each
@@ -421,7 +422,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];
         if (op.op == OP_DELAY || op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX ||
-            op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS)
+            op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC)
             plan.splittable = false;  // state that is not a modular sum
         int dep = 0;
         for (int j = 0; j < kMaxIn; j++)

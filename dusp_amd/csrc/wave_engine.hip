@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }  // else: accumulate from 0 — the segment's phase total
             }
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC)
                 os[0] = A.init_state[op.state_slot];
             // Delay's carried input sample is engine-internal (no descriptor carries it): a continued render takes it
             // from where the previous launch left it
@@ -659,6 +659,42 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (op.op == OP_CB_WRITER) continue;  // no outlet
                 break;
             }
+            case OP_MULTI_OSC: {  // MultiChannelOsc.js:21-38: `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`
+                // The remainder keeps the dividend's sign, so the phase is not a modular sum (a negative excursion reads
+                // `undefined` -> NaN until the sum comes back): the 256 phases come from the serial lane, in f64 exactly
+                // as the reference adds them; the table lookups and the lerp are lane-parallel.
+                double *ss = opstate + (size_t)u * kOpState;  // [0] phase
+                const V4 f = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                double *T = scratch;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) T[lane * 4 + c] = (double)f.v[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    double ph = ss[0];
+                    ph = (ph != ph || ph == 0.0) ? 0.0 : ph;  // `this.phase[c] = this.phase[c] || 0`
+#pragma unroll 4
+                    for (int k = 0; k < kChunk; ++k) {
+                        double p = ph + T[k];
+                        if (fabs(p) >= srd) p = (p > 0.0 && p < 2.0 * srd) ? p - srd : (p < 0.0 && p > -2.0 * srd) ? p + srd : fmod(p, srd);
+                        T[k] = ph = p;
+                    }
+                    ss[0] = ph;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *gtab = A.tables + (size_t)op.attr * A.table_stride;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double phase = T[lane * 4 + c];
+                    if (!(phase >= 0.0 && phase <= srd)) { out.v[c] = __builtin_nanf(""); continue; }  // typed-array[NaN / negative] is undefined
+                    const double lo = floor(phase), fraction = phase - lo;
+                    const int idx = (int)lo;
+                    out.v[c] = (float)((double)gtab[idx] * (1.0 - fraction) + (double)gtab[fraction != 0.0 ? idx + 1 : idx] * fraction);
+                }
+                __builtin_amdgcn_wave_barrier();
+                break;
+            }
             case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
                 break;
@@ -718,7 +754,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const double *os = opstate + (size_t)u * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC)
                 st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];
