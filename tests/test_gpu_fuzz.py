@@ -13,15 +13,18 @@ from dusp_amd import descriptor, render, runtime
 pytestmark = pytest.mark.gpu
 
 
-def random_circuit(rng):
-    """A random feed-forward-or-feedback circuit; returns the unit to render."""
-    pool = [d.Osc(rng.choice([110, 220.5, 3.25, 1000.125])), d.Ramp(rng.choice([600, 3000]), 1, rng.choice([0, 0.25])).trigger()]
+def random_circuit(rng, crng=None):
+    """A random feed-forward-or-feedback circuit; returns the unit to render.  `rng` decides the STRUCTURE, `crng` (default:
+    the same stream) the inlet constants — so one structure seed with several constant seeds gives a batch of voices."""
+    structure = rng
+    rng = _Split(structure, crng if crng is not None else structure)
+    pool = [d.Osc(rng.cchoice([110, 220.5, 3.25, 1000.125])), d.Ramp(rng.choice([600, 3000]), 1, rng.choice([0, 0.25])).trigger()]
 
     def pick():
         return rng.choice(pool)
 
     def const_or_signal(lo, hi):
-        return pick() if rng.random() < 0.35 else round(rng.uniform(lo, hi), 3)
+        return pick() if rng.random() < 0.35 else round(rng.cuniform(lo, hi), 3)
 
     feedback_sum = None
     if rng.random() < 0.4:  # a loop: Sum(x, <closed later>)
@@ -30,13 +33,13 @@ def random_circuit(rng):
     for _ in range(rng.randint(3, 9)):
         kind = rng.randrange(17)
         if kind == 0:
-            u = d.Osc(d.Sum(d.Multiply(pick(), rng.choice([20, 200])), rng.choice([220, 440.5])), rng.choice(["sin", "saw", "triangle", "square"]))
+            u = d.Osc(d.Sum(d.Multiply(pick(), rng.cchoice([20, 200])), rng.cchoice([220, 440.5])), rng.choice(["sin", "saw", "triangle", "square"]))
         elif kind == 1:
             u = d.Multiply(pick(), const_or_signal(-1, 1))
         elif kind == 2:
             u = d.Sum(pick(), const_or_signal(-1, 1))
         elif kind == 3:
-            u = d.Filter(pick(), rng.choice([500, 2000.5]) if rng.random() < 0.6 else d.Sum(d.Multiply(pick(), 300), 1500), rng.choice(["LP", "HP"]))
+            u = d.Filter(pick(), rng.cchoice([500, 2000.5]) if rng.random() < 0.6 else d.Sum(d.Multiply(pick(), 300), 1500), rng.choice(["LP", "HP"]))
         elif kind == 4:
             u = d.Delay(pick(), rng.choice([256, 300.25, 700, 1000.5]), 2048)
         elif kind == 5:
@@ -52,9 +55,9 @@ def random_circuit(rng):
             u = d.Shape(rng.choice(["decay", "attack", "semiSine", "decaySquared"]), const_or_signal(0.004, 0.05) if rng.random() < 0.5 else 0.01,
                         rng.uniform(-1, 0), rng.uniform(0.5, 2)).trigger()
         elif kind == 9:
-            u = d.AHD(rng.uniform(0.001, 0.01), rng.uniform(0, 0.01), rng.uniform(0.002, 0.02)).trigger()
+            u = d.AHD(rng.cuniform(0.001, 0.01), rng.cuniform(0, 0.01), rng.cuniform(0.002, 0.02)).trigger()
         elif kind == 10:
-            u = d.Multiply(d.Timer(), rng.choice([1, 100]))
+            u = d.Multiply(d.Timer(), rng.cchoice([2, 100]))
         elif kind == 11:
             u = d.SampleRateRedux(pick(), const_or_signal(2, 40))
         elif kind == 12:
@@ -68,7 +71,7 @@ def random_circuit(rng):
             w = d.CircleBufferWriter(buf)
             w.preWipe = rng.random() < 0.7
             w.IN = pick()
-            tap = d.CircleBufferReader(buf, rng.choice([0.006, 0.011]))
+            tap = d.CircleBufferReader(buf, rng.cchoice([0.006, 0.011]))
             tap.chain(w)
             if rng.random() < 0.5:
                 fb = d.CircleBufferWriter(buf, 0.004)
@@ -80,8 +83,51 @@ def random_circuit(rng):
         pool.append(u)
     out = pool[-1]
     if feedback_sum is not None:
-        feedback_sum.B = d.Multiply(out, rng.uniform(-0.5, 0.5))
+        feedback_sum.B = d.Multiply(out, rng.cuniform(-0.5, 0.5))
     return out
+
+
+class _Split:
+    """Structure decisions from one stream, inlet constants from another."""
+
+    def __init__(self, structure, constants):
+        self.s, self.c = structure, constants
+
+    def choice(self, xs): return self.s.choice(xs)
+    def random(self): return self.s.random()
+    def randint(self, a, b): return self.s.randint(a, b)
+    def randrange(self, n): return self.s.randrange(n)
+    def uniform(self, a, b): return self.s.uniform(a, b)
+    def cchoice(self, xs): return self.c.choice(xs)
+    def cuniform(self, a, b): return self.c.uniform(a, b)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_batch_wave_equals_chunk(seed):
+    """The same, as a batch: one random structure, 5 voices that differ in their inlet constants (-> per-instance
+    parameters), rendered as ONE program by both engines."""
+    d.configure(48000)
+    try:
+        exs = [descriptor.extract(random_circuit(random.Random(seed), random.Random(1000 * seed + k))) for k in range(5)]
+        uni = descriptor.unify(exs)
+    except (RecursionError, descriptor.DuspError):
+        pytest.skip("degenerate graph")
+    ctx = render.context(48000)
+    progs = []
+    for engine in (runtime.ENGINE_CHUNK, runtime.ENGINE_WAVE):
+        try:
+            progs.append(ctx.build(uni.words, engine))
+        except runtime.DuspHipError as e:
+            assert e.status == -2
+            for p in progs:
+                p.close()
+            pytest.skip(e.message)
+    n = 256 * 6 + 77
+    want = progs[0].render(n, uni.n_instances, uni.params)
+    got = progs[1].render(n, uni.n_instances, uni.params)
+    assert np.array_equal(got, want, equal_nan=True)
+    for p in progs:
+        p.close()
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DUSP_FUZZ_SEEDS", "100"))))
