@@ -167,3 +167,37 @@ def test_random_circuit_wave_equals_chunk(seed):
     assert np.array_equal(np.concatenate([first, second], axis=2), want, equal_nan=True)
     for p in (chunk, wave, chain):
         p.close()
+
+
+@pytest.mark.parametrize("seed,n_inst", [(17, 1100), (23, 2500), (29, 700), (31, 4200), (41, 300), (43, 900), (47, 600), (53, 1300), (59, 2100)])
+def test_random_large_batch_wave_equals_chunk(seed, n_inst):
+    """Hundreds to thousands of instances: the wave engine packs 2-16 wavefronts per workgroup (shared table image,
+    cooperative Filter stage, surplus waves in the last workgroup); still bit-identical to the chunk engine."""
+    d.configure(48000)
+    # two real extractions fix the structure and show which constants vary; the parameter table is then drawn directly
+    exs = [descriptor.extract(random_circuit(random.Random(seed), random.Random(7000 * seed + k))) for k in range(2)]
+    try:
+        uni = descriptor.unify(exs)
+    except descriptor.DuspError:
+        pytest.skip("degenerate graph")
+    if not uni.n_params:
+        pytest.skip("no varying constant")
+    rng = np.random.RandomState(seed)
+    lo, hi = uni.params.min(axis=1, keepdims=True), uni.params.max(axis=1, keepdims=True)
+    params = (lo + (hi - lo) * rng.rand(uni.n_params, n_inst)).astype(np.float32)
+    ctx = render.context(48000)
+    progs = []
+    for engine in (runtime.ENGINE_CHUNK, runtime.ENGINE_WAVE):
+        try:
+            progs.append(ctx.build(uni.words, engine))
+        except runtime.DuspHipError as e:
+            assert e.status == -2
+            for p in progs:
+                p.close()
+            pytest.skip(e.message)
+    n = 256 * 4 + 9
+    want = progs[0].render(n, n_inst, params)
+    got = progs[1].render(n, n_inst, params)
+    assert np.array_equal(got, want, equal_nan=True)
+    for p in progs:
+        p.close()
