@@ -211,11 +211,17 @@ static int finish_build(dusp_program *prog) {
     dusp_ctx *ctx = prog->ctx;
     int engine = prog->requested_engine;
     prog->fused = dusp::FusedPlan();
-    prog->wave = dusp::WavePlan();
+    {
+        auto checked = std::move(prog->wave.ramp_checked);  // verdicts survive re-planning
+        prog->wave = dusp::WavePlan();
+        prog->wave.ramp_checked = std::move(checked);
+    }
     const bool fusable = dusp::plan_fused(prog->P, prog->fused);
     const bool wavable = dusp::plan_wave(prog->P, prog->wave);
     for (size_t k = 0; k < prog->wave.osc_level.size() && k < prog->P.ops.size(); k++)  // FM depth, for time-split rendering
         if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
+    for (size_t k = 0; k < prog->wave.ramp_fastdiv.size() && k < prog->P.ops.size(); k++)
+        if (prog->P.ops[k].op == dusp::OP_RAMP) prog->P.ops[k].attr = prog->wave.ramp_fastdiv[k];
     if (engine == DUSP_ENGINE_FUSED && !fusable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
     if (engine == DUSP_ENGINE_WAVE && !wavable)
@@ -488,6 +494,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.clock0 = (uint64_t)P.g.clock0;
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
         w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
+        w.n_params = (uint32_t)P.g.n_params;
         w.ring_samples = (uint64_t)P.ring_samples;
         const bool resume = prog->keep_memory;
         if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");

@@ -99,6 +99,7 @@ struct WaveArgs {
     // (a feedback edge reads its producer's PREVIOUS chunk); resume = this launch continues one
     float *saved_bufs;
     uint32_t save_bufs, resume;
+    uint32_t n_params, param_bytes;  // the instance's parameter column is copied into LDS once (param_bytes per wave; 0: read from HBM)
 };
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
@@ -112,6 +113,10 @@ struct WavePlan {
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
     std::vector<int> osc_level;  // per device op (-1: not an Osc)
+    std::vector<int> ramp_fastdiv;  // per device op: 1 = t / duration may be computed with the verified 2-FMA reciprocal
+    // (duration, smallest verified start t) of Ramps already checked: a continued render's t sequence is a suffix
+    struct RampChecked { double d, t0; bool ok; };
+    std::vector<RampChecked> ramp_checked;
     int lds_table_id = -1;
     std::string why;
 };
@@ -411,6 +416,25 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
             return no("unit the wave engine does not run (short / modulated delay lines, MonoDelay, ReadBackDelay)");
         }
+    }
+    // Ramp: t / duration with a 2-FMA reciprocal refinement where it provably equals the division on every t this Ramp
+    // can take (exhaustive host check, as for the fused kernels; the verdict is remembered across continuations, whose
+    // t sequences are suffixes of the one already checked)
+    plan.ramp_fastdiv.assign(P.ops.size(), 0);
+    for (size_t k = 0; k < P.ops.size(); k++) {
+        const DevOp &op = P.ops[k];
+        if (op.op != OP_RAMP) continue;
+        const double d = op.d[0], t0 = P.init_state[(size_t)op.state_slot];
+        const bool playing = P.init_state[(size_t)op.state_slot + 1] != 0;
+        bool known = false, ok = false;
+        for (const auto &c : plan.ramp_checked)
+            if (c.d == d && t0 >= c.t0 && t0 - c.t0 == std::floor(t0 - c.t0)) { known = true; ok = c.ok; break; }
+        if (!known) {
+            ok = d < 16777216.0 && ramp_fastdiv_ok(t0, d, true);  // (as if playing: covers an idle Ramp that is triggered later)
+            plan.ramp_checked.push_back({d, t0, ok});
+        }
+        (void)playing;
+        plan.ramp_fastdiv[k] = ok ? 1 : 0;
     }
     // Time-split rendering: without Filters / Delays / feedback the only state that crosses a chunk boundary is each
     // oscillator's phase, and that is a modular SUM of its increments — segments can be rendered independently once

@@ -133,6 +133,16 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     f32x4 *bufs = (f32x4 *)mine;                                            // [n_bufs][64] float4 = chunk buffers
     double *opstate = (double *)(mine + (size_t)A.n_bufs * 1024);           // [n_ops][kOpState] per-unit state
     double *scratch = opstate + (size_t)A.n_ops * kOpState;                 // Filter: P[256], b1[256], b2[256]
+    // This instance's parameter column, fetched once: an operand that is a per-instance parameter would otherwise cost an
+    // HBM round trip per unit and chunk, which a wavefront has nothing to hide behind.
+    const float *pvals = A.params ? A.params + inst : nullptr;
+    uint32_t pstride = A.n_inst;
+    if (A.param_bytes) {
+        float *mine_p = (float *)(mine + A.wave_bytes - A.param_bytes);
+        for (uint32_t k = lane; k < A.n_params; k += 64) mine_p[k] = A.params[(size_t)k * A.n_inst + inst];
+        pvals = mine_p;
+        pstride = 1;
+    }
     // Osc: [0] phase carry (u64 bits, 2^-36 units), [1] poison flag.  Delay: [0] previous input sample.
     // Filter: [0] has_lastF [1] lastF [2..6] a0 a1 a2 b1 b2 [7..10] x1 x2 y1 y2
 
@@ -185,7 +195,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             case OP_OSC: {  // Osc.js:35-47
                 unsigned long long *carry = (unsigned long long *)(opstate + (size_t)u * kOpState);
                 uint32_t *poison = (uint32_t *)(carry + 1);
-                const V4 f = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 f = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 long long q[4];
                 bool bad = false;
                 const bool lane_constant = op.in[0].kind != SRC_BUF;  // wave-uniform: f is a constant / parameter
@@ -245,6 +255,17 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const double duration = op.d[0], y0 = op.d[1], dy = op.d[2] - op.d[1];
                 const double t0 = A.init_state[op.state_slot];
                 const bool playing = A.init_state[op.state_slot + 1] != 0.0;
+                if (op.attr & 1) {  // host-verified: the refined reciprocal equals tt / duration on this Ramp's whole t sequence
+                    const double rcp = 1.0 / duration;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double tt = playing ? fmin(t0 + (double)(n0 + c + 1), duration) : t0;
+                        double q = tt * rcp;
+                        q = fma(fma(-q, duration, tt), rcp, q);
+                        out.v[c] = (float)(y0 + q * dy);
+                    }
+                    break;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const double tt = playing ? fmin(t0 + (double)(n0 + c + 1), duration) : t0;
@@ -254,8 +275,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             case OP_FILTER: {  // Filter.js:27-51
                 double *fs = opstate + (size_t)u * kOpState;
-                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
-                const V4 fv = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 fv = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 const bool f_const = op.in[1].kind != SRC_BUF;  // wave-uniform
                 double k0[5];
                 if (f_const) {
@@ -373,7 +394,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             case OP_DELAY: {  // Delay.js:20-41, constant delay D + phi with 256 <= D <= len - 256 (plan_wave checks)
                 double *ds = opstate + (size_t)u * kOpState;
-                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const int64_t len = op.ring_len;
                 double dconst = (double)op.in[1].cval;
                 if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
@@ -419,14 +440,14 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_MULTIPLY: {  // Multiply.js:23-34
-                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
-                const V4 y = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 for (int c = 0; c < 4; ++c) out.v[c] = x.v[c] * y.v[c];
                 break;
             }
             case OP_SUM: {  // Sum.js:33-44
-                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
-                const V4 y = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 for (int c = 0; c < 4; ++c) out.v[c] = x.v[c] + y.v[c];
                 break;
             }
@@ -434,9 +455,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             // out of the wave's LDS scratch (a few instructions per sample), everything else stays lane-parallel
             case OP_SHAPE: {  // Shape/index.js:28-59
                 double *ss = opstate + (size_t)u * kOpState;  // [0] t [1] playing [2] finished
-                const V4 dur = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
-                const V4 mn = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
-                const V4 mx = load_operand(op.in[2], bufs, lane, A.params, A.n_inst, inst);
+                const V4 dur = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 mn = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
+                const V4 mx = load_operand(op.in[2], bufs, lane, pvals, pstride, 0);
                 const float *data = A.tables + (size_t)(op.attr & 255) * A.table_stride;
                 const double left = (op.attr & 256) ? (double)data[0] : op.d[0];
                 const double right = (op.attr & 512) ? (double)data[sr] : op.d[1];
@@ -510,7 +531,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     if (o.kind == SRC_BUF) rows[k] = (const float *)(bufs + (size_t)o.idx * 64);
                     else {
                         float *r = Y + (k + 1) * kChunk;
-                        const float cst = o.kind == SRC_PARAM ? A.params[(size_t)o.idx * A.n_inst + inst] : o.cval;
+                        const float cst = o.kind == SRC_PARAM ? pvals[(size_t)o.idx * pstride] : o.cval;
                         ((f32x4 *)r)[lane] = f32x4{cst, cst, cst, cst};
                         rows[k] = r;
                     }
@@ -572,7 +593,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     if (o.kind == SRC_BUF) rows[k] = (const float *)(bufs + (size_t)o.idx * 64);
                     else {
                         float *r = Y + (k + 2) * kChunk;
-                        const float cst = o.kind == SRC_PARAM ? A.params[(size_t)o.idx * A.n_inst + inst] : o.cval;
+                        const float cst = o.kind == SRC_PARAM ? pvals[(size_t)o.idx * pstride] : o.cval;
                         ((f32x4 *)r)[lane] = f32x4{cst, cst, cst, cst};
                         rows[k] = r;
                     }
@@ -627,7 +648,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // (index = floor((T + t -+ sr*offset) % len), negatives wrapped), one per sample, lane-parallel.  Several
                 // nodes share a ring and tick one after another, so each node waits for the wave's earlier ring traffic.
                 double *ss = opstate + (size_t)u * kOpState;  // [0] the node's private sample counter
-                const float off = op.in[0].kind == SRC_PARAM ? A.params[(size_t)op.in[0].idx * A.n_inst + inst] : op.in[0].cval;
+                const float off = op.in[0].kind == SRC_PARAM ? pvals[(size_t)op.in[0].idx * pstride] : op.in[0].cval;
                 const double origin = op.op == OP_CB_READER ? ss[0] - srd * (double)off : ss[0] + srd * (double)off;
                 const bool ok = fabs(origin) < 9.0e15;  // NaN / Inf offsets read `undefined` and write nowhere
                 const int64_t len = op.ring_len;
@@ -640,7 +661,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 V4 x;
-                if (op.op == OP_CB_WRITER && !(op.attr & 2)) x = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                if (op.op == OP_CB_WRITER && !(op.attr & 2)) x = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     int64_t idx = base + lane * 4 + c;
@@ -664,7 +685,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // `undefined` -> NaN until the sum comes back): the 256 phases come from the serial lane, in f64 exactly
                 // as the reference adds them; the table lookups and the lerp are lane-parallel.
                 double *ss = opstate + (size_t)u * kOpState;  // [0] phase
-                const V4 f = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                const V4 f = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 double *T = scratch;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) T[lane * 4 + c] = (double)f.v[c];
@@ -696,14 +717,14 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_REPEATER: {  // Repeater.js:23-30
-                out = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
+                out = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 break;
             }
             case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: {
                 V4 w[kMaxIn];
 #pragma unroll
                 for (int k = 0; k < kMaxIn; ++k)
-                    if (k < op.n_in) w[k] = load_operand(op.in[k], bufs, lane, A.params, A.n_inst, inst);
+                    if (k < op.n_in) w[k] = load_operand(op.in[k], bufs, lane, pvals, pstride, 0);
                     else w[k] = w[0];
                 for (int c = 0; c < 4; ++c) {
                     const float v[kMaxIn] = {w[0].v[c], w[1].v[c], w[2].v[c], w[3].v[c], w[4].v[c]};
@@ -712,8 +733,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             default: {  // stateless elementwise maps (map_ops.hpp)
-                const V4 x = load_operand(op.in[0], bufs, lane, A.params, A.n_inst, inst);
-                const V4 y = load_operand(op.in[1], bufs, lane, A.params, A.n_inst, inst);
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 for (int c = 0; c < 4; ++c) out.v[c] = map_apply(op.op, x.v[c], y.v[c], op.d[0]);
                 break;
             }
@@ -839,7 +860,8 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
-    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_modulated_filter != 0);
+    A.param_bytes = A.n_params && A.n_params <= 2048 ? (A.n_params * 4 + 15) & ~15u : 0;
+    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_modulated_filter != 0) + A.param_bytes;
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
     const size_t one_wave = A.wave_bytes + (A.has_filter ? 258 * 8 + 260 * 4 : 0);
