@@ -104,8 +104,13 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
 
     for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
         const int64_t clock = a.clock0 + (int64_t)ck * kChunk;
-        for (uint32_t u = 0; u < a.n_ops; ++u) {
-            const DevOp &op = a.ops[u];
+        // the first chunks of a circuit whose channel counts are still growing have op lists of their own
+        const uint64_t chunk_no = (uint64_t)(clock / kChunk);
+        const bool warm = chunk_no < a.n_warm;
+        const DevOp *ops = warm ? a.ops + a.warm_first[chunk_no] : a.ops;
+        const uint32_t n_ops = warm ? a.warm_n[chunk_no] : a.n_ops;
+        for (uint32_t u = 0; u < n_ops; ++u) {
+            const DevOp &op = ops[u];
             float *outp = a.scratch + (size_t)(op.out_buf >= 0 ? op.out_buf : 0) * kChunk * NP + i;
             double *st = a.state + (size_t)op.state_slot * NP + i;
             switch (op.op) {

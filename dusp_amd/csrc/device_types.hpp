@@ -26,6 +26,7 @@ enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand k
 constexpr int kNumTables = 9;      // 0-4 oscillator wave tables, 5-8 Shape tables (decay, attack, semiSine, decaySquared)
 constexpr int kFirstShapeTable = 5;
 constexpr int kChunk = 256;
+constexpr int kMaxWarmChunks = 8;  // chunks at the start of a render that may run their own op list (program.hpp infer_channels)
 
 #if defined(__HIPCC__)
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what __builtin_nontemporal_store accepts
@@ -60,6 +61,8 @@ struct ChunkArgs {
     uint64_t n_samples;
     int64_t clock0;
     uint32_t n_ops, n_out, n_inst, n_pad, n_chunks, sample_rate, table_stride, flags;
+    // chunk k < n_warm (counted from clock 0) runs ops[warm_first[k] .. +warm_n[k]) instead of ops[0 .. n_ops)
+    uint32_t n_warm, warm_first[kMaxWarmChunks], warm_n[kMaxWarmChunks];
 };
 constexpr uint32_t kChunkFlagResumable = 1;  // segments will follow: Delay keeps to the reference's read-modify-write ring protocol
 

@@ -266,8 +266,16 @@ static int finish_build(dusp_program *prog) {
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const dusp::Program &P = prog->P;
-    HIP_TRY(ctx, prog->d_ops.ensure(P.ops.size()));
+    size_t n_all_ops = P.ops.size();  // the settled op list, then the lists of the warm-up chunks (if any)
+    for (const auto &w : P.warm_ops) n_all_ops += w.size();
+    HIP_TRY(ctx, prog->d_ops.ensure(n_all_ops));
     HIP_TRY(ctx, hipMemcpy(prog->d_ops.p, P.ops.data(), P.ops.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
+    n_all_ops = P.ops.size();
+    for (const auto &w : P.warm_ops) {
+        if (!w.empty())
+            HIP_TRY(ctx, hipMemcpy(prog->d_ops.p + n_all_ops, w.data(), w.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
+        n_all_ops += w.size();
+    }
     HIP_TRY(ctx, prog->d_out_bufs.ensure(P.out_bufs.size()));
     HIP_TRY(ctx, hipMemcpy(prog->d_out_bufs.p, P.out_bufs.data(), P.out_bufs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!P.init_state.empty()) {
@@ -585,6 +593,12 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     a.sample_rate = (uint32_t)P.g.sample_rate;
     a.table_stride = ctx->table_stride;
     a.flags = (prog->resumable && prog->persistent) ? dusp::kChunkFlagResumable : 0u;
+    a.n_warm = (uint32_t)P.warm_ops.size();
+    for (uint32_t k = 0, at = a.n_ops; k < a.n_warm; k++) {
+        a.warm_first[k] = at;
+        a.warm_n[k] = (uint32_t)P.warm_ops[k].size();
+        at += a.warm_n[k];
+    }
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
     if (prog->engine == DUSP_ENGINE_LOOP) {
         const int w = prog->loop.osc.attr;

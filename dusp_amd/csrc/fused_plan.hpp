@@ -178,6 +178,7 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         plan.why = why;
         return false;
     };
+    if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
     if (!P.feed_forward) return no("feedback edge");
     if (!g.rings.empty() || P.ring_samples) return no("rings");
     if (P.out_bufs.size() != 1) return no("multichannel output");
@@ -360,6 +361,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         plan.ok = false;
         return false;
     };
+    if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
     // CircleBuffer nodes: with a lane-constant offset a node touches 256 consecutive slots per chunk (lane-parallel);
     // a modulated offset can make two samples of one chunk meet in one slot, and a ring shorter than a chunk wraps onto itself
     for (const DevOp &op : P.ops)
@@ -469,6 +471,7 @@ inline bool plan_loop(const Program &P, LoopShape &L, std::string &why) {
         why = w;
         return false;
     };
+    if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
     if (P.ops.size() != 5 || P.g.units.size() != 5 || P.out_bufs.size() != 1 || !P.g.rings.empty()) return no("not a 5-unit mono loop");
     int pos[16];
     for (int &p : pos) p = -1;

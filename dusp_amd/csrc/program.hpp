@@ -59,11 +59,15 @@ struct Graph {
     int64_t clock0 = 0;
     std::vector<RingDesc> rings;
     std::vector<UnitDesc> units;
+    // Channel counts of the first chunks, while they still differ from the settled ones: warm_counts[p][u] = channels of unit
+    // u's outlet after chunk p (see infer_channels).  Empty for almost every graph.
+    std::vector<std::vector<int>> warm_counts;
 };
 
 struct Program {
     Graph g;
     std::vector<DevOp> ops;
+    std::vector<std::vector<DevOp>> warm_ops;  // op lists of chunks 0 .. warm_ops.size()-1 when channel counts grow at first
     std::vector<int32_t> out_bufs;
     std::vector<double> init_state;  // one value per state slot, broadcast to every instance
     std::vector<DevRing> dev_rings;
@@ -302,26 +306,52 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     return 1;
 }
 
+// The reference grows channel lists lazily while it ticks.  One pass over the units in process order, with every outlet
+// starting at one channel (Piglet.js:13), is exactly what its first chunk does: a unit that is scheduled BEFORE one of
+// its inputs (a feedback edge, or one of the DAG edges the reference's process order gets "wrong") still sees that
+// input's previous channel count.  Pass p therefore yields the counts of chunk p; they only grow, and once a pass
+// changes nothing they are settled.  Graphs whose first pass is already settled need nothing special; otherwise the
+// counts of the first chunks are kept and those chunks run their own op lists (Program::warm_ops).
+
 inline bool infer_channels(Graph &g, std::string &err) {
-    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;  // outlets start with one channel (Piglet.js:13)
-    std::vector<int> first_pass;
-    for (int pass = 0; pass < 66; pass++) {
+    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;
+    std::vector<std::vector<int>> hist;
+    for (int pass = 0;; pass++) {
         bool changed = false;
         for (auto &u : g.units) {
             for (auto &in : u.inlets)
                 if (in.kind == IN_CONNECT && g.units[(size_t)in.src_unit].n_out == 0)
                     return fail(err, "a unit without a data outlet (CircleBufferWriter, Retriggerer) feeds an inlet");
             int n = unit_channels(g, u);
+            if (n > 64) return fail(err, "more than 64 channels on one outlet are not supported on the GPU path");
             if (n != u.n_out) { u.n_out = n; changed = true; }
         }
-        if (pass == 0)
-            for (auto &u : g.units) first_pass.push_back(u.n_out);
-        if (!changed) break;
-        if (pass == 65) return fail(err, "channel counts do not settle");
+        if (pass > 0 && !changed) break;
+        std::vector<int> now;
+        for (auto &u : g.units) now.push_back(u.n_out);
+        hist.push_back(now);
+        if (pass > 70) return fail(err, "channel counts do not settle");
     }
-    for (size_t i = 0; i < g.units.size(); i++)
-        if (g.units[i].n_out != first_pass[i])
-            return fail(err, "channel count grows through a feedback edge (not supported on the GPU path)");
+    // hist[p] = counts after chunk p; the last entry equals the settled counts: drop it and every trailing equal
+    while (!hist.empty()) {
+        bool same = true;
+        for (size_t i = 0; i < g.units.size(); i++) same = same && hist.back()[i] == g.units[i].n_out;
+        if (!same) break;
+        hist.pop_back();
+    }
+    for (auto &h : hist)
+        for (size_t i = 0; i < g.units.size(); i++) {
+            const int op = g.units[i].op;
+            // a channel that appears late must start from the same state as in the reference: true for stateless units,
+            // Filter (per-channel memory, coefficients a pure function of f) and MultiChannelOsc (phase[c] || 0), but
+            // not for units whose channels share a running counter
+            if (h[i] != g.units[i].n_out && (op == OP_DELAY || op == OP_READBACK_DELAY || op == OP_SAMPLE_RATE_REDUX))
+                return fail(err, "channel count of a Delay / ReadBackDelay / SampleRateRedux grows after the first chunk "
+                                 "(not supported on the GPU path)");
+        }
+    if (hist.size() > (size_t)kMaxWarmChunks)
+        return fail(err, "channel counts take more than " + std::to_string(kMaxWarmChunks) + " chunks to settle (not supported on the GPU path)");
+    g.warm_counts = hist;
     for (auto &u : g.units) {
         if (u.op == OP_DELAY && u.inlets[1].n_channels(g.units) > u.inlets[0].n_channels(g.units))
             return fail(err, "Delay with more delay channels than input channels is not supported "
@@ -368,194 +398,227 @@ inline bool expand(Program &P, std::string &err) {
             ring_pos += r.len;
         }
     }
+    // One DevOp of unit `ui`, output channel `c`.  alloc: the settled program — state slots and rings are handed out as
+    // the ops are made.  !alloc: a warm-up chunk — `op` starts as a copy of the settled op (same slots, same ring) and
+    // only its operands are bound again, against the channel counts g.units[..].n_out holds at that moment.
+    bool alloc = true;
     auto slot = [&](double init) {
-        P.init_state.push_back(init);
-        return (int)P.init_state.size() - 1;
+        if (alloc) P.init_state.push_back(init);
+        return 0;
     };
+    auto own_ring = [&](DevOp &op, int64_t len) {
+        if (!alloc) return;
+        op.ring_len = len;
+        op.ring_base = ring_pos;
+        P.dev_rings.push_back({ring_pos, len});
+        ring_pos += len;
+    };
+    auto make_op = [&](size_t ui, int c, DevOp &op) {
+        UnitDesc &u = g.units[ui];
+        switch (u.op) {
+        case OP_OSC:
+            op.attr = (int)u.attrs[0];
+            op.in[0] = make_operand(g, u.inlets[0], 0);  // mono inlet: channel 0 (Piglet.js:56-61)
+            slot(u.state[0]);
+            break;
+        case OP_RAMP:
+            op.d[0] = u.attrs[0];
+            op.d[1] = u.attrs[1];
+            op.d[2] = u.attrs[2];
+            slot(u.state[0]);
+            slot(u.state[1] != 0 ? 1.0 : 0.0);
+            break;
+        case OP_MULTIPLY:
+        case OP_SUM:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], c);
+            break;
+        case OP_FILTER: {
+            op.attr = (int)u.attrs[0];
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], 0);  // f is a mono inlet (Filter.js:9)
+            const int have = (int)u.state[7];
+            for (int k = 0; k < 7; k++) slot(u.state[(size_t)k]);  // has_lastF, lastF, a0, a1, a2, b1, b2
+            for (int k = 0; k < 4; k++) slot(c < have ? u.state[(size_t)(8 + 4 * c + k)] : 0.0);  // x1 x2 y1 y2
+            break;
+        }
+        case OP_DELAY: {
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], c);
+            own_ring(op, (int64_t)u.attrs[0]);
+            slot(0.0);  // previous input sample (chunk engine's constant-delay path)
+            break;
+        }
+        case OP_CB_READER:
+        case OP_CB_WRITER: {
+            const RingDesc &r = g.rings[(size_t)u.attrs[0]];
+            const DevRing &dr = P.dev_rings[(size_t)(r.first_dev_ring + c)];
+            op.ring_base = dr.base;
+            op.ring_len = dr.len;
+            op.attr = u.attrs[1] != 0 ? 1 : 0;  // postWipe / preWipe
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            if (u.op == OP_CB_WRITER) {
+                const int nin = u.inlets[1].n_channels(g.units);
+                if (c < nin) op.in[1] = make_operand(g, u.inlets[1], c);  // `if(this.in[c])`: no modulo (Writer.js:19)
+                else op.attr |= 2;                                          // nothing to mix on this channel
+            }
+            slot(u.state[0]);
+            break;
+        }
+        case OP_REPEATER:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            break;
+        case OP_SUBTRACT:  // `this.a[c] || zeroChunk`: a missing channel is silence, no modulo (Subtract.js:20-21)
+            for (int k = 0; k < 2; k++) {
+                if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+                else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
+            }
+            break;
+        case OP_DIVIDE: case OP_POW: case OP_CLIP: case OP_HARD_CLIP_ABOVE: case OP_HARD_CLIP_BELOW:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], c);  // modulo broadcast
+            break;
+        case OP_GAIN:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], 0);  // gain is a mono inlet (Gain.js:6)
+            break;
+        case OP_FIXED_MULTIPLY:
+            op.in[0] = make_operand(g, u.inlets[0], 0);
+            op.d[0] = u.attrs[0];
+            break;
+        case OP_SECONDS_TO_SAMPLES:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.d[0] = (double)g.sample_rate;
+            break;
+        case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            break;
+        case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_MONO_DELAY: case OP_READBACK_DELAY: {
+            const bool mono = u.op != OP_READBACK_DELAY;
+            op.in[0] = make_operand(g, u.inlets[0], mono ? 0 : c);
+            if (u.inlets.size() > 1) op.in[1] = make_operand(g, u.inlets[1], mono ? 0 : c);
+            own_ring(op, (int64_t)u.attrs[0]);
+            if (u.op != OP_MONO_DELAY) slot(u.state[0]);  // tBuffer (MonoDelay indexes with the circuit clock)
+            break;
+        }
+        case OP_MULTI_OSC:
+            op.attr = (int)u.attrs[0];
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            slot(c < (int)u.state[0] ? u.state[(size_t)(1 + c)] : 0.0);  // `this.phase[c] = this.phase[c] || 0`
+            break;
+        case OP_PAN:  // mono inlets (Pan.js:6-7); one device op per output channel
+            op.attr = c;
+            op.n_in = 2;
+            op.in[0] = make_operand(g, u.inlets[0], 0);
+            op.in[1] = make_operand(g, u.inlets[1], 0);
+            op.d[0] = u.attrs[0];
+            break;
+        case OP_MIDI_TO_FREQUENCY:
+            op.n_in = 1;
+            op.in[0] = make_operand(g, u.inlets[0], 0);
+            break;
+        case OP_RESCALE:  // every inlet but `in` broadcasts by modulo (Rescale.js:29-32)
+            op.n_in = 5;
+            for (int k = 0; k < 5; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+            break;
+        case OP_CROSS_FADER:  // `this.a[c] || zeroChannel` (CrossFader.js:23-24); dial is mono
+            op.n_in = 3;
+            for (int k = 0; k < 2; k++) {
+                if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
+                else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
+            }
+            op.in[2] = make_operand(g, u.inlets[2], 0);
+            break;
+        case OP_VECTOR_MAGNITUDE:
+            op.n_in = u.inlets[0].n_channels(g.units);
+            for (int k = 0; k < op.n_in; k++) op.in[k] = make_operand(g, u.inlets[0], k);
+            break;
+        case OP_TIMER:
+            op.d[0] = u.attrs[0];
+            slot(u.state[0]);
+            break;
+        case OP_SHAPE:  // mono inlets duration / min / max; attr: table id | left-is-shape << 8 | right-is-shape << 9
+            op.n_in = 3;
+            for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
+            op.attr = (int)u.attrs[0] | (u.attrs[1] != 0 ? 256 : 0) | (u.attrs[3] != 0 ? 512 : 0);
+            op.d[0] = u.attrs[2];  // leftEdge as a number
+            op.d[1] = u.attrs[4];  // rightEdge as a number
+            slot(u.state[0]);                    // t
+            slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
+            slot(u.state[2] != 0 ? 1.0 : 0.0);   // finished
+            break;
+        case OP_AHD:
+            op.n_in = 3;
+            for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
+            op.d[0] = u.attrs[0];  // samplePeriod
+            slot(u.state[0]);                    // state (0 off, 1 attack, 2 hold, 3 decay)
+            slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
+            slot(u.state[2]);                    // t
+            break;
+        case OP_SAMPLE_RATE_REDUX:  // every channel keeps its own copy of the (shared) counter next to its held value
+            op.in[0] = make_operand(g, u.inlets[0], c);
+            op.in[1] = make_operand(g, u.inlets[1], 0);  // ammount is mono (SampleRateRedux.js:6)
+            slot(u.state[0]);
+            slot(c < (int)u.state[1] ? u.state[(size_t)(2 + c)] : 0.0);  // unwritten output channels read 0
+            break;
+        case OP_CONCAT_CHANNELS: {  // a plain copy of one input channel (ConcatChannels.js:19-30)
+            const int na = u.inlets[0].n_channels(g.units);
+            op.op = OP_REPEATER;
+            op.in[0] = c < na ? make_operand(g, u.inlets[0], c) : make_operand(g, u.inlets[1], c - na);
+            break;
+        }
+        case OP_PICK_CHANNEL: {  // constant index (checked by parse): a copy of channel c % n (PickChannel.js:20)
+            const int n = u.inlets[0].n_channels(g.units);
+            op.op = OP_REPEATER;
+            op.in[0] = make_operand(g, u.inlets[0], (int)std::fmod(u.inlets[1].vals[0], (double)n));
+            break;
+        }
+        }
+    };
+    auto n_dev_ops = [&](const UnitDesc &u, int n_out) { return u.op == OP_CB_WRITER ? g.rings[(size_t)u.attrs[0]].nch : n_out; };
     for (size_t ui = 0; ui < g.units.size(); ui++) {
         UnitDesc &u = g.units[ui];
         u.first_op = (int)P.ops.size();
         u.first_slot = (int)P.init_state.size();
         for (auto &in : u.inlets)
             if (in.kind == IN_CONNECT && (size_t)in.src_unit >= ui) P.feed_forward = false;
-        const int n_dev = (u.op == OP_CB_WRITER) ? g.rings[(size_t)u.attrs[0]].nch : u.n_out;
-        for (int c = 0; c < n_dev; c++) {
+        for (int c = 0; c < n_dev_ops(u, u.n_out); c++) {
             DevOp op{};
             op.op = u.op;
             op.unit = (int)ui;
             op.out_buf = u.n_out ? u.first_buf + c : -1;
             op.state_slot = (int)P.init_state.size();
             op.ring_base = op.ring_len = 0;
-            switch (u.op) {
-            case OP_OSC:
-                op.attr = (int)u.attrs[0];
-                op.in[0] = make_operand(g, u.inlets[0], 0);  // mono inlet: channel 0 (Piglet.js:56-61)
-                slot(u.state[0]);
-                break;
-            case OP_RAMP:
-                op.d[0] = u.attrs[0];
-                op.d[1] = u.attrs[1];
-                op.d[2] = u.attrs[2];
-                slot(u.state[0]);
-                slot(u.state[1] != 0 ? 1.0 : 0.0);
-                break;
-            case OP_MULTIPLY:
-            case OP_SUM:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], c);
-                break;
-            case OP_FILTER: {
-                op.attr = (int)u.attrs[0];
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], 0);  // f is a mono inlet (Filter.js:9)
-                const int have = (int)u.state[7];
-                for (int k = 0; k < 7; k++) slot(u.state[(size_t)k]);  // has_lastF, lastF, a0, a1, a2, b1, b2
-                for (int k = 0; k < 4; k++) slot(c < have ? u.state[(size_t)(8 + 4 * c + k)] : 0.0);  // x1 x2 y1 y2
-                break;
-            }
-            case OP_DELAY: {
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], c);
-                op.ring_len = (int64_t)u.attrs[0];
-                op.ring_base = ring_pos;
-                slot(0.0);  // previous input sample (chunk engine's constant-delay path)
-                P.dev_rings.push_back({ring_pos, op.ring_len});
-                ring_pos += op.ring_len;
-                break;
-            }
-            case OP_CB_READER:
-            case OP_CB_WRITER: {
-                const RingDesc &r = g.rings[(size_t)u.attrs[0]];
-                const DevRing &dr = P.dev_rings[(size_t)(r.first_dev_ring + c)];
-                op.ring_base = dr.base;
-                op.ring_len = dr.len;
-                op.attr = u.attrs[1] != 0 ? 1 : 0;  // postWipe / preWipe
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                if (u.op == OP_CB_WRITER) {
-                    const int nin = u.inlets[1].n_channels(g.units);
-                    if (c < nin) op.in[1] = make_operand(g, u.inlets[1], c);  // `if(this.in[c])`: no modulo (Writer.js:19)
-                    else op.attr |= 2;                                          // nothing to mix on this channel
-                }
-                slot(u.state[0]);
-                break;
-            }
-            case OP_REPEATER:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                break;
-            case OP_SUBTRACT:  // `this.a[c] || zeroChunk`: a missing channel is silence, no modulo (Subtract.js:20-21)
-                for (int k = 0; k < 2; k++) {
-                    if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
-                    else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
-                }
-                break;
-            case OP_DIVIDE: case OP_POW: case OP_CLIP: case OP_HARD_CLIP_ABOVE: case OP_HARD_CLIP_BELOW:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], c);  // modulo broadcast
-                break;
-            case OP_GAIN:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], 0);  // gain is a mono inlet (Gain.js:6)
-                break;
-            case OP_FIXED_MULTIPLY:
-                op.in[0] = make_operand(g, u.inlets[0], 0);
-                op.d[0] = u.attrs[0];
-                break;
-            case OP_SECONDS_TO_SAMPLES:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.d[0] = (double)g.sample_rate;
-                break;
-            case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                break;
-            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_MONO_DELAY: case OP_READBACK_DELAY: {
-                const bool mono = u.op != OP_READBACK_DELAY;
-                op.in[0] = make_operand(g, u.inlets[0], mono ? 0 : c);
-                if (u.inlets.size() > 1) op.in[1] = make_operand(g, u.inlets[1], mono ? 0 : c);
-                op.ring_len = (int64_t)u.attrs[0];
-                op.ring_base = ring_pos;
-                P.dev_rings.push_back({ring_pos, op.ring_len});
-                ring_pos += op.ring_len;
-                if (u.op != OP_MONO_DELAY) slot(u.state[0]);  // tBuffer (MonoDelay indexes with the circuit clock)
-                break;
-            }
-            case OP_MULTI_OSC:
-                op.attr = (int)u.attrs[0];
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                slot(c < (int)u.state[0] ? u.state[(size_t)(1 + c)] : 0.0);  // `this.phase[c] = this.phase[c] || 0`
-                break;
-            case OP_PAN:  // mono inlets (Pan.js:6-7); one device op per output channel
-                op.attr = c;
-                op.n_in = 2;
-                op.in[0] = make_operand(g, u.inlets[0], 0);
-                op.in[1] = make_operand(g, u.inlets[1], 0);
-                op.d[0] = u.attrs[0];
-                break;
-            case OP_MIDI_TO_FREQUENCY:
-                op.n_in = 1;
-                op.in[0] = make_operand(g, u.inlets[0], 0);
-                break;
-            case OP_RESCALE:  // every inlet but `in` broadcasts by modulo (Rescale.js:29-32)
-                op.n_in = 5;
-                for (int k = 0; k < 5; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
-                break;
-            case OP_CROSS_FADER:  // `this.a[c] || zeroChannel` (CrossFader.js:23-24); dial is mono
-                op.n_in = 3;
-                for (int k = 0; k < 2; k++) {
-                    if (c < u.inlets[(size_t)k].n_channels(g.units)) op.in[k] = make_operand(g, u.inlets[(size_t)k], c);
-                    else op.in[k] = DevOperand{SRC_CONST, 0, 0.f, 0};
-                }
-                op.in[2] = make_operand(g, u.inlets[2], 0);
-                break;
-            case OP_VECTOR_MAGNITUDE:
-                op.n_in = u.inlets[0].n_channels(g.units);
-                for (int k = 0; k < op.n_in; k++) op.in[k] = make_operand(g, u.inlets[0], k);
-                break;
-            case OP_TIMER:
-                op.d[0] = u.attrs[0];
-                slot(u.state[0]);
-                break;
-            case OP_SHAPE:  // mono inlets duration / min / max; attr: table id | left-is-shape << 8 | right-is-shape << 9
-                op.n_in = 3;
-                for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
-                op.attr = (int)u.attrs[0] | (u.attrs[1] != 0 ? 256 : 0) | (u.attrs[3] != 0 ? 512 : 0);
-                op.d[0] = u.attrs[2];  // leftEdge as a number
-                op.d[1] = u.attrs[4];  // rightEdge as a number
-                slot(u.state[0]);                    // t
-                slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
-                slot(u.state[2] != 0 ? 1.0 : 0.0);   // finished
-                break;
-            case OP_AHD:
-                op.n_in = 3;
-                for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
-                op.d[0] = u.attrs[0];  // samplePeriod
-                slot(u.state[0]);                    // state (0 off, 1 attack, 2 hold, 3 decay)
-                slot(u.state[1] != 0 ? 1.0 : 0.0);   // playing
-                slot(u.state[2]);                    // t
-                break;
-            case OP_SAMPLE_RATE_REDUX:  // every channel keeps its own copy of the (shared) counter next to its held value
-                op.in[0] = make_operand(g, u.inlets[0], c);
-                op.in[1] = make_operand(g, u.inlets[1], 0);  // ammount is mono (SampleRateRedux.js:6)
-                slot(u.state[0]);
-                slot(c < (int)u.state[1] ? u.state[(size_t)(2 + c)] : 0.0);  // unwritten output channels read 0
-                break;
-            case OP_CONCAT_CHANNELS: {  // a plain copy of one input channel (ConcatChannels.js:19-30)
-                const int na = u.inlets[0].n_channels(g.units);
-                op.op = OP_REPEATER;
-                op.in[0] = c < na ? make_operand(g, u.inlets[0], c) : make_operand(g, u.inlets[1], c - na);
-                break;
-            }
-            case OP_PICK_CHANNEL: {  // constant index (checked by parse): a copy of channel c % n (PickChannel.js:20)
-                const int n = u.inlets[0].n_channels(g.units);
-                op.op = OP_REPEATER;
-                op.in[0] = make_operand(g, u.inlets[0], (int)std::fmod(u.inlets[1].vals[0], (double)n));
-                break;
-            }
-            }
+            make_op(ui, c, op);
             if (c == 0) u.slots_per_ch = (int)P.init_state.size() - u.first_slot;
             P.ops.push_back(op);
         }
     }
     P.ring_samples = ring_pos;
+    // Warm-up chunks: replay the channel growth of infer_channels, binding every op's operands against the counts the
+    // reference's unit would see at that point of that chunk (units before it: this chunk's, units after it: last chunk's).
+    if (!g.warm_counts.empty()) {
+        alloc = false;
+        std::vector<int> settled;
+        for (auto &u : g.units) settled.push_back(u.n_out);
+        for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;
+        for (const auto &counts : g.warm_counts) {
+            std::vector<DevOp> ops;
+            for (size_t ui = 0; ui < g.units.size(); ui++) {
+                UnitDesc &u = g.units[ui];
+                for (int c = 0; c < n_dev_ops(u, counts[ui]); c++) {
+                    DevOp op = P.ops[(size_t)(u.first_op + c)];
+                    for (auto &o : op.in) o = DevOperand{};
+                    // (no unit asks for its OWN count while its operands are bound: only its inputs' matter)
+                    make_op(ui, c, op);
+                    ops.push_back(op);
+                }
+                u.n_out = counts[ui];
+            }
+            P.warm_ops.push_back(std::move(ops));
+        }
+        for (size_t i = 0; i < g.units.size(); i++) g.units[i].n_out = settled[i];
+    }
     const UnitDesc &ou = g.units[(size_t)g.out_unit];
     for (int c = 0; c < ou.n_out; c++) P.out_bufs.push_back(ou.first_buf + c);
     (void)err;

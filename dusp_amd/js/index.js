@@ -3,6 +3,7 @@
  * constructors of the units the MI355X render path executes. */
 const graph = require('./lib/graph')
 const renderChannelData = require('./lib/renderChannelData')
+const patches = require('./lib/patches')
 
 module.exports = {
   renderChannelData,
@@ -25,5 +26,8 @@ module.exports = {
     Delay: graph.Delay, CircleBufferReader: graph.CircleBufferReader, CircleBufferWriter: graph.CircleBufferWriter,
     Repeater: graph.Repeater,
   },
+  Patch: patches.Patch,
+  patches,
   ...graph,
+  ...patches,
 }

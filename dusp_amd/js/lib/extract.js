@@ -145,7 +145,9 @@ function extract(target, opts = {}) {
           if (typeof e === 'number') return [0, e]
           throw 'dusp-hip: Shape edge must be "shape" or a number (' + unit.label + ')'
         }
-        if (unit._finish || unit.onFinish) throw 'dusp-hip: finish callbacks cannot run on the GPU path (' + unit.label + ')'
+        // a hook marked hostOnly (lib/patches.js Boop) only keeps host-side books: write-back runs it once the state shows `finished`
+        if (unit._finish || (unit.onFinish && !unit.onFinish.hostOnly && !opts.allowFinishHooks))
+          throw 'dusp-hip: finish callbacks cannot run on the GPU path (' + unit.label + ')'
         attrs = [table, ...edge(unit.leftEdge), ...edge(unit.rightEdge)]
         state = [unit.t, unit.playing ? 1 : 0, unit.finished ? 1 : 0]
         break

@@ -536,7 +536,27 @@ class CombFilter extends FixedDelay { // CombFilter.js:4-9
   }
   set totalReverbTime(RVT) { this.FEEDBACKGAIN = Math.pow(0.001, this.delayTimeInSeconds / RVT) } // CombFilter.js:23-25
 }
-class AllPass extends CombFilter {} // AllPass.js:4-7
+class AllPass extends CombFilter { // AllPass.js:4-7, random builders :19-51
+  static random(maxDelayTime, maxFeedbackGain) {
+    return new AllPass((maxDelayTime || 1) * Math.random(), (maxFeedbackGain || 1) * Math.random())
+  }
+  static manyRandom(n, maxDelay, maxFeedback) {
+    const list = []
+    for (let i = 0; i < n; i++) {
+      Math.random() // the reference draws a third number here and never uses it (AllPass.js:29)
+      list.push(new AllPass(Math.random() * maxDelay, Math.random() * maxFeedback))
+    }
+    return list
+  }
+  static manyRandomInSeries(n, maxDelayTime, maxFeedbackGain) {
+    const list = []
+    for (let i = 0; i < n; i++) {
+      list[i] = AllPass.random(maxDelayTime, maxFeedbackGain)
+      if (i !== 0) list[i].IN = list[i - 1].OUT
+    }
+    return { list, IN: list[0].IN, OUT: list[n - 1].OUT }
+  }
+}
 class MonoDelay extends Unit { // MonoDelay.js:3-14 — delay in SAMPLES, fixed 5 s ring
   constructor(input, delay) {
     super()
@@ -575,6 +595,9 @@ class MultiChannelOsc extends Unit { // Osc/MultiChannelOsc.js:7-17 — one phas
     this._waveform = w
   }
   resetPhase() { for (const i in this.phase) this.phase[i] = 0 }
+  randomPhaseFlip() { // MultiChannelOsc.js:58-62 (a no-op on a fresh unit: no channel has a phase yet)
+    if (Math.random() < 0.5) for (const i in this.phase) this.phase[i] += config.sampleRate / 2
+  }
 }
 
 /* ---- rest of the elementwise sweep (SURVEY.md §8f-1) */
@@ -697,6 +720,22 @@ class Shape extends Unit { // Shape/index.js:7-23,107-122 — a table read once 
   }
   trigger() { this.playing = true; this.t = 0; return this }
   stop() { this.playing = false }
+  randomDecay(maxDuration) { // Shape/index.js:157-162
+    this.shape = 'decay'
+    this.DURATION = Math.random() * (maxDuration || 5)
+    this.MIN = 0
+    this.MAX = 1
+  }
+  static randomShapeStr() { // Shape/index.js:145-148 — in the key order of the reference's shape tables
+    const keys = Object.keys(SHAPES)
+    return keys[Math.floor(Math.random() * keys.length)]
+  }
+  static randomDecay(maxDuration) { return new Shape('decaySquared', Math.random() * (maxDuration || 5)) }
+  static randomInRange(maxDuration, minMin, maxMax) { // Shape/index.js:124-143
+    const a = minMin + Math.random() * (maxMax - minMin)
+    const b = minMin + Math.random() * (maxMax - minMin)
+    return new Shape(Shape.randomShapeStr(), Math.random() * (maxDuration || 1), Math.min(a, b), Math.max(a, b))
+  }
 }
 class AHD extends Unit { // AHD.js:6-34 — attack / hold / decay times in seconds
   constructor(attack, hold, decay) {

@@ -45,7 +45,9 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
     else if (spec.op === OP.TIMER) unit.t = n.stateDownload(prog, 0, u)[0]
     else if (spec.op === OP.SHAPE) {
       const s = n.stateDownload(prog, 0, u)
+      const finishedNow = s[2] !== 0 && !unit.finished
       unit.t = s[0]; unit.playing = s[1] !== 0; unit.finished = s[2] !== 0
+      if (finishedNow && unit.onFinish) unit.onFinish() // hostOnly hooks only (the extractor refuses the rest)
     } else if (spec.op === OP.AHD) {
       const s = n.stateDownload(prog, 0, u)
       unit.state = s[0]; unit.playing = s[1] !== 0; unit.t = s[2]

@@ -13,12 +13,15 @@ const graph = require('./graph')
 const quick = require('./quick')
 const { parseExpression } = require('./parse')
 
-/* constructor name -> class: everything lib/graph.js can execute (reference src/patchesAndComponents.js) */
+/* constructor name -> class: everything lib/graph.js can execute and the patches built from it
+ * (reference src/patchesAndComponents.js: patches override components of the same name) */
 const COMPONENTS = {}
 for (const name of Object.keys(graph)) {
   const C = graph[name]
   if (typeof C === 'function' && C.prototype instanceof graph.Unit) COMPONENTS[name] = C
 }
+const patches = require('./patches')
+for (const name of Object.keys(patches)) if (name !== 'Patch') COMPONENTS[name] = patches[name]
 
 const SHORTHAND = { // reference src/construct/shorthandConstructors.js:3-46
   O: (f) => new graph.Osc(f),
@@ -77,7 +80,7 @@ function constructObject(node, index) {
   }
   for (const attr of node.attributes) {
     const upper = attr.property.toUpperCase()
-    const asInlet = Object.values(obj.inlets).find((inlet) => inlet.name.toUpperCase() === upper)
+    const asInlet = obj[upper] && obj[upper].isInlet // also true for a patch's aliased inlets (constructObject.js:38-40)
     const value = construct(attr.value, index)
     if (asInlet) obj[upper] = value
     else obj[attr.property] = value

@@ -49,11 +49,15 @@ for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardCli
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
 more.Shape = ref('components/Shape')
 more.AHD = ref('components/AHD.js')
+const patches = {}
+for (const n of ['Mixer', 'SimpleDelay', 'StereoOsc', 'LFO', 'MidiOsc', 'BandFilter', 'MultiTapDelay', 'DelayMixer', 'TriggerGroup',
+  'Synth', 'SpaceChannel', 'Space', 'ScaryPatch', 'Boop', 'SineBoop', 'SpaceBoop', 'FMOsc', 'ManyOsc', 'StereoDetune',
+  'FrequencyGroup', 'AttenuationMatrix', 'APStack', 'APWeb']) patches[n] = ref('patches/' + n + '.js')
 const shapeTables = ref('components/Shape/shapeTables.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
 const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
-  CircleBufferReader, CircleBufferWriter, quick, ...more }, SR)
+  CircleBufferReader, CircleBufferWriter, quick, ...more, patches }, SR)
 const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
 
 async function main() {
@@ -62,7 +66,7 @@ async function main() {
   for (const c of cases) {
     if (ONLY && !ONLY.includes(c.name)) continue
     const target = c.build()
-    const ex = extract(target, { allowEvents: true }) // before rendering: captures the initial state
+    const ex = extract(target, { allowEvents: true, allowFinishHooks: true }) // before rendering: captures the initial state
     const order = ex.circuit.units.map((u) => u.label + ':' + u.processIndex)
     const cd = await renderChannelData(target, c.duration)
     const n = cd[0].length
@@ -79,7 +83,8 @@ async function main() {
       n_samples: n, n_channels: cd.length, windows, sha256_full: h.digest('hex'),
       reference_unit_order: order.length <= 64 ? order : order.slice(0, 8).concat(['...' + order.length + ' units']) }
     fs.writeFileSync(path.join(OUT, c.name + '.json'), JSON.stringify(meta, null, 1) + '\n')
-    ;(c.name.startsWith('ev_') ? eventIndex : c.name.startsWith('rt_') ? hostIndex : index).push(c.name)
+    // ev_: scheduled events (both hosts); rt_ and ev_patch_: features only the JS host has (host-ticked units, patches)
+    ;(c.name.startsWith('rt_') || c.name.startsWith('ev_patch_') ? hostIndex : c.name.startsWith('ev_') ? eventIndex : index).push(c.name)
     console.log(c.name, 'n=' + n, 'ch=' + cd.length, 'units=' + order.length)
   }
   // wave tables: hashes of all five, plus the few entries the docs quote (SURVEY.md §8c)

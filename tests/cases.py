@@ -103,11 +103,40 @@ def _srr_nan():
     return r
 
 
+def _grow_stereo():
+    s = Sum(Osc(440), 0)
+    s.B = Multiply(s, [0.5, -0.25])
+    return s
+
+
+def _grow_filter():
+    s = Sum(Osc(300, "saw"), 0)
+    f = Filter(s, 1500)
+    s.B = Multiply(f, [0.4, 0.2, -0.3])
+    return f
+
+
+def _grow_multiosc():
+    f = Sum(200, 0)
+    osc = MultiChannelOsc(f)
+    f.B = Multiply(osc, [30, 50])
+    return osc
+
+
+def _grow_two_loops():
+    a, b = Sum(Osc(220), 0), Sum(Osc(331, "triangle"), 0)
+    a.B = Multiply(b, 0.5)
+    b.B = Multiply(a, [0.25, -0.5])
+    return Sum(a, b)
+
+
 def builders(sr):
     """name -> zero-argument builder; call d.configure(sr) first (done by build())."""
     voices = lambda n: [Osc(k * 10) for k in range(1, n + 1)]
     b = {
         "osc440_1s": lambda: Osc(440),
+        "grow_feedback_stereo": _grow_stereo, "grow_feedback_filter": _grow_filter,
+        "grow_feedback_multiosc": _grow_multiosc, "grow_two_loops": _grow_two_loops,
         "cfg2_literal": lambda: Multiply(Osc(Ramp(200, 100, 2)), Osc(3)),
         "cfg2_sweep": lambda: Multiply(Osc(Ramp(2 * sr, 200, 100).trigger()), Osc(3)),
         "ramp_300": lambda: Ramp(300, 0.25, 2).trigger(),

@@ -12,7 +12,7 @@ module.exports = function goldenCases(L, SR) {
     Subtract, Divide, PolarityInvert, Abs, Clip, HardClipAbove, HardClipBelow, SecondsToSamples, FixedMultiply, Gain,
     DecibelToScaler, SemitoneToRatio, Pow, FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc,
     Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
-    Shape, AHD, Retriggerer } = L
+    Shape, AHD, Retriggerer } = L // + L.patches (optional): the patch builders
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
   const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
@@ -340,5 +340,167 @@ module.exports = function goldenCases(L, SR) {
       tm.scheduleTrigger(0.02)
       return new Osc(new Multiply(tm, 20000))
     }, 0.05)
+
+  /* Channel counts that grow AFTER the first chunk: a unit ticked before one of its inputs (feedback edge) sees that
+   * input's previous chunk — one channel at first, more later — so its own outlet gains channels on the second chunk or
+   * later (the reference grows channel lists lazily; the device runs those first chunks with their own op lists). */
+  add('grow_feedback_stereo', () => {
+    const sum = new Sum(new Osc(440), 0)
+    sum.B = new Multiply(sum, [0.5, -0.25])
+    return sum
+  }, 0.03)
+  add('grow_feedback_filter', () => {
+    const sum = new Sum(new Osc(300, 'saw'), 0)
+    const f = new Filter(sum, 1500)
+    sum.B = new Multiply(f, [0.4, 0.2, -0.3])
+    return f
+  }, 0.04)
+  if (MultiChannelOsc)
+    add('grow_feedback_multiosc', () => {
+      const f = new Sum(200, 0)
+      const osc = new MultiChannelOsc(f)
+      f.B = new Multiply(osc, [30, 50])
+      return osc
+    }, 0.04)
+  add('grow_two_loops', () => { // the second loop only learns about the first one's channels a chunk later
+    const a = new Sum(new Osc(220), 0), b = new Sum(new Osc(331, 'triangle'), 0)
+    a.B = new Multiply(b, 0.5)
+    b.B = new Multiply(a, [0.25, -0.5])
+    return new Sum(a, b)
+  }, 0.04)
+
+  /* Patches (reference src/patches/): host-side builders over the units above.  Builders that draw random numbers run
+   * under a seeded Math.random so that both libraries build the same graph. */
+  const P = L.patches
+  const seeded = (seed, fn) => () => {
+    const original = Math.random, log = console.log
+    let x = seed >>> 0
+    Math.random = () => { x = (Math.imul(x, 1664525) + 1013904223) >>> 0; return x / 4294967296 }
+    console.log = () => {} // a few reference patches print while they build
+    try { return fn() } finally { Math.random = original; console.log = log }
+  }
+  if (P) {
+    const quiet = (fn) => seeded(1, fn)
+    add('patch_mixer', () => {
+      const m = new P.Mixer(new Osc(220), new Osc(330.5, 'saw'))
+      m.addInput(new Osc(441)).addMultiplied(new Osc(55, 'square'), 0.25).addAttenuated(new Osc(880), -12).addAttenuated(new Osc(3), 0)
+      return m
+    }, 0.02)
+    add('patch_mixer_one', () => new P.Mixer(new Osc(220)), 0.01)
+    add('patch_simple_delay', () =>
+      new P.SimpleDelay(new Multiply(new Osc(300), new Ramp(2000, 1, 0).trigger()), 0.0123, 0.5, 0.3), 0.1)
+    add('patch_simple_delay_defaults', () => new P.SimpleDelay(new Osc(100)), 0.02)
+    add('patch_stereo_osc', () => { const o = new P.StereoOsc(62, -6, 0.3); o.waveform = 'saw'; return o }, 0.02)
+    add('patch_stereo_osc_vibrato', () => {
+      const o = new P.StereoOsc(57, 0, -0.5)
+      o.PCONTROL = new P.LFO(6, 0.5, 0)
+      return o
+    }, 0.25)
+    add('patch_lfo', () => new Osc(new P.LFO(3, 50, 400, 'triangle')), 0.5, [[0, 4096], [SR / 4, 2048]])
+    add('patch_lfo_defaults', () => new P.LFO(), 0.02)
+    add('patch_midi_osc', () => new P.MidiOsc(57), 0.02)
+    add('patch_band_filter', quiet(() => new P.BandFilter(new Osc(110, 'saw'), 300, 2000)), 0.05)
+    add('patch_multitap', () => {
+      const burst = new Multiply(new Osc(500), new Ramp(700, 1, 0).trigger())
+      const d = new P.MultiTapDelay(1, 4800, burst)
+      const a = d.addTap(1000), b = d.addTap(2345.5), c = d.addFeedback(3000, 0.6, 0)
+      return Sum.many([a, b, c])
+    }, 0.2)
+    add('patch_delay_mixer', () => {
+      const d = new P.DelayMixer(1, 4800)
+      d.addInput(new Multiply(new Osc(500), new Ramp(700, 1, 0).trigger()), 300)
+      d.addInput(new Osc(3), 1000.5, 0.25)
+      d.addInput(new Osc(220, 'saw'), 0, 0.1)
+      return d
+    }, 0.1)
+    add('patch_space', () => new P.Space(new Osc(440), [0.5, 1]), 0.05)
+    add('patch_space_moving', () =>
+      new P.Space(new Osc(330, 'saw'), new ConcatChannels(new P.LFO(2, 3, 0), new P.LFO(3, 2, 1, 'triangle'))), 0.25)
+    add('patch_space_stereo4', () => P.Space.stereo(new Osc(440), [-0.25, 2]), 0.03)
+    add('patch_space_channel', () => {
+      const c = new P.SpaceChannel([1, 1])
+      c.IN = new Osc(200)
+      c.PLACEMENT = [4, 5]
+      return c
+    }, 0.05)
+    add('patch_scary', () => new P.ScaryPatch(new ConcatChannels(new Osc(200), new Osc(0.7)), 2), 0.1)
+    add('patch_boop', () => new P.Boop(440, 0.02), 0.05)
+    add('patch_sine_boop', () => new P.SineBoop(72, 0.03).trigger(), 0.05)
+    add('patch_sine_boop_idle', quiet(() => new P.SineBoop()), 0.01)
+    add('patch_space_boop', () => { const b = new P.SpaceBoop(64, 'saw', 0.04, 'decaySquared', [1, 0.5]); b.trigger(); return b }, 0.06)
+    add('patch_space_boop_retuned', () => { const b = new P.SpaceBoop(); b.trigger(70, 0.02); return b }, 0.04)
+    add('patch_fm_osc', seeded(7, () => {
+      const o = new P.FMOsc(220)
+      o.addModulatorOsc(110, 7)
+      o.addModulator(new Osc(3), 0.5)
+      return o
+    }), 0.1)
+    add('patch_fm_osc_cleared', seeded(8, () => { const o = new P.FMOsc(); o.addModulatorOsc(50, 12); o.clearModulation(); return o }), 0.01)
+    add('patch_many_osc', () => P.ManyOsc.ofFrequencies(110, [1, 1.5, 2.01, 3.997]), 0.05)
+    add('patch_many_osc_random', seeded(11, () => P.ManyOsc.random(5, 100, 2000)), 0.02)
+    add('patch_many_osc_shared_f', () => P.ManyOsc.ofFrequencies(new P.LFO(2, 20, 200), [1, 2, 3]), 0.25, [[0, 2048], [SR / 8, 2048]])
+    add('patch_stereo_detune', () => new MultiChannelOsc(new P.StereoDetune(220, 0.3)), 0.05)
+    add('patch_stereo_detune_random', seeded(5, () => new MultiChannelOsc(P.StereoDetune.random(new P.LFO(1, 10, 300), 0.5))), 0.05)
+    add('patch_frequency_group', () => {
+      const fg = new P.FrequencyGroup(110)
+      const h = fg.addHarmonic(1.5)
+      return new Sum(new Osc(fg.fOuts[0]), new Osc(h))
+    }, 0.03)
+    add('patch_frequency_group_random', seeded(3, () => {
+      const fg = new P.FrequencyGroup()
+      return Sum.many(fg.addRandomHarmonics(4).map((f) => new Osc(f)))
+    }), 0.03)
+    add('patch_ap_stack', seeded(21, () => { const st = new P.APStack(4, 0.01, 0.5); st.IN = new Osc(220, 'saw'); return st }), 0.1)
+    add('patch_ap_web', seeded(22, () => { const w = new P.APWeb(4, 0.01, 0.3); w.IN = new Osc(150, 'square'); return w }), 0.1)
+    add('patch_attenuation_matrix', seeded(23, () => {
+      const nodes = [new FixedDelay(0.004), new FixedDelay(0.0071), new Filter(0, 900)]
+      const m = new P.AttenuationMatrix({ nodes, allowFeedback: false, pConnection: 0.8, pMix: 0.9, minAmmount: -12, maxAmmount: -3 })
+      m.IN = new Multiply(new Osc(400), new Ramp(600, 1, 0).trigger())
+      return m
+    }), 0.1)
+    add('patch_lfo_random', seeded(31, () => new Osc(P.LFO.randomInRange(8, 100, 900, 'saw'))), 0.25, [[0, 4096]])
+    add('patch_shape_random', seeded(32, () => Shape.randomInRange(0.03, -1, 1).trigger()), 0.05)
+    add('patch_all_pass_series', seeded(33, () => { const s = AllPass.manyRandomInSeries(3, 0.01, 0.6); s.IN.set(new Osc(300, 'saw')); return s.OUT }), 0.05)
+
+    // patches and scheduled events: Patch.schedule runs the callback with the patch as `this`; the events travel on units[0]
+    add('ev_patch_trigger_group', () => {
+      const tg = new P.TriggerGroup()
+      tg.addTrigger(new P.Boop(440, 0.01))
+      tg.addTrigger(new P.SineBoop(76, 0.015), 'high')
+      tg.scheduleTrigger(0.02, 0)
+      tg.scheduleTrigger(0.03, 'high')
+      tg.scheduleTrigger(0.04, 'nobody')
+      return tg
+    }, 0.06)
+    add('ev_patch_schedule', () => {
+      const lfo = new P.LFO(4, 100, 300)
+      lfo.schedule(0.02, function () { this.F = 40; this.waveform = 'square' })
+      lfo.schedule(0.04, function () { this.trigger() })
+      return new Osc(lfo)
+    }, 0.06)
+    add('ev_patch_synth', () => {
+      const s = new P.Synth()
+      const env = s.addEnvelope(new Shape('decay', 0.01))
+      const osc = new Osc(500)
+      s.addUnits(env, osc)
+      s._trigger = function (p) { osc.F = p }
+      s.aliasOutlet(new Multiply(osc, env).OUT)
+      s.schedule(0.01, function () { this.trigger(700) })
+      s.schedule(0.03, function () { this.trigger(350.5) })
+      return s
+    }, 0.05)
+    add('ev_patch_space_boop', () => {
+      const b = new P.SpaceBoop(60, 'sin', 0.01)
+      b.schedule([0.005, 0.02], function () { this.trigger() })
+      b.schedule(0.03, function () { this.trigger(72, 0.004); this.PLACEMENT = [-2, 1] })
+      return b
+    }, 0.045)
+    add('ev_patch_stereo_osc', () => {
+      const o = new P.StereoOsc(60, -3, 0)
+      o.schedule(0.01, function () { this.P = 67; this.PAN = -1 })
+      o.scheduleTrigger(0.02)
+      return o
+    }, 0.03)
+  }
   return cases
 }

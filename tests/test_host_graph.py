@@ -8,7 +8,9 @@ from conftest import ALL_GOLDEN, Golden
 from dusp_amd import descriptor
 
 
-@pytest.mark.parametrize("name", ALL_GOLDEN)
+# patch_* vectors come from the reference's patch builders, which only the JS host mirrors (dusp_amd/js/lib/patches.js);
+# their descriptors still feed the oracle and GPU parity tests
+@pytest.mark.parametrize("name", [n for n in ALL_GOLDEN if not n.startswith("patch_")])
 def test_python_graph_extracts_to_the_reference_descriptor(name):
     g = Golden(name)
     ex = descriptor.extract(cases.build(name, g.sample_rate))
