@@ -258,7 +258,7 @@ static int finish_build(dusp_program *prog) {
     }
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
-                 : (loopable && prog->loop_two_stage) ? DUSP_ENGINE_LOOP
+                 : (loopable && (prog->loop_two_stage || prog->wave.ring_events)) ? DUSP_ENGINE_LOOP  // (one lane per voice beats slot rounds)
                  : wavable ? DUSP_ENGINE_WAVE
                  : loopable ? DUSP_ENGINE_LOOP
                            : DUSP_ENGINE_CHUNK;
@@ -502,6 +502,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.clock0 = (uint64_t)P.g.clock0;
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
         w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
+        w.ring_events = prog->wave.ring_events ? 1u : 0u;
         w.n_params = (uint32_t)P.g.n_params;
         w.ring_samples = (uint64_t)P.ring_samples;
         const bool resume = prog->keep_memory;

@@ -87,6 +87,7 @@ struct WaveArgs {
     float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
     uint64_t ring_samples, clock0;
     uint32_t has_filter, has_modulated_filter;
+    uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
     // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
     // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
     // in 2^-36 units (bit 63 = poisoned by a NaN / Inf increment).
@@ -110,6 +111,7 @@ inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_modulated_fil
 
 struct WavePlan {
     bool ok = false, has_filter = false, has_modulated_filter = false;
+    bool ring_events = false;  // a delay line that goes through ordered slot operations (short / signal-rate Delay, MonoDelay, ReadBackDelay)
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
     std::vector<int> osc_level;  // per device op (-1: not an Osc)
@@ -353,6 +355,16 @@ inline void build_sum_voices(const FusedPlan &plan, uint32_t sample_rate, int gb
     }
 }
 
+// Delay with a constant delay of at least a chunk, and a chunk short of the ring's length: the wave engine's write-once
+// ring protocol (same predicate as delay_is_write_once in wave_engine.hip); other Delays go through ordered slot operations.
+inline bool delay_write_once(const DevOp &op) {
+    if (op.in[1].kind != SRC_CONST) return false;
+    const double len = (double)op.ring_len;
+    double dconst = (double)op.in[1].cval;
+    if (dconst >= len) dconst = std::fmod(dconst, len);
+    return std::floor(dconst) >= kChunk && std::floor(dconst) + kChunk <= len;
+}
+
 // Can the wave engine (one wavefront per instance, chunk buffers in LDS) run this program?
 inline bool plan_wave(const Program &P, WavePlan &plan) {
     const Graph &g = P.g;
@@ -370,13 +382,16 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
             if (op.ring_len < kChunk || op.ring_len >= (1ll << 31)) return no("CircleBuffer shorter than a chunk");
         }
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
-    plan.has_filter = plan.has_modulated_filter = false;
+    plan.has_filter = plan.has_modulated_filter = plan.ring_events = false;
     for (const DevOp &op : P.ops) {
+        plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY;
         plan.has_filter = plan.has_filter || op.op == OP_FILTER;
         // per-wave scratch (3 x 256 doubles): a Filter with a connected cutoff, or a unit with a serial stage
         plan.has_modulated_filter = plan.has_modulated_filter || (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) || op.op == OP_SHAPE ||
                                     op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX || op.op == OP_FIXED_DELAY ||
-                                    op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC;
+                                    op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
+                                    (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY ||
+                                    op.op == OP_READBACK_DELAY;  // (slot-ownership table of the ordered ring operations)
     }
     if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");
@@ -396,14 +411,9 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
                 return no("Ramp outside the closed-form regime");
             break;
         }
-        case OP_DELAY: {  // only a constant delay of at least one chunk reads and writes its ring in parallel
-            if (op.in[1].kind != SRC_CONST) return no("Delay with a connected / per-instance delay");
-            double dconst = (double)op.in[1].cval;
-            const double len = (double)op.ring_len;
-            if (dconst >= len) dconst = std::fmod(dconst, len);
-            if (!(std::floor(dconst) >= kChunk && std::floor(dconst) + kChunk <= len)) return no("Delay shorter than a chunk");
+        case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:  // write-once ring protocol or ordered slot operations (wave_engine.hip)
+            if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("delay ring out of range");
             break;
-        }
         case OP_FILTER:
         case OP_MULTIPLY:
         case OP_SUM:
@@ -416,7 +426,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
             break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;  // stateless maps
-            return no("unit the wave engine does not run (short / modulated delay lines, MonoDelay, ReadBackDelay)");
+            return no("unit the wave engine does not run");
         }
     }
     // Ramp: t / duration with a 2-FMA reciprocal refinement where it provably equals the division on every t this Ramp
@@ -448,7 +458,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];
         if (op.op == OP_DELAY || op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX ||
-            op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC)
+            op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
+            op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY)
             plan.splittable = false;  // state that is not a modular sum
         int dep = 0;
         for (int j = 0; j < kMaxIn; j++)

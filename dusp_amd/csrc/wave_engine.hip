@@ -80,6 +80,16 @@ struct V4 {
     float v[4];
 };
 
+// Delay with a constant delay of at least a chunk (and a chunk short of the ring's length): reads and writes of one chunk
+// never meet, every slot receives its two taps from neighbouring samples — computed in registers, written once.
+__device__ __forceinline__ bool delay_is_write_once(const DevOp &op) {
+    if (op.in[1].kind != SRC_CONST) return false;
+    const double len = (double)op.ring_len;
+    double dconst = (double)op.in[1].cval;
+    if (dconst >= len) dconst = fmod(dconst, len);
+    return floor(dconst) >= (double)kChunk && floor(dconst) + (double)kChunk <= len;
+}
+
 __device__ __forceinline__ V4 load_operand(const DevOperand &o, const f32x4 *bufs, uint32_t lane, const float *params,
                                            uint32_t n_inst, uint32_t inst) {
     V4 r;
@@ -104,7 +114,9 @@ __device__ __forceinline__ long long wave_inclusive_scan(long long x, uint32_t l
 
 }  // namespace
 
-template <int TBL, int WAVES>
+// TBL: half wave table in LDS.  WAVES: wavefronts (instances) per workgroup.  RING: carries the ordered slot operations of
+// short / signal-rate delay lines — a separate variant, so that programs without them keep the leaner kernel.
+template <int TBL, int WAVES, int RING>
 __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BLOCK = WAVES * 64;
@@ -172,7 +184,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }  // else: accumulate from 0 — the segment's phase total
             }
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY)
                 os[0] = A.init_state[op.state_slot];
             // Delay's carried input sample is engine-internal (no descriptor carries it): a continued render takes it
             // from where the previous launch left it
@@ -392,7 +404,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 continue;  // the output chunk is already in LDS
             }
-            case OP_DELAY: {  // Delay.js:20-41, constant delay D + phi with 256 <= D <= len - 256 (plan_wave checks)
+            case OP_DELAY:  // Delay.js:20-41
+              if (!RING || delay_is_write_once(op)) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
                 double *ds = opstate + (size_t)u * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const int64_t len = op.ring_len;
@@ -438,7 +451,123 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 63) ds[0] = (double)x.v[3];
                 break;
-            }
+              }
+              [[fallthrough]];
+            case OP_MONO_DELAY: case OP_READBACK_DELAY: if constexpr (RING != 0) {
+                // Delay lines whose taps can land anywhere: signal-rate or sub-chunk delays (Delay.js:26-40), MonoDelay
+                // (MonoDelay.js:16-30), ReadBackDelay (ReadBackDelay.js:24-44).  The reference walks the chunk sample by
+                // sample — read-and-clear one slot, add a tap to each of two others — in f32, so the ORDER of the operations
+                // on one slot matters, while operations on different slots commute.  Each lane owns four samples = up
+                // to twelve slot operations, keyed 3 t + j in the reference's order.  Rounds: every pending operation bids
+                // for its slot with its key (ds_min_u32 on a 1024-entry table indexed by slot mod 1024: two slots sharing
+                // an entry only cost extra rounds), the lowest key of each entry performs its operation on the ring in
+                // HBM, and so on until nothing is pending — three rounds for a steady delay, whatever the modulation does
+                // the result is the reference's.
+                double *ss = opstate + (size_t)u * kOpState;
+                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const V4 dl = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
+                const uint32_t len = (uint32_t)op.ring_len;
+                const double dlen = (double)len;
+                float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
+                uint32_t *own = (uint32_t *)scratch;
+                constexpr uint32_t kOwnMask = 1023u, kFree = 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
+                const bool is_delay = op.op == OP_DELAY, is_readback = op.op == OP_READBACK_DELAY;
+                // operation j of a sample — Delay: read-clear, add, add; MonoDelay: add, add, read-clear; ReadBackDelay: store, read
+                const int j_read = is_delay ? 0 : is_readback ? 1 : 2;
+                const double T0 = ss[0];  // ReadBackDelay's running sample count
+                const uint32_t tb0 = is_readback ? (uint32_t)(int64_t)fmod(T0, dlen) : (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+                int32_t slot[4][3];
+                double val[4][3];
+                uint32_t pending = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t t = lane * 4 + c;
+                    const uint32_t tb = (tb0 + t) % len;
+                    const double xin = (double)x.v[c];
+                    out.v[c] = 0.f;
+                    // (selects, not `slot[c][j_read] = ..`: a runtime index would put the arrays into scratch memory)
+                    if (is_readback) {
+                        double r = (T0 + (double)t) - (double)dl.v[c] + dlen;
+                        r = (r >= 0.0 && r < dlen) ? r : fmod(r, dlen);
+                        const bool valid = r >= 0.0 && r < dlen && r == floor(r);  // a fractional or negative index reads `undefined`
+                        slot[c][0] = (int32_t)tb; val[c][0] = xin;
+                        slot[c][1] = valid ? (int32_t)r : -1; val[c][1] = 0.0;
+                        slot[c][2] = -1; val[c][2] = 0.0;
+                        if (!valid) out.v[c] = __builtin_nanf("");
+                    } else {
+                        double tWrite = (double)tb + (double)dl.v[c];
+                        if (!(tWrite >= 0.0 && tWrite < dlen))
+                            tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
+                        const double lo = floor(tWrite), frac = tWrite - trunc(tWrite);
+                        double hi = ceil(tWrite);
+                        if (!is_delay && hi >= dlen) hi -= dlen;  // MonoDelay wraps the ceil tap, Delay drops it at index len
+                        const int32_t slo = (lo >= 0.0 && lo < dlen) ? (int32_t)lo : -1, shi = (hi >= 0.0 && hi < dlen) ? (int32_t)hi : -1;
+                        const double vlo = xin * (1.0 - frac), vhi = xin * frac;
+                        slot[c][0] = is_delay ? (int32_t)tb : slo; val[c][0] = is_delay ? 0.0 : vlo;
+                        slot[c][1] = is_delay ? slo : shi;          val[c][1] = is_delay ? vlo : vhi;
+                        slot[c][2] = is_delay ? shi : (int32_t)tb;  val[c][2] = is_delay ? vhi : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (slot[c][j] >= 0) pending |= 1u << (c * 3 + j);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                while (__any(pending != 0)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if (pending & (1u << (c * 3 + j)))
+                                __hip_atomic_fetch_min(&own[(uint32_t)slot[c][j] & kOwnMask], (lane * 4 + c) * 3 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t won = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if ((pending & (1u << (c * 3 + j))) && own[(uint32_t)slot[c][j] & kOwnMask] == (lane * 4 + c) * 3 + j) won |= 1u << (c * 3 + j);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // the winners' slots are distinct: all their loads first (up to twelve L2 round trips in flight per lane), then the stores
+                    float was[4][3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            was[c][j] = 0.f;
+                            if (!(won & (1u << (c * 3 + j)))) continue;
+                            own[(uint32_t)slot[c][j] & kOwnMask] = kFree;
+                            // (plain accesses: the wavefront's ring traffic goes through one L1 in order, and each round ends with vmcnt(0))
+                            if (!(is_readback && j == 0)) was[c][j] = ring[slot[c][j]];
+                        }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            if (!(won & (1u << (c * 3 + j)))) continue;
+                            float *p = ring + slot[c][j];
+                            if (j == j_read) {
+                                out.v[c] = was[c][j];
+                                if (!is_readback && live) *p = 0.f;
+                            } else if (is_readback) {
+                                if (live) *p = (float)val[c][j];
+                            } else if (live)
+                                *p = (float)((double)was[c][j] + val[c][j]);
+                        }
+                    pending &= ~won;
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this round's ring traffic has landed before the next one starts
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 63 && is_delay) ss[0] = (double)x.v[3];
+                if (lane == 0 && is_readback) ss[0] = T0 + (double)kChunk;
+                __builtin_amdgcn_wave_barrier();
+                break;
+            } else break;  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
             case OP_MULTIPLY: {  // Multiply.js:23-34
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -775,7 +904,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const double *os = opstate + (size_t)u * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY)
                 st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];
@@ -837,9 +966,9 @@ hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uin
     return hipGetLastError();
 }
 
-template <int TBL, int WAVES>
+template <int TBL, int WAVES, int RING>
 static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = dusp_wave_kernel<TBL, WAVES>;
+    auto kernel = dusp_wave_kernel<TBL, WAVES, RING>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -875,25 +1004,32 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     const int fit = (int)((budget - table_bytes) / (A.wave_bytes + shared_per_wave));
     const unsigned want = (A.n_inst * A.n_seg + 255) / 256;  // (virtual) instances per CU on a 256-CU part
     int waves = 1;
-    while (waves < 16 && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
+    const int most = A.ring_events ? 8 : 16;  // (the RING variant wants its 256 VGPRs: two waves per SIMD)
+    while (waves < most && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
-#define DUSP_W(T, W) launch_wave_one<T, W>(A, lds_bytes, stream)
-    if (table_bytes) {
-        switch (waves) {
-        case 16: return DUSP_W(1, 16);
-        case 8: return DUSP_W(1, 8);
-        case 4: return DUSP_W(1, 4);
-        case 2: return DUSP_W(1, 2);
-        default: return DUSP_W(1, 1);
-        }
+#define DUSP_W(T, W, R) launch_wave_one<T, W, R>(A, lds_bytes, stream)
+    const int variant = (table_bytes ? 1 : 0) | (A.ring_events ? 2 : 0);
+    switch (variant * 32 + waves) {
+    case 0 * 32 + 16: return DUSP_W(0, 16, 0);
+    case 0 * 32 + 8: return DUSP_W(0, 8, 0);
+    case 0 * 32 + 4: return DUSP_W(0, 4, 0);
+    case 0 * 32 + 2: return DUSP_W(0, 2, 0);
+    case 0 * 32 + 1: return DUSP_W(0, 1, 0);
+    case 1 * 32 + 16: return DUSP_W(1, 16, 0);
+    case 1 * 32 + 8: return DUSP_W(1, 8, 0);
+    case 1 * 32 + 4: return DUSP_W(1, 4, 0);
+    case 1 * 32 + 2: return DUSP_W(1, 2, 0);
+    case 1 * 32 + 1: return DUSP_W(1, 1, 0);
+    case 2 * 32 + 8: return DUSP_W(0, 8, 1);
+    case 2 * 32 + 4: return DUSP_W(0, 4, 1);
+    case 2 * 32 + 2: return DUSP_W(0, 2, 1);
+    case 2 * 32 + 1: return DUSP_W(0, 1, 1);
+    case 3 * 32 + 8: return DUSP_W(1, 8, 1);
+    case 3 * 32 + 4: return DUSP_W(1, 4, 1);
+    case 3 * 32 + 2: return DUSP_W(1, 2, 1);
+    case 3 * 32 + 1: return DUSP_W(1, 1, 1);
     }
-    switch (waves) {
-    case 16: return DUSP_W(0, 16);
-    case 8: return DUSP_W(0, 8);
-    case 4: return DUSP_W(0, 4);
-    case 2: return DUSP_W(0, 2);
-    default: return DUSP_W(0, 1);
-    }
+    return hipErrorInvalidValue;
 #undef DUSP_W
 }
 
