@@ -222,6 +222,11 @@ static int finish_build(dusp_program *prog) {
         if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
     for (size_t k = 0; k < prog->wave.ramp_fastdiv.size() && k < prog->P.ops.size(); k++)
         if (prog->P.ops[k].op == dusp::OP_RAMP) prog->P.ops[k].attr = prog->wave.ramp_fastdiv[k];
+    // A continuation of a resumable program never fails over the engine: the circuit's state may have left the regime of the
+    // engine the program was built with (an oscillator phase gone NaN, ...); the choice then falls to AUTO's rules below.
+    if (prog->rendered && prog->resumable &&
+        ((engine == DUSP_ENGINE_FUSED && !fusable) || (engine == DUSP_ENGINE_WAVE && !wavable)))
+        engine = DUSP_ENGINE_AUTO;
     if (engine == DUSP_ENGINE_FUSED && !fusable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
     if (engine == DUSP_ENGINE_WAVE && !wavable)

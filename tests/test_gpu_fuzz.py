@@ -1,5 +1,6 @@
 """Differential fuzzing of the engines: random circuits built from every unit the wave engine runs — oscillators (FM),
-ramps, envelopes, filters with constant and modulated cutoffs, delay lines, the comb family, CircleBuffer taps,
+ramps, envelopes, filters with constant and modulated cutoffs, delay lines (constant, sub-chunk, signal-rate; MonoDelay,
+ReadBackDelay), the comb family, CircleBuffer taps,
 feedback edges, multi-channel signals — rendered by the wave engine and by the chunk engine (the reference's schedule,
 pinned by the golden vectors) must agree bit for bit, PCM and written-back state, one-shot and in continued segments."""
 import random
@@ -31,7 +32,7 @@ def random_circuit(rng, crng=None):
         feedback_sum = d.Sum(pick(), 0)
         pool.append(feedback_sum)
     for _ in range(rng.randint(3, 9)):
-        kind = rng.randrange(17)
+        kind = rng.randrange(20)
         if kind == 0:
             u = d.Osc(d.Sum(d.Multiply(pick(), rng.cchoice([20, 200])), rng.cchoice([220, 440.5])), rng.choice(["sin", "saw", "triangle", "square"]))
         elif kind == 1:
@@ -42,6 +43,20 @@ def random_circuit(rng, crng=None):
             u = d.Filter(pick(), rng.cchoice([500, 2000.5]) if rng.random() < 0.6 else d.Sum(d.Multiply(pick(), 300), 1500), rng.choice(["LP", "HP"]))
         elif kind == 4:
             u = d.Delay(pick(), rng.choice([256, 300.25, 700, 1000.5]), 2048)
+        elif kind == 17:  # delay lines whose taps meet inside a chunk: sub-chunk, signal-rate, rings shorter than a chunk
+            how = rng.randrange(4)
+            if how == 0:
+                u = d.Delay(pick(), rng.cchoice([0, 1, 30.5, 100, 255.75]), rng.choice([2048, 300]))
+            elif how == 1:
+                u = d.Delay(pick(), d.Sum(d.Multiply(pick(), rng.cchoice([40, 400])), rng.cchoice([200, 500.5])), 2048)
+            elif how == 2:
+                u = d.Delay(pick(), rng.cchoice([10, 77.25, 150]), rng.choice([100, 200]))
+            else:
+                u = d.Delay(d.Multiply(pick(), [1, -0.5]), [rng.cchoice([20.5, 300]), 700.25], 1024)
+        elif kind == 18:
+            u = d.MonoDelay(pick(), rng.cchoice([0, 12.5, 123.5, 4000]) if rng.random() < 0.5 else d.Sum(d.Multiply(pick(), rng.cchoice([30, 300])), 350))
+        elif kind == 19:
+            u = d.ReadBackDelay(pick(), rng.cchoice([0, 100, 2000]) if rng.random() < 0.6 else d.Multiply(d.Timer(), 48000 * 8), rng.choice([4096, 300]))
         elif kind == 5:
             u = d.CombFilter(rng.choice([0.0007, 0.004, 0.02]), const_or_signal(-0.8, 0.8))
             u.IN = pick()
