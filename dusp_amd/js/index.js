@@ -4,12 +4,14 @@
 const graph = require('./lib/graph')
 const renderChannelData = require('./lib/renderChannelData')
 const patches = require('./lib/patches')
+const dusp = require('./lib/dusp')
 
 module.exports = {
   renderChannelData,
   renderMany: renderChannelData.renderMany,
   quick: require('./lib/quick'),
   unDusp: require('./lib/unDusp'),
+  dusp,
   RenderStream: require('./lib/RenderStream'),
   SegmentRenderer: renderChannelData.SegmentRenderer,
   encodeWav: require('./lib/wav').encodeWav,

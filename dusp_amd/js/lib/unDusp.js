@@ -12,6 +12,7 @@
 const graph = require('./graph')
 const quick = require('./quick')
 const { parseExpression } = require('./parse')
+require('./dusp') // attaches the `dusp` descriptors (flag functions) to the unit classes
 
 /* constructor name -> class: everything lib/graph.js can execute and the patches built from it
  * (reference src/patchesAndComponents.js: patches override components of the same name) */
@@ -85,8 +86,11 @@ function constructObject(node, index) {
     if (asInlet) obj[upper] = value
     else obj[attr.property] = value
   }
-  for (const f of node.flags)
-    if (f.flag === 'trigger' && obj instanceof graph.Shape) obj.trigger() // the only flag function (Shape/index.js:63-67)
+  if (obj.dusp && obj.dusp.flagFunctions) // (only Shape has one: `trigger`, Shape/index.js:63-67)
+    for (const f of node.flags) {
+      const run = obj.dusp.flagFunctions[f.flag]
+      if (run) run.call(obj)
+    }
   return obj
 }
 

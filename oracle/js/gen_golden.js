@@ -41,6 +41,8 @@ const CircleBuffer = ref('CircleBuffer.js')
 const CircleBufferReader = ref('components/CircleBufferReader.js')
 const CircleBufferWriter = ref('components/CircleBufferWriter.js')
 const quick = ref('quick.js')
+const refDusp = ref('dusp.js')
+const normaliseLabels = require('../../tests/js/labels')
 const more = {}
 for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardClipAbove', 'HardClipBelow', 'SecondsToSamples',
   'FixedMultiply', 'Gain', 'DecibelToScaler', 'SemitoneToRatio', 'Pow', 'FixedDelay', 'CombFilter', 'AllPass', 'MonoDelay',
@@ -68,6 +70,7 @@ async function main() {
     const target = c.build()
     const ex = extract(target, { allowEvents: true, allowFinishHooks: true }) // before rendering: captures the initial state
     const order = ex.circuit.units.map((u) => u.label + ':' + u.processIndex)
+    const text = normaliseLabels(refDusp(target.isPatch ? target.defaultOutlet : target)) // the reference's own stringifier, before any tick
     const cd = await renderChannelData(target, c.duration)
     const n = cd[0].length
     const windows = (c.windows || [[0, n]]).map(([a, len]) => [a, Math.min(len, n - a)])
@@ -80,7 +83,7 @@ async function main() {
     fs.writeFileSync(path.join(OUT, c.name + '.desc.f64'),
       Buffer.from(ex.words.buffer, ex.words.byteOffset, ex.words.byteLength))
     const meta = { name: c.name, sample_rate: SR, chunk_size: ex.chunkSize, duration: c.duration,
-      n_samples: n, n_channels: cd.length, windows, sha256_full: h.digest('hex'),
+      n_samples: n, n_channels: cd.length, windows, sha256_full: h.digest('hex'), dusp: text,
       reference_unit_order: order.length <= 64 ? order : order.slice(0, 8).concat(['...' + order.length + ' units']) }
     fs.writeFileSync(path.join(OUT, c.name + '.json'), JSON.stringify(meta, null, 1) + '\n')
     // ev_: scheduled events (both hosts); rt_ and ev_patch_: features only the JS host has (host-ticked units, patches)

@@ -48,6 +48,9 @@ def test_js_graph_mirror_extracts_the_reference_descriptors(sr):
     assert count >= (101 if sr == 48000 else 5)
     rep = run_js("check_descriptors.js", "--sampleRate=%d" % sr)
     assert rep["sampleRate"] == sr and rep["checked"] == count and rep["bad"] == 0 and rep["unifyOk"]
+    # lib/dusp.js prints every case's graph exactly as the reference's dusp() did (labels renumbered), and most of those
+    # strings are fixed points of unDusp -> dusp
+    assert rep["strings"] == count and rep["badStrings"] == 0 and rep["roundTrips"] >= 0.8 * count
 
 
 @needs_node
