@@ -374,24 +374,22 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         return false;
     };
     if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
-    // CircleBuffer nodes: with a lane-constant offset a node touches 256 consecutive slots per chunk (lane-parallel);
-    // a modulated offset can make two samples of one chunk meet in one slot, and a ring shorter than a chunk wraps onto itself
+    // CircleBuffer nodes: with a lane-constant offset a node touches 256 consecutive slots per chunk (lane-parallel); a
+    // signal-rate offset can make two samples of one chunk meet in one slot, and a ring shorter than a chunk wraps onto
+    // itself: those go through the ordered slot operations (below: ring_events)
     for (const DevOp &op : P.ops)
-        if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) {
-            if (op.in[0].kind == SRC_BUF) return no("CircleBuffer node with a signal-rate offset");
-            if (op.ring_len < kChunk || op.ring_len >= (1ll << 31)) return no("CircleBuffer shorter than a chunk");
-        }
+        if ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.ring_len < 1 || op.ring_len >= (1ll << 31))) return no("CircleBuffer ring out of range");
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
     plan.has_filter = plan.has_modulated_filter = plan.ring_events = false;
     for (const DevOp &op : P.ops) {
-        plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY;
+        plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
+                           ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
         plan.has_filter = plan.has_filter || op.op == OP_FILTER;
         // per-wave scratch (3 x 256 doubles): a Filter with a connected cutoff, or a unit with a serial stage
         plan.has_modulated_filter = plan.has_modulated_filter || (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) || op.op == OP_SHAPE ||
                                     op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX || op.op == OP_FIXED_DELAY ||
                                     op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
-                                    (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY ||
-                                    op.op == OP_READBACK_DELAY;  // (slot-ownership table of the ordered ring operations)
+                                    plan.ring_events;  // (slot-ownership table of the ordered ring operations)
     }
     if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");

@@ -198,6 +198,144 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
         }
     __syncthreads();
 
+
+    // ---- Ordered slot operations (RING variant): ring units whose accesses can land anywhere — a Delay with a signal-rate
+    // or sub-chunk delay (Delay.js:26-40), MonoDelay (MonoDelay.js:16-30), ReadBackDelay (ReadBackDelay.js:24-44),
+    // CircleBuffer nodes with a signal-rate offset or a ring shorter than a chunk (CircleBufferReader.js:12-25,
+    // CircleBufferWriter.js:12-25).  The reference walks the chunk sample by sample — read (and clear) one slot, add a tap
+    // to each of two others, ... — in f32, so the ORDER of the operations on one slot matters, while operations on
+    // different slots commute.  Each lane owns four samples = up to twelve slot operations, keyed 3 t + j in the
+    // reference's order.  Rounds: every pending operation bids for its slot with its key (ds_min_u32 on a 1024-entry
+    // table indexed by slot mod 1024: two slots sharing an entry only cost extra rounds), the lowest key of each entry
+    // performs its operation on the ring in HBM, and so on until nothing is pending — three rounds for a steady delay;
+    // whatever the modulation does, the result is the reference's.
+    enum : int { RO_NONE = 0, RO_READ, RO_READ_CLEAR, RO_ADD, RO_STORE };
+    auto ordered_ring_ops = [&](const DevOp &op, uint32_t u, uint32_t g, V4 &out) {
+        double *ss = opstate + (size_t)u * kOpState;
+        const bool is_delay = op.op == OP_DELAY, is_mono = op.op == OP_MONO_DELAY, is_readback = op.op == OP_READBACK_DELAY;
+        const bool is_reader = op.op == OP_CB_READER, is_writer = op.op == OP_CB_WRITER;
+        const bool writer_mixes = is_writer && !(op.attr & 2);
+        // operand 0: the signal (delay lines) or the offset (CircleBuffer nodes); operand 1: the delay / the writer's input
+        const V4 p0 = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+        V4 p1 = {{0.f, 0.f, 0.f, 0.f}};
+        if (!is_reader && !(is_writer && !writer_mixes)) p1 = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
+        const uint32_t len = (uint32_t)op.ring_len;
+        const double dlen = (double)len;
+        float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
+        uint32_t *own = (uint32_t *)scratch;
+        constexpr uint32_t kOwnMask = 1023u, kFree = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
+        // what operation j of a sample does
+        int kind[3];
+        kind[0] = is_delay ? RO_READ_CLEAR : is_mono ? RO_ADD : is_readback ? RO_STORE
+                  : is_reader ? ((op.attr & 1) ? RO_READ_CLEAR : RO_READ)
+                  : (op.attr & 1) ? RO_STORE : writer_mixes ? RO_ADD : RO_NONE;  // writer: preWipe then mix = store; mix alone = add
+        kind[1] = is_delay || is_mono ? RO_ADD : is_readback ? RO_READ : RO_NONE;
+        kind[2] = is_delay ? RO_ADD : is_mono ? RO_READ_CLEAR : RO_NONE;
+        const double T0 = ss[0];  // ReadBackDelay / CircleBuffer nodes: the unit's running sample count
+        const uint32_t tb0 = is_readback ? (uint32_t)(int64_t)fmod(T0, dlen) : (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+        int32_t slot[4][3];
+        double val[4][3];
+        uint32_t pending = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t t = lane * 4 + c;
+            const uint32_t tb = (tb0 + t) % len;
+            out.v[c] = 0.f;
+            // (selects, not `slot[c][j_read] = ..`: a runtime index would put the arrays into scratch memory)
+            if (is_reader || is_writer) {  // CircleBuffer.js:16-18: floor(t % len), negatives wrapped; NaN / Inf go nowhere
+                const double at = is_reader ? T0 + (double)t - srd * (double)p0.v[c] : T0 + (double)t + srd * (double)p0.v[c];
+                double m = (at >= 0.0 && at < dlen) ? at : fmod(at, dlen);
+                m = floor(m);
+                if (m < 0.0) m += dlen;
+                const bool valid = m >= 0.0 && m < dlen;
+                slot[c][0] = valid ? (int32_t)m : -1; val[c][0] = writer_mixes ? (double)p1.v[c] : 0.0;
+                slot[c][1] = slot[c][2] = -1; val[c][1] = val[c][2] = 0.0;
+                if (is_reader && !valid) out.v[c] = __builtin_nanf("");
+            } else if (is_readback) {
+                double r = (T0 + (double)t) - (double)p1.v[c] + dlen;
+                r = (r >= 0.0 && r < dlen) ? r : fmod(r, dlen);
+                const bool valid = r >= 0.0 && r < dlen && r == floor(r);  // a fractional or negative index reads `undefined`
+                slot[c][0] = (int32_t)tb; val[c][0] = (double)p0.v[c];
+                slot[c][1] = valid ? (int32_t)r : -1; val[c][1] = 0.0;
+                slot[c][2] = -1; val[c][2] = 0.0;
+                if (!valid) out.v[c] = __builtin_nanf("");
+            } else {
+                const double xin = (double)p0.v[c];
+                double tWrite = (double)tb + (double)p1.v[c];
+                if (!(tWrite >= 0.0 && tWrite < dlen))
+                    tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
+                const double lo = floor(tWrite), frac = tWrite - trunc(tWrite);
+                double hi = ceil(tWrite);
+                if (is_mono && hi >= dlen) hi -= dlen;  // MonoDelay wraps the ceil tap, Delay drops it at index len
+                const int32_t slo = (lo >= 0.0 && lo < dlen) ? (int32_t)lo : -1, shi = (hi >= 0.0 && hi < dlen) ? (int32_t)hi : -1;
+                const double vlo = xin * (1.0 - frac), vhi = xin * frac;
+                slot[c][0] = is_delay ? (int32_t)tb : slo; val[c][0] = is_delay ? 0.0 : vlo;
+                slot[c][1] = is_delay ? slo : shi;          val[c][1] = is_delay ? vlo : vhi;
+                slot[c][2] = is_delay ? shi : (int32_t)tb;  val[c][2] = is_delay ? vhi : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (slot[c][j] >= 0 && kind[j] != RO_NONE) pending |= 1u << (c * 3 + j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nodes of one CircleBuffer tick one after another
+        __builtin_amdgcn_wave_barrier();
+        while (__any(pending != 0)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (pending & (1u << (c * 3 + j)))
+                        __hip_atomic_fetch_min(&own[(uint32_t)slot[c][j] & kOwnMask], (lane * 4 + c) * 3 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t won = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if ((pending & (1u << (c * 3 + j))) && own[(uint32_t)slot[c][j] & kOwnMask] == (lane * 4 + c) * 3 + j) won |= 1u << (c * 3 + j);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the winners' slots are distinct: all their loads first (up to twelve L2 round trips in flight per lane), then the stores
+            // (plain accesses: the wavefront's ring traffic goes through one L1 in order, and each round ends with vmcnt(0))
+            float was[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    was[c][j] = 0.f;
+                    if (!(won & (1u << (c * 3 + j)))) continue;
+                    own[(uint32_t)slot[c][j] & kOwnMask] = kFree;
+                    if (kind[j] != RO_STORE) was[c][j] = ring[slot[c][j]];
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (!(won & (1u << (c * 3 + j)))) continue;
+                    float *p = ring + slot[c][j];
+                    if (kind[j] == RO_READ || kind[j] == RO_READ_CLEAR) {
+                        out.v[c] = was[c][j];
+                        if (kind[j] == RO_READ_CLEAR && live) *p = 0.f;
+                    } else if (kind[j] == RO_STORE) {
+                        if (live) *p = (float)val[c][j];
+                    } else if (live)
+                        *p = (float)((double)was[c][j] + val[c][j]);
+                }
+            pending &= ~won;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this round's ring traffic has landed before the next one starts
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 63 && is_delay) ss[0] = (double)p0.v[3];
+        if (lane == 0 && (is_readback || is_reader || is_writer)) ss[0] = T0 + (double)kChunk;
+        __builtin_amdgcn_wave_barrier();
+    };
+    (void)ordered_ring_ops;
+
     for (uint32_t g = g_begin; g < g_end; ++g) {
         const uint64_t n0 = (uint64_t)g * kChunk + lane * 4;  // index of this lane's first sample
         for (uint32_t u = 0; u < A.n_ops; ++u) {
@@ -453,121 +591,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
               }
               [[fallthrough]];
-            case OP_MONO_DELAY: case OP_READBACK_DELAY: if constexpr (RING != 0) {
-                // Delay lines whose taps can land anywhere: signal-rate or sub-chunk delays (Delay.js:26-40), MonoDelay
-                // (MonoDelay.js:16-30), ReadBackDelay (ReadBackDelay.js:24-44).  The reference walks the chunk sample by
-                // sample — read-and-clear one slot, add a tap to each of two others — in f32, so the ORDER of the operations
-                // on one slot matters, while operations on different slots commute.  Each lane owns four samples = up
-                // to twelve slot operations, keyed 3 t + j in the reference's order.  Rounds: every pending operation bids
-                // for its slot with its key (ds_min_u32 on a 1024-entry table indexed by slot mod 1024: two slots sharing
-                // an entry only cost extra rounds), the lowest key of each entry performs its operation on the ring in
-                // HBM, and so on until nothing is pending — three rounds for a steady delay, whatever the modulation does
-                // the result is the reference's.
-                double *ss = opstate + (size_t)u * kOpState;
-                const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
-                const V4 dl = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
-                const uint32_t len = (uint32_t)op.ring_len;
-                const double dlen = (double)len;
-                float *ring = A.rings + (size_t)inst * (size_t)A.ring_samples + (size_t)op.ring_base;
-                uint32_t *own = (uint32_t *)scratch;
-                constexpr uint32_t kOwnMask = 1023u, kFree = 0xffffffffu;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
-                const bool is_delay = op.op == OP_DELAY, is_readback = op.op == OP_READBACK_DELAY;
-                // operation j of a sample — Delay: read-clear, add, add; MonoDelay: add, add, read-clear; ReadBackDelay: store, read
-                const int j_read = is_delay ? 0 : is_readback ? 1 : 2;
-                const double T0 = ss[0];  // ReadBackDelay's running sample count
-                const uint32_t tb0 = is_readback ? (uint32_t)(int64_t)fmod(T0, dlen) : (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
-                int32_t slot[4][3];
-                double val[4][3];
-                uint32_t pending = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t t = lane * 4 + c;
-                    const uint32_t tb = (tb0 + t) % len;
-                    const double xin = (double)x.v[c];
-                    out.v[c] = 0.f;
-                    // (selects, not `slot[c][j_read] = ..`: a runtime index would put the arrays into scratch memory)
-                    if (is_readback) {
-                        double r = (T0 + (double)t) - (double)dl.v[c] + dlen;
-                        r = (r >= 0.0 && r < dlen) ? r : fmod(r, dlen);
-                        const bool valid = r >= 0.0 && r < dlen && r == floor(r);  // a fractional or negative index reads `undefined`
-                        slot[c][0] = (int32_t)tb; val[c][0] = xin;
-                        slot[c][1] = valid ? (int32_t)r : -1; val[c][1] = 0.0;
-                        slot[c][2] = -1; val[c][2] = 0.0;
-                        if (!valid) out.v[c] = __builtin_nanf("");
-                    } else {
-                        double tWrite = (double)tb + (double)dl.v[c];
-                        if (!(tWrite >= 0.0 && tWrite < dlen))
-                            tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
-                        const double lo = floor(tWrite), frac = tWrite - trunc(tWrite);
-                        double hi = ceil(tWrite);
-                        if (!is_delay && hi >= dlen) hi -= dlen;  // MonoDelay wraps the ceil tap, Delay drops it at index len
-                        const int32_t slo = (lo >= 0.0 && lo < dlen) ? (int32_t)lo : -1, shi = (hi >= 0.0 && hi < dlen) ? (int32_t)hi : -1;
-                        const double vlo = xin * (1.0 - frac), vhi = xin * frac;
-                        slot[c][0] = is_delay ? (int32_t)tb : slo; val[c][0] = is_delay ? 0.0 : vlo;
-                        slot[c][1] = is_delay ? slo : shi;          val[c][1] = is_delay ? vlo : vhi;
-                        slot[c][2] = is_delay ? shi : (int32_t)tb;  val[c][2] = is_delay ? vhi : 0.0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (slot[c][j] >= 0) pending |= 1u << (c * 3 + j);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                while (__any(pending != 0)) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            if (pending & (1u << (c * 3 + j)))
-                                __hip_atomic_fetch_min(&own[(uint32_t)slot[c][j] & kOwnMask], (lane * 4 + c) * 3 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t won = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            if ((pending & (1u << (c * 3 + j))) && own[(uint32_t)slot[c][j] & kOwnMask] == (lane * 4 + c) * 3 + j) won |= 1u << (c * 3 + j);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // the winners' slots are distinct: all their loads first (up to twelve L2 round trips in flight per lane), then the stores
-                    float was[4][3];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            was[c][j] = 0.f;
-                            if (!(won & (1u << (c * 3 + j)))) continue;
-                            own[(uint32_t)slot[c][j] & kOwnMask] = kFree;
-                            // (plain accesses: the wavefront's ring traffic goes through one L1 in order, and each round ends with vmcnt(0))
-                            if (!(is_readback && j == 0)) was[c][j] = ring[slot[c][j]];
-                        }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (!(won & (1u << (c * 3 + j)))) continue;
-                            float *p = ring + slot[c][j];
-                            if (j == j_read) {
-                                out.v[c] = was[c][j];
-                                if (!is_readback && live) *p = 0.f;
-                            } else if (is_readback) {
-                                if (live) *p = (float)val[c][j];
-                            } else if (live)
-                                *p = (float)((double)was[c][j] + val[c][j]);
-                        }
-                    pending &= ~won;
-                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this round's ring traffic has landed before the next one starts
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (lane == 63 && is_delay) ss[0] = (double)x.v[3];
-                if (lane == 0 && is_readback) ss[0] = T0 + (double)kChunk;
-                __builtin_amdgcn_wave_barrier();
+            case OP_MONO_DELAY: case OP_READBACK_DELAY:
+                if constexpr (RING != 0) ordered_ring_ops(op, u, g, out);  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
                 break;
-            } else break;  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
             case OP_MULTIPLY: {  // Multiply.js:23-34
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -773,6 +799,12 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_CB_READER: case OP_CB_WRITER: {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
+                if constexpr (RING != 0)
+                    if (op.in[0].kind == SRC_BUF || op.ring_len < kChunk) {  // accesses that can meet inside the chunk
+                        ordered_ring_ops(op, u, g, out);
+                        if (op.op == OP_CB_WRITER) continue;  // no outlet
+                        break;
+                    }
                 // Lane-constant offset: the node's 256 accesses of a chunk are 256 consecutive slots of the ring
                 // (index = floor((T + t -+ sr*offset) % len), negatives wrapped), one per sample, lane-parallel.  Several
                 // nodes share a ring and tick one after another, so each node waits for the wave's earlier ring traffic.

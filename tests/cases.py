@@ -43,6 +43,37 @@ def _cb2():
     return reader
 
 
+def _cb_moving_tap():
+    buffer = CircleBuffer(1, 0.05)
+    writer = CircleBufferWriter(buffer)
+    writer.preWipe = True
+    writer.IN = Osc(330, "saw")
+    tap = CircleBufferReader(buffer, Sum(Multiply(Osc(3), 0.004), 0.01))
+    tap.chain(writer)
+    fast = CircleBufferReader(buffer, Sum(Multiply(Osc(700), 0.002), 0.02))
+    fast.chain(writer)
+    return Sum(tap, fast)
+
+
+def _cb_moving_writer():
+    buffer = CircleBuffer(1, 0.02)
+    writer = CircleBufferWriter(buffer, Sum(Multiply(Osc(900), 0.003), 0.004))
+    writer.IN = Osc(440)
+    reader = CircleBufferReader(buffer, 0.001)
+    reader.postWipe = True
+    reader.chain(writer)
+    return reader
+
+
+def _cb_short_ring():
+    buffer = CircleBuffer(1, 0.003)
+    writer = CircleBufferWriter(buffer)
+    writer.IN = Multiply(Osc(500), Ramp(3000, 1, 0).trigger())
+    reader = CircleBufferReader(buffer, 0.002)
+    reader.chain(writer)
+    return reader
+
+
 def _mult_inlet_zero():
     m = Multiply(Osc(440), 2)
     m.B = 0
@@ -159,6 +190,7 @@ def builders(sr):
         "fm_sum": lambda: Osc(Sum(Multiply(Osc(3.5, "triangle"), 300), 220.25)),
         "circlebuffer_taps": _taps,
         "circlebuffer_2ch": _cb2,
+        "circlebuffer_moving_tap": _cb_moving_tap, "circlebuffer_moving_writer": _cb_moving_writer, "circlebuffer_short_ring": _cb_short_ring,
         "osc440_480": lambda: Osc(440),
         "mult_2ch": lambda: Multiply(Osc(440), [0.5, 0.25]),
         "repeater": lambda: Repeater(quick.mult(Osc(123.4), 1)),

@@ -109,6 +109,36 @@ module.exports = function goldenCases(L, SR) {
     return reader
   }, 0.05)
 
+  // CircleBuffer nodes whose accesses can meet inside a chunk: a moving tap (chorus), a moving writer, a ring shorter than a chunk
+  add('circlebuffer_moving_tap', () => {
+    const buffer = new CircleBuffer(1, 0.05)
+    const writer = new CircleBufferWriter(buffer)
+    writer.preWipe = true
+    writer.IN = new Osc(330, 'saw')
+    const tap = new CircleBufferReader(buffer, new Sum(new Multiply(new Osc(3), 0.004), 0.01)) // up to 0.58 samples per sample
+    tap.chain(writer)
+    const fast = new CircleBufferReader(buffer, new Sum(new Multiply(new Osc(700), 0.002), 0.02)) // the tap moves faster than time
+    fast.chain(writer)
+    return new Sum(tap, fast)
+  }, 0.1)
+  add('circlebuffer_moving_writer', () => {
+    const buffer = new CircleBuffer(1, 0.02)
+    const writer = new CircleBufferWriter(buffer, new Sum(new Multiply(new Osc(900), 0.003), 0.004)) // writes pile up on slots (mix)
+    writer.IN = new Osc(440)
+    const reader = new CircleBufferReader(buffer, 0.001)
+    reader.postWipe = true
+    reader.chain(writer)
+    return reader
+  }, 0.06)
+  add('circlebuffer_short_ring', () => { // 144 slots: a chunk laps the ring
+    const buffer = new CircleBuffer(1, 0.003)
+    const writer = new CircleBufferWriter(buffer)
+    writer.IN = new Multiply(new Osc(500), new Ramp(3000, 1, 0).trigger())
+    const reader = new CircleBufferReader(buffer, 0.002)
+    reader.chain(writer)
+    return reader
+  }, 0.05)
+
   // G8: length not a multiple of the chunk; 2-channel output; Repeater; quick.mult(x, 1) elision
   add('osc440_480', () => new Osc(440), 0.01)
   add('mult_2ch', () => new Multiply(new Osc(440), [0.5, 0.25]), 0.02)

@@ -82,11 +82,15 @@ def random_circuit(rng, crng=None):
         elif kind == 14:
             u = d.MultiChannelOsc(d.Sum(d.Multiply(pick(), [30, -60]), [200, 300.5]))
         elif kind == 15:  # a CircleBuffer with two taps, one of them fed back
-            buf = d.CircleBuffer(1, rng.choice([0.02, 0.05]))
+            buf = d.CircleBuffer(1, rng.choice([0.02, 0.05, 0.003]))  # (0.003 s: a ring shorter than a chunk)
             w = d.CircleBufferWriter(buf)
             w.preWipe = rng.random() < 0.7
             w.IN = pick()
-            tap = d.CircleBufferReader(buf, rng.cchoice([0.006, 0.011]))
+            if rng.random() < 0.3:  # a moving tap: a signal-rate offset
+                tap = d.CircleBufferReader(buf, d.Sum(d.Multiply(pick(), rng.cchoice([0.002, 0.0004])), rng.cchoice([0.006, 0.011])))
+                tap.postWipe = rng.random() < 0.3
+            else:
+                tap = d.CircleBufferReader(buf, rng.cchoice([0.006, 0.011]))
             tap.chain(w)
             if rng.random() < 0.5:
                 fb = d.CircleBufferWriter(buf, 0.004)
