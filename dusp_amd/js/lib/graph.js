@@ -780,27 +780,73 @@ class Retriggerer extends Unit { // Retriggerer.js:3-43 — calls target.trigger
     if (this.RATE.connected) throw 'dusp-hip: Retriggerer with a signal-rate `rate` is not supported on the GPU path (' + this.label + ')'
     return this.RATE.signalChunk.channelData[0][0]
   }
-  hostTick(chunkSize, commit = true) { // one chunk; returns true when it fired (and, committing, triggers the target)
+  /* Host-tick protocol (lib/renderChannelData.js SegmentRenderer): hostTick() runs the unit's tick for the chunk that is
+   * about to be rendered; peekBegin() / peekNext() then look ahead one chunk at a time WITHOUT touching the unit's state
+   * (would it fire in that chunk?), and skipQuiet(n) commits n looked-at chunks that fired nothing. */
+  hostTick(chunkSize) {
     const rate = this.rateConstant()
-    let t = this.t, fired = false
+    let fired = false
     for (let k = 0; k < chunkSize; k++) {
-      t += rate
-      if (t >= this.sampleRate) { fired = true; if (commit && this._target && this._target.trigger) this._target.trigger(); t -= this.sampleRate }
+      this.t += rate
+      if (this.t >= this.sampleRate) { fired = true; if (this._target && this._target.trigger) this._target.trigger(); this.t -= this.sampleRate }
     }
-    if (commit) this.t = t
     return fired
   }
-  quietChunks(chunkSize, limit) { // how many of the next `limit` chunks pass without firing (state untouched)
+  peekBegin() { this._peekT = this.t }
+  peekNext(chunkSize) {
     const rate = this.rateConstant()
-    let t = this.t
-    for (let c = 0; c < limit; c++)
-      for (let k = 0; k < chunkSize; k++) { t += rate; if (t >= this.sampleRate) return c }
-    return limit
+    let fired = false
+    for (let k = 0; k < chunkSize; k++) {
+      this._peekT += rate
+      if (this._peekT >= this.sampleRate) { fired = true; this._peekT -= this.sampleRate }
+    }
+    return fired
   }
   skipQuiet(chunkSize, chunks) { const rate = this.rateConstant(); for (let k = 0; k < chunks * chunkSize; k++) this.t += rate }
 }
 
-module.exports = { Retriggerer, Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+/* SporadicRetrigger.js:3-31 — every chunk, with probability rate * chunkSize / sampleRate, calls target.trigger().  One
+ * Math.random() per chunk and unit, in tick order: the host ticks it exactly so (looking ahead draws the numbers of the
+ * coming chunks in the same chunk-major order and keeps them on a tape), which makes a render reproducible under a
+ * seeded Math.random just like the reference's. */
+class SporadicRetriggerer extends Unit {
+  constructor(target, rate) {
+    super()
+    this.addInlet('rate', { mono: true })
+    if (target) this.target = target
+    this.RATE = rate || 1
+    this._tape = [] // numbers already drawn for chunks not yet rendered
+  }
+  get target() { return this._target }
+  set target(target) {
+    if (target) {
+      this._target = target
+      this.chainBefore(target)
+    }
+  }
+  get isHostTicked() { return true }
+  rateConstant() {
+    if (this.RATE.connected) throw 'dusp-hip: SporadicRetriggerer with a signal-rate `rate` is not supported on the GPU path (' + this.label + ')'
+    return this.RATE.signalChunk.channelData[0][0]
+  }
+  fires(r, chunkSize) { return r < this.rateConstant() * chunkSize / this.sampleRate }
+  hostTick(chunkSize) {
+    if (!(this._target && this._target.trigger)) return false // (the reference draws nothing without a target)
+    const r = this._tape.length ? this._tape.shift() : Math.random()
+    if (!this.fires(r, chunkSize)) return false
+    this._target.trigger()
+    return true
+  }
+  peekBegin() { this._peekAt = 0 }
+  peekNext(chunkSize) {
+    if (!(this._target && this._target.trigger)) return false
+    if (this._peekAt >= this._tape.length) this._tape.push(Math.random())
+    return this.fires(this._tape[this._peekAt++], chunkSize)
+  }
+  skipQuiet(chunkSize, chunks) { if (this._target && this._target.trigger) this._tape.splice(0, chunks) }
+}
+
+module.exports = { Retriggerer, SporadicRetriggerer, Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
   FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,

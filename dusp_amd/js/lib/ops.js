@@ -78,6 +78,7 @@ const UNITS = Object.freeze({
   Shape: { op: OP.SHAPE, inlets: ['duration', 'min', 'max'] },
   AHD: { op: OP.AHD, inlets: ['attack', 'hold', 'decay'] },
   Retriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
+  SporadicRetriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, SHAPES, UNITS }

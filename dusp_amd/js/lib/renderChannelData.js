@@ -85,7 +85,7 @@ class SegmentRenderer {
     this.circuit = this.first.circuit
     this.chunk = this.first.chunkSize
     this.sampleRate = this.first.sampleRate
-    // units that act through host callbacks between chunks (Retriggerer): ticked here, firing = segment boundary
+    // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer): ticked here, firing = segment boundary
     this.tickers = this.circuit.units.filter((u) => UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick)
     for (const u of this.tickers)
       if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
@@ -114,9 +114,17 @@ class SegmentRenderer {
       }
       if (this.tickers.length) { // this chunk's host ticks (after the events, as in Circuit.tick), then run up to the next firing
         for (const u of this.tickers) u.hostTick(chunk)
+        // look ahead chunk by chunk, every ticker in tick order (the random ones draw their numbers in the reference's
+        // order), never past the next scheduled event; the first chunk in which anything fires starts the next segment
         const room = (next - this.clock) / chunk - 1
-        let quiet = room
-        for (const u of this.tickers) quiet = Math.min(quiet, u.quietChunks(chunk, quiet))
+        let quiet = 0
+        for (const u of this.tickers) u.peekBegin()
+        while (quiet < room) {
+          let fires = false
+          for (const u of this.tickers) fires = u.peekNext(chunk) || fires
+          if (fires) break
+          quiet++
+        }
         for (const u of this.tickers) u.skipQuiet(chunk, quiet)
         next = this.clock + (1 + quiet) * chunk
       }

@@ -6,8 +6,8 @@
  * way it threads (and loses) the `#id` index: only an object's named attributes share the index of the object they
  * belong to — positional arguments and the two sides of an operator each start from scratch, so "#id" references
  * resolve inside "[Multiply a:[Osc #x 3] b:#x]" but not in "[Osc #x 3] * #x" (the reference throws there, and so
- * does this).  `!` builds a Retriggerer, which this package ticks on the host between segments.  `~!`
- * (SporadicRetriggerer: random) and `then` (rewires the graph from a finish callback) are refused with a "dusp-hip:" string.
+ * does this).  `!` / `~!` build a Retriggerer / SporadicRetriggerer, which this package ticks on the host
+ * between segments.  `then` (rewires the graph from a finish callback) is refused with a "dusp-hip:" string.
  */
 const graph = require('./graph')
 const quick = require('./quick')
@@ -137,7 +137,11 @@ function constructOperation(node, index) {
       a.trigger()
       new graph.Retriggerer(a, b)
       return a
-    case 'then': case '~!':
+    case '~!': // sporadic retrigger (constructOperation.js:78-82; unlike `!` it does not trigger first)
+      if (!a.stop || !a.trigger) throw "invalide use of '!~' operator"
+      new graph.SporadicRetriggerer(a, b)
+      return a
+    case 'then':
       throw 'dusp-hip: operator ' + node.operator + ' is not supported on the GPU path'
     default: throw 'Unknown operator: ' + node.operator
   }

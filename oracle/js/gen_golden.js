@@ -49,6 +49,7 @@ for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardCli
   'ReadBackDelay', 'Pan', 'MidiToFrequency', 'Rescale', 'CrossFader', 'VectorMagnitude', 'Timer', 'SampleRateRedux',
   'ConcatChannels', 'PickChannel', 'Retriggerer']) more[n] = ref('components/' + n + '.js')
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
+more.SporadicRetriggerer = ref('components/SporadicRetrigger.js')
 more.Shape = ref('components/Shape')
 more.AHD = ref('components/AHD.js')
 const patches = {}
@@ -58,7 +59,8 @@ for (const n of ['Mixer', 'SimpleDelay', 'StereoOsc', 'LFO', 'MidiOsc', 'BandFil
 const shapeTables = ref('components/Shape/shapeTables.js')
 const waveTables = ref('components/Osc/waveTables.js')
 
-const cases = require('../../tests/js/cases')({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
+const goldenCases = require('../../tests/js/cases')
+const cases = goldenCases({ Osc, Ramp, Multiply, Sum, Filter, Delay, Repeater, CircleBuffer,
   CircleBufferReader, CircleBufferWriter, quick, ...more, patches }, SR)
 const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
 
@@ -67,11 +69,13 @@ async function main() {
   const index = [], eventIndex = [], hostIndex = []
   for (const c of cases) {
     if (ONLY && !ONLY.includes(c.name)) continue
-    const target = c.build()
-    const ex = extract(target, { allowEvents: true, allowFinishHooks: true }) // before rendering: captures the initial state
-    const order = ex.circuit.units.map((u) => u.label + ':' + u.processIndex)
-    const text = normaliseLabels(refDusp(target.isPatch ? target.defaultOutlet : target)) // the reference's own stringifier, before any tick
-    const cd = await renderChannelData(target, c.duration)
+    const [target, ex, order, text, cd] = await goldenCases.withSeed(c.seed, async () => {
+      const target = c.build()
+      const ex = extract(target, { allowEvents: true, allowFinishHooks: true }) // before rendering: captures the initial state
+      const order = ex.circuit.units.map((u) => u.label + ':' + u.processIndex)
+      const text = normaliseLabels(refDusp(target.isPatch ? target.defaultOutlet : target)) // the reference's own stringifier, before any tick
+      return [target, ex, order, text, await renderChannelData(target, c.duration)]
+    })
     const n = cd[0].length
     const windows = (c.windows || [[0, n]]).map(([a, len]) => [a, Math.min(len, n - a)])
     const h = crypto.createHash('sha256')

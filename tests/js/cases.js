@@ -15,7 +15,8 @@ module.exports = function goldenCases(L, SR) {
     Shape, AHD, Retriggerer } = L // + L.patches (optional): the patch builders
   const S = (name) => (SR === 48000 ? name : name + '_sr' + SR)
   const cases = []
-  const add = (name, build, duration, windows) => cases.push({ name: S(name), build, duration, windows })
+  // opts.seed: build AND render under a seeded Math.random (units that draw random numbers while they tick)
+  const add = (name, build, duration, windows, opts) => cases.push({ name: S(name), build, duration, windows, ...(opts || {}) })
 
   // G1: configs[0] — single [Osc 440], 1 s
   add('osc440_1s', () => new Osc(440), 1)
@@ -364,6 +365,36 @@ module.exports = function goldenCases(L, SR) {
       return new Delay(new Multiply(new Osc(700), r), 1000.5, 4096)
     }, 0.3)
   }
+  // SporadicRetriggerer: one Math.random() per chunk decides whether the target is triggered; reproducible under a seeded
+  // Math.random, in the reference and here alike (`seed` makes the generator and the checkers install one)
+  if (L.SporadicRetriggerer) {
+    const { SporadicRetriggerer } = L
+    add('rt_sporadic', () => {
+      const s = new Shape('decay', 0.01).trigger()
+      new SporadicRetriggerer(s, 40)
+      return new Multiply(new Osc(440), s)
+    }, 0.5, undefined, { seed: 101 })
+    add('rt_sporadic_two_and_regular', () => { // two random units and a regular one: the draws interleave chunk by chunk
+      const a = new Shape('decay', 0.008).trigger(), b = new Ramp(1500, 1, 0).trigger(), c = new AHD(0.001, 0.002, 0.01)
+      new SporadicRetriggerer(a, 60)
+      new SporadicRetriggerer(b, 25)
+      new Retriggerer(c, 17)
+      return Sum.many([new Multiply(new Osc(330), a), new Multiply(new Osc(550, 'saw'), b), new Multiply(new Osc(110), c)])
+    }, 0.5, undefined, { seed: 202 })
+    add('rt_sporadic_with_events', () => { // a scheduled event that itself draws a number: the order of the draws is the reference's
+      const s = new Shape('decaySquared', 0.02).trigger()
+      const r = new SporadicRetriggerer(s, 30)
+      const osc = new Osc(300)
+      osc.schedule([0.1, 0.2, 0.3], function () { this.F = 200 + 400 * Math.random() })
+      r.schedule(0.25, function () { this.RATE = 120 })
+      return new Multiply(osc, s)
+    }, 0.4, undefined, { seed: 303 })
+    add('rt_sporadic_certain', () => { // rate * chunk / sampleRate >= 1: fires every chunk
+      const s = new Shape('decay', 0.004).trigger()
+      new SporadicRetriggerer(s, 400)
+      return s
+    }, 0.03, undefined, { seed: 404 })
+  }
   if (Timer)
     add('ev_timer_trigger', () => {
       const tm = new Timer()
@@ -533,4 +564,13 @@ module.exports = function goldenCases(L, SR) {
     }, 0.03)
   }
   return cases
+}
+
+/* run fn (sync or async) under a seeded Math.random, then put the original back */
+module.exports.withSeed = async function withSeed(seed, fn) {
+  if (seed === undefined) return fn()
+  const original = Math.random
+  let x = seed >>> 0
+  Math.random = () => { x = (Math.imul(x, 1664525) + 1013904223) >>> 0; return x / 4294967296 }
+  try { return await fn() } finally { Math.random = original }
 }

@@ -18,7 +18,7 @@ for (const c of cases) {
   if (!fs.existsSync(file)) continue
   const buf = fs.readFileSync(file)
   const want = new Float64Array(buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength))
-  const target = c.build()
+  const target = c.build() // (no case draws random numbers while it is BUILT outside its own seeded wrapper)
   const meta = JSON.parse(fs.readFileSync(path.join(GOLDEN, c.name + '.json'), 'utf8'))
   if (meta.dusp !== undefined) {
     const raw = lib.dusp(target.isPatch ? target.defaultOutlet : target)

@@ -6,7 +6,8 @@ const path = require('path')
 const lib = require('../../dusp_amd/js')
 const SR = lib.config.sampleRate
 const GOLDEN = path.join(__dirname, '..', 'golden')
-const cases = require('./cases')(lib, SR)
+const goldenCases = require('./cases')
+const cases = goldenCases(lib, SR)
 const USES_DEVICE_TAN = /^(loop_|filter_|map_gain|map_db_semitone|map_pow|map_fm_semitone|rest_pan|rest_midi|ev_filter|ev_loop|rt_|str_)/ // device tan() / pow()
 
 async function main() {
@@ -17,8 +18,7 @@ async function main() {
     const meta = JSON.parse(fs.readFileSync(metaFile))
     const buf = fs.readFileSync(path.join(GOLDEN, c.name + '.pcm.f32'))
     const want = new Float32Array(buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength))
-    const target = c.build()
-    const cd = await lib.renderChannelData(target, c.duration)
+    const cd = await goldenCases.withSeed(c.seed, () => lib.renderChannelData(c.build(), c.duration))
     let ok = cd.length === meta.n_channels && cd.sampleRate === SR && cd[0].length === meta.n_samples
     let at = 0, maxErr = 0, scale = 0, exact = true
     for (let ch = 0; ok && ch < meta.n_channels; ch++)
