@@ -9,7 +9,7 @@ from .descriptor import DuspError  # noqa: F401
 from .graph import (Abs, AllPass, Circuit, CircleBuffer, CircleBufferReader, CircleBufferWriter, Clip, CombFilter, DecibelToScaler, Delay,  # noqa: F401
                     Divide, Filter, FixedDelay, FixedMultiply, Gain, MonoDelay, MultiChannelOsc, ReadBackDelay, HardClipAbove, HardClipBelow, Multiply, Osc, PolarityInvert, Pow,
                     Ramp, Repeater, SecondsToSamples, SemitoneToRatio, Subtract, Sum, Unit,
-                    AHD, ConcatChannels, CrossFader, MidiToFrequency, Pan, PickChannel, Rescale, SampleRateRedux, Shape, Timer, VectorMagnitude)
+                    AHD, ConcatChannels, CrossFader, HostSource, MidiToFrequency, Pan, PickChannel, Rescale, SampleRateRedux, Shape, Timer, VectorMagnitude)
 from .render import ChannelData, render_many, renderChannelData  # noqa: F401
 from .runtime import Context, DuspHipError, Program  # noqa: F401
 

@@ -501,6 +501,12 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[2 * NP] = tt;
                 break;
             }
+            case OP_INPUT: {  // a signal the host computed (Noise.js:16-27 draws Math.random() per sample): stream op.attr
+                const float *src = a.inputs + ((size_t)op.attr * a.n_inst + (i < a.n_inst ? i : a.n_inst - 1)) * a.n_samples;
+                const uint64_t t0 = (uint64_t)ck * kChunk;
+                for (int t = 0; t < kChunk; ++t) outp[(size_t)t * NP] = t0 + t < a.n_samples ? src[t0 + t] : 0.f;  // (past the end: never copied out)
+                break;
+            }
             case OP_TIMER: {  // Timer.js:36-41: a running f64 sum of 1/sampleRate, rounded to f32 per sample
                 double tt = st[0];
                 const double period = op.d[0];

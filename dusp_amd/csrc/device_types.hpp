@@ -17,6 +17,7 @@ enum : int {
     OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
     OP_SHAPE, OP_AHD,  // envelopes
     OP_HOST_ONLY,      // a unit that produces no signal and acts through host callbacks (Retriggerer): keeps its place in the unit list
+    OP_INPUT,          // a unit whose signal the HOST computes (Noise: Math.random() per sample): reads input stream `attr`
     OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW,    // stateless maps of at most two operands (map_apply)
     OP_WIDE_FIRST = OP_PAN, OP_WIDE_LAST = OP_VECTOR_MAGNITUDE  // stateless maps of up to kMaxIn operands (map_wide)
 };
@@ -57,6 +58,7 @@ struct ChunkArgs {
     float *rings;           // [ring_samples][n_pad]
     const float *params;    // [n_params][n_inst]
     const float *tables;    // [kNumTables][table_stride]
+    const float *inputs;    // [n_inputs][n_inst][n_samples]   host-generated signals (OP_INPUT); NULL without any
     float *out;             // [n_inst][n_out][n_samples]
     uint64_t n_samples;
     int64_t clock0;

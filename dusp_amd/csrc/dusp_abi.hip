@@ -92,7 +92,7 @@ struct dusp_program {
     // host-side conveniences for segment-by-segment rendering (many short renders + state downloads per second)
     std::vector<double> h_state;   // copy of d_state / d_fused_state, fetched once per render on the first state download
     bool h_state_valid = false;
-    DevBuf<float> d_host_out, d_host_par, d_host_frames;  // dusp_render_host staging, grown on demand
+    DevBuf<float> d_host_out, d_host_par, d_host_frames, d_host_in;  // dusp_render_host staging, grown on demand
     int requested_engine = DUSP_ENGINE_AUTO;
     bool resumable = false;      // built with DUSP_ENGINE_RESUMABLE
     bool persistent = false;     // rings / feedback edges: device memory carries over between segments (CHUNK engine only)
@@ -375,6 +375,7 @@ void dusp_program_destroy(dusp_program *prog) {
     prog->d_rings_wave.release();
     prog->d_host_par.release();
     prog->d_host_frames.release();
+    prog->d_host_in.release();
     prog->d_rings.release();
     prog->d_state.release();
     prog->d_fused_state.release();
@@ -396,6 +397,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     info->n_params = (uint32_t)g.n_params;
     info->engine = (uint32_t)prog->engine;
     info->n_device_ops = (uint32_t)prog->P.ops.size();
+    info->n_inputs = (uint32_t)g.n_inputs;
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
@@ -417,9 +419,26 @@ static int check_tables(dusp_program *prog) {
     return DUSP_OK;
 }
 
+static int render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
+                         float *d_out, void *stream_);
+
 int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, float *d_out,
                        void *stream_) {
     if (!prog) return DUSP_ERR_ARG;
+    if (prog->P.g.n_inputs > 0)
+        CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "render: the program reads host-generated input streams; use dusp_render_device_inputs / dusp_render_host_inputs");
+    return render_device(prog, n_instances, n_samples, d_params, nullptr, d_out, stream_);
+}
+
+int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
+                              float *d_out, void *stream_) {
+    if (!prog) return DUSP_ERR_ARG;
+    if (prog->P.g.n_inputs > 0 && !d_inputs) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "render: the program has input streams but d_inputs is NULL");
+    return render_device(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_);
+}
+
+static int render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
+                         float *d_out, void *stream_) {
     dusp_ctx *ctx = prog->ctx;
     const dusp::Program &P = prog->P;
     if (n_instances < 1 || n_instances > (1u << 24)) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: n_instances must be in [1, 2^24]");
@@ -490,6 +509,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
         w.out_bufs = prog->d_out_bufs.p;
         w.params = d_params;
         w.tables = ctx->d_tables;
+        w.inputs = d_inputs;
         w.out = d_out;
         w.state = prog->d_state.p;
         w.init_state = prog->d_init.p;
@@ -588,6 +608,7 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     a.rings = prog->d_rings.p;
     a.params = d_params;
     a.tables = ctx->d_tables;
+    a.inputs = d_inputs;
     a.out = d_out;
     a.n_samples = n_samples;
     a.clock0 = P.g.clock0;
@@ -623,14 +644,22 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     return DUSP_OK;
 }
 
-static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out, bool interleaved);
+static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, const float *h_inputs, float *h_out,
+                       bool interleaved);
 
 int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out) {
-    return render_host(prog, n_instances, n_samples, h_params, h_out, false);
+    return render_host(prog, n_instances, n_samples, h_params, nullptr, h_out, false);
 }
 
 int dusp_render_host_interleaved(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out) {
-    return render_host(prog, n_instances, n_samples, h_params, h_out, true);
+    return render_host(prog, n_instances, n_samples, h_params, nullptr, h_out, true);
+}
+
+int dusp_render_host_inputs(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, const float *h_inputs,
+                            float *h_out, int interleaved) {
+    if (!prog) return DUSP_ERR_ARG;
+    if (prog->P.g.n_inputs > 0 && !h_inputs) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "render: the program has input streams but h_inputs is NULL");
+    return render_host(prog, n_instances, n_samples, h_params, h_inputs, h_out, interleaved != 0);
 }
 
 int dusp_interleave_device(dusp_ctx *ctx, const float *d_planar, size_t n_instances, size_t n_channels, size_t n_samples, float *d_interleaved,
@@ -646,7 +675,8 @@ int dusp_interleave_device(dusp_ctx *ctx, const float *d_planar, size_t n_instan
     return DUSP_OK;
 }
 
-static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, float *h_out, bool interleaved) {
+static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, const float *h_inputs, float *h_out,
+                       bool interleaved) {
     if (!prog) return DUSP_ERR_ARG;
     dusp_ctx *ctx = prog->ctx;
     if (!h_out) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: h_out is NULL");
@@ -664,8 +694,16 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
         d_par = prog->d_host_par.p;
         e = hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     }
+    const size_t n_in = (size_t)prog->P.g.n_inputs * n_instances * n_samples;
+    float *d_in = nullptr;
+    if (n_in && !h_inputs) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: the program reads host-generated input streams; use dusp_render_host_inputs");
+    if (n_in && e == hipSuccess) {
+        HIP_TRY(ctx, prog->d_host_in.ensure(n_in));
+        d_in = prog->d_host_in.p;
+        e = hipMemcpyAsync(d_in, h_inputs, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) {
-        rc = dusp_render_device(prog, n_instances, n_samples, d_par, d_out, ctx->stream);
+        rc = render_device(prog, n_instances, n_samples, d_par, d_in, d_out, ctx->stream);
         const size_t n_ch = prog->P.out_bufs.size();
         if (rc == DUSP_OK && interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
             HIP_TRY(ctx, prog->d_host_frames.ensure(n_out));

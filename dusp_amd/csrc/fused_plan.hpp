@@ -87,6 +87,7 @@ struct WaveArgs {
     float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
     uint64_t ring_samples, clock0;
     uint32_t has_filter, has_modulated_filter;
+    const float *inputs;   // [n_inputs][n_inst][n_samples] host-generated signals (OP_INPUT)
     uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
     // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
     // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
@@ -419,6 +420,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
         case OP_SHAPE: case OP_AHD: case OP_TIMER: case OP_SAMPLE_RATE_REDUX: break;  // serial stage on one lane, rest lane-parallel
         case OP_CB_READER: case OP_CB_WRITER: break;                                     // checked above
         case OP_MULTI_OSC: break;                                                        // phases on the serial lane, lookups lane-parallel
+        case OP_INPUT: break;                                                            // a float4 per lane from the host's stream
         case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:                     // lane-parallel in rounds of the ring length
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
             break;

@@ -56,6 +56,7 @@ struct DevRing {
 
 struct Graph {
     int sample_rate = 0, chunk = 0, n_params = 0, out_unit = 0;
+    int n_inputs = 0;  // host-generated input streams the INPUT units read (largest index + 1)
     int64_t clock0 = 0;
     std::vector<RingDesc> rings;
     std::vector<UnitDesc> units;
@@ -257,6 +258,11 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         case OP_HOST_ONLY:
             if (!need(0, 0, 0)) return fail(err, where + "bad host-only record");
             break;
+        case OP_INPUT:
+            if (!need(0, 1, 0)) return fail(err, where + "bad input record");
+            if (!(u.attrs[0] >= 0 && u.attrs[0] < 4096) || u.attrs[0] != std::floor(u.attrs[0])) return fail(err, where + "input index out of range");
+            g.n_inputs = std::max(g.n_inputs, (int)u.attrs[0] + 1);
+            break;
         case OP_CONCAT_CHANNELS:
             if (!need(2, 0, 0)) return fail(err, where + "bad ConcatChannels record");
             break;
@@ -298,7 +304,7 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_MIDI_TO_FREQUENCY: return 1;                                   // only channel 0 is ever stored (MidiToFrequency.js:18)
     case OP_RESCALE: return std::max(1, nin(0));                           // Rescale.js:26
     case OP_CROSS_FADER: return std::max(1, std::max(nin(0), nin(1)));     // CrossFader.js:22
-    case OP_VECTOR_MAGNITUDE: case OP_TIMER: case OP_PICK_CHANNEL: case OP_SHAPE: case OP_AHD: return 1;  // mono outlets
+    case OP_VECTOR_MAGNITUDE: case OP_TIMER: case OP_PICK_CHANNEL: case OP_SHAPE: case OP_AHD: case OP_INPUT: return 1;  // mono outlets
     case OP_SAMPLE_RATE_REDUX: return std::max(1, nin(0));                 // SampleRateRedux.js:23-24
     case OP_CONCAT_CHANNELS: return nin(0) + nin(1);                       // ConcatChannels.js:18
     }
@@ -536,6 +542,9 @@ inline bool expand(Program &P, std::string &err) {
         case OP_TIMER:
             op.d[0] = u.attrs[0];
             slot(u.state[0]);
+            break;
+        case OP_INPUT:
+            op.attr = (int)u.attrs[0];
             break;
         case OP_SHAPE:  // mono inlets duration / min / max; attr: table id | left-is-shape << 8 | right-is-shape << 9
             op.n_in = 3;

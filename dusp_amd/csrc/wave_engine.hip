@@ -594,6 +594,12 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             case OP_MONO_DELAY: case OP_READBACK_DELAY:
                 if constexpr (RING != 0) ordered_ring_ops(op, u, g, out);  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
                 break;
+            case OP_INPUT: {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
+                const float *src = A.inputs + ((size_t)op.attr * A.n_inst + inst) * A.n_samples;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out.v[c] = n0 + c < A.n_samples ? src[n0 + c] : 0.f;
+                break;
+            }
             case OP_MULTIPLY: {  // Multiply.js:23-34
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);

@@ -21,6 +21,7 @@ OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, O
  OP_CONCAT_CHANNELS, OP_PICK_CHANNEL) = range(29, 38)  # rest of §8f-1
 OP_SHAPE, OP_AHD = 38, 39  # envelopes (§8f-3)
 OP_HOST_ONLY = 40  # no signal: the unit acts through host callbacks between segments (Retriggerer)
+OP_INPUT = 41  # a signal the host computes (graph.HostSource; the JS host's Noise): attribute = stream index
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
@@ -64,6 +65,7 @@ UNITS = {
     "PickChannel": (OP_PICK_CHANNEL, ["in", "c"]),
     "Shape": (OP_SHAPE, ["duration", "min", "max"]),
     "AHD": (OP_AHD, ["attack", "hold", "decay"]),
+    "HostSource": (OP_INPUT, []),
 }
 DATA_OUTLET = {"MidiToFrequency": "frequency"}  # every other unit's data outlet is "out" (MidiToFrequency.js:6)
 
@@ -77,7 +79,8 @@ class DuspError(Exception):
 
 
 class Extraction:
-    def __init__(self, words, const_sites, labels, sample_rate, chunk_size, circuit):
+    def __init__(self, words, const_sites, labels, sample_rate, chunk_size, circuit, sources=()):
+        self.sources = list(sources)  # HostSource units in stream order (their `samples` feed the render's inputs)
         self.words = words
         self.const_sites = const_sites  # [(kind_pos, val_pos, n)]
         self.labels = labels
@@ -124,7 +127,7 @@ def extract(target, allow_events=False, allow_clock=False):
         rings.append(buf)
         return len(rings) - 1
 
-    body, sites, labels = [], [], []
+    body, sites, labels, sources = [], [], [], []
     for unit in units:
         kind = type(unit).__name__
         if kind not in UNITS:
@@ -182,6 +185,9 @@ def extract(target, allow_events=False, allow_clock=False):
             attrs = [float(unit.compensationDB)]  # a plain property (Pan.js:12)
         elif op == OP_TIMER:
             attrs, state = [unit.samplePeriod], [unit.t]
+        elif op == OP_INPUT:
+            attrs = [len(sources)]
+            sources.append(unit)
         elif op == OP_SAMPLE_RATE_REDUX:
             state = [unit.timeSinceLastUpdate, len(unit.val)] + list(unit.val)
         body += [op, len(inlet_names), len(attrs), len(state)]
@@ -210,7 +216,7 @@ def extract(target, allow_events=False, allow_clock=False):
     base = HEADER_WORDS + len(ring_words)
     words = np.array(head + ring_words + body, dtype=np.float64)
     sites = [(k + base, v + base, n) for (k, v, n) in sites]
-    return Extraction(words, sites, labels, outlet.sampleRate, chunk, circuit)
+    return Extraction(words, sites, labels, outlet.sampleRate, chunk, circuit, sources)
 
 
 class Unified:

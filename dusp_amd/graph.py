@@ -804,6 +804,18 @@ class Timer(Unit):
         return self
 
 
+class HostSource(Unit):
+    """A mono signal the HOST provides (descriptor opcode INPUT): `samples` holds the unit's output from circuit time 0 on
+    (zeros past its end).  This is how a unit that only the host can tick enters a device render — the JS host's Noise
+    (reference src/components/Noise.js:16-27: Math.random() per sample) is generated this way — and a way to feed recorded
+    or externally computed audio into a circuit.  No counterpart class in the reference."""
+
+    def __init__(self, samples):
+        super().__init__()
+        self.addOutlet("out", mono=True)
+        self.samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+
+
 class SampleRateRedux(Unit):
     """reference src/components/SampleRateRedux.js:3-16 — sample & hold every `ammount` samples"""
 

@@ -3,8 +3,8 @@
  * Raw C against <node_api.h> (N-API v4+, present in Node 12): no node-gyp, no node-addon-api.
  *   ctxCreate(device) -> ctx            tableUpload(ctx, id, Float32Array)
  *   programBuild(ctx, Float64Array words, engine) -> prog
- *   programInfo(prog) -> { sampleRate, nUnits, nOutChannels, nParams, engine, shape, nDeviceOps }
- *   render(prog, nInstances, nSamples, Float32Array params | null) -> Promise<Float32Array>
+ *   programInfo(prog) -> { sampleRate, nUnits, nOutChannels, nParams, nInputs, engine, shape, nDeviceOps }
+ *   render(prog, nInstances, nSamples, Float32Array params | null[, interleaved[, Float32Array inputs]]) -> Promise<Float32Array>
  *         (runs dusp_render_host on the libuv pool so the event loop stays live)
  *   stateDownload(prog, instance, unit) -> Float64Array
  *   programDestroy(prog), ctxDestroy(ctx), version(), abiVersion()
@@ -251,6 +251,7 @@ static napi_value fn_program_info(napi_env env, napi_callback_info info) {
     SET_U32("nUnits", pi.n_units);
     SET_U32("nOutChannels", pi.n_out_channels);
     SET_U32("nParams", pi.n_params);
+    SET_U32("nInputs", pi.n_inputs);
     SET_U32("nDeviceOps", pi.n_device_ops);
 #undef SET_U32
     NAPI_OK(napi_create_string_utf8(env, pi.engine == DUSP_ENGINE_FUSED ? "fused" : "chunk", NAPI_AUTO_LENGTH, &v));
@@ -296,6 +297,7 @@ typedef struct {
     dusp_ctx *ctx;
     size_t n_instances, n_samples, n_floats;
     float *params;
+    float *inputs; /* host-generated streams [nInputs][nInstances][nSamples] (copied: the caller may reuse its array) */
     float *out;
     int interleaved; /* frames [instance][sample][channel] instead of planar [instance][channel][sample] */
     int rc;
@@ -306,8 +308,10 @@ static void render_execute(napi_env env, void *data) {
     (void)env;
     render_job *j = (render_job *)data;
     pthread_mutex_lock(&g_lock);
-    j->rc = j->interleaved ? dusp_render_host_interleaved(j->prog, j->n_instances, j->n_samples, j->params, j->out)
-                           : dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
+    if (j->inputs) j->rc = dusp_render_host_inputs(j->prog, j->n_instances, j->n_samples, j->params, j->inputs, j->out, j->interleaved);
+    else
+        j->rc = j->interleaved ? dusp_render_host_interleaved(j->prog, j->n_instances, j->n_samples, j->params, j->out)
+                               : dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
     if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->ctx));
     pthread_mutex_unlock(&g_lock);
 }
@@ -339,14 +343,15 @@ static void render_complete(napi_env env, napi_status status, void *data) {
     napi_delete_reference(env, j->prog_ref);
     napi_delete_async_work(env, j->work);
     free(j->params);
+    free(j->inputs);
     free(j->out);
     free(j);
 }
 
 /* render(prog, nInstances, nSamples, params | null [, interleaved]) -> Promise<Float32Array> */
 static napi_value fn_render(napi_env env, napi_callback_info info) {
-    napi_value argv[5];
-    size_t argc = 5;
+    napi_value argv[6];
+    size_t argc = 6;
     if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 4) {
         throw_string(env, "dusp-hip: wrong number of arguments");
         return NULL;
@@ -388,8 +393,27 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
         throw_string(env, "dusp-hip: render: this program needs a parameter table");
         return NULL;
     }
+    if (argc >= 6) napi_typeof(env, argv[5], &vt);
+    if (argc >= 6 && vt != napi_null && vt != napi_undefined) { /* inputs: Float32Array of nInputs * nInstances * nSamples values */
+        void *data;
+        size_t len;
+        if (!typed_array(env, argv[5], napi_float32_array, &data, &len) || len != (size_t)pi.n_inputs * j->n_instances * j->n_samples || !len) {
+            free(j->params);
+            free(j);
+            throw_string(env, "dusp-hip: render: inputs must be a Float32Array of nInputs * nInstances * nSamples values");
+            return NULL;
+        }
+        j->inputs = (float *)malloc(len * sizeof(float) + 1);
+        memcpy(j->inputs, data, len * sizeof(float));
+    } else if (pi.n_inputs) {
+        free(j->params);
+        free(j);
+        throw_string(env, "dusp-hip: render: this program reads host-generated input streams");
+        return NULL;
+    }
     j->out = (float *)malloc(j->n_floats * sizeof(float) + 1);
     if (!j->out) {
+        free(j->inputs);
         free(j->params);
         free(j);
         throw_string(env, "dusp-hip: render: out of host memory for the PCM buffer");

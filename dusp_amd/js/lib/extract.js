@@ -67,10 +67,11 @@ function extract(target, opts = {}) {
   const body = []
   const constSites = [] // {kindPos, valPos, n} relative to body start
   const labels = []
+  const sources = [] // units whose signal the host computes, in stream order
 
   for (const unit of units) {
     const kind = unit.constructor && unit.constructor.name
-    const spec = UNITS[kind]
+    const spec = UNITS[kind] || (unit.isHostSignal ? UNITS.HostSignal : undefined)
     if (!spec) throw 'dusp-hip: unit type not supported on the GPU path: ' + kind + ' (' + unit.label + ')'
     if (unit.tickInterval !== chunkSize)
       throw 'dusp-hip: unit ' + unit.label + ' has tickInterval ' + unit.tickInterval + ' != chunk size ' + chunkSize
@@ -132,6 +133,12 @@ function extract(target, opts = {}) {
       case OP.TIMER:
         attrs = [unit.samplePeriod]; state = [unit.t]
         break
+      case OP.INPUT: // Noise.js:16-27 reads `this.f[0][t]`: a connected f would have to come back from the device
+        if (unit.inlets.f && unit.inlets.f.connected)
+          throw 'dusp-hip: Noise with a signal-rate `f` is not supported on the GPU path (' + unit.label + ')'
+        attrs = [sources.length]
+        sources.push(unit)
+        break
       case OP.HOST_ONLY:
         if (unit.rateConstant) unit.rateConstant() // throws for a connected rate
         else if (unit.inlets.rate && unit.inlets.rate.connected)
@@ -190,7 +197,7 @@ function extract(target, opts = {}) {
   const base = HEADER_WORDS + ringWords.length
   const words = Float64Array.from(head.concat(ringWords, body))
   for (const s of constSites) { s.kindPos += base; s.valPos += base }
-  return { words, constSites, labels, sampleRate, chunkSize, circuit }
+  return { words, constSites, labels, sampleRate, chunkSize, circuit, sources }
 }
 
 /* Turn N structurally identical circuits ("voices" / a parameter sweep) into ONE

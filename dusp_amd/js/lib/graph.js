@@ -846,7 +846,64 @@ class SporadicRetriggerer extends Unit {
   skipQuiet(chunkSize, chunks) { if (this._target && this._target.trigger) this._tape.splice(0, chunks) }
 }
 
-module.exports = { Retriggerer, SporadicRetriggerer, Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
+/* A unit whose signal the HOST computes (descriptor opcode INPUT): hostChunk(chunkSize) returns the unit's next chunk,
+ * called once per chunk in the circuit's tick order, exactly like a `_tick` would be.  The segment loop of
+ * lib/renderChannelData.js collects the chunks of a segment and hands them to the device as an input stream, where the
+ * rest of the circuit reads them like any other outlet.  Looking ahead (peekNext) computes coming chunks early, in the
+ * same chunk-major order as everything else that is ticked on the host, and keeps them on a tape. */
+class HostSignal extends Unit {
+  constructor() {
+    super()
+    this.addOutlet('out', { mono: true })
+    this._tape = []    // chunks computed ahead of time
+    this._segment = [] // chunks of the segment being assembled
+  }
+  get isHostSignal() { return true }
+  get isHostTicked() { return true }
+  hostChunk(chunkSize) { return new Float32Array(chunkSize) } // silence; subclasses compute their signal here
+  hostTick(chunkSize) { this._segment.push(this._tape.length ? this._tape.shift() : this.hostChunk(chunkSize)); return false }
+  peekBegin() { this._peekAt = 0 }
+  peekNext(chunkSize) {
+    if (this._peekAt >= this._tape.length) this._tape.push(this.hostChunk(chunkSize))
+    this._peekAt++
+    return false
+  }
+  skipQuiet(chunkSize, chunks) { for (let k = 0; k < chunks; k++) this._segment.push(this._tape.shift()) }
+  takeSegment(nSamples, into, at) { // this segment's samples (the last chunk may be cut short) -> into[at ..]
+    let done = 0
+    for (const chunk of this._segment) {
+      const n = Math.min(chunk.length, nSamples - done)
+      if (n > 0) into.set(n === chunk.length ? chunk : chunk.subarray(0, n), at + done)
+      done += chunk.length
+    }
+    this._segment = []
+  }
+}
+
+/* Noise.js:3-27 — a sample-and-hold of Math.random() at rate f (default: a fresh number every sample).  The numbers can
+ * only be drawn by the JavaScript engine, in tick order, so the unit is a HostSignal; with a seeded Math.random a render
+ * is reproducible, here as in the reference. */
+class Noise extends HostSignal {
+  constructor(f) {
+    super()
+    this.addInlet('f')
+    this.F = f || this.sampleRate
+    this.phase = 0
+    this.y = Math.random() * 2 - 1
+  }
+  hostChunk(chunkSize) {
+    if (this.F.connected) throw 'dusp-hip: Noise with a signal-rate `f` is not supported on the GPU path (' + this.label + ')'
+    const f = this.F.signalChunk.channelData[0][0], out = new Float32Array(chunkSize)
+    for (let t = 0; t < chunkSize; t++) {
+      this.phase += f
+      if (this.phase >= this.sampleRate) { this.phase = 0; this.y = 2 * Math.random() - 1 }
+      out[t] = this.y
+    }
+    return out
+  }
+}
+
+module.exports = { Retriggerer, SporadicRetriggerer, HostSignal, Noise, Shape, AHD, Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude, Timer, SampleRateRedux, ConcatChannels, PickChannel,
   FixedDelay, CombFilter, AllPass, MonoDelay, ReadBackDelay, MultiChannelOsc, Event, Subtract, Divide, Pow, PolarityInvert, Abs, DecibelToScaler, SemitoneToRatio, SecondsToSamples,
   FixedMultiply, Clip, HardClipAbove, HardClipBelow, Gain,
   Unit, Inlet, Outlet, Circuit, Osc, Ramp, Multiply, Sum, Filter, Delay,

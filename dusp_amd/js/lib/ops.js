@@ -26,6 +26,7 @@ const OP = Object.freeze({
   // envelopes driven by trigger() events (SURVEY.md §8f-3)
   SHAPE: 38, AHD: 39,
   HOST_ONLY: 40, // no signal: the unit acts through host callbacks between segments (Retriggerer)
+  INPUT: 41, // a signal the HOST computes chunk by chunk (Noise: Math.random() per sample); attribute = stream index
 })
 
 const INLET = Object.freeze({ CONST: 0, CONNECT: 1, PARAM: 2 })
@@ -79,6 +80,8 @@ const UNITS = Object.freeze({
   AHD: { op: OP.AHD, inlets: ['attack', 'hold', 'decay'] },
   Retriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
   SporadicRetriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
+  Noise: { op: OP.INPUT, inlets: [], hostTick: true },
+  HostSignal: { op: OP.INPUT, inlets: [], hostTick: true }, // (and every subclass: lib/graph.js)
 })
 
 module.exports = { MAGIC, VERSION, HEADER_WORDS, OP, INLET, WAVEFORMS, WAVEFORM_NAMES, FILTER_KINDS, SHAPES, UNITS }

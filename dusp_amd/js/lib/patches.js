@@ -577,6 +577,17 @@ class APWeb extends Patch { // patches/APWeb.js:5-23 — random all-passes behin
   }
 }
 
+class Worm extends Patch { // patches/Worm.js:7-26 — low-passed noise: a slowly wandering control signal
+  constructor(f = 1) {
+    super()
+    this.addUnits(this.noise = new g.Noise(), this.filter = new g.Filter(this.noise, f))
+    this.aliasInlet(this.filter.F)
+    this.aliasOutlet(this.filter.OUT)
+    this.F = f
+  }
+  static random(fMax = 5) { return new Worm(quick.multiply(fMax, Math.random())) }
+}
+
 LFO.randomInRange = function (maxF, minMin, maxMax, waveform) { // patches/LFO.js:30-49
   const a = minMin + (maxMax - minMin) * Math.random()
   const b = minMin + (maxMax - minMin) * Math.random()
@@ -586,4 +597,4 @@ LFO.randomInRange = function (maxF, minMin, maxMax, waveform) { // patches/LFO.j
 
 module.exports = { Patch, Mixer, SimpleDelay, StereoOsc, LFO, MidiOsc, BandFilter, MultiTapDelay, DelayMixer, TriggerGroup, Synth,
   SpaceChannel, Space, ScaryPatch, Boop, SineBoop, SpaceBoop, FMOsc, ManyOsc, StereoDetune, FrequencyGroup, AttenuationMatrix,
-  APStack, APWeb }
+  APStack, APWeb, Worm }

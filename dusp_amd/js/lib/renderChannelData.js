@@ -85,8 +85,8 @@ class SegmentRenderer {
     this.circuit = this.first.circuit
     this.chunk = this.first.chunkSize
     this.sampleRate = this.first.sampleRate
-    // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer): ticked here, firing = segment boundary
-    this.tickers = this.circuit.units.filter((u) => UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick)
+    // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer; host-computed signals: Noise): ticked here, firing = segment boundary
+    this.tickers = this.circuit.units.filter((u) => (UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick) || u.isHostSignal)
     for (const u of this.tickers)
       if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
     this.hasEvents = !!(this.circuit.events && this.circuit.events.length) || this.tickers.length > 0
@@ -132,7 +132,12 @@ class SegmentRenderer {
       if (!this.prog) this.prog = n.programBuild(contextFor(ex.sampleRate), ex.words, this.engine)
       else n.programContinue(this.prog, ex.words)
       const len = Math.min(next, start + nSamples) - this.clock // the last segment may end inside a chunk
-      const pcm = await n.render(this.prog, 1, len, null) // Float32Array [channel][len]
+      let inputs = null // the host-computed signals of this segment: [source][len]
+      if (ex.sources.length) {
+        inputs = new Float32Array(ex.sources.length * len)
+        ex.sources.forEach((u, k) => u.takeSegment(len, inputs, k * len))
+      }
+      const pcm = await n.render(this.prog, 1, len, null, false, inputs) // Float32Array [channel][len]
       writeBack(n, this.prog, this.circuit, chunk, len) // advances circuit.clock to `next`
       pieces.push({ pcm, len, nChannels: n.programInfo(this.prog).nOutChannels })
       this.clock = next
@@ -175,7 +180,9 @@ async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Arr
 /* N structurally identical circuits (voices, a parameter sweep) as ONE GPU program:
  * resolves to result[instance][channel] = Float32Array(duration * sampleRate). */
 async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
-  const uni = unify(outlets.map(extract))
+  const extractions = outlets.map(extract)
+  if (extractions.some((ex) => ex.sources.length)) throw 'dusp-hip: renderMany does not take circuits with host-computed signals (Noise)'
+  const uni = unify(extractions)
   const nSamples = sampleCount(duration, uni.sampleRate)
   if (nSamples === 0) return outlets.map(() => [])
   const n = native()

@@ -74,6 +74,17 @@ def write_back(prog, circuit, chunk_size, n_samples, instance=0):
     circuit.clock += ((n_samples + chunk_size - 1) // chunk_size) * chunk_size
 
 
+def _host_inputs(sources, clock, length):
+    """This segment's samples of the circuit's HostSource units -> float32 [n_sources, 1, length] (zeros past a source's end)."""
+    if not sources:
+        return None
+    block = np.zeros((len(sources), 1, length), dtype=np.float32)
+    for k, src in enumerate(sources):
+        have = src.samples[clock:clock + length]
+        block[k, 0, :have.size] = have
+    return block
+
+
 def renderChannelData(outlet, duration=1, TypedArray=np.float32, engine=runtime.ENGINE_AUTO, device=-1):
     """Drop-in for reference src/renderChannelData.js:5-49.  Scheduled events (unit.schedule / scheduleTrigger) are
     honoured the way the reference's Circuit.tick does (Circuit.js:23,57-65): every event due before the end of a
@@ -106,7 +117,7 @@ def renderChannelData(outlet, duration=1, TypedArray=np.float32, engine=runtime.
             else:
                 prog.continue_with(ex.words)
             length = min(nxt, n) - clock  # the last segment may end inside a chunk
-            segments.append(prog.render(length, 1)[0])
+            segments.append(prog.render(length, 1, inputs=_host_inputs(ex.sources, clock, length))[0])
             write_back(prog, circuit, chunk, length)  # advances circuit.clock to `nxt`
             clock = nxt
     finally:

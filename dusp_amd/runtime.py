@@ -21,7 +21,7 @@ EXPORTS = [
     "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
-    "dusp_last_kernel_ms", "dusp_fill_device",
+    "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
 ]
 
 
@@ -35,7 +35,7 @@ class DuspHipError(RuntimeError):
 class ProgramInfo(ctypes.Structure):
     _fields_ = [("sample_rate", ctypes.c_uint32), ("chunk_size", ctypes.c_uint32), ("n_units", ctypes.c_uint32),
                 ("n_out_channels", ctypes.c_uint32), ("n_params", ctypes.c_uint32), ("engine", ctypes.c_uint32),
-                ("n_device_ops", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("shape", ctypes.c_char * 64)]
+                ("n_device_ops", ctypes.c_uint32), ("n_inputs", ctypes.c_uint32), ("shape", ctypes.c_char * 64)]
 
 
 _lib = None
@@ -77,6 +77,8 @@ def load():
     L.dusp_state_download.argtypes = [vp, sz, sz, vp, sz]
     L.dusp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dusp_fill_device.argtypes = [vp, vp, sz, ctypes.c_float, vp]
+    L.dusp_render_device_inputs.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
     _lib = L
     return L
 
@@ -151,6 +153,7 @@ class Program:
         self.n_units = info.n_units
         self.n_out_channels = info.n_out_channels
         self.n_params = info.n_params
+        self.n_inputs = info.n_inputs
         self.engine = ENGINE_NAMES.get(info.engine, str(info.engine))
         self.shape = info.shape.decode()
         self.n_device_ops = info.n_device_ops
@@ -162,9 +165,10 @@ class Program:
         self.ctx._check(self._L.dusp_program_continue(self._h, words.ctypes.data, words.size))
         self._read_info()
 
-    def render(self, n_samples, n_instances=1, params=None, interleaved=False):
+    def render(self, n_samples, n_instances=1, params=None, interleaved=False, inputs=None):
         """Host round trip: float32 [n_instances, n_out_channels, n_samples], or — interleaved — frames
-        [n_instances, n_samples, n_out_channels] (the RenderStream / WAV layout, transposed on the device)."""
+        [n_instances, n_samples, n_out_channels] (the RenderStream / WAV layout, transposed on the device).
+        inputs: the host-generated streams of this call, float32 [n_inputs, n_instances, n_samples] (programs with INPUT units)."""
         shape = (n_instances, n_samples, self.n_out_channels) if interleaved else (n_instances, self.n_out_channels, n_samples)
         out = np.empty(shape, dtype=np.float32)
         pp = None
@@ -173,13 +177,22 @@ class Program:
             if params.shape != (self.n_params, n_instances):
                 raise ValueError("params must have shape (n_params=%d, n_instances=%d)" % (self.n_params, n_instances))
             pp = params.ctypes.data
+        if self.n_inputs:
+            inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+            if inputs.shape != (self.n_inputs, n_instances, n_samples):
+                raise ValueError("inputs must have shape (n_inputs=%d, n_instances=%d, n_samples=%d)" % (self.n_inputs, n_instances, n_samples))
+            self.ctx._check(self._L.dusp_render_host_inputs(self._h, n_instances, n_samples, pp, inputs.ctypes.data, out.ctypes.data, int(interleaved)))
+            return out
         call = self._L.dusp_render_host_interleaved if interleaved else self._L.dusp_render_host
         self.ctx._check(call(self._h, n_instances, n_samples, pp, out.ctypes.data))
         return out
 
-    def render_device(self, n_samples, n_instances, d_params, d_out, stream=None):
+    def render_device(self, n_samples, n_instances, d_params, d_out, stream=None, d_inputs=None):
         """Asynchronous render between device pointers (ints), e.g. torch tensors' data_ptr()."""
-        self.ctx._check(self._L.dusp_render_device(self._h, n_instances, n_samples, d_params, d_out, stream))
+        if d_inputs is not None or self.n_inputs:
+            self.ctx._check(self._L.dusp_render_device_inputs(self._h, n_instances, n_samples, d_params, d_inputs, d_out, stream))
+        else:
+            self.ctx._check(self._L.dusp_render_device(self._h, n_instances, n_samples, d_params, d_out, stream))
 
     def state(self, unit, instance=0):
         buf = np.zeros(128, dtype=np.float64)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 2
+#define DUSP_ABI_VERSION 3
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -54,11 +54,12 @@ typedef enum {
  *   FUSED — time-parallel fused kernels for recognised voice shapes (Osc, Osc x Ramp,
  *           Osc x gain, Sum.many chains): one lane per sample, time split across waves,
  *           16-byte coalesced PCM stores.
- *   WAVE  — one wavefront per instance, chunk buffers in LDS, wavefront-wide phase accumulation:
- *           graphs of Osc / Ramp / Multiply / Sum / Repeater / the stateless maps (incl. FM), Filters,
- *           constant Delays of at least one chunk, the comb family, envelopes, Timer, feedback edges;
- *           CircleBuffer nodes with constant offsets; few instances and a long render are split in time when
- *           the graph allows it.
+ *   WAVE  — one wavefront per instance, chunk buffers in LDS, wavefront-wide phase accumulation: every unit
+ *           of the path (FM, Filters, feedback edges, envelopes, the comb family; delay lines and CircleBuffer
+ *           nodes either lane-parallel or, where their accesses can meet inside a chunk, through ordered slot
+ *           operations); few instances and a long render are split in time when the graph allows it.  Refuses
+ *           by regime, not by unit: channel counts that grow during the first chunks, more chunk buffers than
+ *           LDS holds, an oscillator phase outside [0, sampleRate).
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
@@ -66,8 +67,9 @@ typedef enum {
  *
  * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
  * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose
- * circuit owns delay lines / CircleBuffers or has a feedback edge then run on the CHUNK engine and keep
- * their rings and chunk buffers resident between segments. */
+ * circuit owns delay lines / CircleBuffers or has a feedback edge then run on the WAVE or the CHUNK engine and
+ * keep their rings and chunk buffers resident between segments; a continuation never fails over the engine
+ * (a WAVE program whose state leaves that engine's regime migrates to CHUNK). */
 typedef enum {
     DUSP_ENGINE_AUTO = 0, DUSP_ENGINE_CHUNK = 1, DUSP_ENGINE_FUSED = 2, DUSP_ENGINE_WAVE = 3, DUSP_ENGINE_LOOP = 4,
     DUSP_ENGINE_RESUMABLE = 0x100
@@ -81,7 +83,7 @@ typedef struct {
     uint32_t n_params;       /* per-instance parameter slots the descriptor references */
     uint32_t engine;         /* dusp_engine actually selected */
     uint32_t n_device_ops;   /* channel-expanded ops the kernel executes per chunk */
-    uint32_t reserved;
+    uint32_t n_inputs;       /* host-generated input streams the program reads (dusp_render_*_inputs) */
     char shape[64];          /* FUSED: signature of the fused kernel, e.g. "mul(osc(k),ramp)" */
 } dusp_program_info;
 
@@ -142,6 +144,18 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
  * renders, downloads into h_out (same layouts as above) and synchronises. */
 int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
                      const float *h_params, float *h_out);
+
+/* Host-generated signals.  A descriptor may hold INPUT units (opcode 41, attribute = stream index): units whose
+ * output the HOST computes while the rest of the circuit runs on the device — the reference's Noise
+ * (src/components/Noise.js:16-27: a Math.random() per sample, which only the caller's JavaScript engine can draw in
+ * the reference's order), or any source the caller ticks itself.  dusp_program_info.n_inputs says how many streams the
+ * program reads; bind them at every render:
+ *   inputs   f32 [n_inputs][n_instances][n_samples]  (the samples of THIS render call, i.e. of this segment)
+ * The plain render calls refuse a program with inputs. */
+int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_samples,
+                              const float *d_params, const float *d_inputs, float *d_out, void *stream);
+int dusp_render_host_inputs(dusp_program *prog, size_t n_instances, size_t n_samples,
+                            const float *h_params, const float *h_inputs, float *h_out, int interleaved);
 
 /* Wire format (replaces the per-chunk loop of src/RenderStream.js:36-57 as the thing that produces frames):
  * planar PCM f32 [n_instances][n_channels][n_samples], as the render calls write it, to interleaved frames

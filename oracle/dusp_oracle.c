@@ -31,7 +31,8 @@ enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READ
        OP_CONCAT_CHANNELS, OP_PICK_CHANNEL,
        /* envelopes */
        OP_SHAPE, OP_AHD,
-       OP_HOST_ONLY /* no signal: acts through host callbacks (Retriggerer); ticking it is a no-op */ };
+       OP_HOST_ONLY, /* no signal: acts through host callbacks (Retriggerer); ticking it is a no-op */
+       OP_INPUT /* a signal the host computes (the reference's Noise draws Math.random() per sample): copied from a stream the caller hands over */ };
 #define N_TABLES 9 /* 0-4 oscillator wave tables, 5-8 Shape tables */
 #define MAX_INLETS 5
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
@@ -144,6 +145,10 @@ struct dusp_oracle {
     size_t out_unit;
     long clock;
     float *tables[N_TABLES];
+    /* host-generated input streams [n][input_len], bound by dusp_oracle_set_inputs at clock input_clock0 */
+    const float *inputs;
+    size_t input_len;
+    long input_clock0;
 };
 
 /* ---- wave tables (reference src/components/Osc/waveTables.js:5-40) */
@@ -696,6 +701,13 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_CONCAT_CHANNELS: tick_concat_channels(o, u); break;
         case OP_PICK_CHANNEL: tick_pick_channel(o, u); break;
         case OP_HOST_ONLY: break;
+        case OP_INPUT: { /* the chunk the host computed for this unit (zeros past the end of what it handed over) */
+            for (int t = 0; t < o->chunk; t++) {
+                const long at = o->clock - o->input_clock0 + t;
+                u->out.ch[0][t] = (o->inputs && at >= 0 && (size_t)at < o->input_len) ? o->inputs[(size_t)u->ring * o->input_len + (size_t)at] : 0.f;
+            }
+            break;
+        }
         case OP_SHAPE: tick_shape(o, u); break;
         case OP_AHD: tick_ahd(o, u); break;
         default: tick_map(o, u); break;
@@ -905,6 +917,10 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             if (u->n_inlets || n_attr || n_state) FAIL("unit %zu: bad host-only record", i);
             out_channels = 0;
             break;
+        case OP_INPUT:
+            if (u->n_inlets || n_attr != 1 || n_state || !(a[0] >= 0 && a[0] < 4096)) FAIL("unit %zu: bad input record", i);
+            u->ring = (int)a[0]; /* (the stream's index, kept in the field CircleBuffer nodes use for theirs) */
+            break;
         case OP_SHAPE:
             if (u->n_inlets != 3 || n_attr != 5 || n_state != 3 || !(a[0] >= 5 && a[0] <= 8)) FAIL("unit %zu: bad Shape record", i);
             u->shape_table = (int)a[0];
@@ -922,6 +938,14 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
         chunk_init(&u->out, out_channels, o->chunk);
     }
     return o;
+}
+
+/* Bind the host-generated streams the INPUT units read from now on: f32 [n_streams][n_samples], sample 0 = the
+ * oracle's current clock.  The array must stay alive while the oracle renders. */
+void dusp_oracle_set_inputs(dusp_oracle *o, const float *inputs, size_t n_samples) {
+    o->inputs = inputs;
+    o->input_len = n_samples;
+    o->input_clock0 = o->clock;
 }
 
 void dusp_oracle_destroy(dusp_oracle *o) {

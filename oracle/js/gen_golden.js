@@ -50,12 +50,13 @@ for (const n of ['Subtract', 'Divide', 'PolarityInvert', 'Abs', 'Clip', 'HardCli
   'ConcatChannels', 'PickChannel', 'Retriggerer']) more[n] = ref('components/' + n + '.js')
 more.MultiChannelOsc = ref('components/Osc/MultiChannelOsc.js')
 more.SporadicRetriggerer = ref('components/SporadicRetrigger.js')
+more.Noise = ref('components/Noise.js')
 more.Shape = ref('components/Shape')
 more.AHD = ref('components/AHD.js')
 const patches = {}
 for (const n of ['Mixer', 'SimpleDelay', 'StereoOsc', 'LFO', 'MidiOsc', 'BandFilter', 'MultiTapDelay', 'DelayMixer', 'TriggerGroup',
   'Synth', 'SpaceChannel', 'Space', 'ScaryPatch', 'Boop', 'SineBoop', 'SpaceBoop', 'FMOsc', 'ManyOsc', 'StereoDetune',
-  'FrequencyGroup', 'AttenuationMatrix', 'APStack', 'APWeb']) patches[n] = ref('patches/' + n + '.js')
+  'FrequencyGroup', 'AttenuationMatrix', 'APStack', 'APWeb', 'Worm']) patches[n] = ref('patches/' + n + '.js')
 const shapeTables = ref('components/Shape/shapeTables.js')
 const waveTables = ref('components/Osc/waveTables.js')
 

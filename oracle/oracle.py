@@ -37,6 +37,8 @@ def lib():
         L.dusp_oracle_unit_state.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
         L.dusp_oracle_n_units.restype = ctypes.c_size_t
         L.dusp_oracle_n_units.argtypes = [ctypes.c_void_p]
+        L.dusp_oracle_set_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.dusp_oracle_set_inputs.restype = None
         L.dusp_oracle_wavetable.restype = ctypes.c_int
         L.dusp_oracle_wavetable.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _lib = L
@@ -47,8 +49,9 @@ class OracleError(RuntimeError):
     pass
 
 
-def render(desc, n_samples, params=None, n_instances=1, instance=0, max_channels=8, return_state=False):
-    """Render ONE instance of a descriptor on the CPU oracle -> float32 [n_channels, n_samples]."""
+def render(desc, n_samples, params=None, n_instances=1, instance=0, max_channels=8, return_state=False, inputs=None):
+    """Render ONE instance of a descriptor on the CPU oracle -> float32 [n_channels, n_samples].
+    inputs: this instance's host-generated streams, float32 [n_streams, n_samples] (descriptors with INPUT units)."""
     L = lib()
     desc = np.ascontiguousarray(desc, dtype=np.float64)
     pp = None
@@ -60,6 +63,9 @@ def render(desc, n_samples, params=None, n_instances=1, instance=0, max_channels
     if not h:
         raise OracleError(err.value.decode())
     try:
+        if inputs is not None:
+            inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+            L.dusp_oracle_set_inputs(h, inputs.ctypes.data, inputs.shape[1])
         out = np.zeros((max_channels, int(n_samples)), dtype=np.float32)
         nch = L.dusp_oracle_render(h, int(n_samples), out.ctypes.data, max_channels)
         if nch > max_channels:

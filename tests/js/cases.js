@@ -563,6 +563,31 @@ module.exports = function goldenCases(L, SR) {
       return o
     }, 0.03)
   }
+  // Noise: Math.random() per sample (or per 1/f), drawn on the host in tick order and handed to the device as an input stream
+  if (L.Noise) {
+    const { Noise } = L
+    add('rt_noise', () => new Noise(), 0.02, undefined, { seed: 11 })
+    add('rt_noise_held', () => new Multiply(new Noise(1000.5), new Osc(3)), 0.1, undefined, { seed: 12 }) // sample & hold at 1000.5 Hz
+    add('rt_noise_into_delay', () => { // bursts of noise into a feedback delay line: inputs, rings and segments together
+      const env = new Shape('decay', 0.01).trigger()
+      new Retriggerer(env, 15)
+      const sum = new Sum(new Multiply(new Noise(), env), 0)
+      const d = new Delay(sum, 700.5, 4096)
+      sum.B = new Multiply(d, 0.6)
+      return d
+    }, 0.3, undefined, { seed: 13 })
+    add('rt_noise_and_sporadic', () => { // every kind of draw in one circuit: noise samples, sporadic triggers, an event
+      const env = new Shape('decaySquared', 0.015).trigger()
+      new L.SporadicRetriggerer(env, 50)
+      const n1 = new Noise(), n2 = new Noise(4000)
+      n2.schedule(0.12, function () { this.F = 500 + 1000 * Math.random() })
+      return new Sum(new Multiply(n1, env), new Multiply(n2, 0.25))
+    }, 0.25, undefined, { seed: 14 })
+    if (P && P.Worm) {
+      add('rt_noise_worm', () => new Osc(new Sum(new Multiply(new P.Worm(20), 2000), 440)), 0.2, undefined, { seed: 15 })
+      add('rt_noise_worm_random', () => P.Worm.random(50), 0.1, undefined, { seed: 16 })
+    }
+  }
   return cases
 }
 

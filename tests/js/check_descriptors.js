@@ -9,7 +9,8 @@ const path = require('path')
 const lib = require('../../dusp_amd/js')
 const SR = lib.config.sampleRate
 const GOLDEN = path.join(__dirname, '..', 'golden')
-const cases = require('./cases')(lib, SR)
+const goldenCases = require('./cases')
+const cases = goldenCases(lib, SR)
 const normaliseLabels = require('./labels')
 
 let checked = 0, bad = 0, strings = 0, badStrings = 0, roundTrips = 0
@@ -18,7 +19,14 @@ for (const c of cases) {
   if (!fs.existsSync(file)) continue
   const buf = fs.readFileSync(file)
   const want = new Float64Array(buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength))
-  const target = c.build() // (no case draws random numbers while it is BUILT outside its own seeded wrapper)
+  let target // (built under the case's seed, when it has one: Noise draws a number in its constructor)
+  if (c.seed === undefined) target = c.build()
+  else {
+    const original = Math.random
+    let x = c.seed >>> 0
+    Math.random = () => { x = (Math.imul(x, 1664525) + 1013904223) >>> 0; return x / 4294967296 }
+    try { target = c.build() } finally { Math.random = original }
+  }
   const meta = JSON.parse(fs.readFileSync(path.join(GOLDEN, c.name + '.json'), 'utf8'))
   if (meta.dusp !== undefined) {
     const raw = lib.dusp(target.isPatch ? target.defaultOutlet : target)

@@ -47,8 +47,8 @@ async function main() {
   const solo = await lib.renderChannelData(new lib.Multiply(new lib.Osc(110 * 3 + 0.5), new lib.Ramp(2000, 1, 0).trigger()), 2048 / SR)
   report.manyMatchesSolo = many.length === 5 && many[2][0].every((v, i) => v === solo[0][i])
   // unsupported graphs reject with a string
-  class Noise extends lib.Unit { constructor() { super(); this.addOutlet('out') } }
-  report.unsupported = await lib.renderChannelData(new lib.Multiply(new Noise(), 0.5), 0.01).then(() => 'resolved', (e) => e)
+  class Crackle extends lib.Unit { constructor() { super(); this.addOutlet('out') } } // a unit kind this package does not know
+  report.unsupported = await lib.renderChannelData(new lib.Multiply(new Crackle(), 0.5), 0.01).then(() => 'resolved', (e) => e)
   console.log(JSON.stringify(report))
   process.exit(report.failed.length ? 1 : 0)
 }
