@@ -383,7 +383,7 @@ class Boop extends Patch { // patches/Boop.js:6-28 — an Osc under a triggered 
     /* The reference runs this hook inside the tick in which the envelope ends; it only sets flags on the patch, so here
      * it runs when the envelope's state comes back from the device (marked hostOnly for the descriptor extractor). */
     const hook = () => { this.finish() }
-    hook.hostOnly = true
+    Object.defineProperty(hook, 'hostOnly', { get: () => !this.onFinish && !this._finish }) // (not once the patch itself carries a finish hook)
     this.envelope.onFinish = hook
     this.aliasOutlet(this.mult.OUT)
   }

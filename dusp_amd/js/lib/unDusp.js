@@ -141,7 +141,9 @@ function constructOperation(node, index) {
       if (!a.stop || !a.trigger) throw "invalide use of '!~' operator"
       new graph.SporadicRetriggerer(a, b)
       return a
-    case 'then':
+    case 'then': // (constructOperation.js:45-61) a finish hook that REWIRES the circuit: the units it brings in join the
+      // running circuit behind one-chunk-late edges (the reference's process order), i.e. the new device program would have
+      // to inherit the old one's chunk buffers — not carried over today, so the operator is refused
       throw 'dusp-hip: operator ' + node.operator + ' is not supported on the GPU path'
     default: throw 'Unknown operator: ' + node.operator
   }
