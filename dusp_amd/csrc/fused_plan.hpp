@@ -457,10 +457,17 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
     std::vector<int> buf_depth((size_t)std::max(1, P.n_bufs), 0);
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];
-        if (op.op == OP_DELAY || op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX ||
-            op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
-            op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY)
-            plan.splittable = false;  // state that is not a modular sum
+        // Timer and a Shape with a constant duration run on sums that repeat_add() evaluates anywhere in closed form
+        const bool closed_form_sum =
+            (op.op == OP_TIMER && P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300) ||
+            (op.op == OP_SHAPE && (P.init_state[(size_t)op.state_slot + 1] == 0 ||  // idle: t does not move
+                                   (op.in[0].kind == SRC_CONST && P.init_state[(size_t)op.state_slot] >= 0 && 1.0 / (double)op.in[0].cval > 0 &&
+                                    1.0 / (double)op.in[0].cval < 1e300)));
+        if (!closed_form_sum &&
+            (op.op == OP_DELAY || op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX ||
+             op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
+             op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY))
+            plan.splittable = false;  // state that is neither a modular sum nor a closed-form one
         int dep = 0;
         for (int j = 0; j < kMaxIn; j++)
             if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs) dep = std::max(dep, buf_depth[(size_t)op.in[j].idx]);

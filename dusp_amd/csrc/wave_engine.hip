@@ -33,6 +33,7 @@
 
 #include "device_types.hpp"
 #include "fused_device.hpp"
+#include "repeat_add.hpp"
 #include "map_ops.hpp"
 
 namespace dusp {
@@ -191,6 +192,12 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             if (op.op == OP_DELAY && A.resume) os[0] = A.state[(size_t)op.state_slot * A.n_pad + inst];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
                 for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
+            // time-split: a later segment starts from the running sum's value at its first sample (plan_wave admits only
+            // Timers and constant-duration Shapes whose sums repeat_add covers)
+            if (A.n_seg > 1 && g_begin > 0) {
+                if (op.op == OP_TIMER) os[0] = repeat_add(os[0], op.d[0], (uint64_t)g_begin * kChunk);
+                if (op.op == OP_SHAPE && os[1] != 0.0) os[0] = repeat_add(os[0], 1.0 / (double)op.in[0].cval, (uint64_t)g_begin * kChunk);
+            }
             if (op.op == OP_SAMPLE_RATE_REDUX)
                 for (int k = 0; k < 2; ++k) os[k] = A.init_state[op.state_slot + k];
             if (op.op == OP_FILTER)
@@ -623,7 +630,17 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const double left = (op.attr & 256) ? (double)data[0] : op.d[0];
                 const double right = (op.attr & 512) ? (double)data[sr] : op.d[1];
                 double tt[4];
-                if (ss[1] != 0.0) {  // playing: t += 1 / duration[t], a running f64 sum
+                const double c_lane = 1.0 / (double)dur.v[0];
+                if (ss[1] != 0.0 && op.in[0].kind != SRC_BUF && ss[0] >= 0.0 && c_lane > 0.0 && c_lane < 1.0e300) {
+                    // playing with a constant duration: the running sum in closed form (repeat_add), every lane its own four samples
+                    const double t0 = ss[0];
+                    double t = repeat_add(t0, c_lane, (uint64_t)lane * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tt[c] = t = t + c_lane;
+                    const double t_end = __shfl(t, 63, 64);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) ss[0] = t_end;
+                } else if (ss[1] != 0.0) {  // playing: t += 1 / duration[t], a running f64 sum
                     double *T = scratch;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) T[lane * 4 + c] = 1.0 / (double)dur.v[c];
@@ -661,12 +678,21 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (__ballot(over) && lane == 0) ss[2] = 1.0;  // finish() (UnitOrPatch.js:77-84)
                 break;
             }
-            case OP_TIMER: {  // Timer.js:36-41
+            case OP_TIMER: {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
                 double *ss = opstate + (size_t)u * kOpState;
+                const double period = op.d[0], t0 = ss[0];
+                if (t0 >= 0.0 && period > 0.0 && period < 1.0e300) {  // the running sum in closed form, every lane its own four samples
+                    double t = repeat_add(t0, period, (uint64_t)lane * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) out.v[c] = (float)(t = t + period);
+                    const double t_end = __shfl(t, 63, 64);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) ss[0] = t_end;
+                    break;
+                }
                 float *Y = (float *)scratch;
                 if (lane == 0) {
-                    double t = ss[0];
-                    const double period = op.d[0];
+                    double t = t0;
 #pragma unroll 8
                     for (int k = 0; k < kChunk; ++k) {
                         t += period;

@@ -39,3 +39,14 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(runtime.DuspHipError, match="no usable HIP device|HIP error"):
         runtime.Context()
+
+
+def test_repeat_add_equals_the_plain_loop(tmp_path):
+    """dusp_amd/csrc/repeat_add.hpp (Timer's and Shape's running sums n steps at once; what lets the wave engine evaluate
+    them lane-parallel and split a render in time) against sequential f64 additions, on the CPU: 40 000 random cases."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "repeat_add_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "repeat_add_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe, "40000"]).decode().strip().splitlines()[-1])
+    assert rep["cases"] == 40000 and rep["bad"] == 0

@@ -314,3 +314,49 @@ def test_circlebuffer_batch_wave_equals_chunk():
     assert np.array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_running_sums_in_closed_form_equal_the_sequential_engine():
+    """Timer's and Shape's running f64 sums (`t += c`): the wave engine evaluates them with repeat_add() — lane-parallel inside
+    a chunk, and from the render's start for every time segment — the chunk engine adds sample by sample like the reference.
+    300 voices with random durations (per-instance parameters), then one long circuit split in time."""
+    from dusp_amd import descriptor
+    d.configure(48000)
+    rng = np.random.RandomState(11)
+
+    def voice(dur, f):
+        return d.Multiply(d.Osc(d.Sum(d.Multiply(d.Timer(), 50), f)), d.Shape("decaySquared", dur, -0.25, 1).trigger())
+
+    uni = descriptor.unify([descriptor.extract(voice(0.1 + 0.01 * k, 100 + k)) for k in range(3)])
+    V, n = 300, 48000 * 2 + 77
+    params = np.empty((uni.n_params, V), dtype=np.float32)
+    for p in range(uni.n_params):
+        lo, hi = float(uni.params[p].min()), float(uni.params[p].max())
+        params[p] = rng.uniform(0.001, 5.0, V) if hi < 1 else rng.uniform(lo, hi * 3, V)  # durations from 1 ms to 5 s
+    ctx = render.context(48000)
+    outs, states = [], []
+    for engine in (runtime.ENGINE_CHUNK, runtime.ENGINE_WAVE):
+        prog = ctx.build(uni.words, engine)
+        outs.append(prog.render(n, V, params))
+        states.append([[prog.state(u, i) for u in range(prog.n_units)] for i in (0, 7, V - 1)])
+        prog.close()
+    assert np.array_equal(outs[0], outs[1])
+    for a, b in zip(states[0], states[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+    # one circuit, 10 s: AUTO -> wave engine, split in time; the chunk engine is the sequential reference
+    ex = descriptor.extract(voice(1.37, 330.5))
+    n = 480000
+    whole = ctx.build(ex.words, runtime.ENGINE_CHUNK)
+    want = whole.render(n)
+    want_state = [whole.state(u) for u in range(whole.n_units)]
+    whole.close()
+    split = ctx.build(ex.words)
+    assert split.engine == "wave"
+    got = split.render(n)
+    assert split.last_kernel_ms() < 5.0, "not split in time?"
+    got_state = [split.state(u) for u in range(split.n_units)]
+    split.close()
+    assert np.array_equal(got, want)
+    for x, y in zip(got_state, want_state):
+        assert np.array_equal(x, y, equal_nan=True)
