@@ -37,6 +37,7 @@
 #include "device_types.hpp"
 #include "fused_device.hpp"
 #include "fused_plan.hpp"
+#include "repeat_add.hpp"
 
 namespace dusp {
 
@@ -54,6 +55,37 @@ __device__ __forceinline__ float ramp_value(const FusedArgs &A, double tn, doubl
     } else
         q = tt / A.r_d;
     return (float)(A.r_y0 + q * dy);
+}
+
+// Shape/index.js:33-58 for one sample: the 0..1 shape at t (table lerp, or an edge) scaled into [min, max]
+__device__ __forceinline__ float shape_value(const FusedArgs &A, double t, double srd) {
+    const double l = (double)A.s_min, h = (double)A.s_max;
+    if (t <= 0.0) return (float)((A.s_left_is_shape ? (double)A.s_table[0] : A.s_left) * (h - l) + l);
+    if (t > srd) return (float)((A.s_right_is_shape ? (double)A.s_table[(uint32_t)srd] : A.s_right) * (h - l) + l);
+    if (t != t) return __builtin_nanf("");
+    const double fl = floor(t), frac = t - fl;
+    return (float)(l + (h - l) * ((double)A.s_table[(int)ceil(t)] * frac + (double)A.s_table[(int)fl] * (1.0 - frac)));
+}
+
+// The next `steps` values of t = fl(t + c) as integers, when they all stay in t's binade: t_j = (T + j ce) 2^(K-52)
+// (the reasoning of repeat_add.hpp; t is itself such a sum, so it is a multiple of the binade's unit).
+__device__ __forceinline__ bool linear_run(double t, double c, long long steps, long long &T, long long &ce, int &K) {
+    if (!(t > 0.0 && t < 1.0e300)) return false;
+    K = ilogb(t);
+    if (K < -900) return false;
+    const double inv_u = ldexp(1.0, 52 - K);
+    const double Cs = c * inv_u;
+    if (!(Cs < 9.0e15)) return false;
+    const double qd = floor(Cs), fr = Cs - qd;
+    const long long q = (long long)qd;
+    T = (long long)(t * inv_u);
+    if (fr > 0.5) ce = q + 1;
+    else if (fr < 0.5) ce = q;
+    else {
+        if (T & 1) return false;
+        ce = q + (q & 1);
+    }
+    return T + (steps - 1) * ce <= (1ll << 53) - q - 2;  // the last source still keeps sum and result inside the binade
 }
 
 // phase (in units of 2^E) of this lane's 4 samples at the start of segment `seg`:
@@ -109,6 +141,12 @@ __global__ void dusp_fused_prepare(FusedArgs A, OscRec *recs) {
         A.end_state[(size_t)A.ramp_state_word * A.n_inst + inst] = t_end;
         A.end_state[(size_t)(A.ramp_state_word + 1) * A.n_inst + inst] = playing_end ? 1.0 : 0.0;
     }
+    if (A.shape_state_word >= 0) {  // t keeps running while playing; finish() once a tick sees t > sampleRate (Shape/index.js:40-42)
+        const double t_end = A.s_playing ? repeat_add(A.s_t0, A.s_c, T_end) : A.s_t0;
+        A.end_state[(size_t)A.shape_state_word * A.n_inst + inst] = t_end;
+        A.end_state[(size_t)(A.shape_state_word + 1) * A.n_inst + inst] = A.s_playing ? 1.0 : 0.0;
+        A.end_state[(size_t)(A.shape_state_word + 2) * A.n_inst + inst] = (A.s_finished || (T_end > 0 && t_end > srd)) ? 1.0 : 0.0;
+    }
 }
 
 // KIND: fused shape.  TBL: table placement.  R: voices per work item.  FASTDIV / FINITE:
@@ -157,7 +195,34 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
         const double tn_step = A.r_playing ? (double)kChunk : 0.0;
         const double tn_c = A.r_playing ? 1.0 : 0.0;
         double tn;  // Ramp: t0 + (n + 1) for this lane's first sample n of the current step; idle ramp: t0
+        // Shape: t after the samples before this item (closed form), then step by step — as integers while a whole step
+        // stays inside one binade, else every lane jumps to its own samples
+        const double st0 = (KIND == FUSED_OSC_SHAPE && A.s_playing) ? repeat_add(A.s_t0, A.s_c, t_start) : A.s_t0;
+        double st;
         auto ramp4 = [&](float (&rv)[4]) {
+            if (KIND == FUSED_OSC_SHAPE) {
+                if (!A.s_playing) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rv[c] = shape_value(A, st, srd);
+                } else {
+                    long long T, ce;
+                    int K;
+                    if (linear_run(st, A.s_c, kChunk, T, ce, K)) {
+                        T += (long long)(lane * 4) * ce;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            T += ce;
+                            rv[c] = shape_value(A, ldexp((double)T, K - 52), srd);
+                        }
+                        st = ldexp((double)(T + (long long)(kChunk - 4 - lane * 4) * ce), K - 52);  // t after the step's 256 samples
+                    } else {
+                        double t = repeat_add(st, A.s_c, (uint64_t)lane * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) rv[c] = shape_value(A, t = t + A.s_c, srd);
+                        st = __shfl(t, 63, 64);
+                    }
+                }
+            }
             if (KIND == FUSED_OSC_RAMP) {
                 rv[0] = ramp_value<FASTDIV>(A, tn, dy);
 #pragma unroll
@@ -166,7 +231,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
             }
         };
         auto finish = [&](float v, float rv, float gain) {
-            if (KIND == FUSED_OSC_RAMP) v = v * rv;
+            if (KIND == FUSED_OSC_RAMP || KIND == FUSED_OSC_SHAPE) v = v * rv;
             if (KIND == FUSED_OSC_GAIN) v = v * gain;
             return fix_out<FINITE>(v);
         };
@@ -187,6 +252,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                 gain[r] = rc.gain;
             }
             tn = tn0;
+            st = st0;
             float *row = row0;
             auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
                 for (uint32_t g = ga; g < gb; ++g) {
@@ -234,6 +300,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                     gain[r] = rc.gain;
                 }
                 tn = tn0;
+            st = st0;
                 float *row = row0;
                 auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
                     for (uint32_t g = ga; g < gb; ++g) {
@@ -283,6 +350,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                     bad[r] = rc.bad;
                 }
                 tn = tn0;
+            st = st0;
                 float *row = row0;
                 auto run = [&](uint32_t ga, uint32_t gb, auto vec) {
                     for (uint32_t g = ga; g < gb; ++g) {
@@ -354,6 +422,14 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     A.vec4_ok = (L.n_samples % 4 == 0) && (((uintptr_t)L.out & 15) == 0);
     A.osc_state_word = 0;
     A.ramp_state_word = plan.kind == FUSED_OSC_RAMP ? 1 : -1;
+    A.shape_state_word = plan.kind == FUSED_OSC_SHAPE ? 1 : -1;
+    if (plan.kind == FUSED_OSC_SHAPE) {
+        A.s_table = L.tables + (size_t)plan.s_table_id * L.table_stride;
+        A.s_t0 = plan.s_t0; A.s_c = plan.s_c; A.s_min = plan.s_min; A.s_max = plan.s_max;
+        A.s_left = plan.s_left; A.s_right = plan.s_right;
+        A.s_left_is_shape = plan.s_left_is_shape; A.s_right_is_shape = plan.s_right_is_shape;
+        A.s_playing = plan.s_playing; A.s_finished = plan.s_finished;
+    }
     A.fx32_ok = L.table_fx32_ok && env_int("DUSP_FUSED_FX32", 1) ? 1 : 0;
     A.seg_major = env_int("DUSP_FUSED_SEGMAJOR", 0);
 
@@ -401,6 +477,7 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
         if (plan.r_fastdiv) DUSP_L2(FUSED_OSC_RAMP, true, false);
         DUSP_L2(FUSED_OSC_RAMP, false, false);
     case FUSED_OSC_GAIN: DUSP_L2(FUSED_OSC_GAIN, false, false);
+    case FUSED_OSC_SHAPE: DUSP_L2(FUSED_OSC_SHAPE, false, false);
     }
 #undef DUSP_L2
 #undef DUSP_L3

@@ -8,6 +8,7 @@
 //     osc(k)               Osc with an unconnected (constant / per-instance) f
 //     mul(osc(k),ramp)     the per-voice graph of BASELINE configs[2] / [4]
 //     mul(osc(k),k)        Osc times a constant / per-instance gain
+//     mul(osc(k),shape)    Osc under a Shape envelope with constant duration / min / max: the canonical Dusp voice "O440 * D1"
 // Everything else runs on the chunk engine.
 #pragma once
 #include <cmath>
@@ -19,7 +20,7 @@
 
 namespace dusp {
 
-enum : int { FUSED_OSC = 0, FUSED_OSC_RAMP = 1, FUSED_OSC_GAIN = 2, FUSED_SUMCHAIN = 3 };
+enum : int { FUSED_OSC = 0, FUSED_OSC_RAMP = 1, FUSED_OSC_GAIN = 2, FUSED_SUMCHAIN = 3, FUSED_OSC_SHAPE = 4 };
 
 struct FusedPlan {
     std::string shape, why;
@@ -30,6 +31,10 @@ struct FusedPlan {
     // Ramp (Ramp.js:3-14): duration, y0, y1, initial t / playing; rcp = RN(1/duration)
     double r_d = 1, r_y0 = 0, r_y1 = 0, r_t0 = 0, r_rcp = 1;
     int r_playing = 0, r_fastdiv = 0;
+    // Shape (Shape/index.js:7-59) with constant inlets: table, start t, addend 1/duration, range, edges, flags
+    int s_table_id = 0, s_playing = 0, s_finished = 0, s_left_is_shape = 0, s_right_is_shape = 0;
+    double s_t0 = 0, s_c = 0, s_left = 0, s_right = 0;
+    float s_min = 0, s_max = 1;
     // FUSED_SUMCHAIN: the oscillators of a left-deep Sum.many chain, in chain order
     std::vector<double> sum_f, sum_phase0;
     std::vector<int> sum_units;
@@ -149,6 +154,11 @@ struct FusedArgs {
     double phase0;
     double r_d, r_y0, r_y1, r_t0, r_rcp;
     int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok, seg_major, pad2;
+    // FUSED_OSC_SHAPE
+    const float *s_table;  // row of the Shape's table
+    double s_t0, s_c, s_left, s_right;  // edges as values of the 0..1 shape, unless they are "shape" (= the table's end values)
+    float s_min, s_max;
+    int32_t s_playing, s_finished, shape_state_word, s_left_is_shape, s_right_is_shape, pad3;
 };
 
 // q' of Markstein's division-by-reciprocal: q = t*r; rem = fma(-q, d, t); q' = fma(rem, r, q).
@@ -189,7 +199,7 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         if (u.n_out != 1) return no("multichannel unit");
 
     std::vector<int> used(g.units.size(), 0);
-    int osc_unit = -1, ramp_unit = -1;
+    int osc_unit = -1, ramp_unit = -1, shape_unit = -1;
     bool have_gain = false;
     auto leaf_k = [&](const InletDesc &in) { return in.kind != IN_CONNECT && in.vals.size() == 1; };
     auto take_osc = [&](int ui) {
@@ -213,8 +223,11 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
                 const UnitDesc &s = g.units[(size_t)in.src_unit];
                 if (s.op == OP_OSC) {
                     if (!take_osc(in.src_unit)) return no("second Osc / connected f");
-                } else if (s.op == OP_RAMP && ramp_unit < 0) {
+                } else if (s.op == OP_RAMP && ramp_unit < 0 && shape_unit < 0) {
                     ramp_unit = in.src_unit;
+                    used[(size_t)in.src_unit]++;
+                } else if (s.op == OP_SHAPE && ramp_unit < 0 && shape_unit < 0) {
+                    shape_unit = in.src_unit;
                     used[(size_t)in.src_unit]++;
                 } else
                     return no("unsupported Multiply operand");
@@ -228,6 +241,9 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         if (ramp_unit >= 0) {
             plan.kind = FUSED_OSC_RAMP;
             plan.shape = "mul(osc(k),ramp)";
+        } else if (shape_unit >= 0) {
+            plan.kind = FUSED_OSC_SHAPE;
+            plan.shape = "mul(osc(k),shape)";
         } else if (have_gain) {
             plan.kind = FUSED_OSC_GAIN;
             plan.shape = "mul(osc(k),k)";
@@ -319,6 +335,25 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         plan.r_rcp = 1.0 / plan.r_d;
         plan.r_fastdiv = ramp_fastdiv_ok(plan.r_t0, plan.r_d, plan.r_playing != 0) ? 1 : 0;
     }
+    if (shape_unit >= 0) {  // every inlet a single constant: the envelope is the same for all instances of the program
+        const UnitDesc &sh = g.units[(size_t)shape_unit];
+        for (int k = 0; k < 3; k++)
+            if (sh.inlets[(size_t)k].kind != IN_CONST || sh.inlets[(size_t)k].vals.size() != 1) return no("Shape with a connected / per-instance inlet");
+        plan.s_table_id = (int)sh.attrs[0];
+        plan.s_left_is_shape = sh.attrs[1] != 0;
+        plan.s_left = sh.attrs[2];
+        plan.s_right_is_shape = sh.attrs[3] != 0;
+        plan.s_right = sh.attrs[4];
+        plan.s_t0 = sh.state[0];
+        plan.s_playing = sh.state[1] != 0;
+        plan.s_finished = sh.state[2] != 0;
+        plan.s_c = 1.0 / (double)(float)sh.inlets[0].vals[0];
+        plan.s_min = (float)sh.inlets[1].vals[0];
+        plan.s_max = (float)sh.inlets[2].vals[0];
+        // the running sum t += 1/duration in closed form (repeat_add.hpp): needs a positive finite addend from t >= 0
+        if (plan.s_playing && !(plan.s_t0 >= 0 && plan.s_c > 0 && plan.s_c < 1e300)) return no("Shape outside the closed-form regime");
+        if (!std::isfinite(plan.s_t0)) return no("Shape with a non-finite t");
+    }
     plan.unit_state_first.assign(g.units.size(), 0);
     plan.unit_state_count.assign(g.units.size(), 0);
     plan.n_state_words = 0;
@@ -329,6 +364,11 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         plan.unit_state_first[(size_t)ramp_unit] = plan.n_state_words;
         plan.unit_state_count[(size_t)ramp_unit] = 2;
         plan.n_state_words += 2;
+    }
+    if (shape_unit >= 0) {
+        plan.unit_state_first[(size_t)shape_unit] = plan.n_state_words;
+        plan.unit_state_count[(size_t)shape_unit] = 3;
+        plan.n_state_words += 3;
     }
     return true;
 }

@@ -360,3 +360,48 @@ def test_running_sums_in_closed_form_equal_the_sequential_engine():
     assert np.array_equal(got, want)
     for x, y in zip(got_state, want_state):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", ["decay_1s", "attack_short", "semisine_range", "decaysq_numbers", "idle", "midway", "finished_before", "tiny_duration"])
+def test_fused_shape_voice_equals_the_sequential_engine(case):
+    """mul(osc(k), shape): the canonical Dusp voice "O440 * D1" on the fused, time-parallel kernel (Shape's running sum in
+    closed form) against the chunk engine, which adds sample by sample — PCM and state, per-instance frequencies."""
+    from dusp_amd import descriptor
+    d.configure(48000)
+
+    def shape():
+        if case == "decay_1s":
+            return d.Shape("decay", 1).trigger()
+        if case == "attack_short":
+            return d.Shape("attack", 0.0123).trigger()
+        if case == "semisine_range":
+            return d.Shape("semiSine", 0.31, -0.5, 2).trigger()
+        if case == "decaysq_numbers":
+            s = d.Shape("decaySquared", 0.07, 0.25, 0.75).trigger()
+            s.leftEdge, s.rightEdge = 0.5, -1
+            return s
+        if case == "idle":
+            return d.Shape("decay", 0.5, 0.1, 0.9)
+        if case == "midway":
+            s = d.Shape("decay", 0.2).trigger()
+            s.t = 12345.678
+            return s
+        if case == "finished_before":
+            s = d.Shape("attack", 0.1).trigger()
+            s.t, s.finished = 50000.5, True
+            return s
+        return d.Shape("decay", 3e-5).trigger()  # over after two samples
+
+    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Osc(110.5 + 7 * k), shape())) for k in range(3)])
+    V, n = 37, 48000 + 300
+    params = (uni.params[:, :1] + (uni.params[:, 1:2] - uni.params[:, :1]) * np.arange(V)[None, :]).astype(np.float32)
+    ctx = render.context(48000)
+    progs = {e: ctx.build(uni.words, e) for e in (runtime.ENGINE_CHUNK, runtime.ENGINE_AUTO)}
+    assert progs[runtime.ENGINE_AUTO].engine == "fused" and progs[runtime.ENGINE_AUTO].shape == "mul(osc(k),shape)"
+    outs = {e: p.render(n, V, params) for e, p in progs.items()}
+    assert np.array_equal(outs[runtime.ENGINE_CHUNK], outs[runtime.ENGINE_AUTO])
+    for i in (0, V - 1):
+        for u in range(progs[runtime.ENGINE_CHUNK].n_units):
+            assert np.array_equal(progs[runtime.ENGINE_CHUNK].state(u, i), progs[runtime.ENGINE_AUTO].state(u, i), equal_nan=True)
+    for p in progs.values():
+        p.close()

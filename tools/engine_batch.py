@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Wave engine vs chunk engine by batch size for a few general graphs (AUTO picks the wave engine whenever it can plan the
-graph): python tools/engine_batch.py   (1 s per instance)"""
+"""Wave engine vs chunk engine vs what AUTO picks, by batch size, for a few general graphs: python tools/engine_batch.py   (1 s per instance)"""
 import os
 import sys
 
@@ -41,7 +40,8 @@ for name, g in graphs.items():
         params = (base[:, None] + step[:, None] * np.arange(V)[None, :]).astype(np.float32)
         dp = torch.from_numpy(np.ascontiguousarray(params)).cuda()
         row = []
-        for engine in (runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK):
+        auto_name = ''
+        for engine in (runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK, runtime.ENGINE_AUTO):
             prog = ctx.build(full.words, engine)
             out = torch.empty((V, prog.n_out_channels, n), dtype=torch.float32, device="cuda")
             ts = []
@@ -53,6 +53,7 @@ for name, g in graphs.items():
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b))
             row.append(float(np.median(ts)))
+            auto_name = prog.engine
             prog.close()
             del out
-        print("%-26s inst=%-6d wave %9.3f ms   chunk %9.3f ms   (chunk/wave %.2f)" % (name, V, row[0], row[1], row[1] / row[0]), flush=True)
+        print("%-26s inst=%-6d wave %9.3f ms   chunk %9.3f ms   auto(%s) %9.3f ms" % (name, V, row[0], row[1], auto_name, row[2]), flush=True)
