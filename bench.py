@@ -150,6 +150,19 @@ def main():
             gather_info = {"seconds": round(gdt, 4), "inbound_GBps": round(gbytes / gdt / 1e9, 1),
                            "note": "PCM of %d peers sent point-to-point to rank 0 in 16-voice tiles" % (world - 1)}
 
+    # The write ceiling of THIS box, for scale: a fill kernel (16-byte coalesced stores and nothing else) over the same
+    # buffer, after the timed region.  The roofline fraction above is against the 8 TB/s paper peak; HBM3E sustains less
+    # for a pure write stream, and how much varies from box to box.
+    fill_ms = []
+    if rank == 0:
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ctx.fill(d_out.data_ptr(), d_out.numel(), 0.25, stream)
+            b.record()
+            torch.cuda.synchronize()
+            fill_ms.append(a.elapsed_time(b))
+
     if rank == 0:
         total_samples = float(n_voices) * n_samples * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -179,6 +192,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if fill_ms:
+            ceiling = algo_bytes / (min(fill_ms[1:]) * 1e-3) / 1e9
+            line["roofline"]["write_ceiling_measured"] = {"GBps": round(ceiling, 1), "frac_of_it": round(achieved / ceiling, 4),
+                                                          "what": "dusp_fill_device over the same buffer on this box, best of 3"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(words, params, n_samples, args.cpu_seconds)
         if gather_info:
