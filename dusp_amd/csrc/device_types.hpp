@@ -47,6 +47,7 @@ struct DevOp {
     DevOperand in[kMaxIn];   // n_in operands are meaningful (VectorMagnitude: one per input channel)
     double d[3];             // Ramp: duration, y0, y1; FixedMultiply: sf; SecondsToSamples: sample rate; Pan: compensation dB; Timer: period
     int64_t ring_base, ring_len;  // Delay / CircleBuffer nodes: ring location (samples, per instance)
+    int32_t lds_slot, pad;        // wave engine: which block of per-wave LDS state the op owns (-1: a stateless op)
 };
 
 // Arguments of the chunk engine's kernel (chunk_engine.hip).

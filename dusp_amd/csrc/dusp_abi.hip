@@ -274,6 +274,21 @@ static int finish_build(dusp_program *prog) {
     size_t n_all_ops = P.ops.size();  // the settled op list, then the lists of the warm-up chunks (if any)
     for (const auto &w : P.warm_ops) n_all_ops += w.size();
     HIP_TRY(ctx, prog->d_ops.ensure(n_all_ops));
+    std::vector<int32_t> out_bufs = P.out_bufs;
+    if (engine == DUSP_ENGINE_WAVE) {  // the wave engine's view: chunk buffers renamed to their LDS slots, state blocks numbered
+        std::vector<dusp::DevOp> ops = P.ops;
+        const auto &slot = prog->wave.buf_slot;
+        for (size_t k = 0; k < ops.size(); k++) {
+            if (ops[k].out_buf >= 0) ops[k].out_buf = slot[(size_t)ops[k].out_buf];
+            for (auto &in : ops[k].in)
+                if (in.kind == dusp::SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs) in.idx = slot[(size_t)in.idx];
+            ops[k].lds_slot = prog->wave.op_state[k];
+        }
+        for (auto &b : out_bufs) b = slot[(size_t)b];
+        std::vector<dusp::DevOp> ordered(ops.size());
+        for (size_t at = 0; at < ops.size(); at++) ordered[at] = ops[(size_t)prog->wave.order[at]];
+        HIP_TRY(ctx, hipMemcpy(prog->d_ops.p, ordered.data(), ordered.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
+    } else
     HIP_TRY(ctx, hipMemcpy(prog->d_ops.p, P.ops.data(), P.ops.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
     n_all_ops = P.ops.size();
     for (const auto &w : P.warm_ops) {
@@ -281,8 +296,8 @@ static int finish_build(dusp_program *prog) {
             HIP_TRY(ctx, hipMemcpy(prog->d_ops.p + n_all_ops, w.data(), w.size() * sizeof(dusp::DevOp), hipMemcpyHostToDevice));
         n_all_ops += w.size();
     }
-    HIP_TRY(ctx, prog->d_out_bufs.ensure(P.out_bufs.size()));
-    HIP_TRY(ctx, hipMemcpy(prog->d_out_bufs.p, P.out_bufs.data(), P.out_bufs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, prog->d_out_bufs.ensure(out_bufs.size()));
+    HIP_TRY(ctx, hipMemcpy(prog->d_out_bufs.p, out_bufs.data(), out_bufs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!P.init_state.empty()) {
         HIP_TRY(ctx, prog->d_init.ensure(P.init_state.size()));
         HIP_TRY(ctx, hipMemcpy(prog->d_init.p, P.init_state.data(), P.init_state.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -402,7 +417,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE)
-        std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->P.n_bufs);
+        std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     return DUSP_OK;
 }
 
@@ -518,7 +533,8 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         w.n_out = (uint32_t)P.out_bufs.size();
         w.n_inst = n_inst;
         w.n_pad = n_pad;
-        w.n_bufs = (uint32_t)P.n_bufs;
+        w.n_bufs = (uint32_t)prog->wave.n_slots;
+        w.n_state_ops = (uint32_t)prog->wave.n_state_ops;
         w.n_groups = n_chunks;
         w.sample_rate = (uint32_t)P.g.sample_rate;
         w.table_stride = ctx->table_stride;

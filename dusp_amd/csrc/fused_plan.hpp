@@ -93,6 +93,7 @@ struct WaveArgs {
     uint64_t ring_samples, clock0;
     uint32_t has_filter, has_modulated_filter;
     const float *inputs;   // [n_inputs][n_inst][n_samples] host-generated signals (OP_INPUT)
+    uint32_t n_state_ops;  // ops that own a block of LDS state (DevOp::lds_slot)
     uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
     // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
     // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
@@ -111,12 +112,18 @@ struct WaveArgs {
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
 // (the 6 KB scratch is only needed by Filters whose cutoff is connected: per-sample b1 / b2 and their own P)
-inline size_t wave_lds_bytes(size_t n_bufs, size_t n_ops, bool has_modulated_filter) {
-    return (n_bufs * 1024 + n_ops * 96 + (has_modulated_filter ? 3 * 256 * 8 + 16 : 0) + 15) & ~(size_t)15;
+inline size_t wave_lds_bytes(size_t n_bufs, size_t n_state_ops, bool has_modulated_filter) {
+    return (n_bufs * 1024 + n_state_ops * 96 + (has_modulated_filter ? 3 * 256 * 8 + 16 : 0) + 15) & ~(size_t)15;
 }
 
 struct WavePlan {
     bool ok = false, has_filter = false, has_modulated_filter = false;
+    // LDS economy: chunk buffers are handed out by liveness (a feed-forward graph without rings needs a buffer only from its
+    // producer to its last reader within the chunk), and only stateful ops own a state block
+    std::vector<int> order;      // execution order of the device ops (a permutation; see plan_wave)
+    std::vector<int> buf_slot;   // chunk buffer -> LDS slot
+    std::vector<int> op_state;   // device op -> state block (-1: stateless)
+    int n_slots = 0, n_state_ops = 0;
     bool ring_events = false;  // a delay line that goes through ordered slot operations (short / signal-rate Delay, MonoDelay, ReadBackDelay)
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
@@ -432,7 +439,98 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
                                     op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
                                     plan.ring_events;  // (slot-ownership table of the ordered ring operations)
     }
-    if (wave_lds_bytes((size_t)P.n_bufs, P.ops.size(), plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
+    // state blocks: only for the ops that keep something in LDS between chunks
+    plan.op_state.assign(P.ops.size(), -1);
+    plan.n_state_ops = 0;
+    for (size_t k = 0; k < P.ops.size(); k++) {
+        const int o = P.ops[k].op;
+        const bool stateless = o == OP_RAMP || o == OP_MULTIPLY || o == OP_SUM || o == OP_REPEATER || o == OP_INPUT ||
+                               (o >= OP_MAP_FIRST && o <= OP_MAP_LAST) || (o >= OP_WIDE_FIRST && o <= OP_WIDE_LAST);
+        if (!stateless) plan.op_state[k] = plan.n_state_ops++;
+    }
+    // chunk buffers by liveness.  Only where no chunk survives the chunk boundary: a feedback (or late) edge reads its
+    // producer's PREVIOUS chunk, and continued programs with rings park all buffers between launches — those keep one
+    // buffer per outlet channel.  An op's output slot is taken before its inputs' slots are released, so an op never
+    // writes over what it is still reading.
+    plan.buf_slot.assign((size_t)std::max(1, P.n_bufs), 0);
+    plan.order.resize(P.ops.size());
+    for (size_t k = 0; k < P.ops.size(); k++) plan.order[k] = (int)k;
+    if (P.feed_forward && P.ring_samples == 0) {
+        // Such a graph is pure dataflow (private state, no shared rings), so any order that respects the edges computes
+        // the same thing.  The reference's order is level by level — every oscillator of a 200-voice mix before the first
+        // Multiply — which keeps hundreds of chunks alive; depth-first from the output (inputs first, then the op) keeps a
+        // mix-down chain at three or four.
+        std::vector<int> producer((size_t)std::max(1, P.n_bufs), -1);
+        for (size_t k = 0; k < P.ops.size(); k++)
+            if (P.ops[k].out_buf >= 0) producer[(size_t)P.ops[k].out_buf] = (int)k;
+        std::vector<char> done(P.ops.size(), 0);
+        std::vector<int> order;
+        std::vector<std::pair<int, int>> stack;  // (op, next operand to look at)
+        auto visit = [&](int root) {
+            if (done[(size_t)root]) return;
+            stack.push_back({root, 0});
+            done[(size_t)root] = 1;
+            while (!stack.empty()) {
+                auto &top = stack.back();
+                const DevOp &op = P.ops[(size_t)top.first];
+                bool descended = false;
+                while (top.second < kMaxIn) {
+                    const DevOperand &in = op.in[top.second++];
+                    if (in.kind != SRC_BUF || in.idx < 0 || in.idx >= P.n_bufs) continue;
+                    const int src = producer[(size_t)in.idx];
+                    if (src < 0 || done[(size_t)src]) continue;
+                    done[(size_t)src] = 1;
+                    stack.push_back({src, 0});
+                    descended = true;
+                    break;
+                }
+                if (!descended && stack.back().second >= kMaxIn) {
+                    order.push_back(stack.back().first);
+                    stack.pop_back();
+                }
+            }
+        };
+        for (int b : P.out_bufs)
+            if (producer[(size_t)b] >= 0) visit(producer[(size_t)b]);
+        for (size_t k = 0; k < P.ops.size(); k++) visit((int)k);  // units nothing listens to still tick (their state is read back)
+        plan.order = order;
+
+        std::vector<int> last_use((size_t)std::max(1, P.n_bufs), -1);
+        for (size_t at = 0; at < order.size(); at++)
+            for (int j = 0; j < kMaxIn; j++) {
+                const DevOperand &in = P.ops[(size_t)order[at]].in[j];
+                if (in.kind == SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs) last_use[(size_t)in.idx] = (int)at;
+            }
+        for (int b : P.out_bufs) last_use[(size_t)b] = (int)order.size();  // copied out at the end of the chunk
+        std::vector<int> free_slots;
+        int n_slots = 0;
+        std::vector<char> have(plan.buf_slot.size(), 0);
+        for (size_t at = 0; at < order.size(); at++) {
+            const DevOp &op = P.ops[(size_t)order[at]];
+            const int b = op.out_buf;
+            if (b >= 0 && !have[(size_t)b]) {
+                if (free_slots.empty()) plan.buf_slot[(size_t)b] = n_slots++;
+                else { plan.buf_slot[(size_t)b] = free_slots.back(); free_slots.pop_back(); }
+                have[(size_t)b] = 1;
+            }
+            for (int j = 0; j < kMaxIn; j++) {
+                const DevOperand &in = op.in[j];
+                if (in.kind == SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs && last_use[(size_t)in.idx] == (int)at && have[(size_t)in.idx] == 1) {
+                    free_slots.push_back(plan.buf_slot[(size_t)in.idx]);
+                    have[(size_t)in.idx] = 2;  // released
+                }
+            }
+            if (b >= 0 && last_use[(size_t)b] < 0 && have[(size_t)b] == 1) {  // nobody reads it
+                free_slots.push_back(plan.buf_slot[(size_t)b]);
+                have[(size_t)b] = 2;
+            }
+        }
+        plan.n_slots = std::max(1, n_slots);
+    } else {
+        for (size_t b = 0; b < plan.buf_slot.size(); b++) plan.buf_slot[b] = (int)b;
+        plan.n_slots = std::max(1, P.n_bufs);
+    }
+    if (wave_lds_bytes((size_t)plan.n_slots, (size_t)plan.n_state_ops, plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");
     for (const DevOp &op : P.ops) {
         switch (op.op) {

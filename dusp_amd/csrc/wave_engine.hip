@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     float *Yt = (float *)(Pt + WAVES * 258);
     f32x4 *bufs = (f32x4 *)mine;                                            // [n_bufs][64] float4 = chunk buffers
     double *opstate = (double *)(mine + (size_t)A.n_bufs * 1024);           // [n_ops][kOpState] per-unit state
-    double *scratch = opstate + (size_t)A.n_ops * kOpState;                 // Filter: P[256], b1[256], b2[256]
+    double *scratch = opstate + (size_t)A.n_state_ops * kOpState;                 // Filter: P[256], b1[256], b2[256]
     // This instance's parameter column, fetched once: an operand that is a per-instance parameter would otherwise cost an
     // HBM round trip per unit and chunk, which a wavefront has nothing to hide behind.
     const float *pvals = A.params ? A.params + inst : nullptr;
@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     if (lane == 0)
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
-            double *os = opstate + (size_t)u * kOpState;
+            if (op.lds_slot < 0) continue;  // stateless
+            double *os = opstate + (size_t)op.lds_slot * kOpState;
             for (int k = 0; k < kOpState; ++k) os[k] = 0.0;
             if (op.op == OP_OSC) {
                 if (A.n_seg == 1) *(unsigned long long *)os = (unsigned long long)(A.init_state[op.state_slot] * kTwo36);
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     // whatever the modulation does, the result is the reference's.
     enum : int { RO_NONE = 0, RO_READ, RO_READ_CLEAR, RO_ADD, RO_STORE };
     auto ordered_ring_ops = [&](const DevOp &op, uint32_t u, uint32_t g, V4 &out) {
-        double *ss = opstate + (size_t)u * kOpState;
+        double *ss = opstate + (size_t)op.lds_slot * kOpState;
         const bool is_delay = op.op == OP_DELAY, is_mono = op.op == OP_MONO_DELAY, is_readback = op.op == OP_READBACK_DELAY;
         const bool is_reader = op.op == OP_CB_READER, is_writer = op.op == OP_CB_WRITER;
         const bool writer_mixes = is_writer && !(op.attr & 2);
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             V4 out;
             switch (op.op) {
             case OP_OSC: {  // Osc.js:35-47
-                unsigned long long *carry = (unsigned long long *)(opstate + (size_t)u * kOpState);
+                unsigned long long *carry = (unsigned long long *)(opstate + (size_t)op.lds_slot * kOpState);
                 uint32_t *poison = (uint32_t *)(carry + 1);
                 const V4 f = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 long long q[4];
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_FILTER: {  // Filter.js:27-51
-                double *fs = opstate + (size_t)u * kOpState;
+                double *fs = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 fv = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 const bool f_const = op.in[1].kind != SRC_BUF;  // wave-uniform
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     lds_barrier();
                     if (wave == 0 && lane < WAVES) {
                         double *os = (double *)((char *)lds + A.table_bytes + (size_t)lane * A.wave_bytes + (size_t)A.n_bufs * 1024) +
-                                     (size_t)u * kOpState;  // instance `lane`'s state of this Filter
+                                     (size_t)op.lds_slot * kOpState;  // instance `lane`'s state of this Filter
                         const double b1 = os[5], b2 = os[6];
                         double y1 = os[9], y2 = os[10];
                         const double *pr = Pt + lane * 258;
@@ -551,7 +552,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             case OP_DELAY:  // Delay.js:20-41
               if (!RING || delay_is_write_once(op)) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
-                double *ds = opstate + (size_t)u * kOpState;
+                double *ds = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const int64_t len = op.ring_len;
                 double dconst = (double)op.in[1].cval;
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             // ---- units whose state evolves sample by sample with its own roundings: the sequential part runs on lane 0
             // out of the wave's LDS scratch (a few instructions per sample), everything else stays lane-parallel
             case OP_SHAPE: {  // Shape/index.js:28-59
-                double *ss = opstate + (size_t)u * kOpState;  // [0] t [1] playing [2] finished
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t [1] playing [2] finished
                 const V4 dur = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 mn = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
                 const V4 mx = load_operand(op.in[2], bufs, lane, pvals, pstride, 0);
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_TIMER: {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
-                double *ss = opstate + (size_t)u * kOpState;
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 const double period = op.d[0], t0 = ss[0];
                 if (t0 >= 0.0 && period > 0.0 && period < 1.0e300) {  // the running sum in closed form, every lane its own four samples
                     double t = repeat_add(t0, period, (uint64_t)lane * 4);
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 break;
             }
             case OP_AHD: case OP_SAMPLE_RATE_REDUX: {  // AHD.js:35-76, SampleRateRedux.js:21-38
-                double *ss = opstate + (size_t)u * kOpState;
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 float *Y = (float *)scratch;  // [256] output, then up to three operand rows
                 // operands as plain rows: a connected inlet is the producer's chunk buffer, a constant fills a scratch row
                 const float *rows[3];
@@ -771,7 +772,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // A private ring of L slots read and rewritten one slot per sample: sample t depends on sample t - L only,
                 // so a chunk is L (at most 64) independent samples at a time.  The slots the chunk touches — min(L, 256)
                 // of them — are staged in LDS, walked in rounds, and written back.
-                double *ss = opstate + (size_t)u * kOpState;  // [0] tBuffer
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] tBuffer
                 float *Y = (float *)scratch, *R = Y + kChunk;
                 const float *rows[2];
 #pragma unroll
@@ -840,7 +841,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // Lane-constant offset: the node's 256 accesses of a chunk are 256 consecutive slots of the ring
                 // (index = floor((T + t -+ sr*offset) % len), negatives wrapped), one per sample, lane-parallel.  Several
                 // nodes share a ring and tick one after another, so each node waits for the wave's earlier ring traffic.
-                double *ss = opstate + (size_t)u * kOpState;  // [0] the node's private sample counter
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] the node's private sample counter
                 const float off = op.in[0].kind == SRC_PARAM ? pvals[(size_t)op.in[0].idx * pstride] : op.in[0].cval;
                 const double origin = op.op == OP_CB_READER ? ss[0] - srd * (double)off : ss[0] + srd * (double)off;
                 const bool ok = fabs(origin) < 9.0e15;  // NaN / Inf offsets read `undefined` and write nowhere
@@ -877,7 +878,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // The remainder keeps the dividend's sign, so the phase is not a modular sum (a negative excursion reads
                 // `undefined` -> NaN until the sum comes back): the 256 phases come from the serial lane, in f64 exactly
                 // as the reference adds them; the table lookups and the lerp are lane-parallel.
-                double *ss = opstate + (size_t)u * kOpState;  // [0] phase
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] phase
                 const V4 f = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 double *T = scratch;
 #pragma unroll
@@ -955,7 +956,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
             if (op.op != OP_OSC || (uint32_t)op.d[0] != A.pass_level) continue;
-            const double *os = opstate + (size_t)u * kOpState;
+            const double *os = opstate + (size_t)op.lds_slot * kOpState;
             A.seg_sum[((size_t)u * A.n_inst + inst) * A.n_seg + seg] =
                 *(const unsigned long long *)os | ((unsigned long long)(((const uint32_t *)(os + 1))[0] != 0) << 63);
         }
@@ -965,7 +966,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
         for (uint32_t u = 0; u < A.n_ops; ++u) {
             const DevOp &op = A.ops[u];
             double *st = A.state + (size_t)op.state_slot * A.n_pad + inst;
-            const double *os = opstate + (size_t)u * kOpState;
+            const double *os = opstate + (size_t)op.lds_slot * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
                 op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY)
@@ -1054,7 +1055,7 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
     A.param_bytes = A.n_params && A.n_params <= 2048 ? (A.n_params * 4 + 15) & ~15u : 0;
-    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_ops, A.has_modulated_filter != 0) + A.param_bytes;
+    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_state_ops, A.has_modulated_filter != 0) + A.param_bytes;
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
     const size_t one_wave = A.wave_bytes + (A.has_filter ? 258 * 8 + 260 * 4 : 0);

@@ -405,3 +405,31 @@ def test_fused_shape_voice_equals_the_sequential_engine(case):
             assert np.array_equal(progs[runtime.ENGINE_CHUNK].state(u, i), progs[runtime.ENGINE_AUTO].state(u, i), equal_nan=True)
     for p in progs.values():
         p.close()
+
+
+def test_big_mix_down_fits_the_wave_engine_by_buffer_liveness():
+    """200 enveloped voices summed into one output: 800 units, 800 chunk buffers if every outlet kept its own — LDS holds
+    them because a feed-forward graph needs a buffer only from its producer to its last reader — 4 slots here, once the ops run
+    depth-first from the output instead of level by level —, and only the
+    stateful ops own LDS state.  Bit-identical to the chunk engine; split in time, since every state is a closed-form sum."""
+    from dusp_amd import descriptor
+    d.configure(48000)
+    voices = [d.Multiply(d.Osc(55.0 * (k + 1) + 0.25 * (k % 4), ["sin", "saw", "triangle"][k % 3]),
+                         d.Shape(["decay", "decaySquared", "semiSine"][k % 3], 0.05 + 0.01 * k, 0, 1.0 / (k + 1)).trigger()) for k in range(200)]
+    ex = descriptor.extract(d.Sum.many(voices))
+    n = 48000 * 2 + 5
+    ctx = render.context(48000)
+    ref = ctx.build(ex.words, runtime.ENGINE_CHUNK)
+    want = ref.render(n)
+    want_state = [ref.state(u) for u in range(0, ref.n_units, 37)]
+    ref.close()
+    prog = ctx.build(ex.words)
+    assert prog.engine == "wave" and "4 chunk buffers" in prog.shape, (prog.engine, prog.shape)
+    got = prog.render(n)
+    kernel_ms = prog.last_kernel_ms()
+    got_state = [prog.state(u) for u in range(0, prog.n_units, 37)]
+    prog.close()
+    assert np.array_equal(got, want)
+    for a, b in zip(got_state, want_state):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert kernel_ms < 50, kernel_ms
