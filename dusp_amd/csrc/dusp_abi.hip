@@ -217,7 +217,7 @@ static int finish_build(dusp_program *prog) {
         prog->wave.ramp_checked = std::move(checked);
     }
     const bool fusable = dusp::plan_fused(prog->P, prog->fused);
-    const bool wavable = dusp::plan_wave(prog->P, prog->wave);
+    const bool wavable = dusp::plan_wave(prog->P, prog->wave, prog->resumable);
     for (size_t k = 0; k < prog->wave.osc_level.size() && k < prog->P.ops.size(); k++)  // FM depth, for time-split rendering
         if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
     for (size_t k = 0; k < prog->wave.ramp_fastdiv.size() && k < prog->P.ops.size(); k++)

@@ -414,7 +414,8 @@ inline bool delay_write_once(const DevOp &op) {
 }
 
 // Can the wave engine (one wavefront per instance, chunk buffers in LDS) run this program?
-inline bool plan_wave(const Program &P, WavePlan &plan) {
+// will_continue: the program is resumable, i.e. later launches pick up rings and parked chunk buffers in the reference's layout
+inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = false) {
     const Graph &g = P.g;
     auto no = [&](const std::string &why) {
         plan.why = why;
@@ -455,7 +456,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan) {
     plan.buf_slot.assign((size_t)std::max(1, P.n_bufs), 0);
     plan.order.resize(P.ops.size());
     for (size_t k = 0; k < P.ops.size(); k++) plan.order[k] = (int)k;
-    if (P.feed_forward && P.ring_samples == 0) {
+    // (a Delay's ring is private to it; CircleBuffers are shared between nodes whose order matters)
+    if (P.feed_forward && g.rings.empty() && (P.ring_samples == 0 || !will_continue)) {
         // Such a graph is pure dataflow (private state, no shared rings), so any order that respects the edges computes
         // the same thing.  The reference's order is level by level — every oscillator of a 200-voice mix before the first
         // Multiply — which keeps hundreds of chunks alive; depth-first from the output (inputs first, then the op) keeps a
