@@ -880,6 +880,44 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 // as the reference adds them; the table lookups and the lerp are lane-parallel.
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] phase
                 const V4 f = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
+                const float *gtab = A.tables + (size_t)op.attr * A.table_stride;
+                {   // While nothing is negative the missing fix-up cannot matter and the phase IS the Osc's modular sum: every
+                    // increment of the chunk finite, >= 0 and on the 2^-36 grid, the start phase too -> the Osc's exact
+                    // fixed-point wave scan (FM voices built on MultiChannelOsc: the FMOsc / StereoDetune patches).
+                    double ph0 = ss[0];
+                    ph0 = (ph0 != ph0 || ph0 == 0.0) ? 0.0 : ph0;  // `this.phase[c] = this.phase[c] || 0`
+                    bool grid = ph0 >= 0.0 && ph0 < srd && ph0 * kTwo36 == floor(ph0 * kTwo36);
+                    long long q[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        double fd = (double)f.v[c];
+                        grid = grid && fd >= 0.0 && fd < srd;  // (below sampleRate: phase + f stays under 2^17 + 2^17, exact in f64 on this grid)
+                        if (!(fd >= 0.0 && fd < srd)) fd = 0.0;
+                        const double scaled = fd * kTwo36;
+                        grid = grid && scaled == floor(scaled);
+                        q[c] = (long long)scaled;
+                    }
+                    if (__all(grid)) {
+                        const long long total = q[0] + q[1] + q[2] + q[3];
+                        const long long incl = wave_inclusive_scan(total, lane);
+                        const long long before = (long long)(unsigned long long)(ph0 * kTwo36) + (incl - total);
+                        unsigned long long P = mod_u64_lifted((unsigned long long)(before + q[0]) + lift, S, inv_S);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c > 0) {
+                                P += (unsigned long long)q[c];
+                                if (P >= S) P -= S;
+                            }
+                            const uint32_t idx = (uint32_t)(P >> kFracBits);
+                            const double fraction = (double)(P & ((1ull << kFracBits) - 1ull)) * (1.0 / kTwo36);
+                            out.v[c] = (float)((double)gtab[idx] * (1.0 - fraction) + (double)gtab[fraction != 0.0 ? idx + 1 : idx] * fraction);
+                        }
+                        const unsigned long long lastP = __shfl(P, 63, 64);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) ss[0] = (double)lastP * (1.0 / kTwo36);
+                        break;
+                    }
+                }
                 double *T = scratch;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) T[lane * 4 + c] = (double)f.v[c];
@@ -898,7 +936,6 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const float *gtab = A.tables + (size_t)op.attr * A.table_stride;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const double phase = T[lane * 4 + c];
