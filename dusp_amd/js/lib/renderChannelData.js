@@ -180,8 +180,12 @@ async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Arr
 /* N structurally identical circuits (voices, a parameter sweep) as ONE GPU program:
  * resolves to result[instance][channel] = Float32Array(duration * sampleRate). */
 async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
-  const extractions = outlets.map(extract)
-  if (extractions.some((ex) => ex.sources.length)) throw 'dusp-hip: renderMany does not take circuits with host-computed signals (Noise)'
+  const extractions = outlets.map((o) => extract(o))
+  // one launch for all circuits: nothing ticks on the host in between, so units that need that are refused, not ignored
+  for (const ex of extractions)
+    for (const u of ex.circuit.units)
+      if (u.isHostSignal || (UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick))
+        throw 'dusp-hip: renderMany does not take circuits with host-ticked units (' + u.label + '): render them one by one'
   const uni = unify(extractions)
   const nSamples = sampleCount(duration, uni.sampleRate)
   if (nSamples === 0) return outlets.map(() => [])

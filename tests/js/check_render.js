@@ -46,6 +46,9 @@ async function main() {
   const many = await lib.renderMany(voices, 2048 / SR)
   const solo = await lib.renderChannelData(new lib.Multiply(new lib.Osc(110 * 3 + 0.5), new lib.Ramp(2000, 1, 0).trigger()), 2048 / SR)
   report.manyMatchesSolo = many.length === 5 && many[2][0].every((v, i) => v === solo[0][i])
+  // renderMany runs one launch for all voices: a circuit whose unit needs host ticks in between is refused, not mis-rendered
+  const ticking = () => { const e = new lib.Shape('decay', 0.01).trigger(); new lib.Retriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) }
+  report.manyRefusesHostTicked = await lib.renderMany([ticking(), ticking()], 0.01).then(() => 'resolved', (e) => String(e))
   // unsupported graphs reject with a string
   class Crackle extends lib.Unit { constructor() { super(); this.addOutlet('out') } } // a unit kind this package does not know
   report.unsupported = await lib.renderChannelData(new lib.Multiply(new Crackle(), 0.5), 0.01).then(() => 'resolved', (e) => e)
