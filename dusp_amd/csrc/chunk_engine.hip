@@ -501,6 +501,22 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[2 * NP] = tt;
                 break;
             }
+            case OP_RETRIGGER: {  // Retriggerer.js:13-24: an accumulator of `rate`; every crossing of sampleRate triggers the target
+                const Src rate = make_src(op.in[0], a, i);
+                double T = st[0];
+                bool fired = false;
+                for (int t = 0; t < kChunk; ++t) {
+                    T += (double)rate.at(t);
+                    if (T >= sr) { fired = true; T -= sr; }
+                }
+                st[0] = T;
+                if (fired) {  // the target ticks later in this chunk (the Retriggerer is chained before it)
+                    double *ts = a.state + (size_t)op.attr * NP + i;
+                    if ((int)op.d[0] == OP_SHAPE) { ts[0] = 0.0; ts[NP] = 1.0; }   // t = 0, playing
+                    else { ts[0] = 1.0; ts[NP] = 1.0; }                            // AHD: state = attack, playing
+                }
+                break;
+            }
             case OP_INPUT: {  // a signal the host computed (Noise.js:16-27 draws Math.random() per sample): stream op.attr
                 const float *src = a.inputs + ((size_t)op.attr * a.n_inst + (i < a.n_inst ? i : a.n_inst - 1)) * a.n_samples;
                 const uint64_t t0 = (uint64_t)ck * kChunk;

@@ -18,6 +18,7 @@ enum : int {
     OP_SHAPE, OP_AHD,  // envelopes
     OP_HOST_ONLY,      // a unit that produces no signal and acts through host callbacks (Retriggerer): keeps its place in the unit list
     OP_INPUT,          // a unit whose signal the HOST computes (Noise: Math.random() per sample): reads input stream `attr`
+    OP_RETRIGGER,      // Retriggerer whose target is a Shape / AHD of the same circuit: ticks on the device and triggers it in place
     OP_MAP_FIRST = OP_SUBTRACT, OP_MAP_LAST = OP_POW,    // stateless maps of at most two operands (map_apply)
     OP_WIDE_FIRST = OP_PAN, OP_WIDE_LAST = OP_VECTOR_MAGNITUDE  // stateless maps of up to kMaxIn operands (map_wide)
 };

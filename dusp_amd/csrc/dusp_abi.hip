@@ -284,6 +284,8 @@ static int finish_build(dusp_program *prog) {
                 if (in.kind == dusp::SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs) in.idx = slot[(size_t)in.idx];
             ops[k].lds_slot = prog->wave.op_state[k];
         }
+        for (auto &op : ops)
+            if (op.op == dusp::OP_RETRIGGER) op.pad = prog->wave.op_state[(size_t)op.pad];  // target op -> its state block
         for (auto &b : out_bufs) b = slot[(size_t)b];
         std::vector<dusp::DevOp> ordered(ops.size());
         for (size_t at = 0; at < ops.size(); at++) ordered[at] = ops[(size_t)prog->wave.order[at]];

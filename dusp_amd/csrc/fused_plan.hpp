@@ -457,7 +457,9 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     plan.order.resize(P.ops.size());
     for (size_t k = 0; k < P.ops.size(); k++) plan.order[k] = (int)k;
     // (a Delay's ring is private to it; CircleBuffers are shared between nodes whose order matters)
-    if (P.feed_forward && g.rings.empty() && (P.ring_samples == 0 || !will_continue)) {
+    bool has_retrigger = false;  // (acts on another op's state: it has to stay in front of its target, so the reference's order is kept)
+    for (const DevOp &op : P.ops) has_retrigger = has_retrigger || op.op == OP_RETRIGGER;
+    if (P.feed_forward && g.rings.empty() && (P.ring_samples == 0 || !will_continue) && !has_retrigger) {
         // Such a graph is pure dataflow (private state, no shared rings), so any order that respects the edges computes
         // the same thing.  The reference's order is level by level — every oscillator of a 200-voice mix before the first
         // Multiply — which keeps hundreds of chunks alive; depth-first from the output (inputs first, then the op) keeps a
@@ -561,6 +563,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         case OP_CB_READER: case OP_CB_WRITER: break;                                     // checked above
         case OP_MULTI_OSC: break;                                                        // phases on the serial lane, lookups lane-parallel
         case OP_INPUT: break;                                                            // a float4 per lane from the host's stream
+        case OP_RETRIGGER: break;                                                        // 256 additions on one lane; rewrites its target's state block
         case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:                     // lane-parallel in rounds of the ring length
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
             break;
@@ -607,7 +610,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
             (op.op == OP_DELAY || op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX ||
              op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
              op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY))
-            plan.splittable = false;  // state that is neither a modular sum nor a closed-form one
+            plan.splittable = false;
+        if (op.op == OP_RETRIGGER) plan.splittable = false;  // its accumulator wraps by subtraction: no closed form, and its target's state follows it  // state that is neither a modular sum nor a closed-form one
         int dep = 0;
         for (int j = 0; j < kMaxIn; j++)
             if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs) dep = std::max(dep, buf_depth[(size_t)op.in[j].idx]);

@@ -258,6 +258,13 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         case OP_HOST_ONLY:
             if (!need(0, 0, 0)) return fail(err, where + "bad host-only record");
             break;
+        case OP_RETRIGGER: {  // inlets: rate (a constant / parameter); attrs: target unit; state: t
+            if (!need(1, 1, 1)) return fail(err, where + "bad Retriggerer record");
+            if (u.inlets[0].kind == IN_CONNECT || u.inlets[0].vals.size() != 1)
+                return fail(err, where + "Retriggerer with a signal-rate rate is not supported on the GPU path");
+            if (!(u.attrs[0] >= 0 && u.attrs[0] < (double)n_units) || u.attrs[0] != std::floor(u.attrs[0])) return fail(err, where + "Retriggerer target out of range");
+            break;
+        }
         case OP_INPUT:
             if (!need(0, 1, 0)) return fail(err, where + "bad input record");
             if (!(u.attrs[0] >= 0 && u.attrs[0] < 4096) || u.attrs[0] != std::floor(u.attrs[0])) return fail(err, where + "input index out of range");
@@ -293,7 +300,7 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
     case OP_FILTER: return std::max(1, nin(0));                           // Filter.js:31-32
     case OP_DELAY: return std::max(1, std::max(nin(0), nin(1)));          // Delay.js:21
     case OP_CB_READER: return std::max(1, g.rings[(size_t)u.attrs[0]].nch);  // CircleBufferNode.js:19-22
-    case OP_CB_WRITER: case OP_HOST_ONLY: return 0;                       // no data outlet
+    case OP_CB_WRITER: case OP_HOST_ONLY: case OP_RETRIGGER: return 0;    // no data outlet
     case OP_REPEATER: return std::max(1, nin(0));                         // Repeater.js:24-25
     case OP_SUBTRACT: case OP_DIVIDE: case OP_POW: return std::max(nin(0), nin(1));
     case OP_FIXED_MULTIPLY: return 1;                                     // mono in / mono out
@@ -320,7 +327,7 @@ inline int unit_channels(const Graph &g, const UnitDesc &u) {
 // counts of the first chunks are kept and those chunks run their own op lists (Program::warm_ops).
 
 inline bool infer_channels(Graph &g, std::string &err) {
-    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;
+    for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY || u.op == OP_RETRIGGER) ? 0 : 1;
     std::vector<std::vector<int>> hist;
     for (int pass = 0;; pass++) {
         bool changed = false;
@@ -546,6 +553,11 @@ inline bool expand(Program &P, std::string &err) {
         case OP_INPUT:
             op.attr = (int)u.attrs[0];
             break;
+        case OP_RETRIGGER:  // (attr / pad / d[0] — the target's state slot, device op and kind — are filled in once every unit has its ops)
+            op.n_in = 1;
+            op.in[0] = make_operand(g, u.inlets[0], 0);
+            slot(u.state[0]);
+            break;
         case OP_SHAPE:  // mono inlets duration / min / max; attr: table id | left-is-shape << 8 | right-is-shape << 9
             op.n_in = 3;
             for (int k = 0; k < 3; k++) op.in[k] = make_operand(g, u.inlets[(size_t)k], 0);
@@ -584,7 +596,7 @@ inline bool expand(Program &P, std::string &err) {
         }
         }
     };
-    auto n_dev_ops = [&](const UnitDesc &u, int n_out) { return u.op == OP_CB_WRITER ? g.rings[(size_t)u.attrs[0]].nch : n_out; };
+    auto n_dev_ops = [&](const UnitDesc &u, int n_out) { return u.op == OP_CB_WRITER ? g.rings[(size_t)u.attrs[0]].nch : u.op == OP_RETRIGGER ? 1 : n_out; };
     for (size_t ui = 0; ui < g.units.size(); ui++) {
         UnitDesc &u = g.units[ui];
         u.first_op = (int)P.ops.size();
@@ -604,13 +616,22 @@ inline bool expand(Program &P, std::string &err) {
         }
     }
     P.ring_samples = ring_pos;
+    for (auto &op : P.ops)
+        if (op.op == OP_RETRIGGER) {  // trigger(): Shape -> t = 0, playing; AHD -> state = 1, playing (Shape/index.js:107-111, AHD.js:24-28)
+            const UnitDesc &target = g.units[(size_t)g.units[(size_t)op.unit].attrs[0]];
+            if (target.op != OP_SHAPE && target.op != OP_AHD) return fail(err, "Retriggerer target is not a Shape / AHD (not supported on the GPU path)");
+            op.attr = target.first_slot;
+            op.pad = target.first_op;
+            op.d[0] = (double)target.op;
+            op.d[1] = (double)g.sample_rate;
+        }
     // Warm-up chunks: replay the channel growth of infer_channels, binding every op's operands against the counts the
     // reference's unit would see at that point of that chunk (units before it: this chunk's, units after it: last chunk's).
     if (!g.warm_counts.empty()) {
         alloc = false;
         std::vector<int> settled;
         for (auto &u : g.units) settled.push_back(u.n_out);
-        for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY) ? 0 : 1;
+        for (auto &u : g.units) u.n_out = (u.op == OP_CB_WRITER || u.op == OP_HOST_ONLY || u.op == OP_RETRIGGER) ? 0 : 1;
         for (const auto &counts : g.warm_counts) {
             std::vector<DevOp> ops;
             for (size_t ui = 0; ui < g.units.size(); ui++) {

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }  // else: accumulate from 0 — the segment's phase total
             }
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY || op.op == OP_RETRIGGER)
                 os[0] = A.init_state[op.state_slot];
             // Delay's carried input sample is engine-internal (no descriptor carries it): a continued render takes it
             // from where the previous launch left it
@@ -602,6 +602,33 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             case OP_MONO_DELAY: case OP_READBACK_DELAY:
                 if constexpr (RING != 0) ordered_ring_ops(op, u, g, out);  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
                 break;
+            case OP_RETRIGGER: {  // Retriggerer.js:13-24 on one lane; a firing rewrites the target's state block before the target ticks
+                double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t
+                if (lane == 0) {
+                    const double rate = (double)(op.in[0].kind == SRC_PARAM ? pvals[(size_t)op.in[0].idx * pstride] : op.in[0].cval);
+                    double T = ss[0];
+                    bool fired = false;
+                    // most chunks see no crossing: then the accumulator is a plain running sum, which repeat_add() evaluates at once
+                    const double quiet_end = (T >= 0.0 && rate > 0.0 && rate < 1.0e300) ? repeat_add(T, rate, kChunk) : srd;
+                    if (quiet_end < srd) T = quiet_end;
+                    else {
+#pragma unroll 8
+                        for (int k = 0; k < kChunk; ++k) {
+                            T += rate;
+                            if (T >= srd) { fired = true; T -= srd; }
+                        }
+                    }
+                    ss[0] = T;
+                    if (fired) {
+                        double *ts = opstate + (size_t)op.pad * kOpState;  // (pad: the target op's state block)
+                        if ((int)op.d[0] == OP_SHAPE) { ts[0] = 0.0; ts[1] = 1.0; }
+                        else { ts[0] = 1.0; ts[1] = 1.0; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                continue;  // no outlet
+            }
             case OP_INPUT: {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
                 const float *src = A.inputs + ((size_t)op.attr * A.n_inst + inst) * A.n_samples;
 #pragma unroll
@@ -1006,7 +1033,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             const double *os = opstate + (size_t)op.lds_slot * kOpState;
             if (op.op == OP_OSC) st[0] = ((const uint32_t *)(os + 1))[0] ? __builtin_nan("") : (double)*(const unsigned long long *)os * (1.0 / kTwo36);
             if (op.op == OP_DELAY || op.op == OP_TIMER || op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS ||
-                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY)
+                op.op == OP_CB_READER || op.op == OP_CB_WRITER || op.op == OP_MULTI_OSC || op.op == OP_READBACK_DELAY || op.op == OP_RETRIGGER)
                 st[0] = os[0];
             if (op.op == OP_FILTER)
                 for (int k = 0; k < 11; ++k) st[(size_t)k * A.n_pad] = os[k];

@@ -43,6 +43,17 @@ function dataOutletName(unit) { // "out" everywhere except MidiToFrequency's "fr
   return (spec && spec.outlet) || 'out'
 }
 
+/* A Retriggerer (Retriggerer.js:3-43) runs on the device when all it does can be done there: a constant rate, and a target
+ * whose trigger() the device knows — a Shape or an AHD of the same circuit.  Otherwise the host ticks it between segments. */
+function deviceRetrigger(unit, units) {
+  if (!unit || !unit.constructor || unit.constructor.name !== 'Retriggerer') return false
+  const target = unit._target
+  if (!target || !target.constructor || !['Shape', 'AHD'].includes(target.constructor.name)) return false
+  if (units && !units.includes(target)) return false
+  const rate = unit.inlets && unit.inlets.rate
+  return !!rate && !rate.connected
+}
+
 function extract(target, opts = {}) {
   const outlet = toOutlet(target)
   const outUnit = outlet.unit
@@ -71,7 +82,7 @@ function extract(target, opts = {}) {
 
   for (const unit of units) {
     const kind = unit.constructor && unit.constructor.name
-    const spec = UNITS[kind] || (unit.isHostSignal ? UNITS.HostSignal : undefined)
+    const spec = deviceRetrigger(unit, units) ? UNITS.DeviceRetriggerer : UNITS[kind] || (unit.isHostSignal ? UNITS.HostSignal : undefined)
     if (!spec) throw 'dusp-hip: unit type not supported on the GPU path: ' + kind + ' (' + unit.label + ')'
     if (unit.tickInterval !== chunkSize)
       throw 'dusp-hip: unit ' + unit.label + ' has tickInterval ' + unit.tickInterval + ' != chunk size ' + chunkSize
@@ -132,6 +143,9 @@ function extract(target, opts = {}) {
         break
       case OP.TIMER:
         attrs = [unit.samplePeriod]; state = [unit.t]
+        break
+      case OP.RETRIGGER:
+        attrs = [units.indexOf(unit._target)]; state = [unit.t]
         break
       case OP.INPUT: // Noise.js:16-27 reads `this.f[0][t]`: a connected f would have to come back from the device
         if (unit.inlets.f && unit.inlets.f.connected)
@@ -241,4 +255,5 @@ function unify(extractions) {
     sampleRate: first.sampleRate, chunkSize: first.chunkSize }
 }
 
-module.exports = { extract, unify, toOutlet }
+module.exports = {
+  deviceRetrigger, extract, unify, toOutlet }

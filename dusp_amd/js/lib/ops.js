@@ -26,6 +26,7 @@ const OP = Object.freeze({
   // envelopes driven by trigger() events (SURVEY.md §8f-3)
   SHAPE: 38, AHD: 39,
   HOST_ONLY: 40, // no signal: the unit acts through host callbacks between segments (Retriggerer)
+  RETRIGGER: 42, // a Retriggerer whose target is a Shape / AHD of the same circuit: runs on the device (attribute = target unit)
   INPUT: 41, // a signal the HOST computes chunk by chunk (Noise: Math.random() per sample); attribute = stream index
 })
 
@@ -78,7 +79,8 @@ const UNITS = Object.freeze({
   PickChannel: { op: OP.PICK_CHANNEL, inlets: ['in', 'c'] },
   Shape: { op: OP.SHAPE, inlets: ['duration', 'min', 'max'] },
   AHD: { op: OP.AHD, inlets: ['attack', 'hold', 'decay'] },
-  Retriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
+  Retriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true }, // (unless lib/extract.js deviceRetrigger() says it can run on the device)
+  DeviceRetriggerer: { op: OP.RETRIGGER, inlets: ['rate'] },
   SporadicRetriggerer: { op: OP.HOST_ONLY, inlets: [], hostTick: true },
   Noise: { op: OP.INPUT, inlets: [], hostTick: true },
   HostSignal: { op: OP.INPUT, inlets: [], hostTick: true }, // (and every subclass: lib/graph.js)

@@ -11,7 +11,7 @@
  * (state write-back).
  */
 const native = require('./native')
-const { extract, unify } = require('./extract')
+const { extract, unify, deviceRetrigger } = require('./extract')
 const { makeTables } = require('./wavetables')
 const { OP, UNITS } = require('./ops')
 
@@ -35,6 +35,7 @@ function sampleCount(duration, sampleRate) {
 
 function writeBack(n, prog, circuit, chunkSize, nSamples) {
   circuit.units.forEach((unit, u) => {
+    if (deviceRetrigger(unit, circuit.units)) { unit.t = n.stateDownload(prog, 0, u)[0]; return }
     const spec = UNITS[unit.constructor.name]
     if (!spec) return
     if (spec.op === OP.OSC) unit.phase = n.stateDownload(prog, 0, u)[0]
@@ -86,7 +87,8 @@ class SegmentRenderer {
     this.chunk = this.first.chunkSize
     this.sampleRate = this.first.sampleRate
     // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer; host-computed signals: Noise): ticked here, firing = segment boundary
-    this.tickers = this.circuit.units.filter((u) => (UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick) || u.isHostSignal)
+    this.tickers = this.circuit.units.filter((u) => ((UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick) || u.isHostSignal) &&
+      !deviceRetrigger(u, this.circuit.units)) // (a Retriggerer of a Shape / AHD runs on the device)
     for (const u of this.tickers)
       if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
     this.hasEvents = !!(this.circuit.events && this.circuit.events.length) || this.tickers.length > 0
@@ -184,7 +186,7 @@ async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
   // one launch for all circuits: nothing ticks on the host in between, so units that need that are refused, not ignored
   for (const ex of extractions)
     for (const u of ex.circuit.units)
-      if (u.isHostSignal || (UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick))
+      if ((u.isHostSignal || (UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick)) && !deviceRetrigger(u, ex.circuit.units))
         throw 'dusp-hip: renderMany does not take circuits with host-ticked units (' + u.label + '): render them one by one'
   const uni = unify(extractions)
   const nSamples = sampleCount(duration, uni.sampleRate)

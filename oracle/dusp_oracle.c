@@ -32,7 +32,8 @@ enum { OP_OSC = 1, OP_RAMP, OP_MULTIPLY, OP_SUM, OP_FILTER, OP_DELAY, OP_CB_READ
        /* envelopes */
        OP_SHAPE, OP_AHD,
        OP_HOST_ONLY, /* no signal: acts through host callbacks (Retriggerer); ticking it is a no-op */
-       OP_INPUT /* a signal the host computes (the reference's Noise draws Math.random() per sample): copied from a stream the caller hands over */ };
+       OP_INPUT, /* a signal the host computes (the reference's Noise draws Math.random() per sample): copied from a stream the caller hands over */
+       OP_RETRIGGER /* Retriggerer whose target is a Shape / AHD of this circuit: ticked here like any unit */ };
 #define N_TABLES 9 /* 0-4 oscillator wave tables, 5-8 Shape tables */
 #define MAX_INLETS 5
 enum { IN_CONST = 0, IN_CONNECT = 1, IN_PARAM = 2 };
@@ -571,6 +572,21 @@ static void tick_vector_magnitude(dusp_oracle *o, unit_t *u) {
     }
 }
 
+/* reference src/components/Retriggerer.js:13-24; trigger() of the target: Shape/index.js:107-111 (playing, t = 0),
+ * AHD.js:24-28 (state = 1, playing) */
+static void tick_retrigger(dusp_oracle *o, unit_t *u) {
+    const float *rate = inlet_chunk(o, u, 0)->ch[0];
+    unit_t *target = &o->units[u->ring]; /* (the target's index, kept in the field CircleBuffer nodes use for their ring) */
+    for (int t = 0; t < o->chunk; t++) {
+        u->timer_t += (double)rate[t];
+        if (u->timer_t >= o->sr) {
+            if (target->op == OP_SHAPE) { target->playing = 1; target->t = 0; }
+            else if (target->op == OP_AHD) { target->ahd_state = 1; target->playing = 1; }
+            u->timer_t -= o->sr;
+        }
+    }
+}
+
 /* reference src/components/Timer.js:36-41 */
 static void tick_timer(dusp_oracle *o, unit_t *u) {
     for (int t = 0; t < o->chunk; t++) {
@@ -701,6 +717,7 @@ static void circuit_tick(dusp_oracle *o) {
         case OP_CONCAT_CHANNELS: tick_concat_channels(o, u); break;
         case OP_PICK_CHANNEL: tick_pick_channel(o, u); break;
         case OP_HOST_ONLY: break;
+        case OP_RETRIGGER: tick_retrigger(o, u); break;
         case OP_INPUT: { /* the chunk the host computed for this unit (zeros past the end of what it handed over) */
             for (int t = 0; t < o->chunk; t++) {
                 const long at = o->clock - o->input_clock0 + t;
@@ -917,6 +934,12 @@ dusp_oracle *dusp_oracle_create(const double *d, size_t nw, const float *params,
             if (u->n_inlets || n_attr || n_state) FAIL("unit %zu: bad host-only record", i);
             out_channels = 0;
             break;
+        case OP_RETRIGGER:
+            if (u->n_inlets != 1 || n_attr != 1 || n_state != 1 || !(a[0] >= 0 && a[0] < (double)o->n_units)) FAIL("unit %zu: bad Retriggerer record", i);
+            u->ring = (int)a[0];
+            u->timer_t = s[0];
+            out_channels = 0;
+            break;
         case OP_INPUT:
             if (u->n_inlets || n_attr != 1 || n_state || !(a[0] >= 0 && a[0] < 4096)) FAIL("unit %zu: bad input record", i);
             u->ring = (int)a[0]; /* (the stream's index, kept in the field CircleBuffer nodes use for theirs) */
@@ -998,7 +1021,7 @@ size_t dusp_oracle_unit_state(const dusp_oracle *o, size_t i, double *out, size_
     case OP_RAMP: tmp[n++] = u->t; tmp[n++] = u->playing; break;
     case OP_CB_READER: case OP_CB_WRITER: tmp[n++] = u->cb_t; break;
     case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: case OP_READBACK_DELAY: tmp[n++] = u->tBuffer; break;
-    case OP_TIMER: tmp[n++] = u->timer_t; break;
+    case OP_TIMER: case OP_RETRIGGER: tmp[n++] = u->timer_t; break;
     case OP_SHAPE: tmp[n++] = u->t; tmp[n++] = u->playing; tmp[n++] = u->finished; break;
     case OP_AHD: tmp[n++] = u->ahd_state; tmp[n++] = u->playing; tmp[n++] = u->t; break;
     case OP_SAMPLE_RATE_REDUX:

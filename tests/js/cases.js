@@ -359,6 +359,21 @@ module.exports = function goldenCases(L, SR) {
       ra.schedule(0.15, function () { this.RATE = 30 }) // the rate changes on the fly
       return new Sum(new Multiply(new Osc(220), a), new Multiply(new Osc(331), b))
     }, 0.3)
+    // Retriggerers whose target is a Shape / AHD run on the DEVICE (descriptor opcode RETRIGGER): whole renders in one launch
+    add('rt_dev_ahd', () => {
+      const e = new AHD(0.002, 0.003, 0.008)
+      new Retriggerer(e, 31.5)
+      return new Multiply(new Osc(440, 'triangle'), e)
+    }, 0.3)
+    add('rt_dev_rhythm', () => { // two envelopes retriggered at different rates, mixed into a feedback delay line
+      const a = new Shape('decay', 0.012).trigger(), b = new Shape('semiSine', 0.03)
+      new Retriggerer(a, 8)
+      new Retriggerer(b, 5.5)
+      const sum = new Sum(new Sum(new Multiply(new Osc(330), a), new Multiply(new Osc(220.5, 'saw'), b)), 0)
+      const d = new Delay(sum, 2400.5, 8192)
+      sum.B = new Multiply(d, 0.4)
+      return new Sum(sum, d)
+    }, 0.6)
     add('rt_delay_line', () => { // retriggered bursts into a delay line: the ring has to survive the segment boundaries
       const r = new Ramp(600, 1, 0).trigger()
       new Retriggerer(r, 12)

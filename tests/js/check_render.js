@@ -46,8 +46,17 @@ async function main() {
   const many = await lib.renderMany(voices, 2048 / SR)
   const solo = await lib.renderChannelData(new lib.Multiply(new lib.Osc(110 * 3 + 0.5), new lib.Ramp(2000, 1, 0).trigger()), 2048 / SR)
   report.manyMatchesSolo = many.length === 5 && many[2][0].every((v, i) => v === solo[0][i])
+  // ... but a Retriggerer of a Shape / AHD runs on the device, so a batch of retriggered voices is one launch too
+  const beat = (rate, f) => { const e = new lib.Shape('decay', 0.01).trigger(); new lib.Retriggerer(e, rate); return new lib.Multiply(new lib.Osc(f), e) }
+  const beats = [[50, 330.5], [20, 220], [33.25, 110], [400, 55.5]]
+  const manyBeats = await lib.renderMany(beats.map(([r, f]) => beat(r, f)), 0.2)
+  report.manyRetriggered = true
+  for (let k = 0; k < beats.length; k++) {
+    const one = await lib.renderChannelData(beat(...beats[k]), 0.2)
+    report.manyRetriggered = report.manyRetriggered && manyBeats[k][0].length === one[0].length && manyBeats[k][0].every((v, i) => v === one[0][i])
+  }
   // renderMany runs one launch for all voices: a circuit whose unit needs host ticks in between is refused, not mis-rendered
-  const ticking = () => { const e = new lib.Shape('decay', 0.01).trigger(); new lib.Retriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) }
+  const ticking = () => { const e = new lib.Ramp(480, 1, 0).trigger(); new lib.Retriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) } // (a Ramp target is ticked on the host)
   report.manyRefusesHostTicked = await lib.renderMany([ticking(), ticking()], 0.01).then(() => 'resolved', (e) => String(e))
   // unsupported graphs reject with a string
   class Crackle extends lib.Unit { constructor() { super(); this.addOutlet('out') } } // a unit kind this package does not know

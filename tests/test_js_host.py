@@ -123,5 +123,6 @@ def test_js_render_channel_data_matches_reference_golden(sr):
     assert rep["oscPhaseAfter"] == rep["oscPhaseExpected"] and rep["clockAfter"] == 1024
     assert "already been ticked" in rep["secondRenderRejects"]
     assert rep["manyMatchesSolo"] is True
+    assert rep["manyRetriggered"] is True
     assert rep["manyRefusesHostTicked"].startswith("dusp-hip: renderMany does not take circuits with host-ticked units")
     assert rep["unsupported"].startswith("dusp-hip: unit type not supported")
