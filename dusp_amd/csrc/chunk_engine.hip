@@ -512,8 +512,8 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 st[0] = T;
                 if (fired) {  // the target ticks later in this chunk (the Retriggerer is chained before it)
                     double *ts = a.state + (size_t)op.attr * NP + i;
-                    if ((int)op.d[0] == OP_SHAPE) { ts[0] = 0.0; ts[NP] = 1.0; }   // t = 0, playing
-                    else { ts[0] = 1.0; ts[NP] = 1.0; }                            // AHD: state = attack, playing
+                    if ((int)op.d[0] == OP_AHD) { ts[0] = 1.0; ts[NP] = 1.0; }   // state = attack, playing
+                    else { ts[0] = 0.0; ts[NP] = 1.0; }                          // Shape, Ramp: t = 0, playing
                 }
                 break;
             }

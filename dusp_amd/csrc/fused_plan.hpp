@@ -449,6 +449,10 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
                                (o >= OP_MAP_FIRST && o <= OP_MAP_LAST) || (o >= OP_WIDE_FIRST && o <= OP_WIDE_LAST);
         if (!stateless) plan.op_state[k] = plan.n_state_ops++;
     }
+    for (const DevOp &op : P.ops)  // a Ramp that a Retriggerer restarts keeps (t at the restart, sample of the restart, playing) in LDS
+        if (op.op == OP_RETRIGGER && op.pad >= 0 && (size_t)op.pad < P.ops.size() && P.ops[(size_t)op.pad].op == OP_RAMP &&
+            plan.op_state[(size_t)op.pad] < 0)
+            plan.op_state[(size_t)op.pad] = plan.n_state_ops++;
     // chunk buffers by liveness.  Only where no chunk survives the chunk boundary: a feedback (or late) edge reads its
     // producer's PREVIOUS chunk, and continued programs with rings park all buffers between launches — those keep one
     // buffer per outlet channel.  An op's output slot is taken before its inputs' slots are released, so an op never
@@ -589,7 +593,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
             plan.ramp_checked.push_back({d, t0, ok});
         }
         (void)playing;
-        plan.ramp_fastdiv[k] = ok ? 1 : 0;
+        plan.ramp_fastdiv[k] = (ok && plan.op_state[k] < 0) ? 1 : 0;  // (a restarted Ramp runs through t sequences nobody checked)
     }
     // Time-split rendering: without Filters / Delays / feedback the only state that crosses a chunk boundary is each
     // oscillator's phase, and that is a modular SUM of its increments — segments can be rendered independently once

@@ -617,9 +617,10 @@ inline bool expand(Program &P, std::string &err) {
     }
     P.ring_samples = ring_pos;
     for (auto &op : P.ops)
-        if (op.op == OP_RETRIGGER) {  // trigger(): Shape -> t = 0, playing; AHD -> state = 1, playing (Shape/index.js:107-111, AHD.js:24-28)
+        if (op.op == OP_RETRIGGER) {  // trigger(): Shape, Ramp -> t = 0, playing; AHD -> state = 1, playing (Shape/index.js:107-111, Ramp.js:19-23, AHD.js:24-28)
             const UnitDesc &target = g.units[(size_t)g.units[(size_t)op.unit].attrs[0]];
-            if (target.op != OP_SHAPE && target.op != OP_AHD) return fail(err, "Retriggerer target is not a Shape / AHD (not supported on the GPU path)");
+            if (target.op != OP_SHAPE && target.op != OP_AHD && target.op != OP_RAMP)
+                return fail(err, "Retriggerer target is not a Shape / AHD / Ramp (not supported on the GPU path)");
             op.attr = target.first_slot;
             op.pad = target.first_op;
             op.d[0] = (double)target.op;

@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             if (op.op == OP_DELAY && A.resume) os[0] = A.state[(size_t)op.state_slot * A.n_pad + inst];
             if (op.op == OP_SHAPE || op.op == OP_AHD)
                 for (int k = 0; k < 3; ++k) os[k] = A.init_state[op.state_slot + k];
+            if (op.op == OP_RAMP) { os[0] = A.init_state[op.state_slot]; os[1] = 0.0; os[2] = A.init_state[op.state_slot + 1]; }
             // time-split: a later segment starts from the running sum's value at its first sample (plan_wave admits only
             // Timers and constant-duration Shapes whose sums repeat_add covers)
             if (A.n_seg > 1 && g_begin > 0) {
@@ -411,8 +412,18 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             case OP_RAMP: {  // Ramp.js:25-40 in closed form: t(n) = min(t0 + n + 1, duration) while playing
                 const double duration = op.d[0], y0 = op.d[1], dy = op.d[2] - op.d[1];
-                const double t0 = A.init_state[op.state_slot];
-                const bool playing = A.init_state[op.state_slot + 1] != 0.0;
+                double t0 = A.init_state[op.state_slot];
+                bool playing = A.init_state[op.state_slot + 1] != 0.0;
+                if (op.lds_slot >= 0) {  // restarted by a Retriggerer: t was rs[0] at sample rs[1] of this launch (Ramp.js:19-23)
+                    const double *rs = opstate + (size_t)op.lds_slot * kOpState;
+                    playing = rs[2] != 0.0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double tt = playing ? fmin(rs[0] + ((double)(n0 + c + 1) - rs[1]), duration) : rs[0];
+                        out.v[c] = (float)(y0 + (tt / duration) * dy);
+                    }
+                    break;
+                }
                 if (op.attr & 1) {  // host-verified: the refined reciprocal equals tt / duration on this Ramp's whole t sequence
                     const double rcp = 1.0 / duration;
 #pragma unroll
@@ -622,7 +633,10 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     if (fired) {
                         double *ts = opstate + (size_t)op.pad * kOpState;  // (pad: the target op's state block)
                         if ((int)op.d[0] == OP_SHAPE) { ts[0] = 0.0; ts[1] = 1.0; }
-                        else { ts[0] = 1.0; ts[1] = 1.0; }
+                        else if ((int)op.d[0] == OP_RAMP) {
+                            // restart: t = 0 before this chunk's first sample (rs[1] = that sample's index in this launch)
+                            ts[0] = 0.0; ts[1] = (double)((uint64_t)g * kChunk); ts[2] = 1.0;
+                        } else { ts[0] = 1.0; ts[1] = 1.0; }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1042,10 +1056,12 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             if (op.op == OP_SAMPLE_RATE_REDUX)
                 for (int k = 0; k < 2; ++k) st[(size_t)k * A.n_pad] = os[k];
             if (op.op == OP_RAMP) {
-                const double duration = op.d[0], t0 = A.init_state[op.state_slot];
-                const bool playing = A.init_state[op.state_slot + 1] != 0.0;
-                st[0] = playing ? fmin(t0 + (double)T_end, duration) : t0;
-                st[A.n_pad] = (playing && t0 + (double)T_end <= duration) ? 1.0 : 0.0;
+                const double duration = op.d[0];
+                double t0 = A.init_state[op.state_slot], since = (double)T_end;
+                bool playing = A.init_state[op.state_slot + 1] != 0.0;
+                if (op.lds_slot >= 0) { t0 = os[0]; since = (double)T_end - os[1]; playing = os[2] != 0.0; }  // since its last restart
+                st[0] = playing ? fmin(t0 + since, duration) : t0;
+                st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
             }
         }
     }

@@ -44,11 +44,11 @@ function dataOutletName(unit) { // "out" everywhere except MidiToFrequency's "fr
 }
 
 /* A Retriggerer (Retriggerer.js:3-43) runs on the device when all it does can be done there: a constant rate, and a target
- * whose trigger() the device knows — a Shape or an AHD of the same circuit.  Otherwise the host ticks it between segments. */
+ * whose trigger() the device knows — a Shape, an AHD or a Ramp of the same circuit.  Otherwise the host ticks it between segments. */
 function deviceRetrigger(unit, units) {
   if (!unit || !unit.constructor || unit.constructor.name !== 'Retriggerer') return false
   const target = unit._target
-  if (!target || !target.constructor || !['Shape', 'AHD'].includes(target.constructor.name)) return false
+  if (!target || !target.constructor || !['Shape', 'AHD', 'Ramp'].includes(target.constructor.name)) return false
   if (units && !units.includes(target)) return false
   const rate = unit.inlets && unit.inlets.rate
   return !!rate && !rate.connected

@@ -580,7 +580,7 @@ static void tick_retrigger(dusp_oracle *o, unit_t *u) {
     for (int t = 0; t < o->chunk; t++) {
         u->timer_t += (double)rate[t];
         if (u->timer_t >= o->sr) {
-            if (target->op == OP_SHAPE) { target->playing = 1; target->t = 0; }
+            if (target->op == OP_SHAPE || target->op == OP_RAMP) { target->playing = 1; target->t = 0; } /* Ramp.js:19-23 */
             else if (target->op == OP_AHD) { target->ahd_state = 1; target->playing = 1; }
             u->timer_t -= o->sr;
         }

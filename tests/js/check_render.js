@@ -56,7 +56,7 @@ async function main() {
     report.manyRetriggered = report.manyRetriggered && manyBeats[k][0].length === one[0].length && manyBeats[k][0].every((v, i) => v === one[0][i])
   }
   // renderMany runs one launch for all voices: a circuit whose unit needs host ticks in between is refused, not mis-rendered
-  const ticking = () => { const e = new lib.Ramp(480, 1, 0).trigger(); new lib.Retriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) } // (a Ramp target is ticked on the host)
+  const ticking = () => { const e = new lib.Shape('decay', 0.01).trigger(); new lib.SporadicRetriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) } // (random: ticked on the host)
   report.manyRefusesHostTicked = await lib.renderMany([ticking(), ticking()], 0.01).then(() => 'resolved', (e) => String(e))
   // unsupported graphs reject with a string
   class Crackle extends lib.Unit { constructor() { super(); this.addOutlet('out') } } // a unit kind this package does not know
