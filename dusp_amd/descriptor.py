@@ -22,6 +22,7 @@ OP_FIXED_DELAY, OP_COMB_FILTER, OP_ALL_PASS, OP_MONO_DELAY, OP_READBACK_DELAY, O
 OP_SHAPE, OP_AHD = 38, 39  # envelopes (§8f-3)
 OP_HOST_ONLY = 40  # no signal: the unit acts through host callbacks between segments (Retriggerer)
 OP_INPUT = 41  # a signal the host computes (graph.HostSource; the JS host's Noise): attribute = stream index
+OP_RETRIGGER = 42  # a Retriggerer of a Shape / AHD / Ramp, ticked on the device (built by the JS host's extractor)
 IN_CONST, IN_CONNECT, IN_PARAM = 0, 1, 2
 FILTER_KINDS = {"LP": 0, "HP": 1}
 
