@@ -117,7 +117,9 @@ __device__ __forceinline__ long long wave_inclusive_scan(long long x, uint32_t l
 
 // TBL: half wave table in LDS.  WAVES: wavefronts (instances) per workgroup.  RING: carries the ordered slot operations of
 // short / signal-rate delay lines — a separate variant, so that programs without them keep the leaner kernel.
-template <int TBL, int WAVES, int RING>
+// EXT: carries the units beyond Osc / Ramp / Filter / write-once Delay / Multiply / Sum / Repeater / the two-operand maps — the
+// common graphs keep a kernel whose register allocation those units' code does not disturb.
+template <int TBL, int WAVES, int RING, int EXT>
 __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BLOCK = WAVES * 64;
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const double duration = op.d[0], y0 = op.d[1], dy = op.d[2] - op.d[1];
                 double t0 = A.init_state[op.state_slot];
                 bool playing = A.init_state[op.state_slot + 1] != 0.0;
-                if (op.lds_slot >= 0) {  // restarted by a Retriggerer: t was rs[0] at sample rs[1] of this launch (Ramp.js:19-23)
+                if (EXT != 0 && op.lds_slot >= 0) {  // restarted by a Retriggerer: t was rs[0] at sample rs[1] of this launch (Ramp.js:19-23)
                     const double *rs = opstate + (size_t)op.lds_slot * kOpState;
                     playing = rs[2] != 0.0;
 #pragma unroll
@@ -613,7 +615,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             case OP_MONO_DELAY: case OP_READBACK_DELAY:
                 if constexpr (RING != 0) ordered_ring_ops(op, u, g, out);  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
                 break;
-            case OP_RETRIGGER: {  // Retriggerer.js:13-24 on one lane; a firing rewrites the target's state block before the target ticks
+            case OP_RETRIGGER: if constexpr (EXT != 0) {  // Retriggerer.js:13-24 on one lane; a firing rewrites the target's state block before the target ticks
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t
                 if (lane == 0) {
                     const double rate = (double)(op.in[0].kind == SRC_PARAM ? pvals[(size_t)op.in[0].idx * pstride] : op.in[0].cval);
@@ -642,13 +644,13 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 continue;  // no outlet
-            }
-            case OP_INPUT: {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
+            } else break;
+            case OP_INPUT: if constexpr (EXT != 0) {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
                 const float *src = A.inputs + ((size_t)op.attr * A.n_inst + inst) * A.n_samples;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out.v[c] = n0 + c < A.n_samples ? src[n0 + c] : 0.f;
                 break;
-            }
+            } else break;
             case OP_MULTIPLY: {  // Multiply.js:23-34
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             // ---- units whose state evolves sample by sample with its own roundings: the sequential part runs on lane 0
             // out of the wave's LDS scratch (a few instructions per sample), everything else stays lane-parallel
-            case OP_SHAPE: {  // Shape/index.js:28-59
+            case OP_SHAPE: if constexpr (EXT != 0) {  // Shape/index.js:28-59
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t [1] playing [2] finished
                 const V4 dur = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 mn = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -719,8 +721,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 if (__ballot(over) && lane == 0) ss[2] = 1.0;  // finish() (UnitOrPatch.js:77-84)
                 break;
-            }
-            case OP_TIMER: {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
+            } else break;
+            case OP_TIMER: if constexpr (EXT != 0) {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 const double period = op.d[0], t0 = ss[0];
                 if (t0 >= 0.0 && period > 0.0 && period < 1.0e300) {  // the running sum in closed form, every lane its own four samples
@@ -748,8 +750,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 out.v[0] = y[0]; out.v[1] = y[1]; out.v[2] = y[2]; out.v[3] = y[3];
                 __builtin_amdgcn_wave_barrier();
                 break;
-            }
-            case OP_AHD: case OP_SAMPLE_RATE_REDUX: {  // AHD.js:35-76, SampleRateRedux.js:21-38
+            } else break;
+            case OP_AHD: case OP_SAMPLE_RATE_REDUX: if constexpr (EXT != 0) {  // AHD.js:35-76, SampleRateRedux.js:21-38
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 float *Y = (float *)scratch;  // [256] output, then up to three operand rows
                 // operands as plain rows: a connected inlet is the producer's chunk buffer, a constant fills a scratch row
@@ -808,8 +810,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 out.v[0] = y[0]; out.v[1] = y[1]; out.v[2] = y[2]; out.v[3] = y[3];
                 __builtin_amdgcn_wave_barrier();
                 break;
-            }
-            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: {  // FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15
+            } else break;
+            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: if constexpr (EXT != 0) {  // FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15
                 // A private ring of L slots read and rewritten one slot per sample: sample t depends on sample t - L only,
                 // so a chunk is L (at most 64) independent samples at a time.  The slots the chunk touches — min(L, 256)
                 // of them — are staged in LDS, walked in rounds, and written back.
@@ -871,8 +873,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 out.v[0] = y4[0]; out.v[1] = y4[1]; out.v[2] = y4[2]; out.v[3] = y4[3];
                 __builtin_amdgcn_wave_barrier();
                 break;
-            }
-            case OP_CB_READER: case OP_CB_WRITER: {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
+            } else break;
+            case OP_CB_READER: case OP_CB_WRITER: if constexpr (EXT != 0) {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
                 if constexpr (RING != 0)
                     if (op.in[0].kind == SRC_BUF || op.ring_len < kChunk) {  // accesses that can meet inside the chunk
                         ordered_ring_ops(op, u, g, out);
@@ -914,8 +916,8 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (lane == 0) ss[0] += (double)kChunk;
                 if (op.op == OP_CB_WRITER) continue;  // no outlet
                 break;
-            }
-            case OP_MULTI_OSC: {  // MultiChannelOsc.js:21-38: `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`
+            } else break;
+            case OP_MULTI_OSC: if constexpr (EXT != 0) {  // MultiChannelOsc.js:21-38: `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`
                 // The remainder keeps the dividend's sign, so the phase is not a modular sum (a negative excursion reads
                 // `undefined` -> NaN until the sum comes back): the 256 phases come from the serial lane, in f64 exactly
                 // as the reference adds them; the table lookups and the lerp are lane-parallel.
@@ -987,12 +989,12 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 break;
-            }
+            } else break;
             case OP_REPEATER: {  // Repeater.js:23-30
                 out = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 break;
             }
-            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: {
+            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: if constexpr (EXT != 0) {
                 V4 w[kMaxIn];
 #pragma unroll
                 for (int k = 0; k < kMaxIn; ++k)
@@ -1003,7 +1005,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     out.v[c] = map_wide(op.op, op.attr, op.n_in, v, op.d[0]);
                 }
                 break;
-            }
+            } else break;
             default: {  // stateless elementwise maps (map_ops.hpp)
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 y = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -1111,9 +1113,9 @@ hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uin
     return hipGetLastError();
 }
 
-template <int TBL, int WAVES, int RING>
+template <int TBL, int WAVES, int RING, int EXT>
 static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = dusp_wave_kernel<TBL, WAVES, RING>;
+    auto kernel = dusp_wave_kernel<TBL, WAVES, RING, EXT>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -1152,27 +1154,37 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     const int most = A.ring_events ? 8 : 16;  // (the RING variant wants its 256 VGPRs: two waves per SIMD)
     while (waves < most && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
-#define DUSP_W(T, W, R) launch_wave_one<T, W, R>(A, lds_bytes, stream)
-    const int variant = (table_bytes ? 1 : 0) | (A.ring_events ? 2 : 0);
+#define DUSP_W(T, W, R, E) launch_wave_one<T, W, R, E>(A, lds_bytes, stream)
+    const int variant = (table_bytes ? 1 : 0) | (A.ring_events ? 4 : A.ext_units ? 2 : 0);
     switch (variant * 32 + waves) {
-    case 0 * 32 + 16: return DUSP_W(0, 16, 0);
-    case 0 * 32 + 8: return DUSP_W(0, 8, 0);
-    case 0 * 32 + 4: return DUSP_W(0, 4, 0);
-    case 0 * 32 + 2: return DUSP_W(0, 2, 0);
-    case 0 * 32 + 1: return DUSP_W(0, 1, 0);
-    case 1 * 32 + 16: return DUSP_W(1, 16, 0);
-    case 1 * 32 + 8: return DUSP_W(1, 8, 0);
-    case 1 * 32 + 4: return DUSP_W(1, 4, 0);
-    case 1 * 32 + 2: return DUSP_W(1, 2, 0);
-    case 1 * 32 + 1: return DUSP_W(1, 1, 0);
-    case 2 * 32 + 8: return DUSP_W(0, 8, 1);
-    case 2 * 32 + 4: return DUSP_W(0, 4, 1);
-    case 2 * 32 + 2: return DUSP_W(0, 2, 1);
-    case 2 * 32 + 1: return DUSP_W(0, 1, 1);
-    case 3 * 32 + 8: return DUSP_W(1, 8, 1);
-    case 3 * 32 + 4: return DUSP_W(1, 4, 1);
-    case 3 * 32 + 2: return DUSP_W(1, 2, 1);
-    case 3 * 32 + 1: return DUSP_W(1, 1, 1);
+    case 0 * 32 + 16: return DUSP_W(0, 16, 0, 0);
+    case 0 * 32 + 8: return DUSP_W(0, 8, 0, 0);
+    case 0 * 32 + 4: return DUSP_W(0, 4, 0, 0);
+    case 0 * 32 + 2: return DUSP_W(0, 2, 0, 0);
+    case 0 * 32 + 1: return DUSP_W(0, 1, 0, 0);
+    case 1 * 32 + 16: return DUSP_W(1, 16, 0, 0);
+    case 1 * 32 + 8: return DUSP_W(1, 8, 0, 0);
+    case 1 * 32 + 4: return DUSP_W(1, 4, 0, 0);
+    case 1 * 32 + 2: return DUSP_W(1, 2, 0, 0);
+    case 1 * 32 + 1: return DUSP_W(1, 1, 0, 0);
+    case 2 * 32 + 16: return DUSP_W(0, 16, 0, 1);
+    case 2 * 32 + 8: return DUSP_W(0, 8, 0, 1);
+    case 2 * 32 + 4: return DUSP_W(0, 4, 0, 1);
+    case 2 * 32 + 2: return DUSP_W(0, 2, 0, 1);
+    case 2 * 32 + 1: return DUSP_W(0, 1, 0, 1);
+    case 3 * 32 + 16: return DUSP_W(1, 16, 0, 1);
+    case 3 * 32 + 8: return DUSP_W(1, 8, 0, 1);
+    case 3 * 32 + 4: return DUSP_W(1, 4, 0, 1);
+    case 3 * 32 + 2: return DUSP_W(1, 2, 0, 1);
+    case 3 * 32 + 1: return DUSP_W(1, 1, 0, 1);
+    case 4 * 32 + 8: return DUSP_W(0, 8, 1, 1);
+    case 4 * 32 + 4: return DUSP_W(0, 4, 1, 1);
+    case 4 * 32 + 2: return DUSP_W(0, 2, 1, 1);
+    case 4 * 32 + 1: return DUSP_W(0, 1, 1, 1);
+    case 5 * 32 + 8: return DUSP_W(1, 8, 1, 1);
+    case 5 * 32 + 4: return DUSP_W(1, 4, 1, 1);
+    case 5 * 32 + 2: return DUSP_W(1, 2, 1, 1);
+    case 5 * 32 + 1: return DUSP_W(1, 1, 1, 1);
     }
     return hipErrorInvalidValue;
 #undef DUSP_W
