@@ -546,7 +546,7 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
         w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
         w.ring_events = prog->wave.ring_events ? 1u : 0u;
-        w.ext_units = prog->wave.ext_units ? 1u : 0u;
+        w.ext_units = (uint32_t)prog->wave.ext_units;
         w.n_params = (uint32_t)P.g.n_params;
         w.ring_samples = (uint64_t)P.ring_samples;
         const bool resume = prog->keep_memory;

@@ -95,7 +95,7 @@ struct WaveArgs {
     const float *inputs;   // [n_inputs][n_inst][n_samples] host-generated signals (OP_INPUT)
     uint32_t n_state_ops;  // ops that own a block of LDS state (DevOp::lds_slot)
     uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
-    uint32_t ext_units;    // ... or a unit beyond the core set (Osc, Ramp, Filter, write-once Delay, Multiply, Sum, Repeater, two-operand maps)
+    uint32_t ext_units;    // the kernel variant the units ask for: 0 Osc/Ramp/Multiply/Sum/Repeater/maps, 1 + Filter / Delay, 2 anything else
     // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
     // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
     // in 2^-36 units (bit 63 = poisoned by a NaN / Inf increment).
@@ -125,7 +125,7 @@ struct WavePlan {
     std::vector<int> buf_slot;   // chunk buffer -> LDS slot
     std::vector<int> op_state;   // device op -> state block (-1: stateless)
     int n_slots = 0, n_state_ops = 0;
-    bool ext_units = false;    // a unit outside the lean kernel's set (see dusp_wave_kernel's EXT)
+    int ext_units = 0;         // the leanest kernel variant that carries the program's units (dusp_wave_kernel's EXT)
     bool ring_events = false;  // a delay line that goes through ordered slot operations (short / signal-rate Delay, MonoDelay, ReadBackDelay)
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
@@ -431,11 +431,13 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     for (const DevOp &op : P.ops)
         if ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.ring_len < 1 || op.ring_len >= (1ll << 31))) return no("CircleBuffer ring out of range");
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
-    plan.has_filter = plan.has_modulated_filter = plan.ring_events = plan.ext_units = false;
+    plan.has_filter = plan.has_modulated_filter = plan.ring_events = false;
+    plan.ext_units = 0;
     for (const DevOp &op : P.ops) {
         const int o = op.op;
-        plan.ext_units = plan.ext_units || !(o == OP_OSC || o == OP_RAMP || o == OP_FILTER || o == OP_DELAY || o == OP_MULTIPLY || o == OP_SUM ||
-                                             o == OP_REPEATER || (o >= OP_MAP_FIRST && o <= OP_MAP_LAST));
+        const int wants = (o == OP_OSC || o == OP_RAMP || o == OP_MULTIPLY || o == OP_SUM || o == OP_REPEATER || (o >= OP_MAP_FIRST && o <= OP_MAP_LAST)) ? 0
+                          : (o == OP_FILTER || o == OP_DELAY) ? 1 : 2;
+        plan.ext_units = std::max(plan.ext_units, wants);
         plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
                            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
         plan.has_filter = plan.has_filter || op.op == OP_FILTER;

@@ -31,6 +31,9 @@
 // (~0.7 us per chunk) — still two orders of magnitude faster than ticking it on the host.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_types.hpp"
 #include "fused_device.hpp"
 #include "repeat_add.hpp"
@@ -117,8 +120,9 @@ __device__ __forceinline__ long long wave_inclusive_scan(long long x, uint32_t l
 
 // TBL: half wave table in LDS.  WAVES: wavefronts (instances) per workgroup.  RING: carries the ordered slot operations of
 // short / signal-rate delay lines — a separate variant, so that programs without them keep the leaner kernel.
-// EXT: carries the units beyond Osc / Ramp / Filter / write-once Delay / Multiply / Sum / Repeater / the two-operand maps — the
-// common graphs keep a kernel whose register allocation those units' code does not disturb.
+// EXT: which units the variant carries — 0: Osc, Ramp, Multiply, Sum, Repeater, the two-operand maps; 1: + Filter and the
+// write-once Delay; 2: everything else — so that the common graphs keep kernels whose register allocation the other units'
+// code does not disturb.
 template <int TBL, int WAVES, int RING, int EXT>
 __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,7 +420,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 const double duration = op.d[0], y0 = op.d[1], dy = op.d[2] - op.d[1];
                 double t0 = A.init_state[op.state_slot];
                 bool playing = A.init_state[op.state_slot + 1] != 0.0;
-                if (EXT != 0 && op.lds_slot >= 0) {  // restarted by a Retriggerer: t was rs[0] at sample rs[1] of this launch (Ramp.js:19-23)
+                if (EXT >= 2 && op.lds_slot >= 0) {  // restarted by a Retriggerer: t was rs[0] at sample rs[1] of this launch (Ramp.js:19-23)
                     const double *rs = opstate + (size_t)op.lds_slot * kOpState;
                     playing = rs[2] != 0.0;
 #pragma unroll
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 break;
             }
-            case OP_FILTER: {  // Filter.js:27-51
+            case OP_FILTER: if constexpr (EXT >= 1) {  // Filter.js:27-51
                 double *fs = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 fv = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -562,9 +566,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 continue;  // the output chunk is already in LDS
-            }
+            } else break;
             case OP_DELAY:  // Delay.js:20-41
-              if (!RING || delay_is_write_once(op)) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
+              if (EXT >= 1 && (!RING || delay_is_write_once(op))) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
                 double *ds = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const int64_t len = op.ring_len;
@@ -615,7 +619,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             case OP_MONO_DELAY: case OP_READBACK_DELAY:
                 if constexpr (RING != 0) ordered_ring_ops(op, u, g, out);  // (launch_wave_engine picks the RING variant whenever the plan has such a unit)
                 break;
-            case OP_RETRIGGER: if constexpr (EXT != 0) {  // Retriggerer.js:13-24 on one lane; a firing rewrites the target's state block before the target ticks
+            case OP_RETRIGGER: if constexpr (EXT >= 2) {  // Retriggerer.js:13-24 on one lane; a firing rewrites the target's state block before the target ticks
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t
                 if (lane == 0) {
                     const double rate = (double)(op.in[0].kind == SRC_PARAM ? pvals[(size_t)op.in[0].idx * pstride] : op.in[0].cval);
@@ -645,7 +649,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 continue;  // no outlet
             } else break;
-            case OP_INPUT: if constexpr (EXT != 0) {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
+            case OP_INPUT: if constexpr (EXT >= 2) {  // a signal the host computed (Noise): this lane's four samples of stream op.attr
                 const float *src = A.inputs + ((size_t)op.attr * A.n_inst + inst) * A.n_samples;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) out.v[c] = n0 + c < A.n_samples ? src[n0 + c] : 0.f;
@@ -665,7 +669,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
             }
             // ---- units whose state evolves sample by sample with its own roundings: the sequential part runs on lane 0
             // out of the wave's LDS scratch (a few instructions per sample), everything else stays lane-parallel
-            case OP_SHAPE: if constexpr (EXT != 0) {  // Shape/index.js:28-59
+            case OP_SHAPE: if constexpr (EXT >= 2) {  // Shape/index.js:28-59
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;  // [0] t [1] playing [2] finished
                 const V4 dur = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 mn = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (__ballot(over) && lane == 0) ss[2] = 1.0;  // finish() (UnitOrPatch.js:77-84)
                 break;
             } else break;
-            case OP_TIMER: if constexpr (EXT != 0) {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
+            case OP_TIMER: if constexpr (EXT >= 2) {  // Timer.js:36-41: t += samplePeriod, rounded to f32 per sample
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 const double period = op.d[0], t0 = ss[0];
                 if (t0 >= 0.0 && period > 0.0 && period < 1.0e300) {  // the running sum in closed form, every lane its own four samples
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 break;
             } else break;
-            case OP_AHD: case OP_SAMPLE_RATE_REDUX: if constexpr (EXT != 0) {  // AHD.js:35-76, SampleRateRedux.js:21-38
+            case OP_AHD: case OP_SAMPLE_RATE_REDUX: if constexpr (EXT >= 2) {  // AHD.js:35-76, SampleRateRedux.js:21-38
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 float *Y = (float *)scratch;  // [256] output, then up to three operand rows
                 // operands as plain rows: a connected inlet is the producer's chunk buffer, a constant fills a scratch row
@@ -811,7 +815,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 break;
             } else break;
-            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: if constexpr (EXT != 0) {  // FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15
+            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: if constexpr (EXT >= 2) {  // FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15
                 // A private ring of L slots read and rewritten one slot per sample: sample t depends on sample t - L only,
                 // so a chunk is L (at most 64) independent samples at a time.  The slots the chunk touches — min(L, 256)
                 // of them — are staged in LDS, walked in rounds, and written back.
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 break;
             } else break;
-            case OP_CB_READER: case OP_CB_WRITER: if constexpr (EXT != 0) {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
+            case OP_CB_READER: case OP_CB_WRITER: if constexpr (EXT >= 2) {  // CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34
                 if constexpr (RING != 0)
                     if (op.in[0].kind == SRC_BUF || op.ring_len < kChunk) {  // accesses that can meet inside the chunk
                         ordered_ring_ops(op, u, g, out);
@@ -917,7 +921,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (op.op == OP_CB_WRITER) continue;  // no outlet
                 break;
             } else break;
-            case OP_MULTI_OSC: if constexpr (EXT != 0) {  // MultiChannelOsc.js:21-38: `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`
+            case OP_MULTI_OSC: if constexpr (EXT >= 2) {  // MultiChannelOsc.js:21-38: `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`
                 // The remainder keeps the dividend's sign, so the phase is not a modular sum (a negative excursion reads
                 // `undefined` -> NaN until the sum comes back): the 256 phases come from the serial lane, in f64 exactly
                 // as the reference adds them; the table lookups and the lerp are lane-parallel.
@@ -994,7 +998,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 out = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 break;
             }
-            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: if constexpr (EXT != 0) {
+            case OP_PAN: case OP_MIDI_TO_FREQUENCY: case OP_RESCALE: case OP_CROSS_FADER: case OP_VECTOR_MAGNITUDE: if constexpr (EXT >= 2) {
                 V4 w[kMaxIn];
 #pragma unroll
                 for (int k = 0; k < kMaxIn; ++k)
@@ -1151,12 +1155,13 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     const int fit = (int)((budget - table_bytes) / (A.wave_bytes + shared_per_wave));
     const unsigned want = (A.n_inst * A.n_seg + 255) / 256;  // (virtual) instances per CU on a 256-CU part
     int waves = 1;
-    const int most = A.ring_events ? 8 : 16;  // (the RING variant wants its 256 VGPRs: two waves per SIMD)
+    int most = A.ring_events ? 8 : 16;  // (the RING variant wants its 256 VGPRs: two waves per SIMD)
+    if (const char *cap = getenv("DUSP_WAVE_MAX_WAVES")) most = std::max(1, std::min(most, atoi(cap)));  // A/B knob
     while (waves < most && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
 #define DUSP_W(T, W, R, E) launch_wave_one<T, W, R, E>(A, lds_bytes, stream)
-    const int variant = (table_bytes ? 1 : 0) | (A.ring_events ? 4 : A.ext_units ? 2 : 0);
-    switch (variant * 32 + waves) {
+    const int level = A.ring_events ? 3 : (int)A.ext_units;  // 0 / 1 / 2 as EXT; 3 = RING (EXT 2 + ordered slot operations)
+    switch ((level * 2 + (table_bytes ? 1 : 0)) * 32 + waves) {
     case 0 * 32 + 16: return DUSP_W(0, 16, 0, 0);
     case 0 * 32 + 8: return DUSP_W(0, 8, 0, 0);
     case 0 * 32 + 4: return DUSP_W(0, 4, 0, 0);
@@ -1177,14 +1182,24 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     case 3 * 32 + 4: return DUSP_W(1, 4, 0, 1);
     case 3 * 32 + 2: return DUSP_W(1, 2, 0, 1);
     case 3 * 32 + 1: return DUSP_W(1, 1, 0, 1);
-    case 4 * 32 + 8: return DUSP_W(0, 8, 1, 1);
-    case 4 * 32 + 4: return DUSP_W(0, 4, 1, 1);
-    case 4 * 32 + 2: return DUSP_W(0, 2, 1, 1);
-    case 4 * 32 + 1: return DUSP_W(0, 1, 1, 1);
-    case 5 * 32 + 8: return DUSP_W(1, 8, 1, 1);
-    case 5 * 32 + 4: return DUSP_W(1, 4, 1, 1);
-    case 5 * 32 + 2: return DUSP_W(1, 2, 1, 1);
-    case 5 * 32 + 1: return DUSP_W(1, 1, 1, 1);
+    case 4 * 32 + 16: return DUSP_W(0, 16, 0, 2);
+    case 4 * 32 + 8: return DUSP_W(0, 8, 0, 2);
+    case 4 * 32 + 4: return DUSP_W(0, 4, 0, 2);
+    case 4 * 32 + 2: return DUSP_W(0, 2, 0, 2);
+    case 4 * 32 + 1: return DUSP_W(0, 1, 0, 2);
+    case 5 * 32 + 16: return DUSP_W(1, 16, 0, 2);
+    case 5 * 32 + 8: return DUSP_W(1, 8, 0, 2);
+    case 5 * 32 + 4: return DUSP_W(1, 4, 0, 2);
+    case 5 * 32 + 2: return DUSP_W(1, 2, 0, 2);
+    case 5 * 32 + 1: return DUSP_W(1, 1, 0, 2);
+    case 6 * 32 + 8: return DUSP_W(0, 8, 1, 2);
+    case 6 * 32 + 4: return DUSP_W(0, 4, 1, 2);
+    case 6 * 32 + 2: return DUSP_W(0, 2, 1, 2);
+    case 6 * 32 + 1: return DUSP_W(0, 1, 1, 2);
+    case 7 * 32 + 8: return DUSP_W(1, 8, 1, 2);
+    case 7 * 32 + 4: return DUSP_W(1, 4, 1, 2);
+    case 7 * 32 + 2: return DUSP_W(1, 2, 1, 2);
+    case 7 * 32 + 1: return DUSP_W(1, 1, 1, 2);
     }
     return hipErrorInvalidValue;
 #undef DUSP_W
