@@ -493,16 +493,17 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                         // are speculated away — without them a NaN never leaves the recurrence, so testing the block's
                         // last outputs finds one anywhere in it (the block is then redone exactly), and a -0 in place of
                         // +0 can only flip the sign of a later zero (see loop2_engine.hip).
-                        for (int t0 = 0; t0 < kChunk; t0 += 16) {
-                            double pv[16];
+                        constexpr int PB = WAVES >= 16 ? 8 : 16;  // P values per block held in registers (the 16-wave variants have 128 VGPRs)
+                        for (int t0 = 0; t0 < kChunk; t0 += PB) {
+                            double pv[PB];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) pv[k] = pr[t0 + k];
+                            for (int k = 0; k < PB; ++k) pv[k] = pr[t0 + k];
                             __builtin_amdgcn_sched_barrier(0);
                             const double y1_in = y1, y2_in = y2;
                             double u1 = or0w(y1), u2 = or0w(y2);
-                            f32x4 y4[4];
+                            f32x4 y4[PB / 4];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) {
+                            for (int k = 0; k < PB; ++k) {
                                 const float y = (float)((pv[k] - b1 * u1) - b2 * u2);
                                 y4[k >> 2][k & 3] = y;
                                 u2 = u1;
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                                 y1 = y1_in;
                                 y2 = y2_in;
 #pragma unroll
-                                for (int k = 0; k < 16; ++k) {
+                                for (int k = 0; k < PB; ++k) {
                                     const float y = (float)((pv[k] - b1 * or0w(y1)) - b2 * or0w(y2));  // Filter.js:40-46
                                     y4[k >> 2][k & 3] = y;
                                     y2 = or0w(y1);
@@ -523,7 +524,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                                 }
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) yr[(t0 >> 2) + k] = y4[k];
+                            for (int k = 0; k < PB / 4; ++k) yr[(t0 >> 2) + k] = y4[k];
                         }
                         os[9] = y1;
                         os[10] = y2;
