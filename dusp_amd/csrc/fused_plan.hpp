@@ -95,7 +95,7 @@ struct WaveArgs {
     const float *inputs;   // [n_inputs][n_inst][n_samples] host-generated signals (OP_INPUT)
     uint32_t n_state_ops;  // ops that own a block of LDS state (DevOp::lds_slot)
     uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
-    uint32_t ext_units;    // the kernel variant the units ask for: 0 Osc/Ramp/Multiply/Sum/Repeater/maps, 1 + Filter / Delay, 2 anything else
+    uint32_t ext_units;    // what the units ask of the kernel variant: bit 0 Filter / Delay, bit 1 anything beyond Osc/Ramp/Multiply/Sum/Repeater/maps
     // time-split rendering (few instances, long render): every instance is cut into n_seg segments of seg_groups
     // chunks, one wavefront each.  seg_sum / seg_start: [n_ops][n_inst][n_seg] oscillator phase totals / start phases
     // in 2^-36 units (bit 63 = poisoned by a NaN / Inf increment).
@@ -125,7 +125,7 @@ struct WavePlan {
     std::vector<int> buf_slot;   // chunk buffer -> LDS slot
     std::vector<int> op_state;   // device op -> state block (-1: stateless)
     int n_slots = 0, n_state_ops = 0;
-    int ext_units = 0;         // the leanest kernel variant that carries the program's units (dusp_wave_kernel's EXT)
+    int ext_units = 0;         // bit 0: Filter / Delay present, bit 1: units beyond the lean set (dusp_wave_kernel's FILT / EXT)
     bool ring_events = false;  // a delay line that goes through ordered slot operations (short / signal-rate Delay, MonoDelay, ReadBackDelay)
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
@@ -437,7 +437,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         const int o = op.op;
         const int wants = (o == OP_OSC || o == OP_RAMP || o == OP_MULTIPLY || o == OP_SUM || o == OP_REPEATER || (o >= OP_MAP_FIRST && o <= OP_MAP_LAST)) ? 0
                           : (o == OP_FILTER || o == OP_DELAY) ? 1 : 2;
-        plan.ext_units = std::max(plan.ext_units, wants);
+        plan.ext_units |= wants;
         plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
                            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
         plan.has_filter = plan.has_filter || op.op == OP_FILTER;

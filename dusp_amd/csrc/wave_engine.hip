@@ -120,10 +120,10 @@ __device__ __forceinline__ long long wave_inclusive_scan(long long x, uint32_t l
 
 // TBL: half wave table in LDS.  WAVES: wavefronts (instances) per workgroup.  RING: carries the ordered slot operations of
 // short / signal-rate delay lines — a separate variant, so that programs without them keep the leaner kernel.
-// EXT: which units the variant carries — 0: Osc, Ramp, Multiply, Sum, Repeater, the two-operand maps; 1: + Filter and the
-// write-once Delay; 2: everything else — so that the common graphs keep kernels whose register allocation the other units'
-// code does not disturb.
-template <int TBL, int WAVES, int RING, int EXT>
+// Which units a variant carries — always: Osc, Ramp, Multiply, Sum, Repeater, the two-operand maps; FILT: Filter and the
+// write-once Delay; EXT (2): everything else — so that the common graphs keep kernels whose register allocation the other
+// units' code does not disturb.
+template <int TBL, int WAVES, int RING, int EXT, int FILT>
 __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BLOCK = WAVES * 64;
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 }
                 break;
             }
-            case OP_FILTER: if constexpr (EXT >= 1) {  // Filter.js:27-51
+            case OP_FILTER: if constexpr (FILT != 0) {  // Filter.js:27-51
                 double *fs = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const V4 fv = load_operand(op.in[1], bufs, lane, pvals, pstride, 0);
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 continue;  // the output chunk is already in LDS
             } else break;
             case OP_DELAY:  // Delay.js:20-41
-              if (EXT >= 1 && (!RING || delay_is_write_once(op))) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
+              if (FILT != 0 && (!RING || delay_is_write_once(op))) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
                 double *ds = opstate + (size_t)op.lds_slot * kOpState;
                 const V4 x = load_operand(op.in[0], bufs, lane, pvals, pstride, 0);
                 const int64_t len = op.ring_len;
@@ -1118,9 +1118,9 @@ hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uin
     return hipGetLastError();
 }
 
-template <int TBL, int WAVES, int RING, int EXT>
+template <int TBL, int WAVES, int RING, int EXT, int FILT>
 static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = dusp_wave_kernel<TBL, WAVES, RING, EXT>;
+    auto kernel = dusp_wave_kernel<TBL, WAVES, RING, EXT, FILT>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -1160,47 +1160,58 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     if (const char *cap = getenv("DUSP_WAVE_MAX_WAVES")) most = std::max(1, std::min(most, atoi(cap)));  // A/B knob
     while (waves < most && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
-#define DUSP_W(T, W, R, E) launch_wave_one<T, W, R, E>(A, lds_bytes, stream)
-    const int level = A.ring_events ? 3 : (int)A.ext_units;  // 0 / 1 / 2 as EXT; 3 = RING (EXT 2 + ordered slot operations)
-    switch ((level * 2 + (table_bytes ? 1 : 0)) * 32 + waves) {
-    case 0 * 32 + 16: return DUSP_W(0, 16, 0, 0);
-    case 0 * 32 + 8: return DUSP_W(0, 8, 0, 0);
-    case 0 * 32 + 4: return DUSP_W(0, 4, 0, 0);
-    case 0 * 32 + 2: return DUSP_W(0, 2, 0, 0);
-    case 0 * 32 + 1: return DUSP_W(0, 1, 0, 0);
-    case 1 * 32 + 16: return DUSP_W(1, 16, 0, 0);
-    case 1 * 32 + 8: return DUSP_W(1, 8, 0, 0);
-    case 1 * 32 + 4: return DUSP_W(1, 4, 0, 0);
-    case 1 * 32 + 2: return DUSP_W(1, 2, 0, 0);
-    case 1 * 32 + 1: return DUSP_W(1, 1, 0, 0);
-    case 2 * 32 + 16: return DUSP_W(0, 16, 0, 1);
-    case 2 * 32 + 8: return DUSP_W(0, 8, 0, 1);
-    case 2 * 32 + 4: return DUSP_W(0, 4, 0, 1);
-    case 2 * 32 + 2: return DUSP_W(0, 2, 0, 1);
-    case 2 * 32 + 1: return DUSP_W(0, 1, 0, 1);
-    case 3 * 32 + 16: return DUSP_W(1, 16, 0, 1);
-    case 3 * 32 + 8: return DUSP_W(1, 8, 0, 1);
-    case 3 * 32 + 4: return DUSP_W(1, 4, 0, 1);
-    case 3 * 32 + 2: return DUSP_W(1, 2, 0, 1);
-    case 3 * 32 + 1: return DUSP_W(1, 1, 0, 1);
-    case 4 * 32 + 16: return DUSP_W(0, 16, 0, 2);
-    case 4 * 32 + 8: return DUSP_W(0, 8, 0, 2);
-    case 4 * 32 + 4: return DUSP_W(0, 4, 0, 2);
-    case 4 * 32 + 2: return DUSP_W(0, 2, 0, 2);
-    case 4 * 32 + 1: return DUSP_W(0, 1, 0, 2);
-    case 5 * 32 + 16: return DUSP_W(1, 16, 0, 2);
-    case 5 * 32 + 8: return DUSP_W(1, 8, 0, 2);
-    case 5 * 32 + 4: return DUSP_W(1, 4, 0, 2);
-    case 5 * 32 + 2: return DUSP_W(1, 2, 0, 2);
-    case 5 * 32 + 1: return DUSP_W(1, 1, 0, 2);
-    case 6 * 32 + 8: return DUSP_W(0, 8, 1, 2);
-    case 6 * 32 + 4: return DUSP_W(0, 4, 1, 2);
-    case 6 * 32 + 2: return DUSP_W(0, 2, 1, 2);
-    case 6 * 32 + 1: return DUSP_W(0, 1, 1, 2);
-    case 7 * 32 + 8: return DUSP_W(1, 8, 1, 2);
-    case 7 * 32 + 4: return DUSP_W(1, 4, 1, 2);
-    case 7 * 32 + 2: return DUSP_W(1, 2, 1, 2);
-    case 7 * 32 + 1: return DUSP_W(1, 1, 1, 2);
+#define DUSP_W(T, W, R, E, F) launch_wave_one<T, W, R, E, F>(A, lds_bytes, stream)
+    // classes: 0 lean; 1 + Filter / Delay; 2 + the other units, no Filter / Delay; 3 everything; 4 everything + ordered slot operations
+    const int cls = A.ring_events ? 4 : (A.ext_units & 2 ? 2 : 0) + (A.ext_units & 1);
+    switch ((cls * 2 + (table_bytes ? 1 : 0)) * 32 + waves) {
+    case 0 * 32 + 16: return DUSP_W(0, 16, 0, 0, 0);
+    case 0 * 32 + 8: return DUSP_W(0, 8, 0, 0, 0);
+    case 0 * 32 + 4: return DUSP_W(0, 4, 0, 0, 0);
+    case 0 * 32 + 2: return DUSP_W(0, 2, 0, 0, 0);
+    case 0 * 32 + 1: return DUSP_W(0, 1, 0, 0, 0);
+    case 1 * 32 + 16: return DUSP_W(1, 16, 0, 0, 0);
+    case 1 * 32 + 8: return DUSP_W(1, 8, 0, 0, 0);
+    case 1 * 32 + 4: return DUSP_W(1, 4, 0, 0, 0);
+    case 1 * 32 + 2: return DUSP_W(1, 2, 0, 0, 0);
+    case 1 * 32 + 1: return DUSP_W(1, 1, 0, 0, 0);
+    case 2 * 32 + 16: return DUSP_W(0, 16, 0, 0, 1);
+    case 2 * 32 + 8: return DUSP_W(0, 8, 0, 0, 1);
+    case 2 * 32 + 4: return DUSP_W(0, 4, 0, 0, 1);
+    case 2 * 32 + 2: return DUSP_W(0, 2, 0, 0, 1);
+    case 2 * 32 + 1: return DUSP_W(0, 1, 0, 0, 1);
+    case 3 * 32 + 16: return DUSP_W(1, 16, 0, 0, 1);
+    case 3 * 32 + 8: return DUSP_W(1, 8, 0, 0, 1);
+    case 3 * 32 + 4: return DUSP_W(1, 4, 0, 0, 1);
+    case 3 * 32 + 2: return DUSP_W(1, 2, 0, 0, 1);
+    case 3 * 32 + 1: return DUSP_W(1, 1, 0, 0, 1);
+    case 4 * 32 + 16: return DUSP_W(0, 16, 0, 2, 0);
+    case 4 * 32 + 8: return DUSP_W(0, 8, 0, 2, 0);
+    case 4 * 32 + 4: return DUSP_W(0, 4, 0, 2, 0);
+    case 4 * 32 + 2: return DUSP_W(0, 2, 0, 2, 0);
+    case 4 * 32 + 1: return DUSP_W(0, 1, 0, 2, 0);
+    case 5 * 32 + 16: return DUSP_W(1, 16, 0, 2, 0);
+    case 5 * 32 + 8: return DUSP_W(1, 8, 0, 2, 0);
+    case 5 * 32 + 4: return DUSP_W(1, 4, 0, 2, 0);
+    case 5 * 32 + 2: return DUSP_W(1, 2, 0, 2, 0);
+    case 5 * 32 + 1: return DUSP_W(1, 1, 0, 2, 0);
+    case 6 * 32 + 16: return DUSP_W(0, 16, 0, 2, 1);
+    case 6 * 32 + 8: return DUSP_W(0, 8, 0, 2, 1);
+    case 6 * 32 + 4: return DUSP_W(0, 4, 0, 2, 1);
+    case 6 * 32 + 2: return DUSP_W(0, 2, 0, 2, 1);
+    case 6 * 32 + 1: return DUSP_W(0, 1, 0, 2, 1);
+    case 7 * 32 + 16: return DUSP_W(1, 16, 0, 2, 1);
+    case 7 * 32 + 8: return DUSP_W(1, 8, 0, 2, 1);
+    case 7 * 32 + 4: return DUSP_W(1, 4, 0, 2, 1);
+    case 7 * 32 + 2: return DUSP_W(1, 2, 0, 2, 1);
+    case 7 * 32 + 1: return DUSP_W(1, 1, 0, 2, 1);
+    case 8 * 32 + 8: return DUSP_W(0, 8, 1, 2, 1);
+    case 8 * 32 + 4: return DUSP_W(0, 4, 1, 2, 1);
+    case 8 * 32 + 2: return DUSP_W(0, 2, 1, 2, 1);
+    case 8 * 32 + 1: return DUSP_W(0, 1, 1, 2, 1);
+    case 9 * 32 + 8: return DUSP_W(1, 8, 1, 2, 1);
+    case 9 * 32 + 4: return DUSP_W(1, 4, 1, 2, 1);
+    case 9 * 32 + 2: return DUSP_W(1, 2, 1, 2, 1);
+    case 9 * 32 + 1: return DUSP_W(1, 1, 1, 2, 1);
     }
     return hipErrorInvalidValue;
 #undef DUSP_W
