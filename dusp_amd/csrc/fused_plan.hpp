@@ -436,6 +436,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     for (const DevOp &op : P.ops) {
         const int o = op.op;
         const int wants = (o == OP_OSC || o == OP_RAMP || o == OP_MULTIPLY || o == OP_SUM || o == OP_REPEATER || (o >= OP_MAP_FIRST && o <= OP_MAP_LAST)) ? 0
+                          : (o == OP_FILTER && op.in[1].kind == SRC_BUF) ? 3  // a modulated cutoff: per-sample coefficients live in the EXT variants
                           : (o == OP_FILTER || o == OP_DELAY) ? 1 : 2;
         plan.ext_units |= wants;
         plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||

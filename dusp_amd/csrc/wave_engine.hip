@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                     out.v[0] = yv[0]; out.v[1] = yv[1]; out.v[2] = yv[2]; out.v[3] = yv[3];
                     break;
                 }
-                // ---- modulated cutoff: coefficients per sample, recurrence per wave out of its own scratch
+                // ---- modulated cutoff: coefficients per sample, recurrence per wave out of its own scratch (EXT variants only:
+                // a tan() per sample is the bulkiest code of the kernel)
+                if constexpr (EXT < 2) break;
+                else {
                 double *P = scratch, *B1 = scratch + kChunk, *B2 = scratch + 2 * kChunk;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -567,6 +570,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 continue;  // the output chunk is already in LDS
+                }
             } else break;
             case OP_DELAY:  // Delay.js:20-41
               if (FILT != 0 && (!RING || delay_is_write_once(op))) {  // constant delay D + phi with 256 <= D <= len - 256: every slot is written once
