@@ -524,18 +524,26 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         for (size_t at = 0; at < order.size(); at++) {
             const DevOp &op = P.ops[(size_t)order[at]];
             const int b = op.out_buf;
+            // The lean units read their operands into registers before they store anything, so their output may take over
+            // the slot of an operand that dies here; every other unit gets its output slot first.
+            const bool registers_first = op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
+                                         (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST);
+            auto release_dead_inputs = [&]() {
+                for (int j = 0; j < kMaxIn; j++) {
+                    const DevOperand &in = op.in[j];
+                    if (in.kind == SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs && last_use[(size_t)in.idx] == (int)at && have[(size_t)in.idx] == 1) {
+                        free_slots.push_back(plan.buf_slot[(size_t)in.idx]);
+                        have[(size_t)in.idx] = 2;  // released
+                    }
+                }
+            };
+            if (registers_first) release_dead_inputs();
             if (b >= 0 && !have[(size_t)b]) {
                 if (free_slots.empty()) plan.buf_slot[(size_t)b] = n_slots++;
                 else { plan.buf_slot[(size_t)b] = free_slots.back(); free_slots.pop_back(); }
                 have[(size_t)b] = 1;
             }
-            for (int j = 0; j < kMaxIn; j++) {
-                const DevOperand &in = op.in[j];
-                if (in.kind == SRC_BUF && in.idx >= 0 && in.idx < P.n_bufs && last_use[(size_t)in.idx] == (int)at && have[(size_t)in.idx] == 1) {
-                    free_slots.push_back(plan.buf_slot[(size_t)in.idx]);
-                    have[(size_t)in.idx] = 2;  // released
-                }
-            }
+            release_dead_inputs();
             if (b >= 0 && last_use[(size_t)b] < 0 && have[(size_t)b] == 1) {  // nobody reads it
                 free_slots.push_back(plan.buf_slot[(size_t)b]);
                 have[(size_t)b] = 2;

@@ -494,28 +494,11 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                         // last outputs finds one anywhere in it (the block is then redone exactly), and a -0 in place of
                         // +0 can only flip the sign of a later zero (see loop2_engine.hip).
                         constexpr int PB = WAVES >= 16 ? 8 : 16;  // P values per block held in registers (the 16-wave variants have 128 VGPRs)
-                        // (where registers allow — 8 waves per workgroup or fewer — the next block's P values are fetched
-                        // while this block's chain runs: the chain itself never touches LDS)
-                        constexpr bool kPrefetch = WAVES < 16;
-                        double pn[PB];
-                        if (kPrefetch) {
-#pragma unroll
-                            for (int k = 0; k < PB; ++k) pn[k] = pr[k];
-                        }
                         for (int t0 = 0; t0 < kChunk; t0 += PB) {
                             double pv[PB];
-                            if (kPrefetch) {
 #pragma unroll
-                                for (int k = 0; k < PB; ++k) pv[k] = pn[k];
-                                __builtin_amdgcn_sched_barrier(0);
-                                const int tn = t0 + PB < kChunk ? t0 + PB : t0;  // (the last block re-reads itself: no branch)
-#pragma unroll
-                                for (int k = 0; k < PB; ++k) pn[k] = pr[tn + k];
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < PB; ++k) pv[k] = pr[t0 + k];
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                            for (int k = 0; k < PB; ++k) pv[k] = pr[t0 + k];
+                            __builtin_amdgcn_sched_barrier(0);
                             const double y1_in = y1, y2_in = y2;
                             double u1 = or0w(y1), u2 = or0w(y2);
                             f32x4 y4[PB / 4];

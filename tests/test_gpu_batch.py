@@ -409,7 +409,7 @@ def test_fused_shape_voice_equals_the_sequential_engine(case):
 
 def test_big_mix_down_fits_the_wave_engine_by_buffer_liveness():
     """200 enveloped voices summed into one output: 800 units, 800 chunk buffers if every outlet kept its own — LDS holds
-    them because a feed-forward graph needs a buffer only from its producer to its last reader — 4 slots here, once the ops run
+    them because a feed-forward graph needs a buffer only from its producer to its last reader — 3 slots here, once the ops run
     depth-first from the output instead of level by level —, and only the
     stateful ops own LDS state.  Bit-identical to the chunk engine; split in time, since every state is a closed-form sum."""
     from dusp_amd import descriptor
@@ -424,7 +424,7 @@ def test_big_mix_down_fits_the_wave_engine_by_buffer_liveness():
     want_state = [ref.state(u) for u in range(0, ref.n_units, 37)]
     ref.close()
     prog = ctx.build(ex.words)
-    assert prog.engine == "wave" and "4 chunk buffers" in prog.shape, (prog.engine, prog.shape)
+    assert prog.engine == "wave" and "3 chunk buffers" in prog.shape, (prog.engine, prog.shape)
     got = prog.render(n)
     kernel_ms = prog.last_kernel_ms()
     got_state = [prog.state(u) for u in range(0, prog.n_units, 37)]
