@@ -544,7 +544,7 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         w.lds_table_id = prog->wave.lds_table_id;
         w.clock0 = (uint64_t)P.g.clock0;
         w.has_filter = prog->wave.has_filter ? 1u : 0u;
-        w.has_modulated_filter = prog->wave.has_modulated_filter ? 1u : 0u;
+        w.scratch_bytes = (uint32_t)prog->wave.scratch_bytes;
         w.ring_events = prog->wave.ring_events ? 1u : 0u;
         w.ext_units = (uint32_t)prog->wave.ext_units;
         w.n_params = (uint32_t)P.g.n_params;

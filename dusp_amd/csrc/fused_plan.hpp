@@ -91,7 +91,7 @@ struct WaveArgs {
     uint32_t table_bytes, wave_bytes;
     float *rings;            // [n_inst][ring_samples]  Delay rings (wave-engine layout)
     uint64_t ring_samples, clock0;
-    uint32_t has_filter, has_modulated_filter;
+    uint32_t has_filter, scratch_bytes;  // scratch_bytes: per-wave LDS scratch the program's units need (0: none)
     const float *inputs;   // [n_inputs][n_inst][n_samples] host-generated signals (OP_INPUT)
     uint32_t n_state_ops;  // ops that own a block of LDS state (DevOp::lds_slot)
     uint32_t ring_events;  // the program has a delay line that needs ordered slot operations: the kernel variant that carries them
@@ -113,12 +113,13 @@ struct WaveArgs {
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
 // (the 6 KB scratch is only needed by Filters whose cutoff is connected: per-sample b1 / b2 and their own P)
-inline size_t wave_lds_bytes(size_t n_bufs, size_t n_state_ops, bool has_modulated_filter) {
-    return (n_bufs * 1024 + n_state_ops * 96 + (has_modulated_filter ? 3 * 256 * 8 + 16 : 0) + 15) & ~(size_t)15;
+inline size_t wave_lds_bytes(size_t n_bufs, size_t n_state_ops, size_t scratch_bytes) {
+    return (n_bufs * 1024 + n_state_ops * 96 + (scratch_bytes ? scratch_bytes + 16 : 0) + 15) & ~(size_t)15;
 }
 
 struct WavePlan {
-    bool ok = false, has_filter = false, has_modulated_filter = false;
+    bool ok = false, has_filter = false;
+    int scratch_bytes = 0;  // per-wave LDS scratch: the largest any unit of the program asks for
     // LDS economy: chunk buffers are handed out by liveness (a feed-forward graph without rings needs a buffer only from its
     // producer to its last reader within the chunk), and only stateful ops own a state block
     std::vector<int> order;      // execution order of the device ops (a permutation; see plan_wave)
@@ -431,7 +432,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     for (const DevOp &op : P.ops)
         if ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.ring_len < 1 || op.ring_len >= (1ll << 31))) return no("CircleBuffer ring out of range");
     if (g.sample_rate > 131072) return no("sample rate above 2^17");
-    plan.has_filter = plan.has_modulated_filter = plan.ring_events = false;
+    plan.has_filter = plan.ring_events = false;
+    plan.scratch_bytes = 0;
     plan.ext_units = 0;
     for (const DevOp &op : P.ops) {
         const int o = op.op;
@@ -442,12 +444,18 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         plan.ring_events = plan.ring_events || (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
                            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
         plan.has_filter = plan.has_filter || op.op == OP_FILTER;
-        // per-wave scratch (3 x 256 doubles): a Filter with a connected cutoff, or a unit with a serial stage
-        plan.has_modulated_filter = plan.has_modulated_filter || (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) || op.op == OP_SHAPE ||
-                                    op.op == OP_AHD || op.op == OP_TIMER || op.op == OP_SAMPLE_RATE_REDUX || op.op == OP_FIXED_DELAY ||
-                                    op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_MULTI_OSC ||
-                                    plan.ring_events;  // (slot-ownership table of the ordered ring operations)
+        // per-wave scratch: what the unit's serial stage (or its fallback) lays out there
+        int scratch = 0;
+        if (o == OP_FILTER && op.in[1].kind == SRC_BUF) scratch = 3 * 256 * 8;             // P, b1, b2 per sample (f64)
+        else if (o == OP_SHAPE) {                                                          // the running sum's 256 addends — not for a
+            const double c = op.in[0].kind == SRC_CONST ? 1.0 / (double)op.in[0].cval : 0.0;  // constant duration that repeat_add covers
+            scratch = (c > 0 && c < 1e300 && P.init_state[(size_t)op.state_slot] >= 0) ? 0 : 256 * 8;
+        } else if (o == OP_TIMER) scratch = (P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300) ? 0 : 256 * 4;
+        else if (o == OP_AHD || o == OP_SAMPLE_RATE_REDUX || o == OP_FIXED_DELAY || o == OP_COMB_FILTER || o == OP_ALL_PASS) scratch = 4 * 256 * 4;
+        else if (o == OP_MULTI_OSC) scratch = 256 * 8;
+        plan.scratch_bytes = std::max(plan.scratch_bytes, scratch);
     }
+    if (plan.ring_events) plan.scratch_bytes = std::max(plan.scratch_bytes, 1024 * 4);  // slot-ownership table of the ordered ring operations
     // state blocks: only for the ops that keep something in LDS between chunks
     plan.op_state.assign(P.ops.size(), -1);
     plan.n_state_ops = 0;
@@ -554,7 +562,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         for (size_t b = 0; b < plan.buf_slot.size(); b++) plan.buf_slot[b] = (int)b;
         plan.n_slots = std::max(1, P.n_bufs);
     }
-    if (wave_lds_bytes((size_t)plan.n_slots, (size_t)plan.n_state_ops, plan.has_modulated_filter) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
+    if (wave_lds_bytes((size_t)plan.n_slots, (size_t)plan.n_state_ops, (size_t)plan.scratch_bytes) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");
     for (const DevOp &op : P.ops) {
         switch (op.op) {

@@ -52,4 +52,26 @@ DUSP_HOST_DEVICE double repeat_add(double t, double c, uint64_t n) {
     return t;
 }
 
+
+// The next `steps` values of t = fl(t + c) as integers, when they all stay in t's binade: t_j = (T + j ce) 2^(K-52)
+// (the reasoning of repeat_add.hpp; t is itself such a sum, so it is a multiple of the binade's unit).
+DUSP_HOST_DEVICE bool linear_run(double t, double c, long long steps, long long &T, long long &ce, int &K) {
+    if (!(t > 0.0 && t < 1.0e300)) return false;
+    K = ilogb(t);
+    if (K < -900) return false;
+    const double inv_u = ldexp(1.0, 52 - K);
+    const double Cs = c * inv_u;
+    if (!(Cs < 9.0e15)) return false;
+    const double qd = floor(Cs), fr = Cs - qd;
+    const long long q = (long long)qd;
+    T = (long long)(t * inv_u);
+    if (fr > 0.5) ce = q + 1;
+    else if (fr < 0.5) ce = q;
+    else {
+        if (T & 1) return false;
+        ce = q + (q & 1);
+    }
+    return T + (steps - 1) * ce <= (1ll << 53) - q - 2;  // the last source still keeps sum and result inside the binade
+}
+
 }  // namespace dusp

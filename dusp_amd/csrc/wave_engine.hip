@@ -687,10 +687,20 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 if (ss[1] != 0.0 && op.in[0].kind != SRC_BUF && ss[0] >= 0.0 && c_lane > 0.0 && c_lane < 1.0e300) {
                     // playing with a constant duration: the running sum in closed form (repeat_add), every lane its own four samples
                     const double t0 = ss[0];
-                    double t = repeat_add(t0, c_lane, (uint64_t)lane * 4);
+                    long long T, ce;
+                    int K;
+                    double t_end;
+                    if (linear_run(t0, c_lane, kChunk, T, ce, K)) {  // the whole chunk inside one binade: t_j = (T + j ce) 2^(K-52)
+                        long long Tl = T + (long long)(lane * 4) * ce;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) tt[c] = t = t + c_lane;
-                    const double t_end = __shfl(t, 63, 64);
+                        for (int c = 0; c < 4; ++c) tt[c] = ldexp((double)(Tl += ce), K - 52);
+                        t_end = ldexp((double)(T + (long long)kChunk * ce), K - 52);
+                    } else {
+                        double t = repeat_add(t0, c_lane, (uint64_t)lane * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) tt[c] = t = t + c_lane;
+                        t_end = __shfl(t, 63, 64);
+                    }
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) ss[0] = t_end;
                 } else if (ss[1] != 0.0) {  // playing: t += 1 / duration[t], a running f64 sum
@@ -735,10 +745,20 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_wave_kernel(WaveArgs A) {
                 double *ss = opstate + (size_t)op.lds_slot * kOpState;
                 const double period = op.d[0], t0 = ss[0];
                 if (t0 >= 0.0 && period > 0.0 && period < 1.0e300) {  // the running sum in closed form, every lane its own four samples
-                    double t = repeat_add(t0, period, (uint64_t)lane * 4);
+                    long long T, ce;
+                    int K;
+                    double t_end;
+                    if (linear_run(t0, period, kChunk, T, ce, K)) {
+                        long long Tl = T + (long long)(lane * 4) * ce;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) out.v[c] = (float)(t = t + period);
-                    const double t_end = __shfl(t, 63, 64);
+                        for (int c = 0; c < 4; ++c) out.v[c] = (float)ldexp((double)(Tl += ce), K - 52);
+                        t_end = ldexp((double)(T + (long long)kChunk * ce), K - 52);
+                    } else {
+                        double t = repeat_add(t0, period, (uint64_t)lane * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) out.v[c] = (float)(t = t + period);
+                        t_end = __shfl(t, 63, 64);
+                    }
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) ss[0] = t_end;
                     break;
@@ -1146,7 +1166,7 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
     A.param_bytes = A.n_params && A.n_params <= 2048 ? (A.n_params * 4 + 15) & ~15u : 0;
-    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_state_ops, A.has_modulated_filter != 0) + A.param_bytes;
+    A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_state_ops, A.scratch_bytes) + A.param_bytes;
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
     const size_t one_wave = A.wave_bytes + (A.has_filter ? 258 * 8 + 260 * 4 : 0);

@@ -21,7 +21,7 @@ static uint64_t xr() {
 
 int main(int argc, char **argv) {
     const int iterations = argc > 1 ? atoi(argv[1]) : 40000;
-    long bad = 0, cases = 0;
+    long bad = 0, cases = 0, linear = 0;
     for (int it = 0; it < iterations; it++) {
         double c, t;
         const int kind = it % 8;
@@ -47,9 +47,26 @@ int main(int argc, char **argv) {
         const uint64_t n = (it % 16 == 0) ? xr() % 2000000 : xr() % 3000;
         const double want = seq(t, c, n), got = dusp::repeat_add(t, c, n);
         cases++;
+        // linear_run: when it says the next 256 sums stay in t's binade, they are (T + j ce) 2^(K-52), one by one
+        {
+            long long T, ce;
+            int K;
+            if (t > 0 && dusp::linear_run(t, c, 256, T, ce, K)) {
+                linear++;
+                double x = t;
+                for (long long j = 1; j <= 256; j++) {
+                    x = x + c;
+                    const double y = ldexp((double)(T + j * ce), K - 52);
+                    if (memcmp(&x, &y, 8) != 0) {
+                        if (bad++ < 10) printf("BAD linear t=%a c=%a j=%lld want=%a got=%a\n", t, c, j, x, y);
+                        break;
+                    }
+                }
+            }
+        }
         if (memcmp(&want, &got, 8) != 0 && bad++ < 10)
             printf("BAD t=%a c=%a n=%llu want=%a got=%a\n", t, c, (unsigned long long)n, want, got);
     }
-    printf("{\"cases\": %ld, \"bad\": %ld}\n", cases, bad);
+    printf("{\"cases\": %ld, \"bad\": %ld, \"linear_runs\": %ld}\n", cases, bad, linear);
     return bad != 0;
 }

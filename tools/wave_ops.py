@@ -22,6 +22,9 @@ graphs = {
     "fm: osc(osc*40+220)": lambda k: d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + k / 100), 40), 220 + k / 4)),
     "ramp": lambda k: d.Multiply(d.Ramp(sr, 1, 0).trigger(), 0.5 + k / 1e5),
     "mul(osc, 0.5)": lambda k: d.Multiply(d.Osc(110 + k / 8), 0.5),
+    "shape(k)": lambda k: d.Shape("decay", 0.5 + k / 1e4).trigger(),
+    "mul(osc, shape(k))": lambda k: d.Multiply(d.Osc(110 + k / 8), d.Shape("decay", 0.5 + k / 1e4).trigger()),
+    "timer * k": lambda k: d.Multiply(d.Timer(), 1.0 + k / 1e4),
     "filter(osc)": lambda k: d.Filter(d.Osc(110 + k / 8), 800),
     "allpass(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.AllPass(0.0021, 0.6)),
 }
