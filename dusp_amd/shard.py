@@ -3,8 +3,19 @@
 Instances (voices / sweep points) share no state, so the path shards with NO data-path collective:
 rank r renders the contiguous instance range instance_range(n, r, world) on its own GPU.  The only
 exchange the north star names is an optional gather of the rendered PCM onto rank 0 (RCCL over xGMI
-on the GPU box, gloo in the CPU tests), done tile by tile so the root never has to hold more than
-one tile per peer beyond its own shard.
+on the GPU box, gloo in the CPU tests).
+
+The gather works in ROUNDS of voice tiles.  In round k every peer sends the k-th tile of its shard and
+rank 0 has one receive posted per peer, all in one batch (one ncclGroup on RCCL): xGMI is point-to-point,
+each peer owns its own link to the root, so the inbound rate is the sum over links instead of one link at
+a time.  Receives land directly in their final place of the root's [n_instances, ...] tensor — no staging
+buffer, no second copy.  A round only waits for the tile it carries, so a caller can render tile k+1 on
+its render stream while round k is on the wire (render_and_gather).
+
+Mix-down (the `Sum.many` reading of BASELINE configs[2]) across ranks: every rank folds its own voices in
+the reference's left-deep order (Sum.js:18-29) into one partial; reduce_mixdown() adds the partials onto
+rank 0 (an f32 sum reduction; RCCL picks the order).  The summation order then differs from the single
+left-deep chain at the rank boundaries — tolerance-level, not bit-exact.
 """
 import torch
 import torch.distributed as dist
@@ -17,33 +28,122 @@ def instance_range(n_instances, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def n_tile_rounds(n_instances, world, tile):
+    """Rounds a tiled gather takes: tiles of the largest shard."""
+    largest = instance_range(n_instances, 0, world)[1]
+    return (largest + tile - 1) // tile
+
+
+class TileGather:
+    """Gathers per-rank PCM [n_local, ...] onto rank 0, one voice tile per rank and round, all peers at once.
+
+    rank 0:  `full` is the [n_instances, ...] destination (allocated here unless handed in); round(k)
+             posts one irecv per peer straight into full[peer range].
+    peers:   round(k) posts one isend of local[k*tile : (k+1)*tile].
+    round() returns the posted requests; wait() blocks (on RCCL: makes the current stream wait) for all of them.
+    """
+
+    def __init__(self, n_instances, local, group=None, tile=64, full=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_instances, self.tile, self.local = n_instances, max(1, int(tile)), local
+        self.spans = [instance_range(n_instances, r, self.world) for r in range(self.world)]
+        lo, hi = self.spans[self.rank]
+        if local.shape[0] != hi - lo:
+            raise ValueError("rank %d holds %d instances, its range is [%d, %d)" % (self.rank, local.shape[0], lo, hi))
+        self.n_rounds = n_tile_rounds(n_instances, self.world, self.tile)
+        self.full = full
+        if self.rank == 0 and self.full is None:
+            self.full = torch.empty((n_instances,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self._pending = []
+
+    def _global_rank(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def round(self, k):
+        a = k * self.tile
+        ops = []
+        if self.rank == 0:
+            lo, hi = self.spans[0]
+            b = min(a + self.tile, hi - lo)
+            if a < b and self.full[lo + a:lo + b].data_ptr() != self.local[a:b].data_ptr():
+                self.full[lo + a:lo + b].copy_(self.local[a:b], non_blocking=True)  # the root's own shard
+            for src in range(1, self.world):
+                lo, hi = self.spans[src]
+                b = min(a + self.tile, hi - lo)
+                if a < b:
+                    ops.append(dist.P2POp(dist.irecv, self.full[lo + a:lo + b], self._global_rank(src), self.group))
+        else:
+            lo, hi = self.spans[self.rank]
+            b = min(a + self.tile, hi - lo)
+            if a < b:
+                ops.append(dist.P2POp(dist.isend, self.local[a:b], self._global_rank(0), self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._pending.extend(reqs)
+        return reqs
+
+    def wait(self):
+        for r in self._pending:
+            r.wait()
+        self._pending = []
+        return self.full
+
+
 def gather_pcm(local, n_instances, group=None, tile=64, sink=None):
     """Gather per-rank PCM [n_local, channels, samples] onto rank 0 in instance order.
 
-    `sink(lo, hi, tensor)` is called on rank 0 for every gathered tile of global instances [lo, hi);
-    without a sink rank 0 returns the full [n_instances, channels, samples] tensor (others return None).
-    Point-to-point sends keep each peer on its single xGMI link to the root; tiles bound the root's
-    staging memory.
-    """
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    full = None
-    if rank == 0 and sink is None:
-        full = torch.empty((n_instances,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    Without a sink rank 0 returns the full [n_instances, channels, samples] tensor (others return None).
+    `sink(lo, hi, tensor)` is called on rank 0 for every gathered range of global instances [lo, hi), after
+    the round that carried it has landed (for callers that stream the PCM on instead of keeping it)."""
+    g = TileGather(n_instances, local.contiguous(), group=group, tile=tile)
+    for k in range(g.n_rounds):
+        g.round(k)
+        if sink is not None:
+            g.wait()
+            if g.rank == 0:
+                a = k * g.tile
+                for lo, hi in g.spans:
+                    b = min(a + g.tile, hi - lo)
+                    if a < b:
+                        sink(lo + a, lo + b, g.full[lo + a:lo + b])
+    g.wait()
+    return g.full if (g.rank == 0 and sink is None) else None
 
-        def sink(lo, hi, t):  # noqa: F811
-            full[lo:hi] = t
 
-    for src in range(world):
-        lo, hi = instance_range(n_instances, src, world)
-        for a in range(lo, hi, tile):
-            b = min(a + tile, hi)
-            if src == 0:
-                if rank == 0:
-                    sink(a, b, local[a - lo:b - lo])
-            elif rank == src:
-                dist.send(local[a - lo:b - lo].contiguous(), dst=0, group=group)
-            elif rank == 0:
-                buf = torch.empty((b - a,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-                dist.recv(buf, src=src, group=group)
-                sink(a, b, buf)
-    return full
+def render_and_gather(render_tile, local, n_instances, group=None, tile=64, full=None):
+    """Render this rank's shard tile by tile and gather it onto rank 0, overlapped: tile k+1 renders on the current
+    stream while round k of the gather moves on a second stream (RCCL's transfers are ordered after the render of the
+    tile they carry by an event, nothing else).
+
+    render_tile(a, b) must enqueue the render of local instances [a, b) into local[a:b] on the CURRENT stream.
+    Returns the root's full tensor (None elsewhere).  On CPU tensors (gloo, tests) the same rounds run synchronously."""
+    g = TileGather(n_instances, local, group=group, tile=tile, full=full)
+    n_local = local.shape[0]
+    on_gpu = local.is_cuda
+    comm = torch.cuda.Stream(device=local.device) if on_gpu else None
+    for k in range(g.n_rounds):
+        a, b = k * g.tile, min((k + 1) * g.tile, n_local)
+        if a < b:
+            render_tile(a, b)
+        if on_gpu:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                g.round(k)
+        else:
+            g.round(k)
+    if on_gpu:
+        with torch.cuda.stream(comm):
+            g.wait()
+        torch.cuda.current_stream(local.device).wait_stream(comm)
+    else:
+        g.wait()
+    return g.full if g.rank == 0 else None
+
+
+def reduce_mixdown(partial, group=None):
+    """Sum the ranks' left-deep partial mixes [channels, samples] onto rank 0 (f32 reduction).  Returns the mix on
+    rank 0, None elsewhere.  The partial is overwritten on the root."""
+    dist.reduce(partial, dst=(dist.get_global_rank(group, 0) if group is not None else 0), op=dist.ReduceOp.SUM, group=group)
+    return partial if dist.get_rank(group) == 0 else None

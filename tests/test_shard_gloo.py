@@ -1,9 +1,11 @@
-"""N>1 path on CPU: two gloo ranks shard the voices, each 'renders' its own range, rank 0 gathers.
+"""N>1 path on CPU: gloo ranks shard the voices, each 'renders' its own range tile by tile, rank 0 gathers.
 
 The GPU box runs the same host logic with backend 'nccl' (RCCL); here the renderer is the CPU oracle
-(test infrastructure) so that the gathered PCM can be checked against a single-process render."""
+(test infrastructure) so that the gathered PCM can be checked against a single-process render.  The HIP
+renderer goes through the very same code at world_size 1 in test_sharded_render_on_the_gpu (-m gpu)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -13,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
-from dusp_amd.shard import instance_range
+from dusp_amd.shard import instance_range, n_tile_rounds
 
 
 def test_instance_range_partitions_exactly():
@@ -24,43 +26,114 @@ def test_instance_range_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+            assert n_tile_rounds(n, world, 5) == (max(sizes) + 4) // 5
 
 
-def _worker(rank, world, port, n_voices, n_samples, result_path):
+def _voices(n_voices, n_samples):
+    import dusp_amd as d
+    from dusp_amd import descriptor
+    d.configure(48000)
+    return descriptor.unify([descriptor.extract(d.Multiply(d.Osc(20 + k / 8), d.Ramp(n_samples, 1, 0).trigger()))
+                             for k in range(n_voices)])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_voices, n_samples, tile, result_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import dusp_amd as d
-    from dusp_amd import descriptor
-    from dusp_amd.shard import gather_pcm, instance_range
+    from dusp_amd.shard import gather_pcm, instance_range, reduce_mixdown, render_and_gather
     from oracle import oracle
-    d.configure(48000)
-    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Osc(20 + k / 8), d.Ramp(n_samples, 1, 0).trigger()))
-                            for k in range(n_voices)])
+    uni = _voices(n_voices, n_samples)
     lo, hi = instance_range(n_voices, rank, world)
-    local = np.stack([oracle.render(uni.words, n_samples, params=uni.params, n_instances=n_voices, instance=i)
-                      for i in range(lo, hi)])
-    full = gather_pcm(torch.from_numpy(local), n_voices, tile=2)
+    local = torch.zeros((hi - lo, 1, n_samples), dtype=torch.float32)
+    rendered = []
+
+    def render_tile(a, b):  # what the GPU box does with dusp_render_device on voices [lo+a, lo+b)
+        rendered.append((a, b))
+        for i in range(a, b):
+            local[i] = torch.from_numpy(oracle.render(uni.words, n_samples, params=uni.params, n_instances=n_voices, instance=lo + i))
+
+    full = render_and_gather(render_tile, local, n_voices, tile=tile)
+    assert rendered == [(a, min(a + tile, hi - lo)) for a in range(0, hi - lo, tile)]
+    again = gather_pcm(local, n_voices, tile=tile + 1)  # one-shot gather of an already rendered shard, other tiling
+    seen = []
+    gather_pcm(local, n_voices, tile=tile, sink=lambda a, b, t: seen.append((a, b, t.clone())))
+    mix = reduce_mixdown(local.sum(dim=0))  # [1, n_samples] partial -> sum over ranks on the root
     if rank == 0:
+        assert torch.equal(full, again)
+        via_sink = torch.zeros_like(full)
+        for a, b, t in seen:
+            via_sink[a:b] = t
+        assert torch.equal(full, via_sink) and sum(b - a for a, b, _ in seen) == n_voices
         np.save(result_path, full.numpy())
+        np.save(result_path + ".mix.npy", mix.numpy())
+    else:
+        assert full is None and again is None and mix is None and not seen
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather(tmp_path, oracle):
-    n_voices, n_samples, world = 7, 700, 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+@pytest.mark.parametrize("world,n_voices,tile", [(2, 7, 2), (3, 8, 1)])
+def test_ranks_shard_render_and_gather(tmp_path, oracle, world, n_voices, tile):
+    n_samples = 700
     result = str(tmp_path / "gathered.npy")
-    mp.spawn(_worker, args=(world, port, n_voices, n_samples, result), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_voices, n_samples, tile, result), nprocs=world, join=True)
     got = np.load(result)
-    import dusp_amd as d
-    from dusp_amd import descriptor
-    d.configure(48000)
-    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Osc(20 + k / 8), d.Ramp(n_samples, 1, 0).trigger()))
-                            for k in range(n_voices)])
+    uni = _voices(n_voices, n_samples)
     want = np.stack([oracle.render(uni.words, n_samples, params=uni.params, n_instances=n_voices, instance=i)
                      for i in range(n_voices)])
     assert got.shape == want.shape and np.array_equal(got, want)
+    mix = np.load(result + ".mix.npy")
+    assert np.allclose(mix, want.astype(np.float64).sum(axis=0), rtol=0, atol=1e-5 * n_voices)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` starts its own ranks — but only after counting devices, without touching one."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_sharded_render_on_the_gpu(oracle):
+    """world_size 1 on the GPU box: the HIP renderer driven by the sharding code (tile-pipelined render + gather), bit-exact
+    against the oracle; then `bench.py --gpus 2` on this one-GPU box must fail cleanly."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    from dusp_amd import runtime
+    from dusp_amd.shard import render_and_gather
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_voices, n_samples, tile = 37, 5000, 8
+        uni = _voices(n_voices, n_samples)
+        ctx = runtime.Context(0, 48000)
+        prog = ctx.build(uni.words)
+        d_params = torch.from_numpy(uni.params).cuda()
+        local = torch.zeros((n_voices, 1, n_samples), dtype=torch.float32, device="cuda")
+        keep = []
+
+        def render_tile(a, b):
+            p = d_params[:, a:b].contiguous()
+            keep.append(p)
+            prog.render_device(n_samples, b - a, p.data_ptr(), local[a:b].data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+        full = render_and_gather(render_tile, local, n_voices, tile=tile)
+        torch.cuda.synchronize()
+        got = full.cpu().numpy()
+        for i in range(n_voices):
+            want = oracle.render(uni.words, n_samples, params=uni.params, n_instances=n_voices, instance=i)
+            assert np.array_equal(got[i], want), "voice %d" % i
+    finally:
+        dist.destroy_process_group()
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert r.returncode != 0 and "only 1 GPU(s) visible" in (r.stderr + r.stdout)
