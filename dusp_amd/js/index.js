@@ -3,12 +3,12 @@
  * constructors of the units the MI355X render path executes. */
 const graph = require('./lib/graph')
 const renderChannelData = require('./lib/renderChannelData')
-const patches = require('./lib/patches')
 const dusp = require('./lib/dusp')
 
 module.exports = {
   renderChannelData,
   renderMany: renderChannelData.renderMany,
+  renderDescriptor: renderChannelData.renderDescriptor,
   quick: require('./lib/quick'),
   unDusp: require('./lib/unDusp'),
   dusp,
@@ -28,8 +28,5 @@ module.exports = {
     Delay: graph.Delay, CircleBufferReader: graph.CircleBufferReader, CircleBufferWriter: graph.CircleBufferWriter,
     Repeater: graph.Repeater,
   },
-  Patch: patches.Patch,
-  patches,
   ...graph,
-  ...patches,
 }

@@ -212,7 +212,27 @@ async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
   }
 }
 
+/* A flat descriptor (what lib/extract.js produces — from this package's graph classes or from the reference's own objects,
+ * patches included: their units reach the extractor as they are) rendered as it stands: no host objects, hence no events,
+ * no host-ticked units, no state write-back.  Resolves to channelData like renderChannelData. */
+async function renderDescriptor(words, nSamples, { engine = 0 } = {}) {
+  const sampleRate = words[2]
+  const n = native()
+  const prog = n.programBuild(contextFor(sampleRate), words, engine)
+  try {
+    const info = n.programInfo(prog)
+    const pcm = await n.render(prog, 1, nSamples, null)
+    const channelData = []
+    for (let c = 0; c < info.nOutChannels; c++) channelData.push(pcm.subarray(c * nSamples, (c + 1) * nSamples))
+    channelData.sampleRate = sampleRate
+    return channelData
+  } finally {
+    n.programDestroy(prog)
+  }
+}
+
 module.exports = renderChannelData
 module.exports.renderChannelData = renderChannelData
+module.exports.renderDescriptor = renderDescriptor
 module.exports.renderMany = renderMany
 module.exports.SegmentRenderer = SegmentRenderer

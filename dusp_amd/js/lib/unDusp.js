@@ -14,15 +14,14 @@ const quick = require('./quick')
 const { parseExpression } = require('./parse')
 require('./dusp') // attaches the `dusp` descriptors (flag functions) to the unit classes
 
-/* constructor name -> class: everything lib/graph.js can execute and the patches built from it
- * (reference src/patchesAndComponents.js: patches override components of the same name) */
+/* constructor name -> class: everything lib/graph.js can execute (reference src/patchesAndComponents.js; the reference's
+ * patches are host-side builders that wire these units — they are not mirrored here: with the real `dusp` package a
+ * patch's units reach the extractor as they are, INTEGRATION.md) */
 const COMPONENTS = {}
 for (const name of Object.keys(graph)) {
   const C = graph[name]
   if (typeof C === 'function' && C.prototype instanceof graph.Unit) COMPONENTS[name] = C
 }
-const patches = require('./patches')
-for (const name of Object.keys(patches)) if (name !== 'Patch') COMPONENTS[name] = patches[name]
 
 const SHORTHAND = { // reference src/construct/shorthandConstructors.js:3-46
   O: (f) => new graph.Osc(f),

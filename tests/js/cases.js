@@ -538,45 +538,6 @@ module.exports = function goldenCases(L, SR) {
     add('patch_shape_random', seeded(32, () => Shape.randomInRange(0.03, -1, 1).trigger()), 0.05)
     add('patch_all_pass_series', seeded(33, () => { const s = AllPass.manyRandomInSeries(3, 0.01, 0.6); s.IN.set(new Osc(300, 'saw')); return s.OUT }), 0.05)
 
-    // patches and scheduled events: Patch.schedule runs the callback with the patch as `this`; the events travel on units[0]
-    add('ev_patch_trigger_group', () => {
-      const tg = new P.TriggerGroup()
-      tg.addTrigger(new P.Boop(440, 0.01))
-      tg.addTrigger(new P.SineBoop(76, 0.015), 'high')
-      tg.scheduleTrigger(0.02, 0)
-      tg.scheduleTrigger(0.03, 'high')
-      tg.scheduleTrigger(0.04, 'nobody')
-      return tg
-    }, 0.06)
-    add('ev_patch_schedule', () => {
-      const lfo = new P.LFO(4, 100, 300)
-      lfo.schedule(0.02, function () { this.F = 40; this.waveform = 'square' })
-      lfo.schedule(0.04, function () { this.trigger() })
-      return new Osc(lfo)
-    }, 0.06)
-    add('ev_patch_synth', () => {
-      const s = new P.Synth()
-      const env = s.addEnvelope(new Shape('decay', 0.01))
-      const osc = new Osc(500)
-      s.addUnits(env, osc)
-      s._trigger = function (p) { osc.F = p }
-      s.aliasOutlet(new Multiply(osc, env).OUT)
-      s.schedule(0.01, function () { this.trigger(700) })
-      s.schedule(0.03, function () { this.trigger(350.5) })
-      return s
-    }, 0.05)
-    add('ev_patch_space_boop', () => {
-      const b = new P.SpaceBoop(60, 'sin', 0.01)
-      b.schedule([0.005, 0.02], function () { this.trigger() })
-      b.schedule(0.03, function () { this.trigger(72, 0.004); this.PLACEMENT = [-2, 1] })
-      return b
-    }, 0.045)
-    add('ev_patch_stereo_osc', () => {
-      const o = new P.StereoOsc(60, -3, 0)
-      o.schedule(0.01, function () { this.P = 67; this.PAN = -1 })
-      o.scheduleTrigger(0.02)
-      return o
-    }, 0.03)
   }
   // Noise: Math.random() per sample (or per 1/f), drawn on the host in tick order and handed to the device as an input stream
   if (L.Noise) {
@@ -598,10 +559,6 @@ module.exports = function goldenCases(L, SR) {
       n2.schedule(0.12, function () { this.F = 500 + 1000 * Math.random() })
       return new Sum(new Multiply(n1, env), new Multiply(n2, 0.25))
     }, 0.25, undefined, { seed: 14 })
-    if (P && P.Worm) {
-      add('rt_noise_worm', () => new Osc(new Sum(new Multiply(new P.Worm(20), 2000), 440)), 0.2, undefined, { seed: 15 })
-      add('rt_noise_worm_random', () => P.Worm.random(50), 0.1, undefined, { seed: 16 })
-    }
   }
   return cases
 }
