@@ -30,6 +30,20 @@ constexpr int kFirstShapeTable = 5;
 constexpr int kChunk = 256;
 constexpr int kMaxWarmChunks = 8;  // chunks at the start of a render that may run their own op list (program.hpp infer_channels)
 
+// A/B switches for tools/ and tests.  They are read from the environment ONCE, when a context is created
+// (dusp_ctx_create), never on the launch path; the defaults are the product.
+struct Knobs {
+    int fused_table_global = 0;  // DUSP_FUSED_TABLE=global: wave table from L2 even when the LDS half-table applies
+    int fused_R = 4;             // DUSP_FUSED_R: voices per work item (1, 4, 8)
+    int fused_items = 4;         // DUSP_FUSED_ITEMS: work items per resident wave
+    int fused_fx32 = 1;          // DUSP_FUSED_FX32=0: no 32.32 fixed-point phase path
+    int fused_segmajor = 0;      // DUSP_FUSED_SEGMAJOR=1: item order
+    int loop2 = 1;               // DUSP_LOOP2=0: one-stage loop kernel
+    int loop_wide = 1;           // DUSP_LOOP_WIDE=0: narrow two-stage loop kernel
+    int wave_segments = -1;      // DUSP_WAVE_SEGMENTS=n: force n time segments (0 / 1: off; -1: automatic)
+    int wave_max_waves = 0;      // DUSP_WAVE_MAX_WAVES=n: cap the wavefronts per workgroup (0: no cap)
+};
+
 #if defined(__HIPCC__)
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what __builtin_nontemporal_store accepts
 #endif

@@ -5,9 +5,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dusp_hip.h"
@@ -23,9 +26,9 @@ hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uin
                                 uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, hipStream_t stream);
 hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
-hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, hipStream_t stream);
+hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, bool wide, hipStream_t stream);
 hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
-hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream);
+hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, int max_waves_cap, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
 }  // namespace dusp
 
@@ -43,6 +46,10 @@ struct dusp_ctx {
     bool table_finite[dusp::kNumTables] = {false, false, false, false, false};
     bool table_fx32_ok[dusp::kNumTables] = {false, false, false, false, false};  // min nonzero |T| >= 2^-20
     int n_cus = 256;
+    dusp::Knobs knobs;  // A/B switches, read from the environment once (dusp_ctx_create)
+    // pinned host buffers handed out by dusp_host_alloc (in_use) or waiting for reuse
+    struct HostBuf { void *p; size_t bytes; bool in_use; };
+    std::vector<HostBuf> host_pool;
 };
 
 template <class T>
@@ -102,6 +109,27 @@ struct dusp_program {
     DevBuf<float> d_saved_bufs, d_rings_wave;  // wave engine, resumable: outlets' last chunk; rings parked during a migration
     int64_t next_clock = 0;      // circuit clock the last render stopped at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;  // stream of the most recent render (workspaces and state are ordered on it)
+
+    dusp_program() = default;
+    dusp_program(const dusp_program &) = delete;
+    dusp_program &operator=(const dusp_program &) = delete;
+    ~dusp_program() {  // every exit path — a failed build included — gives the device memory back
+        if (ctx) (void)hipSetDevice(ctx->device);
+        for (DevBuf<float> *b : {&d_scratch, &d_rings, &d_host_out, &d_host_par, &d_host_frames, &d_host_in, &d_saved_bufs, &d_rings_wave}) b->release();
+        for (DevBuf<double> *b : {&d_init, &d_state, &d_fused_state}) b->release();
+        d_ops.release();
+        d_out_bufs.release();
+        d_seg.release();
+        d_recs.release();
+        d_sum_voices.release();
+        if (pin[0]) (void)hipHostFree(pin[0]);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+    // dusp_render_host* into pageable memory: pinned staging tiles, two per copy worker (download_staged)
+    float *pin[1] = {nullptr};
+    size_t pin_floats = 0;
 };
 
 #define CTX_FAIL(ctx, code, msg)  \
@@ -119,6 +147,46 @@ struct dusp_program {
         }                                                                                         \
     } while (0)
 
+// Exception firewall: nothing thrown inside the library (std::bad_alloc / std::length_error from a container sized by a
+// descriptor, ...) may cross the C boundary — it would be std::terminate for the caller.  Every entry point that can
+// allocate runs its body through guarded(): the exception becomes a status + message like any other failure.
+template <class F>
+static int guarded(std::string &err, const char *who, F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try { err = std::string(who) + ": out of host memory"; } catch (...) {}
+        return DUSP_ERR_NOMEM;
+    } catch (const std::length_error &e) {
+        try { err = std::string(who) + ": size out of range (" + e.what() + ")"; } catch (...) {}
+        return DUSP_ERR_ARG;
+    } catch (const std::exception &e) {
+        try { err = std::string(who) + ": " + e.what(); } catch (...) {}
+        return DUSP_ERR_ARG;
+    } catch (...) {
+        try { err = std::string(who) + ": unknown internal error"; } catch (...) {}
+        return DUSP_ERR_ARG;
+    }
+}
+
+static dusp::Knobs read_knobs() {
+    dusp::Knobs k;
+    auto num = [](const char *name, int fallback) {
+        const char *e = getenv(name);
+        return e && *e ? atoi(e) : fallback;
+    };
+    if (const char *t = getenv("DUSP_FUSED_TABLE")) k.fused_table_global = t[0] == 'g';
+    k.fused_R = num("DUSP_FUSED_R", k.fused_R);
+    k.fused_items = num("DUSP_FUSED_ITEMS", k.fused_items);
+    k.fused_fx32 = num("DUSP_FUSED_FX32", k.fused_fx32);
+    k.fused_segmajor = num("DUSP_FUSED_SEGMAJOR", k.fused_segmajor);
+    k.loop2 = num("DUSP_LOOP2", k.loop2);
+    k.loop_wide = num("DUSP_LOOP_WIDE", k.loop_wide);
+    k.wave_segments = num("DUSP_WAVE_SEGMENTS", k.wave_segments);
+    k.wave_max_waves = num("DUSP_WAVE_MAX_WAVES", k.wave_max_waves);
+    return k;
+}
+
 extern "C" {
 
 const char *dusp_version(void) { return "dusp-hip 0.1.0 (gfx950)"; }
@@ -127,6 +195,7 @@ int dusp_abi_version(void) { return DUSP_ABI_VERSION; }
 const char *dusp_last_error(const dusp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
 
 int dusp_ctx_create(int device, dusp_ctx **out) {
+    return guarded(g_error, "dusp_ctx_create", [&]() -> int {
     if (!out) {
         g_error = "dusp_ctx_create: out is NULL";
         return DUSP_ERR_ARG;
@@ -159,8 +228,10 @@ int dusp_ctx_create(int device, dusp_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
+    ctx->knobs = read_knobs();
     *out = ctx.release();
     return DUSP_OK;
+    });
 }
 
 void dusp_ctx_destroy(dusp_ctx *ctx) {
@@ -171,11 +242,13 @@ void dusp_ctx_destroy(dusp_ctx *ctx) {
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    for (auto &b : ctx->host_pool) (void)hipHostFree(b.p);
     delete ctx;
 }
 
 int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n) {
     if (!ctx) return DUSP_ERR_ARG;
+    return guarded(ctx->err, "dusp_table_upload", [&]() -> int {
     if (table_id < 0 || table_id >= dusp::kNumTables || !table || n < 9 || n > (1u << 22) + 1)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_table_upload: bad table id, pointer or length");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -204,6 +277,7 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     ctx->table_fx32_ok[table_id] = big;
     ctx->table_set[table_id] = true;
     return DUSP_OK;
+    });
 }
 
 // Engine selection + upload of the program constants; shared by build and continue.
@@ -239,10 +313,8 @@ static int finish_build(dusp_program *prog) {
         const double len = (double)prog->loop.delay.ring_len;
         double dconst = (double)dl.cval;
         if (dconst >= len) dconst = std::fmod(dconst, len);
-        const char *knob = getenv("DUSP_LOOP2");
         prog->loop_two_stage = dl.kind == dusp::SRC_CONST && std::floor(dconst) >= dusp::kChunk &&
-                               std::floor(dconst) + dusp::kChunk <= len && prog->P.g.sample_rate <= 131072 &&
-                               !(knob && knob[0] == '0');
+                               std::floor(dconst) + dusp::kChunk <= len && prog->P.g.sample_rate <= 131072 && ctx->knobs.loop2 != 0;
     }
     if (engine == DUSP_ENGINE_LOOP && !loopable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
@@ -314,14 +386,14 @@ static int compile_status(dusp_ctx *ctx, const char *who, const std::string &err
 
 int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int engine, dusp_program **out) {
     if (!ctx) return DUSP_ERR_ARG;
+    return guarded(ctx->err, "dusp_program_build", [&]() -> int {
     if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: out is NULL");
     *out = nullptr;
     const bool resumable = (engine & DUSP_ENGINE_RESUMABLE) != 0;
     engine &= ~DUSP_ENGINE_RESUMABLE;
     if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE && engine != DUSP_ENGINE_LOOP)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
-    std::unique_ptr<dusp_program> prog(new (std::nothrow) dusp_program);
-    if (!prog) CTX_FAIL(ctx, DUSP_ERR_ARG, "out of memory");
+    std::unique_ptr<dusp_program> prog(new dusp_program);  // (its destructor frees whatever a failing step below has allocated)
     prog->ctx = ctx;
     prog->requested_engine = engine;
     prog->resumable = resumable;
@@ -334,11 +406,13 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     HIP_TRY(ctx, hipEventCreate(&prog->ev1));
     *out = prog.release();
     return DUSP_OK;
+    });
 }
 
 int dusp_program_continue(dusp_program *prog, const double *desc, size_t n_words) {
     if (!prog) return DUSP_ERR_ARG;
     dusp_ctx *ctx = prog->ctx;
+    return guarded(ctx->err, "dusp_program_continue", [&]() -> int {
     if (!prog->rendered) CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_program_continue: nothing has been rendered yet");
     dusp::Program next;
     std::string err;
@@ -367,39 +441,42 @@ int dusp_program_continue(dusp_program *prog, const double *desc, size_t n_words
     const int engine_before = prog->engine;
     // The wave engine writes every Delay slot once, with its final value; after a change of the delay new taps can land on
     // slots that already hold data, which only the chunk engine's read-modify-write protocol accumulates like the reference.
+    bool delay_changed = prog->delay_changed;
     for (size_t k = 0; k < P.ops.size(); k++)
         if (P.ops[k].op == dusp::OP_DELAY) {
             const dusp::DevOperand &a = P.ops[k].in[1], &b = next.ops[k].in[1];
-            if (a.kind != b.kind || a.idx != b.idx || std::memcmp(&a.cval, &b.cval, sizeof(float)) != 0) prog->delay_changed = true;
+            if (a.kind != b.kind || a.idx != b.idx || std::memcmp(&a.cval, &b.cval, sizeof(float)) != 0) delay_changed = true;
         }
+    // All or nothing: if planning or the upload fails, the program goes back to the circuit it was rendering (host plans AND
+    // the device copies of its constants), so a later render never runs a mixture of the two.
+    struct Before {
+        dusp::Program P; bool delay_changed; int engine;
+    } before{std::move(prog->P), prog->delay_changed, prog->engine};
     prog->P = std::move(next);
-    if (int rc = finish_build(prog)) return rc;
+    prog->delay_changed = delay_changed;
+    if (int rc = finish_build(prog)) {
+        const std::string why = ctx->err;
+        prog->P = std::move(before.P);
+        prog->delay_changed = before.delay_changed;
+        const int requested = prog->requested_engine;
+        prog->requested_engine = before.engine;  // re-plan the old circuit onto the engine it was on
+        const int back = finish_build(prog);
+        prog->requested_engine = requested;
+        ctx->err = back == DUSP_OK ? why : why + " (and the previous program could not be restored: " + ctx->err + ")";
+        return rc;
+    }
     prog->keep_memory = persistent;
     if (persistent && engine_before == DUSP_ENGINE_WAVE && prog->engine == DUSP_ENGINE_CHUNK) prog->migrate_to_chunk = true;
     return DUSP_OK;
+    });
 }
 
 void dusp_program_destroy(dusp_program *prog) {
     if (!prog) return;
     (void)hipSetDevice(prog->ctx->device);
+    // renders may have gone to a caller's stream: wait for what the last one recorded, not only for the context's own stream
+    if (prog->rendered && prog->ev1) (void)hipEventSynchronize(prog->ev1);
     (void)hipStreamSynchronize(prog->ctx->stream);
-    prog->d_ops.release();
-    prog->d_out_bufs.release();
-    prog->d_init.release();
-    prog->d_scratch.release();
-    prog->d_host_out.release();
-    prog->d_saved_bufs.release();
-    prog->d_rings_wave.release();
-    prog->d_host_par.release();
-    prog->d_host_frames.release();
-    prog->d_host_in.release();
-    prog->d_rings.release();
-    prog->d_state.release();
-    prog->d_fused_state.release();
-    prog->d_recs.release();
-    prog->d_sum_voices.release();
-    if (prog->ev0) (void)hipEventDestroy(prog->ev0);
-    if (prog->ev1) (void)hipEventDestroy(prog->ev1);
     delete prog;
 }
 
@@ -454,8 +531,16 @@ int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_s
     return render_device(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_);
 }
 
+static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
+                                   float *d_out, void *stream_);
+
 static int render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
                          float *d_out, void *stream_) {
+    return guarded(prog->ctx->err, "render", [&]() -> int { return render_device_unguarded(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_); });
+}
+
+static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
+                                   float *d_out, void *stream_) {
     dusp_ctx *ctx = prog->ctx;
     const dusp::Program &P = prog->P;
     if (n_instances < 1 || n_instances > (1u << 24)) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: n_instances must be in [1, 2^24]");
@@ -465,6 +550,10 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
     if (int rc = check_tables(prog)) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    // A program's workspaces (state, rings, scratch, voice records) are reused from render to render: a render on ANOTHER
+    // stream than the previous one first waits for what that one recorded.
+    if (prog->rendered && prog->last_stream != stream) HIP_TRY(ctx, hipStreamWaitEvent(stream, prog->ev1, 0));
+    prog->last_stream = stream;
     const uint32_t n_inst = (uint32_t)n_instances;
     const uint32_t n_chunks = (uint32_t)((n_samples + dusp::kChunk - 1) / dusp::kChunk);
 
@@ -482,6 +571,7 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         L.table_antisym = ctx->table_antisym[prog->fused.table_id];
         L.table_finite = ctx->table_finite[prog->fused.table_id];
         L.table_fx32_ok = ctx->table_fx32_ok[prog->fused.table_id];
+        L.knobs = ctx->knobs;
         HIP_TRY(ctx, prog->d_recs.ensure(n_inst));
         L.recs = prog->d_recs.p;
         HIP_TRY(ctx, prog->d_fused_state.ensure((size_t)std::max(1, prog->fused.n_state_words) * n_inst));
@@ -568,10 +658,9 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         w.seg_groups = n_chunks;
         w.max_osc_level = prog->wave.max_osc_level;
         if (prog->wave.splittable) {
-            const char *knob = getenv("DUSP_WAVE_SEGMENTS");  // 0 / 1: off; n: force n segments
             const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
             uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
-            if (knob) n_seg = (uint64_t)std::max(0, atoi(knob));
+            if (ctx->knobs.wave_segments >= 0) n_seg = (uint64_t)ctx->knobs.wave_segments;  // 0 / 1: off; n: force n segments
             n_seg = std::max<uint64_t>(1, std::min<uint64_t>(n_seg, n_chunks));
             if (n_seg > 1) {
                 w.seg_groups = (uint32_t)((n_chunks + n_seg - 1) / n_seg);
@@ -586,7 +675,7 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
         }
         const bool lds_ok = w.lds_table_id >= 0 && ctx->table_antisym[w.lds_table_id] && P.g.sample_rate % 2 == 0;
         HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
-        HIP_TRY(ctx, dusp::launch_wave_engine(w, lds_ok, stream));
+        HIP_TRY(ctx, dusp::launch_wave_engine(w, lds_ok, ctx->knobs.wave_max_waves, stream));
         HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
         prog->last_n_inst = n_inst;
         prog->last_n_pad = n_pad;
@@ -649,7 +738,7 @@ static int render_device(dusp_program *prog, size_t n_instances, size_t n_sample
     if (prog->engine == DUSP_ENGINE_LOOP) {
         const int w = prog->loop.osc.attr;
         if (prog->loop_two_stage)
-            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, stream));
+            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->knobs.loop_wide != 0, stream));
         else
             HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
     } else
@@ -694,11 +783,93 @@ int dusp_interleave_device(dusp_ctx *ctx, const float *d_planar, size_t n_instan
     return DUSP_OK;
 }
 
+// Device -> host delivery of the rendered PCM (what renderChannelData's caller finally holds).
+//   * h_out is pinned memory (dusp_host_alloc, or registered by the caller): one asynchronous DMA straight into it.
+//   * h_out is pageable and large: kCopyWorkers worker threads, each with its own stream and a pair of pinned staging
+//     tiles, walk disjoint ranges of the output — DMA of tile i+1 into one tile while the CPU copies tile i out of the
+//     other.  (A plain hipMemcpy to pageable memory stages through ONE pinned buffer with ONE copying thread: 10-13 GB/s.)
+//   * small outputs (event-segmented rendering: hundreds of short renders a second): plain asynchronous copy.
+constexpr size_t kCopyTileFloats = (size_t)2 << 20;   // 8 MiB staging tiles
+constexpr int kCopyWorkers = 4;
+constexpr size_t kStagedMinFloats = (size_t)8 << 20;  // 32 MiB: below this the staging pipeline is not worth its threads
+
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();  // an unregistered pointer is reported as an error: not one of ours
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+static hipError_t download_staged(dusp_program *prog, float *h_out, const float *d_src, size_t n_floats) {
+    dusp_ctx *ctx = prog->ctx;
+    const size_t need = (size_t)kCopyWorkers * 2 * kCopyTileFloats;
+    if (prog->pin_floats < need) {
+        if (prog->pin[0]) (void)hipHostFree(prog->pin[0]);
+        prog->pin[0] = nullptr;
+        prog->pin_floats = 0;
+        hipError_t e = hipHostMalloc((void **)&prog->pin[0], need * sizeof(float), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        prog->pin_floats = need;
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // the render (and the interleave) have finished: the workers only copy
+    if (e != hipSuccess) return e;
+    hipError_t results[kCopyWorkers];
+    std::thread workers[kCopyWorkers];
+    const size_t n_tiles = (n_floats + kCopyTileFloats - 1) / kCopyTileFloats;
+    for (int w = 0; w < kCopyWorkers; w++) {
+        results[w] = hipSuccess;
+        workers[w] = std::thread([&, w]() {
+            hipError_t &r = results[w];
+            hipStream_t st = nullptr;
+            if ((r = hipSetDevice(ctx->device)) != hipSuccess || (r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return;
+            float *tile[2] = {prog->pin[0] + (size_t)(2 * w) * kCopyTileFloats, prog->pin[0] + (size_t)(2 * w + 1) * kCopyTileFloats};
+            // this worker's tiles: a contiguous range (neighbouring pages of h_out are faulted in by one thread)
+            const size_t t0 = n_tiles * (size_t)w / kCopyWorkers, t1 = n_tiles * (size_t)(w + 1) / kCopyWorkers;
+            auto span = [&](size_t t, size_t &at, size_t &n) {
+                at = t * kCopyTileFloats;
+                n = std::min(kCopyTileFloats, n_floats - at);
+            };
+            hipEvent_t done[2] = {nullptr, nullptr};
+            if ((r = hipEventCreateWithFlags(&done[0], hipEventDisableTiming)) == hipSuccess) r = hipEventCreateWithFlags(&done[1], hipEventDisableTiming);
+            size_t at, n;
+            for (size_t t = t0; r == hipSuccess && t < std::min(t0 + 2, t1); t++) {  // prime both tiles
+                span(t, at, n);
+                if ((r = hipMemcpyAsync(tile[(t - t0) & 1], d_src + at, n * sizeof(float), hipMemcpyDeviceToHost, st)) == hipSuccess)
+                    r = hipEventRecord(done[(t - t0) & 1], st);
+            }
+            for (size_t t = t0; r == hipSuccess && t < t1; t++) {
+                const int k = (int)((t - t0) & 1);
+                if ((r = hipEventSynchronize(done[k])) != hipSuccess) break;
+                span(t, at, n);
+                std::memcpy(h_out + at, tile[k], n * sizeof(float));
+                if (t + 2 < t1) {
+                    span(t + 2, at, n);
+                    if ((r = hipMemcpyAsync(tile[k], d_src + at, n * sizeof(float), hipMemcpyDeviceToHost, st)) == hipSuccess)
+                        r = hipEventRecord(done[k], st);
+                }
+            }
+            (void)hipStreamSynchronize(st);
+            if (done[0]) (void)hipEventDestroy(done[0]);
+            if (done[1]) (void)hipEventDestroy(done[1]);
+            (void)hipStreamDestroy(st);
+        });
+    }
+    for (auto &t : workers) t.join();
+    for (hipError_t r : results)
+        if (r != hipSuccess) return r;
+    return hipSuccess;
+}
+
 static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples, const float *h_params, const float *h_inputs, float *h_out,
                        bool interleaved) {
     if (!prog) return DUSP_ERR_ARG;
     dusp_ctx *ctx = prog->ctx;
+    return guarded(ctx->err, "render", [&]() -> int {
     if (!h_out) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: h_out is NULL");
+    if (n_instances < 1 || n_instances > (1u << 24) || n_samples < 1 || n_samples > (1ull << 31))
+        CTX_FAIL(ctx, DUSP_ERR_ARG, "render: n_instances must be in [1, 2^24] and n_samples in [1, 2^31]");
     const size_t n_par = (size_t)prog->P.g.n_params * n_instances;
     if (n_par && !h_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but h_params is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -706,48 +877,91 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
     // staging buffers live with the program (grown on demand): a segmented render calls this hundreds of times a second
     HIP_TRY(ctx, prog->d_host_out.ensure(std::max<size_t>(1, n_out)));
     float *d_out = prog->d_host_out.p, *d_par = nullptr, *d_frames = nullptr;
-    int rc = DUSP_OK;
-    hipError_t e = hipSuccess;
     if (n_par) {
         HIP_TRY(ctx, prog->d_host_par.ensure(n_par));
         d_par = prog->d_host_par.p;
-        e = hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(d_par, h_params, n_par * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     const size_t n_in = (size_t)prog->P.g.n_inputs * n_instances * n_samples;
     float *d_in = nullptr;
     if (n_in && !h_inputs) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: the program reads host-generated input streams; use dusp_render_host_inputs");
-    if (n_in && e == hipSuccess) {
+    if (n_in) {
         HIP_TRY(ctx, prog->d_host_in.ensure(n_in));
         d_in = prog->d_host_in.p;
-        e = hipMemcpyAsync(d_in, h_inputs, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        HIP_TRY(ctx, hipMemcpyAsync(d_in, h_inputs, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
-    if (e == hipSuccess) {
-        rc = render_device(prog, n_instances, n_samples, d_par, d_in, d_out, ctx->stream);
-        const size_t n_ch = prog->P.out_bufs.size();
-        if (rc == DUSP_OK && interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
-            HIP_TRY(ctx, prog->d_host_frames.ensure(n_out));
-            d_frames = prog->d_host_frames.p;
-            rc = dusp_interleave_device(ctx, d_out, n_instances, n_ch, n_samples, d_frames, ctx->stream);
-        }
-        if (rc == DUSP_OK) {
-            e = hipMemcpyAsync(h_out, d_frames ? d_frames : d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        }
+    if (int rc = render_device_unguarded(prog, n_instances, n_samples, d_par, d_in, d_out, ctx->stream)) return rc;
+    const size_t n_ch = prog->P.out_bufs.size();
+    if (interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
+        HIP_TRY(ctx, prog->d_host_frames.ensure(n_out));
+        d_frames = prog->d_host_frames.p;
+        if (int rc = dusp_interleave_device(ctx, d_out, n_instances, n_ch, n_samples, d_frames, ctx->stream)) return rc;
     }
-    if (rc != DUSP_OK) return rc;
-    if (e != hipSuccess) CTX_FAIL(ctx, DUSP_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e));
+    const float *d_src = d_frames ? d_frames : d_out;
+    if (n_out >= kStagedMinFloats && !is_pinned_host(h_out)) {
+        HIP_TRY(ctx, download_staged(prog, h_out, d_src, n_out));
+    } else {  // pinned destination: one DMA at link speed; small output: not worth more
+        HIP_TRY(ctx, hipMemcpyAsync(h_out, d_src, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return DUSP_OK;
+    });
+}
+
+int dusp_host_alloc(dusp_ctx *ctx, size_t n_bytes, void **out) {
+    if (!ctx) return DUSP_ERR_ARG;
+    return guarded(ctx->err, "dusp_host_alloc", [&]() -> int {
+    if (!out) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_host_alloc: out is NULL");
+    *out = nullptr;
+    if (n_bytes < 1 || n_bytes > ((size_t)1 << 40)) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_host_alloc: size out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // smallest free buffer that fits and is not wastefully large; pinning fresh pages is the slow part, so buffers are kept
+    dusp_ctx::HostBuf *best = nullptr;
+    for (auto &b : ctx->host_pool)
+        if (!b.in_use && b.bytes >= n_bytes && b.bytes <= n_bytes + n_bytes / 4 + 65536 && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) {
+        best->in_use = true;
+        *out = best->p;
+        return DUSP_OK;
+    }
+    size_t idle = 0;  // keep the pool's idle part bounded: free idle buffers first when the new one would push it past 4 GiB
+    for (auto &b : ctx->host_pool) idle += b.in_use ? 0 : b.bytes;
+    for (size_t k = ctx->host_pool.size(); k-- > 0 && idle + n_bytes > ((size_t)4 << 30);)
+        if (!ctx->host_pool[k].in_use) {
+            idle -= ctx->host_pool[k].bytes;
+            (void)hipHostFree(ctx->host_pool[k].p);
+            ctx->host_pool.erase(ctx->host_pool.begin() + (long)k);
+        }
+    ctx->host_pool.reserve(ctx->host_pool.size() + 1);
+    void *p = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&p, n_bytes, hipHostMallocDefault));
+    ctx->host_pool.push_back({p, n_bytes, true});
+    *out = p;
+    return DUSP_OK;
+    });
+}
+
+int dusp_host_free(dusp_ctx *ctx, void *p) {
+    if (!ctx) return DUSP_ERR_ARG;
+    if (!p) return DUSP_OK;
+    for (auto &b : ctx->host_pool)
+        if (b.p == p && b.in_use) {
+            b.in_use = false;  // stays pinned for the next render of that size (dusp_ctx_destroy releases the pool)
+            return DUSP_OK;
+        }
+    CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_host_free: not a live buffer of this context");
 }
 
 int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double *out, size_t cap) {
     if (!prog) return DUSP_ERR_ARG;
     dusp_ctx *ctx = prog->ctx;
+    return guarded(ctx->err, "dusp_state_download", [&]() -> int {
     if (!prog->rendered) CTX_FAIL(ctx, DUSP_ERR_STATE, "dusp_state_download: nothing has been rendered yet");
     const dusp::Graph &g = prog->P.g;
     if (unit >= g.units.size() || instance >= prog->last_n_inst || !out)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_state_download: unit / instance out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(prog->ev1));  // the render may have gone to a caller's stream: wait for what IT recorded
     const dusp::UnitDesc &u = g.units[unit];
     std::vector<double> words;
     auto or0 = [](double v) { return (v != v || v == 0) ? 0.0 : v; };
@@ -813,6 +1027,7 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
     }
     for (size_t k = 0; k < words.size() && k < cap; k++) out[k] = words[k];
     return (int)words.size();
+    });
 }
 
 int dusp_last_kernel_ms(dusp_program *prog, float *ms) {

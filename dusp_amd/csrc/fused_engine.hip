@@ -373,13 +373,6 @@ static hipError_t launch_one(const FusedArgs &A, const OscRec *recs, int grid, s
     return hipGetLastError();
 }
 
-// A/B knobs for tools/abench.py: DUSP_FUSED_TABLE=global|lds, DUSP_FUSED_R=1|4|8, DUSP_FUSED_FX32=0|1,
-// DUSP_FUSED_ITEMS=<items per wave>
-static int env_int(const char *name, int fallback) {
-    const char *e = getenv(name);
-    return e && *e ? atoi(e) : fallback;
-}
-
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream) {
     FusedArgs A{};
     A.params = L.params;
@@ -409,18 +402,16 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
         A.s_left_is_shape = plan.s_left_is_shape; A.s_right_is_shape = plan.s_right_is_shape;
         A.s_playing = plan.s_playing; A.s_finished = plan.s_finished;
     }
-    A.fx32_ok = L.table_fx32_ok && env_int("DUSP_FUSED_FX32", 1) ? 1 : 0;
-    A.seg_major = env_int("DUSP_FUSED_SEGMAJOR", 0);
+    A.fx32_ok = L.table_fx32_ok && L.knobs.fused_fx32 ? 1 : 0;  // (knobs: device_types.hpp, read when the context was created)
+    A.seg_major = L.knobs.fused_segmajor;
 
     int tbl = (L.table_antisym && L.sample_rate % 2 == 0) ? 1 : 0;
-    const char *tenv = getenv("DUSP_FUSED_TABLE");
-    if (tenv && tenv[0] == 'g') tbl = 0;
+    if (L.knobs.fused_table_global) tbl = 0;
     const size_t lds_bytes = tbl ? half_table_lds_bytes(L.sample_rate) : 0;
     if (lds_bytes > 160 * 1024) tbl = 0;
 
     // R voices per item share one Ramp evaluation per step; without a Ramp there is nothing to share
-    int R = 4;
-    R = env_int("DUSP_FUSED_R", R);
+    int R = L.knobs.fused_R;
     if (R != 1 && R != 4 && R != 8) R = 4;
     // Items: (voice block, segment).  Aim at `per_wave` equal items for every resident wave so that all
     // waves finish together; segments of at least 16 steps keep the per-item jump-ahead negligible.
@@ -428,7 +419,7 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     const int grid = tbl ? L.n_cus : L.n_cus * 8;
     const uint64_t total_waves = (uint64_t)grid * (block / 64);
     const uint64_t n_blk = (A.n_inst + R - 1) / R;
-    const uint64_t per_wave = (uint64_t)env_int("DUSP_FUSED_ITEMS", 4);
+    const uint64_t per_wave = (uint64_t)std::max(1, L.knobs.fused_items);
     uint64_t n_seg = (total_waves * per_wave + n_blk - 1) / n_blk;
     if (n_seg < 1) n_seg = 1;
     uint64_t seg = (A.n_groups + n_seg - 1) / n_seg;

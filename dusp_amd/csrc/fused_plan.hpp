@@ -113,6 +113,8 @@ struct WaveArgs {
 
 // LDS one wave of the wave engine needs: chunk buffers + 12 doubles of state per op + the Filter scratch (P, b1, b2)
 // (the 6 KB scratch is only needed by Filters whose cutoff is connected: per-sample b1 / b2 and their own P)
+// the instance's parameter column, copied into the wave's LDS once (too many parameters: read from HBM instead)
+inline size_t wave_param_bytes(size_t n_params) { return n_params && n_params <= 2048 ? (n_params * 4 + 15) & ~(size_t)15 : 0; }
 inline size_t wave_lds_bytes(size_t n_bufs, size_t n_state_ops, size_t scratch_bytes) {
     return (n_bufs * 1024 + n_state_ops * 96 + (scratch_bytes ? scratch_bytes + 16 : 0) + 15) & ~(size_t)15;
 }
@@ -150,6 +152,7 @@ struct FusedLaunch {
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
     bool table_antisym, table_finite, table_fx32_ok;
+    Knobs knobs;
 };
 
 // Kernel arguments (by value).
@@ -562,7 +565,9 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         for (size_t b = 0; b < plan.buf_slot.size(); b++) plan.buf_slot[b] = (int)b;
         plan.n_slots = std::max(1, P.n_bufs);
     }
-    if (wave_lds_bytes((size_t)plan.n_slots, (size_t)plan.n_state_ops, (size_t)plan.scratch_bytes) + (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
+    // (the same sum launch_wave_engine makes for one wavefront: buffers + state + scratch + parameter column + Filter tiles)
+    if (wave_lds_bytes((size_t)plan.n_slots, (size_t)plan.n_state_ops, (size_t)plan.scratch_bytes) + wave_param_bytes((size_t)g.n_params) +
+            (plan.has_filter ? 258 * 8 + 260 * 4 : 0) > 160 * 1024)
         return no("too many chunk buffers for LDS");
     for (const DevOp &op : P.ops) {
         switch (op.op) {

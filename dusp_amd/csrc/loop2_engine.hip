@@ -653,9 +653,8 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
     }
 }
 
-hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, hipStream_t stream) {
-    const char *knob = getenv("DUSP_LOOP_WIDE");
-    if (lds_table_ok && !(knob && knob[0] == '0')) {
+hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, bool wide, hipStream_t stream) {
+    if (lds_table_ok && wide) {  // (wide: Knobs::loop_wide)
         const size_t lds = half_table_lds_bytes(a.sample_rate) + (size_t)kWI * kRow * sizeof(float) + (size_t)3 * kWI * kPPitch * sizeof(double) +
                            (size_t)kWI * sizeof(WideCarry);
         hipError_t e = hipFuncSetAttribute((const void *)dusp_loop3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -102,6 +102,9 @@ inline bool parse(const double *d, size_t nw, Graph &g, std::string &err) {
         return fail(err, "only the standard chunk size 256 is supported (reference src/config.js:6)");
     if (!as_count(d[4], 1 << 20, n_units) || n_units < 1) return fail(err, "bad unit count");
     if (!as_count(d[5], 1 << 16, n_rings)) return fail(err, "bad ring count");
+    // counts are bounded by what the descriptor can actually hold (a unit record is at least 4 words, a ring 2) BEFORE
+    // anything is sized by them
+    if ((size_t)n_units > (nw - kHeaderWords) / 4 || (size_t)n_rings > (nw - kHeaderWords) / 2) return fail(err, "descriptor too short for its unit / ring counts");
     if (!as_count(d[6], 1 << 20, n_params)) return fail(err, "bad parameter count");
     if (!as_count(d[7], (double)n_units - 1, out_unit)) return fail(err, "output unit out of range");
     if (d[8] != 0) return fail(err, "only outlet 0 (\"out\") can be rendered");
@@ -616,6 +619,9 @@ inline bool expand(Program &P, std::string &err) {
         }
     }
     P.ring_samples = ring_pos;
+    // every ring is at most 1e9 samples (parse); all rings of one instance together: 2^31 samples = 8 GiB of f32
+    if (ring_pos > ((int64_t)1 << 31)) return fail(err, "delay lines / CircleBuffers of one circuit instance add up to more than 2^31 samples (not supported on the GPU path)");
+    if (P.ops.size() > ((size_t)1 << 22)) return fail(err, "more than 2^22 channel-expanded ops (not supported on the GPU path)");
     for (auto &op : P.ops)
         if (op.op == OP_RETRIGGER) {  // trigger(): Shape, Ramp -> t = 0, playing; AHD -> state = 1, playing (Shape/index.js:107-111, Ramp.js:19-23, AHD.js:24-28)
             const UnitDesc &target = g.units[(size_t)g.units[(size_t)op.unit].attrs[0]];

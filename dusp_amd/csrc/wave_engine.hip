@@ -1164,8 +1164,8 @@ static hipError_t launch_wave_one(const WaveArgs &A, size_t lds_bytes, hipStream
 }
 
 // Picks the LDS geometry: half table (when the plan has an antisymmetric one) + per-wave chunk buffers.
-hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream) {
-    A.param_bytes = A.n_params && A.n_params <= 2048 ? (A.n_params * 4 + 15) & ~15u : 0;
+hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, int max_waves_cap, hipStream_t stream) {
+    A.param_bytes = (uint32_t)wave_param_bytes(A.n_params);
     A.wave_bytes = (uint32_t)wave_lds_bytes(A.n_bufs, A.n_state_ops, A.scratch_bytes) + A.param_bytes;
     const size_t budget = 160 * 1024;
     size_t table_bytes = lds_table_ok && A.lds_table_id >= 0 ? half_table_lds_bytes(A.sample_rate) : 0;
@@ -1181,7 +1181,7 @@ hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, hipStream_t stream)
     const unsigned want = (A.n_inst * A.n_seg + 255) / 256;  // (virtual) instances per CU on a 256-CU part
     int waves = 1;
     int most = A.ring_events ? 8 : 16;  // (the RING variant wants its 256 VGPRs: two waves per SIMD)
-    if (const char *cap = getenv("DUSP_WAVE_MAX_WAVES")) most = std::max(1, std::min(most, atoi(cap)));  // A/B knob
+    if (max_waves_cap > 0) most = std::max(1, std::min(most, max_waves_cap));  // A/B knob (Knobs::wave_max_waves)
     while (waves < most && waves * 2 <= fit && (unsigned)waves < want) waves *= 2;
     const size_t lds_bytes = table_bytes + (size_t)waves * (A.wave_bytes + shared_per_wave);
 #define DUSP_W(T, W, R, E, F) launch_wave_one<T, W, R, E, F>(A, lds_bytes, stream)

@@ -20,6 +20,8 @@
 
 #include "../../../include/dusp_hip.h"
 
+#define PINNED_MIN_BYTES ((size_t)1 << 20) /* results of at least 1 MiB live in pinned memory (dusp_host_alloc) */
+
 /* a dusp_ctx is not thread-safe and async renders run on pool threads: serialise library calls */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -36,28 +38,48 @@ static void throw_string(napi_env env, const char *msg) {
     if (napi_create_string_utf8(env, msg, NAPI_AUTO_LENGTH, &s) == napi_ok) napi_throw(env, s);
 }
 
+/* Lifetimes.  A program and a pinned PCM buffer both point into their context, and an async render points into its
+ * program, so the boxes count what still depends on them (all counting happens on the JS thread):
+ *   ctx_box.refs        the context external + every program box + every PCM ArrayBuffer backed by the context's pinned pool;
+ *                       the box itself is freed when the last of them is finalized
+ *   ctx_box.n_programs / n_buffers   live programs / pinned PCM buffers: ctxDestroy throws while either is non-zero
+ *   prog_box.in_flight  renders queued or running: programDestroy during one is deferred to its completion */
 typedef struct {
     dusp_ctx *ctx;
+    int refs, n_programs, n_buffers;
 } ctx_box;
 typedef struct {
     dusp_program *prog;
-    dusp_ctx *ctx;
+    ctx_box *cb;
+    int in_flight, destroy_deferred;
 } prog_box;
 
+static void ctx_unref(ctx_box *b) {
+    if (--b->refs > 0) return;
+    if (b->ctx) { /* never destroyed explicitly: the last dependant is gone, release the device side too */
+        pthread_mutex_lock(&g_lock);
+        dusp_ctx_destroy(b->ctx);
+        pthread_mutex_unlock(&g_lock);
+    }
+    free(b);
+}
 static void ctx_finalize(napi_env env, void *data, void *hint) {
     (void)env; (void)hint;
-    ctx_box *b = (ctx_box *)data;
-    /* contexts are kept for the life of the process by the JS layer; an explicit ctxDestroy clears ctx */
-    free(b);
+    ctx_unref((ctx_box *)data);
+}
+static void prog_destroy_now(prog_box *b) {
+    if (!b->prog) return;
+    pthread_mutex_lock(&g_lock);
+    dusp_program_destroy(b->prog);
+    pthread_mutex_unlock(&g_lock);
+    b->prog = NULL;
+    b->cb->n_programs--;
 }
 static void prog_finalize(napi_env env, void *data, void *hint) {
     (void)env; (void)hint;
-    prog_box *b = (prog_box *)data;
-    if (b->prog) {
-        pthread_mutex_lock(&g_lock);
-        dusp_program_destroy(b->prog);
-        pthread_mutex_unlock(&g_lock);
-    }
+    prog_box *b = (prog_box *)data; /* (no render can be in flight: a job holds a reference on this external) */
+    prog_destroy_now(b);
+    ctx_unref(b->cb);
     free(b);
 }
 
@@ -79,7 +101,7 @@ static ctx_box *as_ctx(napi_env env, napi_value v) {
 }
 static prog_box *as_prog(napi_env env, napi_value v) {
     void *p = NULL;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((prog_box *)p)->prog) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((prog_box *)p)->prog || ((prog_box *)p)->destroy_deferred) {
         throw_string(env, "dusp-hip: not a live program");
         return NULL;
     }
@@ -124,9 +146,20 @@ static napi_value fn_ctx_create(napi_env env, napi_callback_info info) {
         return NULL;
     }
     ctx_box *b = (ctx_box *)calloc(1, sizeof *b);
+    if (!b) {
+        dusp_ctx_destroy(ctx);
+        throw_string(env, "dusp-hip: out of host memory");
+        return NULL;
+    }
     b->ctx = ctx;
+    b->refs = 1;
     napi_value ext;
-    NAPI_OK(napi_create_external(env, b, ctx_finalize, NULL, &ext));
+    if (napi_create_external(env, b, ctx_finalize, NULL, &ext) != napi_ok) {
+        dusp_ctx_destroy(ctx);
+        free(b);
+        throw_string(env, "dusp-hip: could not wrap the context");
+        return NULL;
+    }
     return ext;
 }
 
@@ -135,6 +168,13 @@ static napi_value fn_ctx_destroy(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return NULL;
     ctx_box *b = as_ctx(env, argv[0]);
     if (!b) return NULL;
+    if (b->n_programs > 0 || b->n_buffers > 0) { /* they point into the context (device, pinned pool) */
+        char msg[160];
+        snprintf(msg, sizeof msg, "dusp-hip: ctxDestroy: %d program(s) and %d rendered PCM buffer(s) of this context are still alive",
+                 b->n_programs, b->n_buffers);
+        throw_string(env, msg);
+        return NULL;
+    }
     pthread_mutex_lock(&g_lock);
     dusp_ctx_destroy(b->ctx);
     pthread_mutex_unlock(&g_lock);
@@ -188,10 +228,19 @@ static napi_value fn_program_build(napi_env env, napi_callback_info info) {
         return NULL;
     }
     prog_box *pb = (prog_box *)calloc(1, sizeof *pb);
-    pb->prog = prog;
-    pb->ctx = b->ctx;
     napi_value ext;
-    NAPI_OK(napi_create_external(env, pb, prog_finalize, NULL, &ext));
+    if (!pb || napi_create_external(env, pb, prog_finalize, NULL, &ext) != napi_ok) {
+        pthread_mutex_lock(&g_lock);
+        dusp_program_destroy(prog);
+        pthread_mutex_unlock(&g_lock);
+        free(pb);
+        throw_string(env, "dusp-hip: could not wrap the program");
+        return NULL;
+    }
+    pb->prog = prog;
+    pb->cb = b;
+    b->refs++;
+    b->n_programs++;
     return ext;
 }
 
@@ -211,7 +260,7 @@ static napi_value fn_program_continue(napi_env env, napi_callback_info info) {
     pthread_mutex_lock(&g_lock);
     int rc = dusp_program_continue(pb->prog, (const double *)data, len);
     char msg[512];
-    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->ctx));
+    if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->cb->ctx));
     pthread_mutex_unlock(&g_lock);
     if (rc != DUSP_OK) {
         throw_string(env, msg);
@@ -227,10 +276,8 @@ static napi_value fn_program_destroy(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return NULL;
     prog_box *pb = as_prog(env, argv[0]);
     if (!pb) return NULL;
-    pthread_mutex_lock(&g_lock);
-    dusp_program_destroy(pb->prog);
-    pthread_mutex_unlock(&g_lock);
-    pb->prog = NULL;
+    if (pb->in_flight > 0) pb->destroy_deferred = 1; /* a render is using it on a pool thread: destroyed when that completes */
+    else prog_destroy_now(pb);
     return NULL;
 }
 
@@ -273,7 +320,7 @@ static napi_value fn_state_download(napi_env env, napi_callback_info info) {
     pthread_mutex_lock(&g_lock);
     int n = dusp_state_download(pb->prog, instance, unit, words, 512);
     char msg[512];
-    if (n < 0) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->ctx));
+    if (n < 0) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->cb->ctx));
     pthread_mutex_unlock(&g_lock);
     if (n < 0) {
         throw_string(env, msg);
@@ -293,8 +340,8 @@ typedef struct {
     napi_async_work work;
     napi_deferred deferred;
     napi_ref prog_ref; /* keeps the program external alive while the render is in flight */
-    dusp_program *prog;
-    dusp_ctx *ctx;
+    prog_box *pb;
+    int out_pinned; /* out comes from dusp_host_alloc (the context's pinned pool) rather than malloc */
     size_t n_instances, n_samples, n_floats;
     float *params;
     float *inputs; /* host-generated streams [nInputs][nInstances][nSamples] (copied: the caller may reuse its array) */
@@ -308,16 +355,49 @@ static void render_execute(napi_env env, void *data) {
     (void)env;
     render_job *j = (render_job *)data;
     pthread_mutex_lock(&g_lock);
-    if (j->inputs) j->rc = dusp_render_host_inputs(j->prog, j->n_instances, j->n_samples, j->params, j->inputs, j->out, j->interleaved);
-    else
-        j->rc = j->interleaved ? dusp_render_host_interleaved(j->prog, j->n_instances, j->n_samples, j->params, j->out)
-                               : dusp_render_host(j->prog, j->n_instances, j->n_samples, j->params, j->out);
-    if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->ctx));
+    dusp_program *prog = j->pb->prog; /* (in_flight > 0 keeps it alive: programDestroy defers) */
+    if (!prog) {
+        j->rc = DUSP_ERR_STATE;
+        snprintf(j->err, sizeof j->err, "dusp-hip: render: the program has been destroyed");
+    } else {
+        if (j->inputs) j->rc = dusp_render_host_inputs(prog, j->n_instances, j->n_samples, j->params, j->inputs, j->out, j->interleaved);
+        else
+            j->rc = j->interleaved ? dusp_render_host_interleaved(prog, j->n_instances, j->n_samples, j->params, j->out)
+                                   : dusp_render_host(prog, j->n_instances, j->n_samples, j->params, j->out);
+        if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->pb->cb->ctx));
+    }
     pthread_mutex_unlock(&g_lock);
 }
 static void free_pcm(napi_env env, void *data, void *hint) {
     (void)env; (void)hint;
     free(data);
+}
+/* a PCM buffer from the context's pinned pool goes back to it when its ArrayBuffer is collected */
+static void free_pinned_pcm(napi_env env, void *data, void *hint) {
+    (void)env;
+    ctx_box *cb = (ctx_box *)hint;
+    if (cb->ctx) {
+        pthread_mutex_lock(&g_lock);
+        dusp_host_free(cb->ctx, data);
+        pthread_mutex_unlock(&g_lock);
+    }
+    cb->n_buffers--;
+    ctx_unref(cb);
+}
+static void release_out(render_job *j) { /* an output buffer that never reached JavaScript */
+    if (!j->out) return;
+    if (j->out_pinned) {
+        ctx_box *cb = j->pb->cb;
+        if (cb->ctx) {
+            pthread_mutex_lock(&g_lock);
+            dusp_host_free(cb->ctx, j->out);
+            pthread_mutex_unlock(&g_lock);
+        }
+        cb->n_buffers--;
+        ctx_unref(cb);
+    } else
+        free(j->out);
+    j->out = NULL;
 }
 static void render_complete(napi_env env, napi_status status, void *data) {
     render_job *j = (render_job *)data;
@@ -328,7 +408,8 @@ static void render_complete(napi_env env, napi_status status, void *data) {
     }
     if (j->rc == DUSP_OK) {
         napi_value ab;
-        if (napi_create_external_arraybuffer(env, j->out, j->n_floats * sizeof(float), free_pcm, NULL, &ab) == napi_ok &&
+        if (napi_create_external_arraybuffer(env, j->out, j->n_floats * sizeof(float), j->out_pinned ? free_pinned_pcm : free_pcm,
+                                             j->out_pinned ? (void *)j->pb->cb : NULL, &ab) == napi_ok &&
             napi_create_typedarray(env, napi_float32_array, j->n_floats, ab, 0, &result) == napi_ok) {
             j->out = NULL; /* owned by the ArrayBuffer now */
             napi_resolve_deferred(env, j->deferred, result);
@@ -340,11 +421,12 @@ static void render_complete(napi_env env, napi_status status, void *data) {
         napi_create_string_utf8(env, j->err, NAPI_AUTO_LENGTH, &result);
         napi_reject_deferred(env, j->deferred, result); /* a string, like the reference's rejections */
     }
+    release_out(j);
+    if (--j->pb->in_flight == 0 && j->pb->destroy_deferred) prog_destroy_now(j->pb); /* programDestroy came while this render ran */
     napi_delete_reference(env, j->prog_ref);
     napi_delete_async_work(env, j->work);
     free(j->params);
     free(j->inputs);
-    free(j->out);
     free(j);
 }
 
@@ -370,8 +452,11 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
     dusp_program_info pi;
     dusp_program_info_get(pb->prog, &pi);
     render_job *j = (render_job *)calloc(1, sizeof *j);
-    j->prog = pb->prog;
-    j->ctx = pb->ctx;
+    if (!j) {
+        throw_string(env, "dusp-hip: render: out of host memory");
+        return NULL;
+    }
+    j->pb = pb;
     j->n_instances = (size_t)n_inst;
     j->n_samples = (size_t)n_samples;
     j->n_floats = j->n_instances * pi.n_out_channels * j->n_samples;
@@ -387,6 +472,11 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
             return NULL;
         }
         j->params = (float *)malloc(len * sizeof(float) + 1);
+        if (!j->params) {
+            free(j);
+            throw_string(env, "dusp-hip: render: out of host memory for the parameter table");
+            return NULL;
+        }
         memcpy(j->params, data, len * sizeof(float));
     } else if (pi.n_params) {
         free(j);
@@ -404,6 +494,12 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
             return NULL;
         }
         j->inputs = (float *)malloc(len * sizeof(float) + 1);
+        if (!j->inputs) {
+            free(j->params);
+            free(j);
+            throw_string(env, "dusp-hip: render: out of host memory for the input streams");
+            return NULL;
+        }
         memcpy(j->inputs, data, len * sizeof(float));
     } else if (pi.n_inputs) {
         free(j->params);
@@ -411,7 +507,22 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
         throw_string(env, "dusp-hip: render: this program reads host-generated input streams");
         return NULL;
     }
-    j->out = (float *)malloc(j->n_floats * sizeof(float) + 1);
+    /* The result buffer IS the ArrayBuffer JavaScript gets (renderChannelData.js:39 allocates per call; no copy here).  Large
+     * results come from the context's pinned pool so that the download is one DMA at link speed; small ones (event-segmented
+     * rendering makes hundreds a second) from malloc. */
+    if (j->n_floats * sizeof(float) >= PINNED_MIN_BYTES) {
+        void *p = NULL;
+        pthread_mutex_lock(&g_lock);
+        int rc = dusp_host_alloc(pb->cb->ctx, j->n_floats * sizeof(float), &p);
+        pthread_mutex_unlock(&g_lock);
+        if (rc == DUSP_OK) {
+            j->out = (float *)p;
+            j->out_pinned = 1;
+            pb->cb->n_buffers++;
+            pb->cb->refs++;
+        }
+    }
+    if (!j->out) j->out = (float *)malloc(j->n_floats * sizeof(float) + 1);
     if (!j->out) {
         free(j->inputs);
         free(j->params);
@@ -420,11 +531,26 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
         return NULL;
     }
     napi_value promise, name;
-    NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
-    NAPI_OK(napi_create_reference(env, argv[0], 1, &j->prog_ref));
-    NAPI_OK(napi_create_string_utf8(env, "dusp-hip render", NAPI_AUTO_LENGTH, &name));
-    NAPI_OK(napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work));
-    NAPI_OK(napi_queue_async_work(env, j->work));
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &j->prog_ref) != napi_ok ||
+        napi_create_string_utf8(env, "dusp-hip render", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok) {
+        release_out(j);
+        free(j->inputs);
+        free(j->params);
+        free(j);
+        throw_string(env, "dusp-hip: render: could not queue the render");
+        return NULL;
+    }
+    pb->in_flight++;
+    if (napi_queue_async_work(env, j->work) != napi_ok) {
+        pb->in_flight--;
+        release_out(j);
+        free(j->inputs);
+        free(j->params);
+        free(j);
+        throw_string(env, "dusp-hip: render: could not queue the render");
+        return NULL;
+    }
     return promise;
 }
 

@@ -22,6 +22,7 @@ EXPORTS = [
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
     "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
+    "dusp_host_alloc", "dusp_host_free",
 ]
 
 
@@ -79,8 +80,26 @@ def load():
     L.dusp_fill_device.argtypes = [vp, vp, sz, ctypes.c_float, vp]
     L.dusp_render_device_inputs.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
+    L.dusp_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.dusp_host_free.argtypes = [vp, vp]
     _lib = L
     return L
+
+
+PINNED_MIN_BYTES = 1 << 20  # results of at least 1 MiB are delivered in pinned memory (dusp_host_alloc): one DMA, no staging
+
+
+class _PinnedBlock:
+    """Owner of one dusp_host_alloc buffer: handed back to the context's pool when the last array over it goes."""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            self.ctx._host_release(self.ptr)
+        except Exception:
+            pass
 
 
 class Context:
@@ -93,9 +112,34 @@ class Context:
         if rc != 0:
             raise DuspHipError(rc, self._L.dusp_last_error(None).decode())
         self._h = h
+        self._host_live = 0       # pinned result buffers some numpy array still looks at
+        self._close_pending = False
         self.sample_rate = None
         if sample_rate is not None:
             self.upload_tables(sample_rate)
+
+    def host_empty(self, shape, pinned=None):
+        """float32 array for a render result (replaces `new TypedArray(lengthInSamples)`, renderChannelData.js:39).  Large
+        results live in the context's pinned pool so that the download is a direct DMA; the block returns to the pool when
+        the array (and every view of it) has been collected."""
+        n = int(np.prod(shape))
+        if pinned is None:
+            pinned = n * 4 >= PINNED_MIN_BYTES
+        if not pinned or n == 0:
+            return np.empty(shape, dtype=np.float32)
+        p = ctypes.c_void_p()
+        self._check(self._L.dusp_host_alloc(self._h, n * 4, ctypes.byref(p)))
+        self._host_live += 1
+        buf = (ctypes.c_float * n).from_address(p.value)
+        buf._dusp_owner = _PinnedBlock(self, p.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(shape)
+
+    def _host_release(self, ptr):
+        self._host_live -= 1
+        if self._h:
+            self._L.dusp_host_free(self._h, ptr)
+            if self._close_pending and self._host_live == 0:
+                self.close()
 
     def _check(self, rc):
         if rc < 0:
@@ -125,6 +169,9 @@ class Context:
         self._check(self._L.dusp_fill_device(self._h, d_ptr, n_floats, value, stream))
 
     def close(self):
+        if self._h and self._host_live > 0:  # arrays over the pinned pool are still alive: the last one closes
+            self._close_pending = True
+            return
         if self._h:
             self._L.dusp_ctx_destroy(self._h)
             self._h = None
@@ -165,12 +212,12 @@ class Program:
         self.ctx._check(self._L.dusp_program_continue(self._h, words.ctypes.data, words.size))
         self._read_info()
 
-    def render(self, n_samples, n_instances=1, params=None, interleaved=False, inputs=None):
+    def render(self, n_samples, n_instances=1, params=None, interleaved=False, inputs=None, pinned=None):
         """Host round trip: float32 [n_instances, n_out_channels, n_samples], or — interleaved — frames
         [n_instances, n_samples, n_out_channels] (the RenderStream / WAV layout, transposed on the device).
         inputs: the host-generated streams of this call, float32 [n_inputs, n_instances, n_samples] (programs with INPUT units)."""
         shape = (n_instances, n_samples, self.n_out_channels) if interleaved else (n_instances, self.n_out_channels, n_samples)
-        out = np.empty(shape, dtype=np.float32)
+        out = self.ctx.host_empty(shape, pinned)  # pinned=None: by size; False: pageable memory (the staged download)
         pp = None
         if self.n_params:
             params = np.ascontiguousarray(params, dtype=np.float32)

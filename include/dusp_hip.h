@@ -18,11 +18,19 @@
  * Error convention mirrors the reference's (thrown strings that surface as
  * Promise rejections, src/renderChannelData.js:12-17): every call returns 0 on
  * success or a negative dusp_status, and dusp_last_error() returns the message.
+ * No C++ exception ever crosses this boundary and nothing calls abort(): sizes
+ * taken from a descriptor are bounded before anything is allocated, and an
+ * allocation failure inside the library comes back as a status like any other.
  * Nothing here ever falls back to a CPU implementation: without a usable HIP
  * device the calls fail with DUSP_ERR_HIP.
  *
  * Threading: a dusp_ctx is bound to one HIP device and is not thread-safe;
  * different contexts are independent (one context per GPU for multi-GPU use).
+ * Streams: a program's workspaces are reused from render to render; renders of
+ * one program are ordered among themselves whatever streams they are given (a
+ * render on another stream than the previous one waits for it), and
+ * dusp_state_download / dusp_program_destroy wait for the last render wherever
+ * it ran.
  */
 #ifndef DUSP_HIP_H
 #define DUSP_HIP_H
@@ -34,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 3
+#define DUSP_ABI_VERSION 4
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -44,7 +52,8 @@ typedef enum {
     DUSP_ERR_ARG = -1,         /* bad argument / malformed descriptor */
     DUSP_ERR_UNSUPPORTED = -2, /* graph uses something the GPU path does not implement */
     DUSP_ERR_HIP = -3,         /* HIP runtime error (no device, out of memory, launch failure) */
-    DUSP_ERR_STATE = -4        /* call sequence error (e.g. wave table not uploaded) */
+    DUSP_ERR_STATE = -4,       /* call sequence error (e.g. wave table not uploaded) */
+    DUSP_ERR_NOMEM = -5        /* a host allocation failed while the call was being prepared */
 } dusp_status;
 
 /* Engine that executes a program (chosen at build time from the graph's shape):
@@ -140,10 +149,23 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info);
 int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
                        const float *d_params, float *d_out, void *stream);
 
-/* Convenience wrapper for host callers (the N-API addon): uploads h_params,
- * renders, downloads into h_out (same layouts as above) and synchronises. */
+/* Host callers (the N-API addon): uploads h_params, renders, downloads into h_out
+ * (same layouts as above) and synchronises.  The download is what the caller
+ * waits for — PCIe, hundreds of times slower than the render — so:
+ *   h_out from dusp_host_alloc (pinned): one DMA at link speed straight into it;
+ *   h_out pageable and large: several worker threads, each double-buffering pinned
+ *   staging tiles on its own stream, copy disjoint ranges concurrently;
+ *   small outputs: a plain asynchronous copy. */
 int dusp_render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
                      const float *h_params, float *h_out);
+
+/* Result buffers (replaces `new TypedArray(lengthInSamples)` of src/renderChannelData.js:39 as the thing that owns the
+ * returned samples): n_bytes of PINNED host memory from the context's pool.  dusp_render_host* into such a buffer is a
+ * direct device-to-host DMA.  dusp_host_free hands the buffer back to the pool (it stays pinned for the next render of
+ * that size; dusp_ctx_destroy releases everything).  The N-API addon wraps these in external ArrayBuffers whose
+ * finalizer calls dusp_host_free. */
+int dusp_host_alloc(dusp_ctx *ctx, size_t n_bytes, void **out);
+int dusp_host_free(dusp_ctx *ctx, void *p);
 
 /* Host-generated signals.  A descriptor may hold INPUT units (opcode 41, attribute = stream index): units whose
  * output the HOST computes while the rest of the circuit runs on the device — the reference's Noise

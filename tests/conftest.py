@@ -52,3 +52,24 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+_knob_contexts = {}
+
+
+def knob_context(sample_rate, **knobs):
+    """A context created under the given DUSP_* A/B knobs (the library reads them ONCE, in dusp_ctx_create); cached per setting."""
+    from dusp_amd import runtime
+    key = (sample_rate,) + tuple(sorted(knobs.items()))
+    if key not in _knob_contexts:
+        saved = {k: os.environ.get(k) for k in knobs}
+        os.environ.update({k: str(v) for k, v in knobs.items()})
+        try:
+            _knob_contexts[key] = runtime.Context(-1, sample_rate)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _knob_contexts[key]

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_abi():
     L = runtime.load()
-    assert L.dusp_abi_version() == 3
+    assert L.dusp_abi_version() == 4
     assert b"gfx950" in L.dusp_version()
 
 
@@ -50,3 +50,14 @@ def test_repeat_add_equals_the_plain_loop(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "repeat_add_check.cpp")])
     rep = json.loads(subprocess.check_output([exe, "40000"]).decode().strip().splitlines()[-1])
     assert rep["cases"] == 40000 and rep["bad"] == 0 and rep["linear_runs"] > 10000  # (linear_run: whole chunks inside one binade, checked sample by sample)
+
+
+def test_descriptor_sizes_are_bounded_before_anything_is_allocated(tmp_path):
+    """dusp_amd/csrc/program.hpp on the CPU: a 2^40-sample ring, a 2^40 maxDelay, delay lines that add up past 2^31 samples
+    and unit / ring counts the descriptor cannot hold all come back as error strings (-> a dusp_status), no exception."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "compile_bounds_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "compile_bounds_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] == 6 and rep["bad"] == 0

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import dusp_amd as d
+from conftest import knob_context
 from dusp_amd import descriptor, render, runtime
 
 pytestmark = pytest.mark.gpu
@@ -204,7 +205,7 @@ def test_config4_sweep_shard_full_size(oracle):
         prog.close()
 
 
-def test_loop_kernels_agree_bit_for_bit(monkeypatch):
+def test_loop_kernels_agree_bit_for_bit():
     """The two-stage feedback-voice kernels (delay >= one chunk; wide and narrow variant), the one-stage loop kernel
     and the generic chunk engine execute the same operations in the same order per sample: identical PCM and state."""
     d.configure(48000)
@@ -216,14 +217,11 @@ def test_loop_kernels_agree_bit_for_bit(monkeypatch):
     for delay in (480, 300.25, 3840):
         uni = descriptor.unify([descriptor.extract(loop(k, delay)) for k in range(0, 1700, 41)])
         n = 256 * 9 + 17
-        ctx = render.context(48000)
         results = []
         # two-stage wide (32 instances / workgroup, table in LDS), two-stage narrow, one-stage, generic chunk engine
         for engine, knob, wide in ((runtime.ENGINE_LOOP, "1", "1"), (runtime.ENGINE_LOOP, "1", "0"), (runtime.ENGINE_LOOP, "0", "1"),
                                    (runtime.ENGINE_CHUNK, "1", "1")):
-            monkeypatch.setenv("DUSP_LOOP2", knob)
-            monkeypatch.setenv("DUSP_LOOP_WIDE", wide)
-            prog = ctx.build(uni.words, engine)
+            prog = knob_context(48000, DUSP_LOOP2=knob, DUSP_LOOP_WIDE=wide).build(uni.words, engine)
             if engine == runtime.ENGINE_LOOP:
                 assert ("two-stage" in prog.shape) == (knob == "1")
             pcm = prog.render(n, uni.n_instances, uni.params)
@@ -260,7 +258,7 @@ def test_render_host_interleaved_matches_planar():
     prog.close()
 
 
-def test_time_split_with_many_instances_and_parameters(monkeypatch):
+def test_time_split_with_many_instances_and_parameters():
     """Time-split wave rendering of a BATCH: per-instance parameters feed both FM levels; every (instance, segment)
     pair gets its own wavefront and the per-instance prefix of phase totals.  Must equal the unsplit render."""
     d.configure(48000)
@@ -269,18 +267,17 @@ def test_time_split_with_many_instances_and_parameters(monkeypatch):
     uni = descriptor.unify([descriptor.extract(voice(k)) for k in range(7)])
     assert uni.n_params >= 3
     n = 256 * 37 + 100
-    ctx = render.context(48000)
-    prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
-    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", "1")
+    prog = knob_context(48000, DUSP_WAVE_SEGMENTS=1).build(uni.words, runtime.ENGINE_WAVE)
     want = prog.render(n, uni.n_instances, uni.params)
     want_state = [prog.state(u, instance=5) for u in range(prog.n_units)]
+    prog.close()
     for segs in ("3", "11", "38"):
-        monkeypatch.setenv("DUSP_WAVE_SEGMENTS", segs)
+        prog = knob_context(48000, DUSP_WAVE_SEGMENTS=segs).build(uni.words, runtime.ENGINE_WAVE)
         got = prog.render(n, uni.n_instances, uni.params)
         assert np.array_equal(got, want), segs
         for a, b in zip([prog.state(u, instance=5) for u in range(prog.n_units)], want_state):
             assert np.array_equal(a, b, equal_nan=True)
-    prog.close()
+        prog.close()
 
 
 def test_circlebuffer_batch_wave_equals_chunk():

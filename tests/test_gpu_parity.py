@@ -8,7 +8,7 @@ there the north star's tolerance applies,
 import numpy as np
 import pytest
 
-from conftest import ALL_GOLDEN, Golden
+from conftest import ALL_GOLDEN, Golden, knob_context
 from dusp_amd import render, runtime
 
 pytestmark = pytest.mark.gpu
@@ -117,20 +117,19 @@ def test_segmented_render_equals_one_shot(name, oracle):
 
 @pytest.mark.parametrize("n_seg", [2, 5, 64])
 @pytest.mark.parametrize("name", ALL_GOLDEN)
-def test_time_split_wave_render_equals_unsplit(name, n_seg, monkeypatch):
+def test_time_split_wave_render_equals_unsplit(name, n_seg):
     """Wave engine, time-split mode (few instances, long render): every instance is cut into segments rendered by
     separate wavefronts after one accumulate + prefix pass per FM level.  Oscillator phases are exact modular sums,
     so PCM and written-back state must equal the unsplit render bit for bit, whatever the number of segments."""
     g = Golden(name)
-    ctx = render.context(g.sample_rate)
-    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", "1")
     try:
-        prog = ctx.build(g.desc, runtime.ENGINE_WAVE)
+        prog = knob_context(g.sample_rate, DUSP_WAVE_SEGMENTS=1).build(g.desc, runtime.ENGINE_WAVE)
     except runtime.DuspHipError:
         pytest.skip("not a wave-engine graph")
     want = prog.render(g.n_samples)[0]
     want_state = [prog.state(u) for u in range(prog.n_units)]
-    monkeypatch.setenv("DUSP_WAVE_SEGMENTS", str(n_seg))
+    prog.close()
+    prog = knob_context(g.sample_rate, DUSP_WAVE_SEGMENTS=n_seg).build(g.desc, runtime.ENGINE_WAVE)
     got = prog.render(g.n_samples)[0]
     got_state = [prog.state(u) for u in range(prog.n_units)]
     prog.close()

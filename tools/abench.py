@@ -40,30 +40,27 @@ def main():
 
     variants = []
     envsets = [("nt", {}), ("nt/segmajor", {"DUSP_FUSED_SEGMAJOR": "1"}), ("nt/it8", {"DUSP_FUSED_ITEMS": "8"}), ("nt/it2", {"DUSP_FUSED_ITEMS": "2"})]
-    ctxs = [("", ctx)]
-    plain = os.path.join(os.path.dirname(runtime.LIB_PATH), "libdusp_hip_plain.so")
-    if os.path.exists(plain):  # same kernels built with plain instead of non-temporal stores
-        runtime.LIB_PATH, runtime._lib = plain, None
-        ctxs.append(("plain:", runtime.Context(0, sr)))
+    KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE", "DUSP_FUSED_SEGMAJOR"]
+
+    def context_under(env):  # the library reads its A/B knobs once, when a context is created
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        return runtime.Context(0, sr)
+
+    ctxs = [(ename, context_under(env)) for ename, env in envsets]
     for kind in ["osc", "oscramp"]:
         for fname, fs in [("int", 10.0 * np.arange(1, V + 1)), ("frac", 20 + np.arange(V) / 8.0)]:
             uni = descriptor.unify([descriptor.extract(graph(kind, float(f))) for f in fs[:2]])
             params = torch.from_numpy(fs.astype(np.float32).reshape(1, V)).cuda()
-            for cname, c in ctxs:
-                prog = c.build(uni.words)
-                for ename, env in (envsets if not cname else envsets[:2]):
-                    variants.append(("%s%s/%s/%s" % (cname, kind, fname, ename), prog, params, env))
-
-    KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE", "DUSP_FUSED_SEGMAJOR"]
+            for ename, c in ctxs:
+                variants.append(("%s/%s/%s" % (kind, fname, ename), c.build(uni.words), params, None))
 
     def run(v):
         name, prog, params, env = v
         if prog is None:
             ctx.fill(out.data_ptr(), out.numel(), 1.0, stream)
         else:
-            for k in KNOBS:
-                os.environ.pop(k, None)
-            os.environ.update(env)
             prog.render_device(n, V, params.data_ptr(), out.data_ptr(), stream)
 
     variants.insert(0, ("fill", None, None, None))
