@@ -1,6 +1,14 @@
 // device_types.hpp — PODs shared by the host compiler and the HIP kernels.
 #pragma once
+#if defined(__HIPCC_RTC__)  // compiled at run time by hiprtc (jit_engine.hip): no host headers there, the basic types come from here
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long uintptr_t;
+#else
 #include <cstdint>
+#endif
 
 namespace dusp {
 
@@ -42,6 +50,7 @@ struct Knobs {
     int loop_wide = 1;           // DUSP_LOOP_WIDE=0: narrow two-stage loop kernel
     int wave_segments = -1;      // DUSP_WAVE_SEGMENTS=n: force n time segments (0 / 1: off; -1: automatic)
     int wave_max_waves = 0;      // DUSP_WAVE_MAX_WAVES=n: cap the wavefronts per workgroup (0: no cap)
+    int wave_jit = 1;            // DUSP_WAVE_JIT=0: keep wave-engine programs on the interpreter (no per-circuit kernels)
 };
 
 #if defined(__HIPCC__)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 #include <new>
 #include <algorithm>
@@ -15,7 +16,10 @@
 
 #include "../../include/dusp_hip.h"
 #include "device_types.hpp"
+#include "device_util.hpp"
 #include "fused_plan.hpp"
+#include "jit_codegen.hpp"
+#include "jit_engine.hpp"
 #include "program.hpp"
 
 namespace dusp {
@@ -45,6 +49,10 @@ struct dusp_ctx {
     bool table_antisym[dusp::kNumTables] = {false, false, false, false, false};
     bool table_finite[dusp::kNumTables] = {false, false, false, false, false};
     bool table_fx32_ok[dusp::kNumTables] = {false, false, false, false, false};  // min nonzero |T| >= 2^-20
+    // TABLE_FORM_*: the uploaded table equals a closed form of the index (saw, square, triangle) or of the sine table's entry
+    // (8bit) on EVERY entry, bit for bit — checked at upload — so kernels may evaluate it instead of gathering (device_util.hpp)
+    int table_form[dusp::kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<float> h_tables[2];  // host copies of table 0 (sine) and table 4 (8bit) for that check
     int n_cus = 256;
     dusp::Knobs knobs;  // A/B switches, read from the environment once (dusp_ctx_create)
     // pinned host buffers handed out by dusp_host_alloc (in_use) or waiting for reuse
@@ -110,14 +118,23 @@ struct dusp_program {
     int64_t next_clock = 0;      // circuit clock the last render stopped at
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;  // stream of the most recent render (workspaces and state are ordered on it)
+    // WAVE programs the circuit compiler takes (jit_codegen.hpp): generated text per workgroup geometry, constants on the device
+    bool jit_ok = false;
+    std::string jit_why;
+    std::map<int, dusp::JitSource> jit_src;  // wavefronts per workgroup -> kernel text (+ constants, scan list)
+    bool jit_consts_uploaded = false;
+    DevBuf<float> d_jit_fk;
+    DevBuf<double> d_jit_dk;
+    DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
 
     dusp_program() = default;
     dusp_program(const dusp_program &) = delete;
     dusp_program &operator=(const dusp_program &) = delete;
     ~dusp_program() {  // every exit path — a failed build included — gives the device memory back
         if (ctx) (void)hipSetDevice(ctx->device);
-        for (DevBuf<float> *b : {&d_scratch, &d_rings, &d_host_out, &d_host_par, &d_host_frames, &d_host_in, &d_saved_bufs, &d_rings_wave}) b->release();
-        for (DevBuf<double> *b : {&d_init, &d_state, &d_fused_state}) b->release();
+        for (DevBuf<float> *b : {&d_scratch, &d_rings, &d_host_out, &d_host_par, &d_host_frames, &d_host_in, &d_saved_bufs, &d_rings_wave, &d_jit_fk}) b->release();
+        for (DevBuf<double> *b : {&d_init, &d_state, &d_fused_state, &d_jit_dk}) b->release();
+        d_jit_scan.release();
         d_ops.release();
         d_out_bufs.release();
         d_seg.release();
@@ -184,6 +201,7 @@ static dusp::Knobs read_knobs() {
     k.loop_wide = num("DUSP_LOOP_WIDE", k.loop_wide);
     k.wave_segments = num("DUSP_WAVE_SEGMENTS", k.wave_segments);
     k.wave_max_waves = num("DUSP_WAVE_MAX_WAVES", k.wave_max_waves);
+    k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
     return k;
 }
 
@@ -276,6 +294,28 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     for (size_t t = 0; big && t < n; t++) big = table[t] == 0.f || std::fabs(table[t]) >= 9.5367431640625e-07f;
     ctx->table_fx32_ok[table_id] = big;
     ctx->table_set[table_id] = true;
+    // closed forms (device_util.hpp): every entry has to match, sign of zero included
+    auto same_bits = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
+    const uint32_t sr = (uint32_t)n - 1;
+    ctx->table_form[table_id] = dusp::TABLE_FORM_DATA;
+    if (table_id >= 1 && table_id <= 3 && n <= 131073) {
+        const int forms[3] = {dusp::TABLE_FORM_SAW, dusp::TABLE_FORM_SQUARE, dusp::TABLE_FORM_TRIANGLE};
+        const dusp::TableForm F = dusp::make_table_form(forms[table_id - 1], sr);
+        bool ok = F.form != dusp::TABLE_FORM_TRIANGLE || sr % 4 == 0;
+        for (uint32_t i = 0; ok && i <= sr; i++) ok = same_bits(dusp::closed_table_entry(F, i), table[i]);
+        if (ok) ctx->table_form[table_id] = F.form;
+    }
+    if (table_id == 0 || table_id == 4) {
+        ctx->h_tables[table_id ? 1 : 0].assign(table, table + n);
+        ctx->table_form[4] = dusp::TABLE_FORM_DATA;
+        const std::vector<float> &sine = ctx->h_tables[0], &bit8 = ctx->h_tables[1];
+        if (sine.size() == n && bit8.size() == n && ctx->table_antisym[0] && sr % 2 == 0) {
+            // as the kernels see the sine table: the half image in LDS, mirrored with a sign above the middle
+            bool ok = true;
+            for (uint32_t i = 0; ok && i <= sr; i++) ok = same_bits(dusp::eightbit_of_sine(i > sr / 2 ? -sine[n - i] : sine[i]), bit8[i]);
+            if (ok) ctx->table_form[4] = dusp::TABLE_FORM_8BIT;
+        }
+    }
     return DUSP_OK;
     });
 }
@@ -340,6 +380,10 @@ static int finish_build(dusp_program *prog) {
                  : loopable ? DUSP_ENGINE_LOOP
                            : DUSP_ENGINE_CHUNK;
     prog->engine = engine;
+    prog->jit_src.clear();
+    prog->jit_consts_uploaded = false;
+    prog->jit_ok = engine == DUSP_ENGINE_WAVE && ctx->knobs.wave_jit != 0 &&
+                   dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, prog->jit_why);
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const dusp::Program &P = prog->P;
@@ -495,7 +539,10 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
-    if (prog->engine == DUSP_ENGINE_WAVE)
+    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
+        std::snprintf(info->shape, sizeof info->shape, "%s, compiled circuit kernel (%d units in registers)", prog->P.feed_forward ? "feed-forward" : "feedback",
+                      (int)prog->P.ops.size());
+    else if (prog->engine == DUSP_ENGINE_WAVE)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     return DUSP_OK;
 }
@@ -529,6 +576,131 @@ int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_s
     if (!prog) return DUSP_ERR_ARG;
     if (prog->P.g.n_inputs > 0 && !d_inputs) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "render: the program has input streams but d_inputs is NULL");
     return render_device(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_);
+}
+
+// WAVE programs the circuit compiler takes: ONE kernel generated for this circuit's structure (jit_codegen.hpp), compiled for
+// gfx950 in process the first time the structure is seen (jit_engine.hip), cached from then on.
+static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uint32_t n_chunks, const float *d_params, const float *d_inputs, float *d_out,
+                      hipStream_t stream) {
+    dusp_ctx *ctx = prog->ctx;
+    const dusp::Program &P = prog->P;
+    const uint32_t n_pad = (n_inst + 63u) & ~63u;
+    const size_t n_slots = P.init_state.size();
+    HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+    if (prog->keep_memory) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: internal error: a continued program with device memory on the compiled path");
+
+    dusp::JitArgs a{};
+    a.params = d_params;
+    a.tables = ctx->d_tables;
+    a.inputs = d_inputs;
+    a.out = d_out;
+    a.state = prog->d_state.p;
+    a.init_state = prog->d_init.p;
+    a.n_samples = n_samples;
+    a.ring_samples = (uint64_t)P.ring_samples;
+    a.clock0 = (uint64_t)P.g.clock0;
+    a.n_inst = n_inst;
+    a.n_pad = n_pad;
+    a.n_groups = n_chunks;
+    a.sample_rate = (uint32_t)P.g.sample_rate;
+    a.table_stride = ctx->table_stride;
+    a.vec4_ok = (n_samples % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
+    a.n_out = (uint32_t)P.out_bufs.size();
+    if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
+        HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
+        HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+    }
+    a.rings = prog->d_rings.p;
+    // Few instances, long render: cut time into segments so that the whole chip works on it
+    a.n_seg = 1;
+    a.seg_groups = n_chunks;
+    if (prog->wave.splittable) {
+        const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
+        uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
+        if (ctx->knobs.wave_segments >= 0) n_seg = (uint64_t)ctx->knobs.wave_segments;
+        n_seg = std::max<uint64_t>(1, std::min<uint64_t>(n_seg, n_chunks));
+        if (n_seg > 1) {
+            a.seg_groups = (uint32_t)((n_chunks + n_seg - 1) / n_seg);
+            a.n_seg = (uint32_t)((n_chunks + a.seg_groups - 1) / a.seg_groups);  // no empty segments
+        }
+    }
+    // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
+    dusp::JitOptions opt;
+    const int t = prog->wave.lds_table_id;
+    if (t >= 0 && ctx->table_antisym[t] && P.g.sample_rate % 2 == 0) {
+        opt.lds_table = t;
+        opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
+    }
+    const size_t budget = 160 * 1024;
+    const size_t per_wave = prog->wave.has_filter ? dusp::jit_filter_tile_bytes(1) : 0;
+    if (opt.lds_table >= 0 && opt.table_bytes + per_wave > budget) opt.lds_table = -1, opt.table_bytes = 0;
+    const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
+    const unsigned want = (unsigned)((n_virtual + 255) / 256);
+    int most = 16;
+    if (ctx->knobs.wave_max_waves > 0) most = std::max(1, std::min(most, ctx->knobs.wave_max_waves));
+    int waves = 1;
+    while (waves < most && (size_t)(waves * 2) * per_wave + opt.table_bytes <= budget && (unsigned)waves < want) waves *= 2;
+
+    hipFunction_t render = nullptr;
+    dusp::JitSource *src = nullptr;
+    for (;;) {  // a kernel that spills at this many wavefronts per workgroup (128 registers each at 16) is rebuilt for half as many
+        opt.waves = waves;
+        auto it = prog->jit_src.find(waves);
+        if (it == prog->jit_src.end()) {
+            dusp::JitSource gen;
+            if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
+            it = prog->jit_src.emplace(waves, std::move(gen)).first;
+        }
+        src = &it->second;
+        std::string err;
+        int scratch = 0;
+        if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
+            CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
+        if (scratch == 0 || waves <= 4) break;
+        waves /= 2;
+    }
+    if (!prog->jit_consts_uploaded) {
+        HIP_TRY(ctx, prog->d_jit_fk.ensure(std::max<size_t>(1, src->fk.size())));
+        HIP_TRY(ctx, prog->d_jit_dk.ensure(std::max<size_t>(1, src->dk.size())));
+        if (!src->fk.empty()) HIP_TRY(ctx, hipMemcpyAsync(prog->d_jit_fk.p, src->fk.data(), src->fk.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        if (!src->dk.empty()) HIP_TRY(ctx, hipMemcpyAsync(prog->d_jit_dk.p, src->dk.data(), src->dk.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        std::vector<int> scan(2 * src->scans.size() + 2, 0);
+        for (size_t i = 0; i < src->scans.size(); i++) {
+            scan[i] = src->scans[i].state_slot;
+            scan[src->scans.size() + i] = src->scans[i].level;
+        }
+        HIP_TRY(ctx, prog->d_jit_scan.ensure(scan.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(prog->d_jit_scan.p, scan.data(), scan.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));  // (the host vectors above are temporaries / may be regenerated)
+        prog->jit_consts_uploaded = true;
+    }
+    a.fk = prog->d_jit_fk.p;
+    a.dk = prog->d_jit_dk.p;
+    const unsigned grid = (unsigned)((n_virtual + (unsigned)waves - 1) / (unsigned)waves);
+    HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+    if (a.n_seg > 1 && !src->scans.empty()) {  // one accumulate pass + prefix per FM level that has scanned oscillators, then the render pass
+        const size_t per = src->scans.size() * (size_t)n_inst * a.n_seg;
+        HIP_TRY(ctx, prog->d_seg.ensure(2 * per));
+        a.seg_sum = prog->d_seg.p;
+        a.seg_start = prog->d_seg.p + per;
+        for (int level : src->pass_levels) {
+            hipFunction_t pass = nullptr;
+            std::string err;
+            if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_pass" + std::to_string(level), &pass, nullptr, err))
+                CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
+            HIP_TRY(ctx, dusp::jit_launch(pass, a, grid, (unsigned)waves * 64, stream));
+            HIP_TRY(ctx, dusp::jit_launch_prefix(a.seg_sum, a.seg_start, prog->d_init.p, prog->d_jit_scan.p, prog->d_jit_scan.p + src->scans.size(),
+                                                 (int)src->scans.size(), level, n_inst, a.n_seg, a.sample_rate, stream));
+        }
+    }
+    HIP_TRY(ctx, dusp::jit_launch(render, a, grid, (unsigned)waves * 64, stream));
+    HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+    prog->last_n_inst = n_inst;
+    prog->last_n_pad = n_pad;
+    prog->rendered = true;
+    prog->h_state_valid = false;
+    prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
+    return DUSP_OK;
 }
 
 static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
@@ -609,6 +781,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
 
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
+    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok) return render_jit(prog, n_inst, n_samples, n_chunks, d_params, d_inputs, d_out, stream);
     if (prog->engine == DUSP_ENGINE_WAVE) {
         HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
         dusp::WaveArgs w{};
@@ -1037,6 +1210,58 @@ int dusp_last_kernel_ms(dusp_program *prog, float *ms) {
     HIP_TRY(ctx, hipEventSynchronize(prog->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(ms, prog->ev0, prog->ev1));
     return DUSP_OK;
+}
+
+int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int lds_table, int compile, char *text, size_t cap) {
+    return guarded(g_error, "dusp_circuit_kernel_source", [&]() -> int {
+    if (!desc || (cap && !text)) {
+        g_error = "dusp_circuit_kernel_source: NULL argument";
+        return DUSP_ERR_ARG;
+    }
+    if (waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16) {
+        g_error = "dusp_circuit_kernel_source: waves must be 1, 2, 4, 8 or 16";
+        return DUSP_ERR_ARG;
+    }
+    dusp::Program P;
+    std::string err;
+    if (!dusp::compile(desc, n_words, P, err, /*continuation=*/true)) {
+        g_error = "dusp_circuit_kernel_source: " + err;
+        return DUSP_ERR_ARG;
+    }
+    dusp::WavePlan plan;
+    if (!dusp::plan_wave(P, plan, false)) {
+        g_error = "dusp_circuit_kernel_source: the wave engine cannot run this graph (" + plan.why + ")";
+        return DUSP_ERR_UNSUPPORTED;
+    }
+    for (size_t k = 0; k < plan.osc_level.size() && k < P.ops.size(); k++)
+        if (plan.osc_level[k] >= 0) P.ops[k].d[0] = (double)plan.osc_level[k];
+    if (!dusp::jit_eligible(P, plan, false, err)) {
+        g_error = "dusp_circuit_kernel_source: not a circuit the compiler takes (" + err + ")";
+        return DUSP_ERR_UNSUPPORTED;
+    }
+    dusp::JitOptions opt;
+    opt.waves = waves;
+    if (lds_table && plan.lds_table_id >= 0 && P.g.sample_rate % 2 == 0) {
+        opt.lds_table = plan.lds_table_id;
+        opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
+        if (opt.table_bytes + (plan.has_filter ? dusp::jit_filter_tile_bytes(waves) : 0) > 160 * 1024) opt.lds_table = -1, opt.table_bytes = 0;
+    }
+    dusp::JitSource src;
+    if (!dusp::jit_generate(P, plan, opt, src)) {
+        g_error = "dusp_circuit_kernel_source: " + src.why;
+        return DUSP_ERR_UNSUPPORTED;
+    }
+    if (compile && !dusp::jit_compile_only(src.text, nullptr, err)) {
+        g_error = "dusp_circuit_kernel_source: " + err;
+        return DUSP_ERR_HIP;
+    }
+    if (cap) {
+        const size_t n = std::min(cap - 1, src.text.size());
+        std::memcpy(text, src.text.data(), n);
+        text[n] = 0;
+    }
+    return (int)std::min<size_t>(src.text.size(), 0x7fffffff);
+    });
 }
 
 int dusp_fill_device(dusp_ctx *ctx, float *d_out, size_t n_floats, float value, void *stream_) {

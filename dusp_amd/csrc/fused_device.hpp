@@ -1,127 +1,4 @@
-// fused_device.hpp — device helpers shared by the fused kernels (fused_engine.hip, sumchain_engine.hip).
+// fused_device.hpp — what the fused kernels (fused_engine.hip, sumchain_engine.hip) share: the device helpers plus their plan structs.
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include "device_types.hpp"
+#include "device_util.hpp"
 #include "fused_plan.hpp"
-
-namespace dusp {
-namespace {
-
-__device__ __forceinline__ int lsb_exponent(double x) {  // x finite, != 0: exponent of its lowest set bit
-    int ex;
-    const double fr = frexp(fabs(x), &ex);
-    const long long m = (long long)ldexp(fr, 53);
-    return ex - 53 + __builtin_ctzll((unsigned long long)m);
-}
-__device__ __forceinline__ uint64_t addmod(uint64_t a, uint64_t b, uint64_t S) {  // a, b < S < 2^63
-    const uint64_t s = a + b;
-    return s >= S ? s - S : s;
-}
-__device__ __forceinline__ uint64_t mulmod(uint64_t a, uint64_t n, uint64_t S) {  // a < S
-    uint64_t acc = 0;
-    for (int bit = 63 - __builtin_clzll(n | 1); bit >= 0; --bit) {
-        acc = addmod(acc, acc, S);
-        if ((n >> bit) & 1) acc = addmod(acc, a, S);
-    }
-    return acc;
-}
-
-__device__ __forceinline__ float operand_value(const DevOperand &o, const float *params, uint32_t n_inst, uint32_t inst) {
-    return o.kind == SRC_PARAM ? params[(size_t)o.idx * n_inst + inst] : o.cval;
-}
-
-// Table access.  TBL == 0: padded full table in global memory (served by L2).
-// TBL == 1: half table H[0..M+1] = T[0..M+1] in LDS (M = sr/2, N = sr+1); T[i] = -H[N-i] above M.
-//   LDS image: blocks of 33 words, block b = H[32b .. 32b+32] (the 33rd word repeats the next
-//   block's first), so word(k) = k + (k >> 5).  The odd pitch spreads the arithmetic progressions a
-//   wave reads (lane l looks up phase0 + 4 l f) over the 32 banks — a linear image measured 9-way
-//   conflicts on average over the 1024-voice sweep, this one 2.8 — and word(k)+1 always holds
-//   H[k+1], so the lerp's pair is two adjacent words.
-template <int TBL>
-struct Table {
-    const float *g;
-    const float *h;
-    uint32_t N, M;
-    __device__ __forceinline__ const float *word(uint32_t k) const {
-        return (const float *)((const char *)h + ((k + (k >> 5)) << 2));  // v_lshrrev + v_add_lshl
-    }
-    __device__ __forceinline__ float at(uint32_t i) const {
-        if (TBL == 0) return g[i];
-        const float v = *word(min(i, N - i));
-        return i > M ? -v : v;
-    }
-    __device__ __forceinline__ void pair(uint32_t i, float &a, float &b) const {  // (T[i], T[i+1])
-        if (TBL == 0) {
-            a = g[i];
-            b = g[i + 1];
-            return;
-        }
-        const bool upper = i > M;
-        const float *p = word(upper ? N - i - 1 : i);
-        const float x = p[0], y = p[1];
-        a = upper ? -y : x;
-        b = upper ? -x : y;
-    }
-};
-
-
-__device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t m, double inv_m) {
-    const uint32_t q = (uint32_t)((double)x * inv_m);
-    uint32_t r = x - q * m;
-    if ((int32_t)r < 0) r += m;
-    if (r >= m) r -= m;
-    return r;
-}
-__device__ __forceinline__ uint64_t mod_u64(uint64_t x, uint64_t m, double inv_m) {  // x < 2^64, m < 2^48
-    const uint64_t q = (uint64_t)((double)x * inv_m);
-    uint64_t r = x - q * m;
-    if ((int64_t)r < 0) r += m;
-    if ((int64_t)r < 0) r += m;
-    if (r >= m) r -= m;
-    if (r >= m) r -= m;
-    return r;
-}
-
-__device__ __forceinline__ unsigned long long mod_u64_lifted(unsigned long long x, unsigned long long m, double inv_m) {
-    return mod_u64(x, m, inv_m);  // x already lifted to a non-negative value below 2^63
-}
-
-template <bool FINITE>
-__device__ __forceinline__ float fix_out(float v) {  // `x || 0` (renderChannelData.js:44): NaN, -0 -> +0
-    if (FINITE) return v + 0.f;                       // operands verified finite on the host: only -0 can occur
-    return (v != v) ? 0.f : v + 0.f;
-}
-
-template <bool VEC>
-__device__ __forceinline__ void store4(float *row, const float (&v)[4], uint64_t t, uint64_t n_samples) {
-    if (VEC) {
-#ifdef DUSP_NT_STORES
-        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4 *)row);
-#else
-        *(f32x4 *)row = f32x4{v[0], v[1], v[2], v[3]};  // plain stores measured 1-2 % faster than `nt` here (tools/abench.py)
-#endif
-    } else
-        for (int c = 0; c < 4; ++c)
-            if (t + c < n_samples) row[c] = v[c];
-}
-
-// Cooperative fill of the LDS half-table image (33-word pitch, see Table<1>).
-template <int BLOCK>
-__device__ __forceinline__ void load_half_table(float *lds, const float *table, uint32_t sample_rate) {
-    const uint32_t last = sample_rate / 2 + 1;
-    const uint32_t n_words = last + (last >> 5) + 2;
-    for (uint32_t q = threadIdx.x; q < n_words; q += BLOCK) {
-        const uint32_t src = (q / 33) * 32 + (q % 33);
-        lds[q] = table[min(src, last)];
-    }
-    __syncthreads();
-}
-
-__host__ __device__ inline size_t half_table_lds_bytes(uint32_t sample_rate) {
-    const uint32_t last = sample_rate / 2 + 1;
-    return ((size_t)(last + (last >> 5) + 2) * sizeof(float) + 15) & ~(size_t)15;
-}
-
-}  // namespace
-}  // namespace dusp

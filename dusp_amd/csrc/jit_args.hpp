@@ -1,0 +1,25 @@
+// jit_args.hpp — kernel arguments of the per-circuit kernels (by value), shared by the host launcher (jit_engine.hip) and
+// the device code hiprtc compiles at run time (jit_prelude.hpp + the text jit_codegen.hpp emits for one circuit).
+#pragma once
+#include "device_types.hpp"
+
+namespace dusp {
+
+struct JitArgs {
+    const float *fk;           // the circuit's f32 constants (inlet constants), in the order the generated code numbers them
+    const double *dk;          // its f64 constants (Ramp duration / y0 / y1, FixedMultiply factor, ...)
+    const float *params;       // [n_params][n_inst]
+    const float *tables;       // [kNumTables][table_stride]
+    const float *inputs;       // [n_inputs][n_inst][n_samples]  host-generated signals (OP_INPUT)
+    float *out;                // [n_inst][n_out][n_samples]
+    double *state;             // [n_slots][n_pad]  end-of-render state (chunk engine's slot layout)
+    const double *init_state;  // [n_slots]
+    float *rings;              // [n_inst][ring_samples]
+    // time-split rendering: [n_ops][n_inst][n_seg] phase totals / start phases of the scanned oscillators (2^-36 units, bit 63 = poisoned)
+    unsigned long long *seg_sum, *seg_start;
+    uint64_t n_samples, ring_samples, clock0;
+    uint32_t n_inst, n_pad, n_groups, sample_rate, table_stride, vec4_ok, n_out, pad0;
+    uint32_t n_seg, seg_groups;  // every instance is cut into n_seg segments of seg_groups chunks, one wavefront each (1: no split)
+};
+
+}  // namespace dusp

@@ -1,0 +1,405 @@
+// jit_codegen.hpp — the circuit compiler's front half: a compiled Program (units in the reference's process order,
+// channel-expanded) -> the TEXT of one HIP kernel that renders exactly that circuit.
+//
+// What the reference does per chunk — Circuit.tick walks `circuit.units` and calls every unit's `_tick`
+// (src/Circuit.js:19-41, src/Unit.js:111-119) — becomes the body of one loop, one statement block per unit, in that order.
+// Operands are named, not fetched: an inlet constant is `kN` (a scalar read once from the constants array), a per-instance
+// parameter `pN`, a connection `vB` = the producing unit's four samples in this lane's registers — or `wB`, the same
+// registers as the PREVIOUS iteration left them, when the producer ticks later than the consumer (a feedback edge or one
+// of the edges the reference's process order gets "late": the reference reads the producer's previous chunk there).
+//
+// The text depends on the circuit's STRUCTURE only (unit kinds, wiring, table ids, which operands are constants): constants
+// travel in the fk / dk arrays, state in init_state, so every circuit of the same shape — and every segment of an
+// event-segmented render — reuses one compiled kernel (jit_engine.hip caches by the text's hash).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+#include "fused_plan.hpp"
+#include "program.hpp"
+
+namespace dusp {
+
+struct JitSource {
+    bool ok = false;
+    std::string why;            // when not ok: what keeps this program on the interpreter
+    std::string text;           // kernels: dusp_jit_render, dusp_jit_pass<L> for every L in pass_levels
+    std::vector<float> fk;      // values of the constants the text names k0, k1, ...
+    std::vector<double> dk;     // ... and d0, d1, ...
+    std::vector<int> pass_levels;                 // time-split rendering: FM levels that have scanned oscillators, ascending
+    struct Scan { int op_pos, state_slot, level; };  // scanned oscillators: position in execution order, state slot, FM level
+    std::vector<Scan> scans;
+    bool has_filter = false;
+    int n_filters = 0;
+};
+
+struct JitOptions {
+    int waves = 16;          // wavefronts per workgroup (compile-time: launch bounds, the Filter stage's tile geometry)
+    int lds_table = -1;      // table id whose half image sits in LDS, or -1
+    size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
+};
+
+// LDS of one workgroup of the generated kernel: the table image, then the Filter stage's hand-over tiles.  Declared
+// statically in the kernel text (a static declaration may take all 160 KiB; dynamic LDS would need a function attribute
+// that module kernels do not have).
+inline size_t jit_filter_tile_bytes(int waves) { return (size_t)waves * (258 * 8 + 260 * 4 + 16); }
+inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
+    return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) + (has_filter ? jit_filter_tile_bytes(opt.waves) : 0));
+}
+
+inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op); }
+
+// Programs the compiler takes.  Everything else stays on the wave engine's interpreter (wave_engine.hip).
+inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_persistent, std::string &why) {
+    auto no = [&](const char *w) {
+        why = w;
+        return false;
+    };
+    if (!plan.ok) return no("not a wave-engine program");
+    if (resumable_persistent) return no("continued programs with delay lines / feedback park their chunk buffers between launches");
+    if (plan.ring_events) return no("delay lines that need ordered slot operations");
+    if (P.ops.size() > 96) return no("more than 96 channel-expanded units: straight-line code would outgrow the instruction cache");
+    if (P.out_bufs.size() > 16) return no("more than 16 output channels");
+    if (!P.g.rings.empty()) return no("CircleBuffers");
+    for (size_t k = 0; k < P.ops.size(); k++) {
+        const DevOp &op = P.ops[k];
+        switch (op.op) {
+        case OP_OSC: case OP_MULTIPLY: case OP_SUM: case OP_REPEATER: case OP_INPUT: break;
+        case OP_RAMP:
+            if (plan.op_state[k] >= 0) return no("a Ramp that a Retriggerer restarts");
+            break;
+        case OP_FILTER:
+            if (op.in[1].kind == SRC_BUF) return no("a Filter with a connected cutoff");
+            break;
+        case OP_DELAY:
+            if (!delay_write_once(op)) return no("a Delay outside the write-once regime");
+            break;
+        case OP_TIMER:
+            if (!(P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300)) return no("a Timer outside the closed-form regime");
+            break;
+        default:
+            if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
+            return no("a unit the circuit compiler does not emit yet");
+        }
+    }
+    return true;
+}
+
+namespace jitgen {
+
+struct Emitter {
+    const Program &P;
+    const WavePlan &plan;
+    JitOptions opt;
+    JitSource &out;
+    std::vector<int> pos_of_op;    // execution position of op k
+    std::vector<int> producer;     // buffer -> producing op (-1: none)
+    std::vector<char> late;        // buffer is read by an op that ticks before its producer: keep last iteration's registers
+    std::vector<int> fconst_of;    // per (op, operand): index into fk, or -1
+    std::string s;
+
+    Emitter(const Program &P_, const WavePlan &plan_, JitOptions o, JitSource &out_) : P(P_), plan(plan_), opt(o), out(out_) {}
+
+    void line(const std::string &t) { s += t; s += '\n'; }
+    static std::string num(long long v) { return std::to_string(v); }
+
+    int add_fk(float v) { out.fk.push_back(v); return (int)out.fk.size() - 1; }
+    int add_dk(double v) { out.dk.push_back(v); return (int)out.dk.size() - 1; }
+
+    bool reads_late(int consumer_pos, int buf) const {
+        const int pr = producer[(size_t)buf];
+        return pr < 0 || pos_of_op[(size_t)pr] >= consumer_pos;
+    }
+    // text of operand j of op k at sample c ("c" may be a literal digit)
+    std::string opnd(int k, int j, const std::string &c) const {
+        const DevOperand &o = P.ops[(size_t)k].in[j];
+        if (o.kind == SRC_BUF) return (reads_late(pos_of_op[(size_t)k], o.idx) ? "w" : "v") + num(o.idx) + "[" + c + "]";
+        if (o.kind == SRC_PARAM) return "p" + num(o.idx);
+        return "k" + num(fconst_of[(size_t)k * kMaxIn + j]);
+    }
+    // operand as a float[4] the unit functions can take by reference
+    std::string opnd_array(int k, int j, const std::string &tmp) {
+        const DevOperand &o = P.ops[(size_t)k].in[j];
+        if (o.kind == SRC_BUF) return (reads_late(pos_of_op[(size_t)k], o.idx) ? "w" : "v") + num(o.idx);
+        const std::string sc = opnd(k, j, "0");
+        line("        const float " + tmp + "[4] = {" + sc + ", " + sc + ", " + sc + ", " + sc + "};");
+        return tmp;
+    }
+    std::string table_args(int table_id) const {  // <IN_LDS> and the global row
+        return std::string(opt.lds_table == table_id ? "true" : "false");
+    }
+    std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
+
+    // ops in the input cone of `roots` (execution positions), for the accumulate passes
+    std::vector<char> cone(const std::vector<int> &roots) const {
+        std::vector<char> in(P.ops.size(), 0);
+        std::vector<int> stack = roots;
+        while (!stack.empty()) {
+            const int k = stack.back();
+            stack.pop_back();
+            if (in[(size_t)k]) continue;
+            in[(size_t)k] = 1;
+            for (int j = 0; j < kMaxIn; j++) {
+                const DevOperand &o = P.ops[(size_t)k].in[j];
+                if (o.kind == SRC_BUF && o.idx >= 0 && o.idx < P.n_bufs && producer[(size_t)o.idx] >= 0) stack.push_back(producer[(size_t)o.idx]);
+            }
+        }
+        return in;
+    }
+
+    // One kernel.  pass_level < 0: the render kernel; else the accumulate pass of that FM level (only the cone of its scanned
+    // oscillators, no lookups for them, no stores; ends by writing their phase totals).
+    void kernel(int pass_level) {
+        const bool render = pass_level < 0;
+        std::vector<char> used(P.ops.size(), 1);
+        if (!render) {
+            std::vector<int> roots;
+            for (const auto &sc : out.scans)
+                if (sc.level == pass_level) roots.push_back(plan.order[(size_t)sc.op_pos]);
+            used = cone(roots);
+        }
+        const std::string W = num(opt.waves);
+        line("extern \"C\" __global__ void __launch_bounds__(" + W + " * 64) " + (render ? std::string("dusp_jit_render") : "dusp_jit_pass" + num(pass_level)) + "(JitArgs A) {");
+        line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, out.has_filter) / 4)) + "];");
+        line("    JitCtx X;");
+        line("    jit_begin<" + W + ", " + num(opt.lds_table) + ">(A, lds, X);");
+        if (out.has_filter) line("    char *tile = (char *)lds + " + num((long long)(opt.lds_table >= 0 ? opt.table_bytes : 0)) + ";");
+        // constants and parameters the used ops name
+        std::vector<char> fk_used(out.fk.size(), 0), dk_used(out.dk.size(), 0);
+        std::vector<int> params_used;
+        for (size_t k = 0; k < P.ops.size(); k++) {
+            if (!used[k]) continue;
+            for (int j = 0; j < kMaxIn; j++) {
+                const DevOperand &o = P.ops[k].in[j];
+                if (fconst_of[k * kMaxIn + j] >= 0) fk_used[(size_t)fconst_of[k * kMaxIn + j]] = 1;
+                if (o.kind == SRC_PARAM && operand_live(P.ops[k], j) && std::find(params_used.begin(), params_used.end(), o.idx) == params_used.end())
+                    params_used.push_back(o.idx);
+            }
+        }
+        for (size_t i = 0; i < out.fk.size(); i++)
+            if (fk_used[i]) line("    const float k" + num((long long)i) + " = A.fk[" + num((long long)i) + "];");
+        for (int p : params_used) line("    const float p" + num(p) + " = jit_param(A, X, " + num(p) + ");");
+        // state of the units
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const int k = plan.order[at];
+            if (!used[(size_t)k]) continue;
+            const DevOp &op = P.ops[(size_t)k];
+            const std::string id = num(k);
+            switch (op.op) {
+            case OP_OSC:
+                if (op.in[0].kind != SRC_BUF) {
+                    line("    JitOscK o" + id + ";");
+                    line("    o" + id + ".begin(A, X, " + opnd(k, 0, "0") + ", " + num(op.state_slot) + ");");
+                } else {
+                    int scan_id = -1;
+                    for (size_t i = 0; i < out.scans.size(); i++)
+                        if (out.scans[i].op_pos == (int)at) scan_id = (int)i;
+                    const bool accumulating = !render && plan.osc_level[(size_t)k] >= pass_level;
+                    line("    JitOscS o" + id + ";");
+                    line("    o" + id + ".begin(A, X, " + num(op.state_slot) + ", " + num(scan_id) + ", " + (accumulating ? "true" : "false") + ");");
+                }
+                break;
+            case OP_FILTER:
+                line("    JitFilterK<" + W + "> f" + id + ";");
+                line("    f" + id + ".begin(A, X, tile, " + num(op.attr) + ", " + opnd(k, 1, "0") + ", " + num(op.state_slot) + ");");
+                break;
+            case OP_DELAY:
+                line("    JitDelayK y" + id + ";");
+                line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
+                break;
+            default: break;
+            }
+        }
+        // registers of late edges: the producer's previous chunk (outlets start as zeros, SignalChunk.js:7)
+        for (int b = 0; b < P.n_bufs; b++)
+            if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]]) line("    float w" + num(b) + "[4] = {0.f, 0.f, 0.f, 0.f};");
+        line("    for (uint32_t g = X.g_begin; g < X.g_end; ++g) {");
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const int k = plan.order[at];
+            if (!used[(size_t)k]) continue;
+            unit(k, (int)at, render, pass_level);
+        }
+        if (render)
+            for (size_t oc = 0; oc < P.out_bufs.size(); oc++) line("        jit_store(A, X, g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + ");");
+        for (int b = 0; b < P.n_bufs; b++)
+            if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
+                line("        for (int c = 0; c < 4; ++c) w" + num(b) + "[c] = v" + num(b) + "[c];");
+        line("    }");
+        if (render) {
+            // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
+            for (size_t k = 0; k < P.ops.size(); k++)
+                if (P.ops[k].op == OP_FILTER) line("    f" + num((long long)k) + ".end(A, X, " + num(P.ops[k].state_slot) + ");");
+            line("    if (X.live && X.seg == X.n_seg - 1 && X.lane == 0) {");
+            for (size_t k = 0; k < P.ops.size(); k++) {
+                const DevOp &op = P.ops[k];
+                const std::string slot = "A.state[(size_t)" + num(op.state_slot) + " * A.n_pad + X.inst]";
+                if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) line("        " + slot + " = o" + num((long long)k) + ".end_phase(A, X);");
+                if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) line("        " + slot + " = o" + num((long long)k) + ".end_phase();");
+                if (op.op == OP_RAMP) line("        jit_ramp_end(A, X, d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
+                if (op.op == OP_TIMER)
+                    line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
+                if (op.op == OP_DELAY) line("        " + slot + " = y" + num((long long)k) + ".carried;");
+            }
+            line("    }");
+        } else {
+            line("    if (X.live && X.lane == 0) {");
+            for (size_t i = 0; i < out.scans.size(); i++)
+                if (out.scans[i].level == pass_level)
+                    line("        A.seg_sum[((size_t)" + num((long long)i) + " * A.n_inst + X.inst) * X.n_seg + X.seg] = o" + num(plan.order[(size_t)out.scans[i].op_pos]) + ".packed();");
+            line("    }");
+        }
+        line("}");
+        line("");
+    }
+
+    std::vector<long long> dconst_of;  // per op: index of its first f64 constant (Ramp: duration, y0, y1; maps / Timer: d[0])
+
+    static bool operand_live(const DevOp &op, int j) {
+        switch (op.op) {
+        case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
+        case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
+        case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
+        default:
+            if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
+            return j < 2;
+        }
+    }
+
+    void unit(int k, int at, bool render, int pass_level) {
+        const DevOp &op = P.ops[(size_t)k];
+        const std::string id = num(k), v = "v" + num(op.out_buf);
+        auto decl = [&]() { line("        float " + v + "[4];"); };
+        auto each = [&](const std::string &expr) {
+            decl();
+            line("        for (int c = 0; c < 4; ++c) " + v + "[c] = " + expr + ";");
+        };
+        const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
+        switch (op.op) {
+        case OP_OSC:
+            decl();
+            if (op.in[0].kind != SRC_BUF)
+                line("        o" + id + ".tick<" + table_args(op.attr) + ">(X, " + table_row(op.attr) + ", " + v + ");");
+            else {
+                const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
+                const std::string f = opnd_array(k, 0, "t" + id);
+                line("        o" + id + ".tick<" + table_args(op.attr) + ", " + (lookup ? "true" : "false") + ">(X, " + table_row(op.attr) + ", " + f + ", " + v + ");");
+                if (!lookup) line("        for (int c = 0; c < 4; ++c) " + v + "[c] = 0.f;");
+            }
+            break;
+        case OP_RAMP:
+            decl();
+            line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(X, g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
+                 num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
+            break;
+        case OP_MULTIPLY: each(opnd(k, 0, "c") + " * " + opnd(k, 1, "c")); break;  // Multiply.js:23-34
+        case OP_SUM: each(opnd(k, 0, "c") + " + " + opnd(k, 1, "c")); break;       // Sum.js:33-44
+        case OP_REPEATER: each(opnd(k, 0, "c")); break;                             // Repeater.js:23-30
+        case OP_TIMER:
+            decl();
+            line("        jit_timer(X, g, " + dref + ", A.init_state[" + num(op.state_slot) + "], " + v + ");");
+            break;
+        case OP_INPUT:
+            decl();
+            line("        jit_input(A, X, g, " + num(op.attr) + ", " + v + ");");
+            break;
+        case OP_FILTER: {
+            decl();
+            const std::string x = opnd_array(k, 0, "t" + id);
+            line("        f" + id + ".tick(X, tile, " + x + ", " + v + ");");
+            break;
+        }
+        case OP_DELAY: {
+            decl();
+            const std::string x = opnd_array(k, 0, "t" + id);
+            line("        y" + id + ".tick(A, X, g, (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0") + ", " + x + ", " + v + ");");
+            break;
+        }
+        default:
+            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) {  // stateless maps of at most two operands (map_ops.hpp)
+                const std::string y = operand_live(op, 1) ? opnd(k, 1, "c") : std::string("0.f");
+                each("map_apply(" + num(op.op) + ", " + opnd(k, 0, "c") + ", " + y + ", " + dref + ")");
+            } else {  // Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude
+                decl();
+                line("        for (int c = 0; c < 4; ++c) {");
+                std::string arr = "            const float in_[kMaxIn] = {";
+                for (int j = 0; j < kMaxIn; j++) arr += (j ? ", " : "") + (j < op.n_in ? opnd(k, j, "c") : opnd(k, 0, "c"));
+                line(arr + "};");
+                line("            " + v + "[c] = map_wide(" + num(op.op) + ", " + num(op.attr) + ", " + num(op.n_in) + ", in_, " + dref + ");");
+                line("        }");
+            }
+            break;
+        }
+        (void)at;
+    }
+
+    bool run() {
+        // execution order and who produces what
+        pos_of_op.assign(P.ops.size(), 0);
+        for (size_t at = 0; at < plan.order.size(); at++) pos_of_op[(size_t)plan.order[at]] = (int)at;
+        producer.assign((size_t)std::max(1, P.n_bufs), -1);
+        for (size_t k = 0; k < P.ops.size(); k++)
+            if (P.ops[k].out_buf >= 0) producer[(size_t)P.ops[k].out_buf] = (int)k;
+        late.assign((size_t)std::max(1, P.n_bufs), 0);
+        fconst_of.assign(P.ops.size() * kMaxIn, -1);
+        dconst_of.assign(P.ops.size(), -1);
+        for (size_t k = 0; k < P.ops.size(); k++) {
+            const DevOp &op = P.ops[k];
+            for (int j = 0; j < kMaxIn; j++) {
+                if (!operand_live(op, j)) continue;
+                const DevOperand &o = op.in[j];
+                if (o.kind == SRC_BUF) {
+                    if (o.idx < 0 || o.idx >= P.n_bufs) { out.why = "operand out of range"; return false; }
+                    if (reads_late(pos_of_op[k], o.idx)) late[(size_t)o.idx] = 1;
+                } else if (o.kind == SRC_CONST)
+                    fconst_of[k * kMaxIn + j] = add_fk(o.cval);
+            }
+            if (op.op == OP_RAMP) {
+                dconst_of[k] = add_dk(op.d[0]);
+                add_dk(op.d[1]);
+                add_dk(op.d[2]);
+            } else if (op.op == OP_DELAY) {
+                dconst_of[k] = add_dk((double)op.ring_base);
+                add_dk((double)op.ring_len);
+            } else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
+                dconst_of[k] = add_dk(op.d[0]);
+            if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }
+        }
+        for (int b : P.out_bufs)
+            if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }
+        // scanned oscillators and the accumulate passes a time-split render needs
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const DevOp &op = P.ops[(size_t)plan.order[at]];
+            if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) {
+                const int level = plan.osc_level[(size_t)plan.order[at]];
+                out.scans.push_back({(int)at, op.state_slot, level});
+                if (std::find(out.pass_levels.begin(), out.pass_levels.end(), level) == out.pass_levels.end()) out.pass_levels.push_back(level);
+            }
+        }
+        std::sort(out.pass_levels.begin(), out.pass_levels.end());
+        line("// generated by dusp_amd/csrc/jit_codegen.hpp — one kernel per topologically sorted Circuit");
+        line("#include \"jit_prelude.hpp\"");
+        line("using namespace dusp;");
+        // f64 constants are read where they are used: declare them as macros over the array (loop-invariant scalar loads)
+        for (size_t i = 0; i < out.dk.size(); i++) line("#define d" + num((long long)i) + " (A.dk[" + num((long long)i) + "])");
+        line("");
+        kernel(-1);
+        if (plan.splittable)
+            for (int L : out.pass_levels) kernel(L);
+        out.text = s;
+        out.ok = true;
+        return true;
+    }
+};
+
+}  // namespace jitgen
+
+inline bool jit_generate(const Program &P, const WavePlan &plan, const JitOptions &opt, JitSource &out) {
+    out = JitSource();
+    jitgen::Emitter e(P, plan, opt, out);
+    return e.run();
+}
+
+}  // namespace dusp

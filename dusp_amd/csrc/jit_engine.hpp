@@ -1,0 +1,20 @@
+// jit_engine.hpp — interface of the circuit compiler's back half (jit_engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "jit_args.hpp"
+
+namespace dusp {
+
+// Compile generated kernel text for gfx950 (no device needed: used by the CPU test of the generator too).  Cached by text.
+bool jit_compile_only(const std::string &text, size_t *code_bytes, std::string &err);
+// The kernel `name` of that text, loaded on `device` (compiles / loads on first use).  scratch_bytes: private memory the
+// compiler had to spill into (0 when the kernel fits its registers).
+bool jit_get_kernel(int device, const std::string &text, const std::string &name, hipFunction_t *fn, int *scratch_bytes, std::string &err);
+hipError_t jit_launch(hipFunction_t fn, const JitArgs &A, unsigned grid, unsigned block, hipStream_t stream);
+hipError_t jit_launch_prefix(const unsigned long long *seg_sum, unsigned long long *seg_start, const double *init_state, const int *d_scan_slot,
+                             const int *d_scan_level, int n_scans, int level, uint32_t n_inst, uint32_t n_seg, uint32_t sample_rate, hipStream_t stream);
+
+}  // namespace dusp

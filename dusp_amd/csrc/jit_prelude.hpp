@@ -1,0 +1,448 @@
+// jit_prelude.hpp — device library of the per-circuit kernels.
+//
+// The circuit compiler (jit_codegen.hpp) turns ONE topologically sorted Circuit into ONE kernel: the chunk loop of
+// Circuit.tick (src/Circuit.js:19-41) with every unit's `_tick` inlined in process order as straight-line code.  The kernel
+// keeps the wave engine's mapping — one WAVEFRONT per circuit instance (or per time segment of one), one lane per 4 samples,
+// 256-sample chunks — but nothing is interpreted and nothing that need not be is staged: a unit's output chunk is four
+// floats in this lane's REGISTERS (a consumer reads exactly the samples its own lane produced), a feedback edge is the same
+// registers carried over from the previous iteration (the reference's implicit one-chunk delay), unit state that is uniform
+// over the wave (phase carries, ramp counters, filter coefficients) sits in scalar registers, and LDS holds only what lanes
+// really share: the wave-table image, the Filter stage's hand-over tiles, a delay line's window.  The functions below are
+// the units; the generated text only declares them, wires their operands and stores the outlet.
+//
+// hiprtc compiles this file (with device_types.hpp, device_util.hpp, map_ops.hpp, repeat_add.hpp, jit_args.hpp: their text
+// is embedded in the library) together with the generated kernel, for gfx950, with -ffp-contract=off like every other
+// kernel here: JS rounds each f64 sub-expression separately and so does this code.
+#pragma once
+#include "device_types.hpp"
+#include "device_util.hpp"
+#include "jit_args.hpp"
+#include "map_ops.hpp"
+#include "repeat_add.hpp"
+
+namespace dusp {
+namespace {
+
+constexpr double kJ36 = 68719476736.0;  // oscillator phases are exact fixed point in units of 2^-36 (SURVEY.md §8a note ii)
+constexpr int kJFrac = 36;
+constexpr unsigned long long kJMask = (1ull << kJFrac) - 1ull;
+
+__device__ __forceinline__ void jit_lds_barrier() {  // orders LDS traffic only: PCM / ring stores stay in flight across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ double jit_or0(double v) { return (v != v || v == 0.0) ? 0.0 : v; }  // JS `v || 0`
+
+// What a wavefront knows about its place: instance, time segment, chunk range.  Everything but `lane` is wave-uniform.
+struct JitCtx {
+    uint32_t lane, wave, inst, seg, g_begin, g_end, sr, n_seg;
+    bool live;  // a short last workgroup keeps its surplus waves alive (they stand at the Filter stage's barriers): they shadow the last instance and never store
+    double srd, inv_S;
+    unsigned long long S, lift;
+    Table<1> table;  // the half-table image in LDS (kernels generated with one)
+    __device__ __forceinline__ uint64_t n0(uint32_t g) const { return (uint64_t)g * kChunk + lane * 4; }  // this lane's first sample of chunk g
+};
+
+template <int WAVES, int LDS_TABLE>
+__device__ __forceinline__ void jit_begin(const JitArgs &A, float *lds, JitCtx &X) {
+    X.sr = A.sample_rate;
+    X.srd = (double)X.sr;
+    X.S = (unsigned long long)X.sr << kJFrac;
+    X.inv_S = 1.0 / (double)X.S;
+    X.lift = X.S * ((1ull << 62) / X.S);  // multiple of S that makes any |x| < 2^62 non-negative before the modulo
+    X.table.g = nullptr;
+    X.table.h = lds;
+    X.table.N = X.sr + 1;
+    X.table.M = X.sr / 2;
+    if (LDS_TABLE >= 0) load_half_table<WAVES * 64>(lds, A.tables + (size_t)LDS_TABLE * A.table_stride, X.sr);
+    X.lane = threadIdx.x & 63u;
+    X.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    X.n_seg = A.n_seg;
+    const uint32_t n_virtual = A.n_inst * A.n_seg;  // a "virtual instance" is one time segment of an instance
+    const uint32_t v = blockIdx.x * WAVES + X.wave;
+    X.live = v < n_virtual;
+    const uint32_t vinst = X.live ? v : n_virtual - 1;
+    X.inst = vinst / A.n_seg;
+    X.seg = vinst - X.inst * A.n_seg;
+    X.g_begin = X.seg * A.seg_groups;
+    X.g_end = A.n_seg == 1 ? A.n_groups : min(X.g_begin + A.seg_groups, A.n_groups);
+}
+
+__device__ __forceinline__ float jit_param(const JitArgs &A, const JitCtx &X, uint32_t slot) { return A.params[(size_t)slot * A.n_inst + X.inst]; }
+
+// (a * n) mod S for a < S < 2^53 and n < 2^32, exactly: the product is cut into pieces that mod_u64 (x < 2^64) can take
+__device__ __forceinline__ unsigned long long jit_mulmod(unsigned long long a, unsigned long long n, unsigned long long S, double inv_S) {
+    const unsigned long long ah = a >> 32, al = a & 0xffffffffull;  // ah < 2^21
+    unsigned long long r = mod_u64(ah * n, S, inv_S);               // (ah n) < 2^53; now r 2^32 mod S in three shifts of <= 11 bits
+    r = mod_u64(r << 11, S, inv_S);
+    r = mod_u64(r << 11, S, inv_S);
+    r = mod_u64(r << 10, S, inv_S);
+    return addmod(r, mod_u64(al * n, S, inv_S), S);
+}
+
+__device__ __forceinline__ long long jit_wave_scan(long long x, uint32_t lane) {  // inclusive prefix sum over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    return x;
+}
+
+// One table lookup pair (T[idx], T[idx + 1]): from the LDS half-table image when the kernel carries this table, else from L2.
+template <bool IN_LDS>
+__device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uint32_t idx, float &a, float &b) {
+    if (IN_LDS) X.table.pair(idx, a, b);
+    else {
+        a = gtab[idx];
+        b = gtab[idx + 1];
+    }
+}
+
+// ---- Osc (src/components/Osc/Osc.js:35-47) with an unconnected f — a constant or a per-instance parameter.  Equal increments:
+// phase(n) = (phase0 + (n + 1) q) mod S in exact 2^-36 fixed point, so the lane jumps to its own samples and thereafter
+// advances by (256 q) mod S per chunk; nothing crosses lanes, nothing is carried but this lane's own phase.
+struct JitOscK {
+    unsigned long long P;          // phase of this lane's first sample of the next chunk
+    unsigned long long q, q256;    // increment per sample / per chunk, mod S (wave-uniform)
+    unsigned long long P_init;     // phase before the render's first sample (wave-uniform)
+    bool bad, whole;               // f is NaN / Inf (every sample NaN); every phase is a whole number (the lerp degenerates to table[phase])
+
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float f, int state_slot) {
+        double fd = (double)f;
+        bad = !(fabs(fd) <= 3.0e38);
+        if (bad) fd = 0.0;
+        if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);  // (a + b) % m == (a + b % m) % m
+        const long long qs = (long long)(fd * kJ36);  // exact for |f| >= 2^-13 (or f == 0)
+        q = qs >= 0 ? (unsigned long long)qs : X.S - (unsigned long long)(-qs);
+        if (q >= X.S) q -= X.S;
+        P_init = (unsigned long long)(A.init_state[state_slot] * kJ36);
+        q256 = jit_mulmod(q, kChunk, X.S, X.inv_S);
+        P = addmod(P_init, jit_mulmod(q, X.n0(X.g_begin) + 1, X.S, X.inv_S), X.S);
+        whole = ((q | P_init) & kJMask) == 0ull;
+    }
+    template <bool IN_LDS>
+    __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
+        unsigned long long Pc = P;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > 0) Pc = addmod(Pc, q, X.S);
+            const uint32_t idx = (uint32_t)(Pc >> kJFrac);
+            float v;
+            if (whole) v = IN_LDS ? X.table.at(idx) : gtab[idx];
+            else {
+                const double fraction = (double)(Pc & kJMask) * (1.0 / kJ36);
+                float ta, tb;
+                jit_pair<IN_LDS>(X, gtab, idx, ta, tb);
+                v = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+            }
+            out[c] = bad ? __builtin_nanf("") : v;
+        }
+        P = addmod(P, q256, X.S);
+    }
+    // the phase after ceil(n_samples / 256) ticks (state write-back)
+    __device__ __forceinline__ double end_phase(const JitArgs &A, const JitCtx &X) const {
+        if (bad) return __builtin_nan("");
+        return (double)addmod(P_init, jit_mulmod(q256, A.n_groups, X.S, X.inv_S), X.S) * (1.0 / kJ36);  // n_groups * 256 samples
+    }
+};
+
+// ---- Osc with a connected f (FM): wavefront-wide phase accumulation.  Increments -> exact 2^-36 fixed point -> prefix of 4
+// inside the lane -> 6-step integer scan over the wave (sums < 2^61, no modulo inside) -> one exact modulo for the lane's
+// first sample, add-and-wrap for the next three.  Carried from chunk to chunk: the phase of the chunk's last sample and a
+// poison flag (a NaN / Inf increment makes the reference's phase NaN for good) — both wave-uniform.
+struct JitOscS {
+    unsigned long long carry;
+    uint32_t poison;
+
+    // accumulating: a pass that only totals this oscillator's increments over the segment (time-split rendering)
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int op_index, bool accumulating) {
+        carry = 0ull;
+        poison = 0u;
+        if (X.n_seg == 1) carry = (unsigned long long)(A.init_state[state_slot] * kJ36);
+        else if (!accumulating) {  // start phase known from the accumulate + prefix passes
+            const unsigned long long v = A.seg_start[((size_t)op_index * A.n_inst + X.inst) * X.n_seg + X.seg];
+            carry = v & ~(1ull << 63);
+            poison = (uint32_t)(v >> 63);
+        }
+    }
+    template <bool IN_LDS, bool LOOKUP>
+    __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, const float (&f)[4], float (&out)[4]) {
+        long long qv[4];
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double fd = (double)f[c];
+            const bool fin = fabs(fd) <= 3.0e38;
+            bad = bad || !fin;
+            if (!fin) fd = 0.0;
+            if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);
+            qv[c] = (long long)(fd * kJ36);
+        }
+        const long long total = qv[0] + qv[1] + qv[2] + qv[3];
+        const long long incl = jit_wave_scan(total, X.lane);
+        const long long before = (long long)carry + (incl - total);
+        const unsigned long long bad_lanes = __ballot(bad);
+        bool dead = poison != 0 || (bad_lanes & ((1ull << X.lane) - 1ull)) != 0;
+        unsigned long long Pc = mod_u64((unsigned long long)(before + qv[0]) + X.lift, X.S, X.inv_S);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > 0) {
+                long long Pn = (long long)Pc + qv[c];
+                if (Pn < 0) Pn += (long long)X.S;
+                if (Pn >= (long long)X.S) Pn -= (long long)X.S;
+                Pc = (unsigned long long)Pn;
+            }
+            dead = dead || !(fabs((double)f[c]) <= 3.0e38);
+            if (LOOKUP) {
+                const uint32_t idx = (uint32_t)(Pc >> kJFrac);
+                const double fraction = (double)(Pc & kJMask) * (1.0 / kJ36);
+                float ta, tb;
+                jit_pair<IN_LDS>(X, gtab, idx, ta, tb);
+                out[c] = dead ? __builtin_nanf("") : (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+            }
+        }
+        // the chunk's last phase, as a scalar (lane 63 holds it)
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)Pc, 63), hi = __builtin_amdgcn_readlane((uint32_t)(Pc >> 32), 63);
+        carry = ((unsigned long long)hi << 32) | lo;
+        if (bad_lanes) poison = 1u;
+    }
+    __device__ __forceinline__ double end_phase() const { return poison ? __builtin_nan("") : (double)carry * (1.0 / kJ36); }
+    __device__ __forceinline__ unsigned long long packed() const { return carry | ((unsigned long long)(poison != 0) << 63); }
+};
+
+// ---- Ramp (src/components/Ramp.js:25-40) in closed form: t(n) = min(t0 + n + 1, duration) while playing.
+// FASTDIV: t / duration by a 2-FMA refined reciprocal that the host has verified against true division on every t this
+// Ramp can take (fused_plan.hpp ramp_fastdiv_ok).
+template <bool FASTDIV>
+__device__ __forceinline__ void jit_ramp(const JitCtx &X, uint32_t g, double duration, double y0, double y1, double t0, bool playing, float (&out)[4]) {
+    const double dy = y1 - y0, rcp = 1.0 / duration;
+    const uint64_t n0 = X.n0(g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double tt = playing ? fmin(t0 + (double)(n0 + c + 1), duration) : t0;
+        double q;
+        if (FASTDIV) {
+            q = tt * rcp;
+            q = fma(fma(-q, duration, tt), rcp, q);
+        } else
+            q = tt / duration;
+        out[c] = (float)(y0 + q * dy);
+    }
+}
+__device__ __forceinline__ void jit_ramp_end(const JitArgs &A, const JitCtx &X, double duration, int state_slot) {
+    const double t0 = A.init_state[state_slot], since = (double)((uint64_t)A.n_groups * kChunk);
+    const bool playing = A.init_state[state_slot + 1] != 0.0;
+    double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+    st[0] = playing ? fmin(t0 + since, duration) : t0;
+    st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
+}
+
+// ---- Timer (src/components/Timer.js:36-41): t += samplePeriod, each sum rounded — in closed form (repeat_add.hpp)
+__device__ __forceinline__ void jit_timer(const JitCtx &X, uint32_t g, double period, double t0, float (&out)[4]) {
+    double t = repeat_add(t0, period, X.n0(g));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (float)(t = t + period);
+}
+
+// ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
+__device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
+    if (!X.live) return;
+    const uint64_t n0 = X.n0(g);
+    const float w[4] = {fix_out<false>(v[0]), fix_out<false>(v[1]), fix_out<false>(v[2]), fix_out<false>(v[3])};
+    float *row = A.out + ((size_t)X.inst * A.n_out + oc) * A.n_samples + n0;
+    if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, w, n0, A.n_samples);
+    else store4<false>(row, w, n0, A.n_samples);
+}
+
+// ---- host-computed signal (Noise): this lane's four samples of input stream `stream`
+__device__ __forceinline__ void jit_input(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t stream, float (&out)[4]) {
+    const float *src = A.inputs + ((size_t)stream * A.n_inst + X.inst) * A.n_samples;
+    const uint64_t n0 = X.n0(g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = n0 + c < A.n_samples ? src[n0 + c] : 0.f;
+}
+
+// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
+__device__ __forceinline__ void jit_filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
+    const double PI = 3.141592653589793;
+    if (kind == 0) {
+        const double lamda = 1.0 / tan(PI * f / sr);
+        const double l2 = lamda * lamda;
+        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
+        k[1] = 2.0 * k[0];
+        k[2] = k[0];
+        k[3] = 2.0 * k[0] * (1.0 - l2);
+        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
+    } else {
+        const double lamda = tan(PI * f / sr);
+        const double l2 = lamda * lamda;
+        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
+        k[1] = 0.0;
+        k[2] = -k[0];
+        k[3] = 2.0 * k[0] * (l2 - 1.0);
+        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
+    }
+}
+
+// ---- Filter (src/components/Filter.js:27-51) with an unconnected cutoff.  The feed-forward half (a0 x + a1 x1) + a2 x2 is
+// lane-parallel (neighbours by shuffle, the two samples before the chunk carried as scalars); the output recurrence
+// y = f32((P - b1 y1) - b2 y2) is serial, so the WAVES instances of a workgroup run theirs side by side: every wave parks
+// its P row in a shared LDS tile, wave 0 runs lane = instance over the rows (its lanes keep y1, y2 of "their" instance in
+// registers from chunk to chunk), every wave picks its Y row up again.  `tile` = Pt[WAVES][258] f64, then Yt[WAVES][260] f32,
+// then b[WAVES][2] f64 (per-instance b1, b2 for wave 0).
+template <int WAVES>
+struct JitFilterK {
+    double k[5];      // a0 a1 a2 b1 b2 of THIS wave's instance (uniform)
+    double x1, x2;    // the two inputs before the chunk (uniform)
+    double y1, y2;    // wave 0: the recurrence's memory of instance `lane` of the workgroup; else unused
+    double b1r, b2r;  // wave 0: that instance's b1, b2
+    double lastF;
+
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, char *tile, int kind, float f, int state_slot) {
+        const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
+        const double ft = (double)f;
+        if (is[0] == 0.0 || ft != is[1]) jit_filter_coefficients(kind, ft, X.srd, k);  // `if (this.f[t] != this.lastF)`
+        else {
+            k[0] = is[2]; k[1] = is[3]; k[2] = is[4]; k[3] = is[5]; k[4] = is[6];
+        }
+        lastF = ft;
+        x1 = is[7];
+        x2 = is[8];
+        y1 = is[9];
+        y2 = is[10];
+        double *bt = (double *)(tile + (size_t)WAVES * (258 * 8 + 260 * 4));
+        if (X.lane == 0) {
+            bt[X.wave * 2] = k[3];
+            bt[X.wave * 2 + 1] = k[4];
+        }
+        jit_lds_barrier();
+        b1r = bt[(X.lane < WAVES ? X.lane : 0) * 2];
+        b2r = bt[(X.lane < WAVES ? X.lane : 0) * 2 + 1];
+        jit_lds_barrier();  // (the next Filter's begin() reuses bt)
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, char *tile, const float (&x)[4], float (&out)[4]) {
+        double *Pt = (double *)tile;
+        float *Yt = (float *)(Pt + WAVES * 258);
+        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
+        double xm1 = X.lane == 0 ? x1 : (double)xl1, xm2 = X.lane == 0 ? x2 : (double)xl2;
+        double *prow = Pt + X.wave * 258;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double xin = (double)x[c];
+            prow[X.lane * 4 + c] = (k[0] * xin + k[1] * jit_or0(xm1)) + k[2] * jit_or0(xm2);
+            xm2 = jit_or0(xm1);
+            xm1 = xin;
+        }
+        // the chunk's last two inputs, for the next chunk's first lanes (lane 63 holds them)
+        x1 = __shfl(xm1, 63, 64);
+        x2 = __shfl(xm2, 63, 64);
+        jit_lds_barrier();
+        if (X.wave == 0 && X.lane < WAVES) {
+            const double *pr = Pt + X.lane * 258;
+            f32x4 *yr = (f32x4 *)(Yt + X.lane * 260);
+            // The `|| 0` selects of Filter.js:42-46 are speculated away: without them a NaN never leaves the recurrence, so testing
+            // a block's last outputs finds one anywhere in it (the block is then redone exactly); a -0 in place of +0 can only flip
+            // the sign of a later zero, which every consumer maps to +0 (see loop2_engine.hip).
+            constexpr int PB = 16;
+            for (int t0 = 0; t0 < kChunk; t0 += PB) {
+                double pv[PB];
+#pragma unroll
+                for (int i = 0; i < PB; ++i) pv[i] = pr[t0 + i];
+                __builtin_amdgcn_sched_barrier(0);
+                const double y1_in = y1, y2_in = y2;
+                double u1 = jit_or0(y1), u2 = jit_or0(y2);
+                f32x4 y4[PB / 4];
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const float y = (float)((pv[i] - b1r * u1) - b2r * u2);
+                    y4[i >> 2][i & 3] = y;
+                    u2 = u1;
+                    u1 = (double)y;
+                }
+                if (u1 == u1 && u2 == u2) {
+                    y1 = u1;
+                    y2 = u2;
+                } else {
+                    y1 = y1_in;
+                    y2 = y2_in;
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) {
+                        const float y = (float)((pv[i] - b1r * jit_or0(y1)) - b2r * jit_or0(y2));  // Filter.js:40-46
+                        y4[i >> 2][i & 3] = y;
+                        y2 = jit_or0(y1);
+                        y1 = (double)y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
+            }
+        }
+        jit_lds_barrier();
+        const f32x4 yv = *(const f32x4 *)(Yt + X.wave * 260 + X.lane * 4);
+        out[0] = yv[0]; out[1] = yv[1]; out[2] = yv[2]; out[3] = yv[3];
+    }
+    // state write-back: coefficients and input history by each wave's lane 0, the recurrence's memory by wave 0's lanes
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) {
+        if (X.live && X.lane == 0) {
+            double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+            st[0] = 1.0;
+            st[A.n_pad] = lastF;
+            for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
+            st[(size_t)7 * A.n_pad] = x1;
+            st[(size_t)8 * A.n_pad] = x2;
+        }
+        const uint32_t mine = blockIdx.x * WAVES + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
+        if (X.wave == 0 && X.lane < WAVES && mine < A.n_inst) {
+            double *st = A.state + (size_t)state_slot * A.n_pad + mine;
+            st[(size_t)9 * A.n_pad] = y1;
+            st[(size_t)10 * A.n_pad] = y2;
+        }
+    }
+};
+// ---- Delay (src/components/Delay.js:20-41) with a constant delay D + phi, 256 <= D <= len - 256: the chunk's 256 reads are one
+// coalesced load from the ring ([instance][slot] in HBM), reads and writes of one chunk never meet, and every slot's final
+// value (ceil tap of sample n-1, then floor tap of sample n, with the reference's two `+=` roundings) is written once.
+struct JitDelayK {
+    double carried;  // the input sample before the chunk (uniform)
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { carried = A.init_state[state_slot]; }
+    __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, int64_t ring_base, int64_t len, float delay, const float (&x)[4],
+                                         float (&out)[4]) {
+        double dconst = (double)delay;
+        if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
+        const double Dfl = floor(dconst), phi = dconst - Dfl;
+        const int64_t D = (int64_t)Dfl;
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        const int64_t s0 = (int64_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+        const float x_left = __shfl_up(x[3], 1, 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int64_t s_ = s0 + X.lane * 4 + c;
+            if (s_ >= len) s_ -= len;
+            out[c] = ring[s_];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int64_t s_ = s0 + X.lane * 4 + c;
+            if (s_ >= len) s_ -= len;
+            int64_t lo = s_ + D;
+            if (lo >= len) lo -= len;
+            const double xin = (double)x[c];
+            const double xprev = c == 0 ? (X.lane == 0 ? carried : (double)x_left) : (double)x[c - 1];
+            float slot;
+            if (phi != 0.0) {
+                slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
+                slot = (float)((double)slot + xin * (1.0 - phi));   // floor tap of sample n
+            } else {
+                slot = (float)(0.0 + xin * 1.0);
+                slot = (float)((double)slot + xin * 0.0);
+            }
+            if (X.live) ring[lo] = slot;
+        }
+        carried = (double)__shfl(x[3], 63, 64);
+    }
+};
+
+}  // namespace
+}  // namespace dusp

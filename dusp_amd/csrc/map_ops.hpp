@@ -1,7 +1,9 @@
 // map_ops.hpp — the stateless elementwise units as one device function.
 // JS computes each of them in f64 and rounds once when storing into the Float32Array chunk.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "device_types.hpp"
 

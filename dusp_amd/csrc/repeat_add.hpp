@@ -2,8 +2,10 @@
 // Host and device: the device kernels use it (wave_engine.hip), the host planner decides with it whether a render can be
 // split in time, and tests/native/repeat_add_check.cpp pins it against the plain loop on the CPU.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
 #include <cstdint>
+#endif
 
 #if defined(__HIPCC__)
 #define DUSP_HOST_DEVICE __host__ __device__ __forceinline__

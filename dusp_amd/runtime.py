@@ -22,7 +22,7 @@ EXPORTS = [
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
     "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
-    "dusp_host_alloc", "dusp_host_free",
+    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source",
 ]
 
 
@@ -82,6 +82,7 @@ def load():
     L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
     L.dusp_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.dusp_host_free.argtypes = [vp, vp]
+    L.dusp_circuit_kernel_source.argtypes = [vp, sz, ci, ci, ci, ctypes.c_char_p, sz]
     _lib = L
     return L
 
@@ -100,6 +101,18 @@ class _PinnedBlock:
             self.ctx._host_release(self.ptr)
         except Exception:
             pass
+
+
+def circuit_kernel_source(words, waves=16, lds_table=True, compile=False):
+    """HIP text of the kernel the circuit compiler generates for a descriptor (dusp_circuit_kernel_source; needs no GPU).
+    Raises DuspHipError(-2) for circuits that stay on the interpreter."""
+    L = load()
+    words = np.ascontiguousarray(words, dtype=np.float64)
+    buf = ctypes.create_string_buffer(1 << 20)
+    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, int(lds_table), int(compile), buf, len(buf))
+    if n < 0:
+        raise DuspHipError(n, L.dusp_last_error(None).decode())
+    return buf.value.decode()
 
 
 class Context:

@@ -63,7 +63,10 @@ typedef enum {
  *   FUSED — time-parallel fused kernels for recognised voice shapes (Osc, Osc x Ramp,
  *           Osc x gain, Sum.many chains): one lane per sample, time split across waves,
  *           16-byte coalesced PCM stores.
- *   WAVE  — one wavefront per instance, chunk buffers in LDS, wavefront-wide phase accumulation: every unit
+ *   WAVE  — one wavefront per instance, wavefront-wide phase accumulation.  Circuits of Osc / Ramp / Multiply / Sum / the
+ *           stateless maps / Timer / Filter and Delay with constant controls (with or without feedback edges) get a kernel
+ *           COMPILED FOR THAT CIRCUIT (units inlined in process order, operands in registers; dusp_circuit_kernel_source);
+ *           the rest runs on an interpreter kernel with chunk buffers in LDS: every unit
  *           of the path (FM, Filters, feedback edges, envelopes, the comb family; delay lines and CircleBuffer
  *           nodes either lane-parallel or, where their accesses can meet inside a chunk, through ordered slot
  *           operations); few instances and a long render are split in time when the graph allows it.  Refuses
@@ -197,6 +200,19 @@ int dusp_render_host_interleaved(dusp_program *prog, size_t n_instances, size_t 
  * Shape: t,playing,finished; AHD: state,playing,t; SampleRateRedux: timeSinceLastUpdate,n,val*n).
  * Returns the number of words (>= 0) or a negative dusp_status. */
 int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double *out, size_t cap);
+
+/* The circuit compiler, on its own (needs no device).  Programs on the WAVE engine whose units it knows are rendered by ONE
+ * kernel generated for that circuit — the chunk loop of src/Circuit.js:19-41 with every unit's `_tick` inlined in process
+ * order, operands in registers — compiled for gfx950 in process (hiprtc) the first time a circuit structure is rendered and
+ * cached afterwards.  This call returns that kernel's HIP text for a descriptor (for inspection, and so that the generator
+ * and the run-time compiler can be tested without a GPU):
+ *   waves      wavefronts per workgroup the text is generated for (1, 2, 4, 8, 16)
+ *   lds_table  non-zero: assume the oscillators' first wave table is antisymmetric (half image in LDS), as a context would find
+ *   compile    non-zero: also compile the text for gfx950
+ *   text, cap  receives at most cap - 1 characters, NUL-terminated (cap 0: nothing is copied)
+ * Returns the length of the text, DUSP_ERR_UNSUPPORTED when the circuit stays on the interpreter (dusp_last_error(NULL) says
+ * why), or another negative dusp_status. */
+int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int lds_table, int compile, char *text, size_t cap);
 
 /* Duration in milliseconds of the most recent render's kernel(s) on this
  * program, measured with HIP events on the launch stream (synchronises). */

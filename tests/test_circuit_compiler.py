@@ -1,0 +1,99 @@
+"""The circuit compiler without a GPU (dusp_amd/csrc/jit_codegen.hpp + jit_engine.hip through dusp_circuit_kernel_source):
+one kernel text per circuit STRUCTURE, constants outside the text, hiprtc compiles it for gfx950 in process.
+What the kernels compute is the GPU tests' business (tests/test_gpu_parity.py renders every golden on them)."""
+import re
+
+import numpy as np
+import pytest
+
+import dusp_amd as d
+from conftest import ALL_GOLDEN, Golden
+from dusp_amd import descriptor, runtime
+
+# a spread of what the compiler takes: plain voices, FM (scanned oscillators + accumulate passes), feedback edges, Filter, Delay, maps
+COMPILED = ["osc440_1s", "voice3_k7", "cfg2_sweep", "fm_mixed", "fm_sum", "mult_2ch", "loop_220", "filter_2ch", "filter_hp", "delay_default",
+            "map_gain", "rest_crossfader", "rest_timer_fm", "osc_triangle"]
+
+
+def source(words, **kw):
+    return runtime.circuit_kernel_source(words, **kw)
+
+
+@pytest.mark.parametrize("name", COMPILED)
+def test_golden_circuits_compile_for_gfx950(name):
+    g = Golden(name)
+    text = source(g.desc, waves=4, compile=True)
+    assert "dusp_jit_render" in text and '#include "jit_prelude.hpp"' in text
+    # one statement block per channel-expanded unit, in process order: every outlet buffer is declared exactly once per kernel
+    render = text.split('extern "C"')[1]
+    bufs = re.findall(r"float (v\d+)\[4\];", render)
+    assert len(bufs) == len(set(bufs)) >= 1
+
+
+def test_what_the_compiler_takes_and_what_stays_on_the_interpreter():
+    taken, refused = 0, {}
+    for name in ALL_GOLDEN:
+        try:
+            source(Golden(name).desc, waves=1)
+            taken += 1
+        except runtime.DuspHipError as e:
+            assert e.status == -2, e
+            refused[name] = e.message
+    assert taken >= 90
+    assert "Filter with a connected cutoff" in refused["filter_lp_mod"]
+    assert "ordered slot operations" in refused["delay_mod"]
+    assert "CircleBuffers" in refused["circlebuffer_taps"]
+    assert "does not emit yet" in refused["env_ahd"]
+
+
+def test_kernel_text_depends_on_structure_not_on_constants():
+    """Constants travel in arrays next to the kernel, so every circuit of one shape — and every segment of an
+    event-segmented render — reuses one compiled kernel."""
+    d.configure(48000)
+
+    def voice(f, mod, depth, gain, length):
+        return d.Multiply(d.Osc(d.Sum(d.Multiply(d.Osc(mod), depth), f)), d.Multiply(d.Ramp(length, 1, 0).trigger(), gain))
+
+    a = source(descriptor.extract(voice(220, 5, 40, 0.5, 48000)).words)
+    b = source(descriptor.extract(voice(331.25, 0.75, 3, 0.125, 9000)).words)
+    assert a == b
+    assert "220" not in a and "0.5" not in a.replace("0.5)", "")  # (no literal constants of the circuit in the text)
+    c = source(descriptor.extract(d.Multiply(d.Osc(d.Sum(d.Multiply(d.Osc(5, "saw"), 40), 220)), d.Multiply(d.Ramp(48000, 1, 0).trigger(), 0.5))).words)
+    assert c != a  # another wave table is another structure
+    # a per-instance parameter instead of a constant is another structure too (pN instead of kN)
+    uni = descriptor.unify([descriptor.extract(voice(f, 5, 40, 0.5, 48000)) for f in (220, 330)])
+    p = source(uni.words)
+    assert p != a and "jit_param(A, X, 0)" in p
+
+
+def test_fm_levels_get_their_accumulate_passes():
+    """Time-split rendering needs every scanned (FM) oscillator's phase total per segment: one pass kernel per FM level,
+    holding only the cone of units that feeds that level's oscillators."""
+    d.configure(48000)
+    inner = d.Osc(d.Sum(d.Multiply(d.Osc(3), 20), 110))        # level 1
+    outer = d.Osc(d.Sum(d.Multiply(inner, 50), 440))            # level 2
+    text = source(descriptor.extract(d.Multiply(outer, d.Ramp(48000, 1, 0).trigger())).words)
+    assert "dusp_jit_pass1" in text and "dusp_jit_pass2" in text and "dusp_jit_pass0" not in text
+    pass1 = text.split("dusp_jit_pass1")[1].split('extern "C"')[0]
+    assert "jit_ramp" not in pass1 and "jit_store" not in pass1   # neither the envelope nor the outlet is in the cone
+    assert pass1.count("JitOscS") == 1                            # the level-2 oscillator is not needed to total level 1
+    # a circuit with a Filter cannot be cut in time: no pass kernels
+    assert "dusp_jit_pass" not in source(descriptor.extract(d.Filter(inner, 800)).words)
+
+
+def test_feedback_edges_read_last_iterations_registers():
+    g = Golden("loop_220")
+    text = source(g.desc, waves=8)
+    late = set(re.findall(r"float (w\d+)\[4\] = \{0\.f", text))
+    assert len(late) == 1                                        # the loop's one back edge: the Filter's previous chunk
+    w = late.pop()
+    assert re.search(r"%s\[c\] = v%s\[c\]" % (w, w[1:]), text)   # carried over at the end of the iteration
+    assert "JitFilterK<8>" in text and "JitDelayK" in text
+
+
+def test_bad_arguments_come_back_as_statuses():
+    g = Golden("osc440_1s")
+    with pytest.raises(runtime.DuspHipError, match="waves must be"):
+        source(g.desc, waves=3)
+    with pytest.raises(runtime.DuspHipError, match="magic"):
+        source(np.zeros(40))
