@@ -210,6 +210,10 @@ struct Emitter {
                 line("    JitDelayK y" + id + ";");
                 line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
                 break;
+            case OP_TIMER:
+                line("    JitTimer c" + id + ";");
+                line("    c" + id + ".begin(A, X, d" + num(dconst_of[(size_t)k]) + ", " + num(op.state_slot) + ");");
+                break;
             default: break;
             }
         }
@@ -299,7 +303,7 @@ struct Emitter {
         case OP_REPEATER: each(opnd(k, 0, "c")); break;                             // Repeater.js:23-30
         case OP_TIMER:
             decl();
-            line("        jit_timer(X, g, " + dref + ", A.init_state[" + num(op.state_slot) + "], " + v + ");");
+            line("        c" + id + ".tick(X, " + dref + ", " + v + ");");
             break;
         case OP_INPUT:
             decl();

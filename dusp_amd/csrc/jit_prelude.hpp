@@ -103,11 +103,19 @@ __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uin
 // ---- Osc (src/components/Osc/Osc.js:35-47) with an unconnected f — a constant or a per-instance parameter.  Equal increments:
 // phase(n) = (phase0 + (n + 1) q) mod S in exact 2^-36 fixed point, so the lane jumps to its own samples and thereafter
 // advances by (256 q) mod S per chunk; nothing crosses lanes, nothing is carried but this lane's own phase.
+// Three wave-uniform forms of the same arithmetic:
+//   whole   f and the start phase are whole numbers: the fraction is 0, `out = table[phase]` (Osc.js:43-45 degenerate)
+//   fx32    every phase is a multiple of 2^-32 (any f32 f with |f| >= 2^-8, i.e. lsb(f) >= 2^-31, from a start phase on that
+//           grid): index and fraction are two u32, advanced by add-with-carry; the fraction converts to f64 in one step
+//   else    the general u64 form
+// All the lookups of a chunk are issued before the first lerp (the branch on the form sits outside the sample loop).
 struct JitOscK {
-    unsigned long long P;          // phase of this lane's first sample of the next chunk
+    uint32_t I, F;                 // fx32 / whole: index and 2^-32 fraction of this lane's first sample of the next chunk
+    uint32_t qI, qF, cI, cF;       // increment per sample / per chunk in the same form (wave-uniform)
+    unsigned long long P;          // general form: phase of this lane's first sample of the next chunk
     unsigned long long q, q256;    // increment per sample / per chunk, mod S (wave-uniform)
     unsigned long long P_init;     // phase before the render's first sample (wave-uniform)
-    bool bad, whole;               // f is NaN / Inf (every sample NaN); every phase is a whole number (the lerp degenerates to table[phase])
+    bool bad, whole, fx32;         // bad: f is NaN / Inf (every sample NaN)
 
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float f, int state_slot) {
         double fd = (double)f;
@@ -121,25 +129,66 @@ struct JitOscK {
         q256 = jit_mulmod(q, kChunk, X.S, X.inv_S);
         P = addmod(P_init, jit_mulmod(q, X.n0(X.g_begin) + 1, X.S, X.inv_S), X.S);
         whole = ((q | P_init) & kJMask) == 0ull;
+        fx32 = ((q | P_init) & 15ull) == 0ull;
+        I = (uint32_t)(P >> kJFrac);
+        F = (uint32_t)((P & kJMask) >> 4);
+        qI = (uint32_t)(q >> kJFrac);
+        qF = (uint32_t)((q & kJMask) >> 4);
+        cI = (uint32_t)(q256 >> kJFrac);
+        cF = (uint32_t)((q256 & kJMask) >> 4);
+    }
+    static __device__ __forceinline__ void step32(uint32_t &i, uint32_t &f, uint32_t di, uint32_t df, uint32_t sr) {  // (i.f + di.df) mod sr
+        const uint32_t f2 = f + df;
+        uint32_t i2 = i + di + (f2 < f ? 1u : 0u);
+        i2 = min(i2, i2 - sr);  // (i2 < 2 sr; an underflow loses the min)
+        f = f2;
+        i = i2;
     }
     template <bool IN_LDS>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
-        unsigned long long Pc = P;
+        if (fx32) {
+            uint32_t iv[4], fv[4];
+            iv[0] = I;
+            fv[0] = F;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c > 0) Pc = addmod(Pc, q, X.S);
-            const uint32_t idx = (uint32_t)(Pc >> kJFrac);
-            float v;
-            if (whole) v = IN_LDS ? X.table.at(idx) : gtab[idx];
-            else {
-                const double fraction = (double)(Pc & kJMask) * (1.0 / kJ36);
-                float ta, tb;
-                jit_pair<IN_LDS>(X, gtab, idx, ta, tb);
-                v = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+            for (int c = 1; c < 4; ++c) {
+                iv[c] = iv[c - 1];
+                fv[c] = fv[c - 1];
+                step32(iv[c], fv[c], qI, qF, X.sr);
             }
-            out[c] = bad ? __builtin_nanf("") : v;
+            if (whole) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[c] = IN_LDS ? X.table.at(iv[c]) : gtab[iv[c]];
+            } else {
+                float ta[4], tb[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, iv[c], ta[c], tb[c]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double fraction = (double)fv[c] * (1.0 / 4294967296.0);
+                    out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
+                }
+            }
+            step32(I, F, cI, cF, X.sr);
+        } else {
+            unsigned long long Pv[4];
+            Pv[0] = P;
+#pragma unroll
+            for (int c = 1; c < 4; ++c) Pv[c] = addmod(Pv[c - 1], q, X.S);
+            float ta[4], tb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
+                out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
+            }
+            P = addmod(P, q256, X.S);
         }
-        P = addmod(P, q256, X.S);
+        if (bad) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = __builtin_nanf("");
+        }
     }
     // the phase after ceil(n_samples / 256) ticks (state write-back)
     __device__ __forceinline__ double end_phase(const JitArgs &A, const JitCtx &X) const {
@@ -185,25 +234,28 @@ struct JitOscS {
         const long long before = (long long)carry + (incl - total);
         const unsigned long long bad_lanes = __ballot(bad);
         bool dead = poison != 0 || (bad_lanes & ((1ull << X.lane) - 1ull)) != 0;
-        unsigned long long Pc = mod_u64((unsigned long long)(before + qv[0]) + X.lift, X.S, X.inv_S);
+        unsigned long long Pv[4];
+        Pv[0] = mod_u64((unsigned long long)(before + qv[0]) + X.lift, X.S, X.inv_S);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c > 0) {
-                long long Pn = (long long)Pc + qv[c];
-                if (Pn < 0) Pn += (long long)X.S;
-                if (Pn >= (long long)X.S) Pn -= (long long)X.S;
-                Pc = (unsigned long long)Pn;
-            }
-            dead = dead || !(fabs((double)f[c]) <= 3.0e38);
-            if (LOOKUP) {
-                const uint32_t idx = (uint32_t)(Pc >> kJFrac);
-                const double fraction = (double)(Pc & kJMask) * (1.0 / kJ36);
-                float ta, tb;
-                jit_pair<IN_LDS>(X, gtab, idx, ta, tb);
-                out[c] = dead ? __builtin_nanf("") : (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
+        for (int c = 1; c < 4; ++c) {
+            long long Pn = (long long)Pv[c - 1] + qv[c];
+            if (Pn < 0) Pn += (long long)X.S;
+            if (Pn >= (long long)X.S) Pn -= (long long)X.S;
+            Pv[c] = (unsigned long long)Pn;
+        }
+        if (LOOKUP) {  // all the lookups of the chunk first, then the lerps
+            float ta[4], tb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dead = dead || !(fabs((double)f[c]) <= 3.0e38);
+                const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
+                out[c] = dead ? __builtin_nanf("") : (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
             }
         }
         // the chunk's last phase, as a scalar (lane 63 holds it)
+        const unsigned long long Pc = Pv[3];
         const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)Pc, 63), hi = __builtin_amdgcn_readlane((uint32_t)(Pc >> 32), 63);
         carry = ((unsigned long long)hi << 32) | lo;
         if (bad_lanes) poison = 1u;
@@ -239,12 +291,30 @@ __device__ __forceinline__ void jit_ramp_end(const JitArgs &A, const JitCtx &X, 
     st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
 }
 
-// ---- Timer (src/components/Timer.js:36-41): t += samplePeriod, each sum rounded — in closed form (repeat_add.hpp)
-__device__ __forceinline__ void jit_timer(const JitCtx &X, uint32_t g, double period, double t0, float (&out)[4]) {
-    double t = repeat_add(t0, period, X.n0(g));
+// ---- Timer (src/components/Timer.js:36-41): t += samplePeriod, each sum rounded to f64 — in closed form (repeat_add.hpp).  The
+// running value before the chunk is carried as a scalar; while a whole chunk stays inside one binade the 256 sums are
+// t_j = (T + j ce) 2^(K-52) (linear_run), else every lane jumps to its own four.
+struct JitTimer {
+    double t;  // value before the next chunk's first sample (uniform)
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double period, int state_slot) {
+        t = repeat_add(A.init_state[state_slot], period, (uint64_t)X.g_begin * kChunk);
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, double period, float (&out)[4]) {
+        long long T, ce;
+        int K;
+        if (linear_run(t, period, kChunk, T, ce, K)) {
+            long long Tl = T + (long long)(X.lane * 4) * ce;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) out[c] = (float)(t = t + period);
-}
+            for (int c = 0; c < 4; ++c) out[c] = (float)ldexp((double)(Tl += ce), K - 52);
+            t = ldexp((double)(T + (long long)kChunk * ce), K - 52);
+        } else {
+            double tt = repeat_add(t, period, (uint64_t)X.lane * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = (float)(tt = tt + period);
+            t = __shfl(tt, 63, 64);
+        }
+    }
+};
 
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
