@@ -81,13 +81,36 @@ __device__ __forceinline__ unsigned long long jit_mulmod(unsigned long long a, u
     return addmod(r, mod_u64(al * n, S, inv_S), S);
 }
 
-__device__ __forceinline__ long long jit_wave_scan(long long x, uint32_t lane) {  // inclusive prefix sum over the 64 lanes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const long long y = __shfl_up(x, d, 64);
-        if ((int)lane >= d) x += y;
-    }
+// Inclusive prefix sum of a 32-bit value over the 64 lanes, in the VALU's own cross-lane network (DPP): four shifts inside
+// each row of 16 lanes, then two row broadcasts — six adds, no LDS crossbar round trips (a ds_bpermute shuffle costs ~50
+// cycles of latency, and a 64-bit scan by shuffles chains twelve of them).
+__device__ __forceinline__ int jit_scan32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
     return x;
+}
+// Inclusive prefix sum of signed 64-bit values with |x| < 2^56 over the 64 lanes: three limbs of 22 bits (the top one signed),
+// scanned separately — a limb's 64-lane sum stays below 2^28 — and put together again.
+__device__ __forceinline__ long long jit_wave_scan(long long x) {
+    const int l0 = (int)((unsigned long long)x & 0x3fffffull), l1 = (int)(((unsigned long long)x >> 22) & 0x3fffffull), l2 = (int)(x >> 44);
+    const long long s0 = jit_scan32(l0), s1 = jit_scan32(l1), s2 = jit_scan32(l2);
+    return s0 + s1 * (1ll << 22) + s2 * (1ll << 44);
+}
+
+// f32 -> exact 2^-36 fixed point, truncated toward zero like the C cast of f * 2^36 (every f32 with |f| >= 2^-13 is a multiple
+// of 2^-36), by integer shifts.  For finite |f| < 2^26; callers send larger magnitudes (which need an fmod by the sample rate
+// first) and non-finite values down their slow path.
+__device__ __forceinline__ long long jit_fix36(float f) {
+    const uint32_t bits = __float_as_uint(f);
+    const int e = (int)((bits >> 23) & 0xffu);
+    const unsigned long long M = (unsigned long long)((bits & 0x7fffffu) | (e ? 0x800000u : 0u));  // (denormals vanish below)
+    const int sh = e - 114;  // value = M 2^(e - 150); times 2^36
+    const unsigned long long mag = sh >= 0 ? M << (sh & 63) : (sh > -24 ? M >> ((-sh) & 63) : 0ull);
+    return (bits >> 31) ? -(long long)mag : (long long)mag;
 }
 
 // One table lookup pair (T[idx], T[idx + 1]): from the LDS half-table image when the kernel carries this table, else from L2.
@@ -219,18 +242,25 @@ struct JitOscS {
     template <bool IN_LDS, bool LOOKUP>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, const float (&f)[4], float (&out)[4]) {
         long long qv[4];
-        bool bad = false;
+        bool bad = false, big = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            double fd = (double)f[c];
-            const bool fin = fabs(fd) <= 3.0e38;
-            bad = bad || !fin;
-            if (!fin) fd = 0.0;
-            if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);
-            qv[c] = (long long)(fd * kJ36);
+            qv[c] = jit_fix36(f[c]);
+            big = big || !(fabsf(f[c]) < (float)X.sr);  // at or above the sample rate, or NaN / Inf
         }
-        const long long total = qv[0] + qv[1] + qv[2] + qv[3];
-        const long long incl = jit_wave_scan(total, X.lane);
+        if (__any(big)) {  // rare: the reference's `phase %= sampleRate` folds such increments ((a + b) % m == (a + b % m) % m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double fd = (double)f[c];
+                const bool fin = fabs(fd) <= 3.0e38;
+                bad = bad || !fin;
+                if (!fin) fd = 0.0;
+                if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);
+                qv[c] = (long long)(fd * kJ36);
+            }
+        }
+        const long long total = qv[0] + qv[1] + qv[2] + qv[3];  // |total| < 4 * 2^53
+        const long long incl = jit_wave_scan(total);
         const long long before = (long long)carry + (incl - total);
         const unsigned long long bad_lanes = __ballot(bad);
         bool dead = poison != 0 || (bad_lanes & ((1ull << X.lane) - 1ull)) != 0;
@@ -249,9 +279,15 @@ struct JitOscS {
             for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                dead = dead || !(fabs((double)f[c]) <= 3.0e38);
                 const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
-                out[c] = dead ? __builtin_nanf("") : (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
+                out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
+            }
+            if (poison != 0 || bad_lanes != 0) {  // (uniform) from the first NaN / Inf increment on, every sample is NaN
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dead = dead || !(fabs((double)f[c]) <= 3.0e38);
+                    if (dead) out[c] = __builtin_nanf("");
+                }
             }
         }
         // the chunk's last phase, as a scalar (lane 63 holds it)
