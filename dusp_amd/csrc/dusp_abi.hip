@@ -121,8 +121,9 @@ struct dusp_program {
     // WAVE programs the circuit compiler takes (jit_codegen.hpp): generated text per workgroup geometry, constants on the device
     bool jit_ok = false;
     std::string jit_why;
-    std::map<int, dusp::JitSource> jit_src;  // wavefronts per workgroup -> kernel text (+ constants, scan list)
+    std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, instances per wavefront) -> kernel text (+ constants, scan list)
     bool jit_consts_uploaded = false;
+    int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
@@ -202,6 +203,7 @@ static dusp::Knobs read_knobs() {
     k.wave_segments = num("DUSP_WAVE_SEGMENTS", k.wave_segments);
     k.wave_max_waves = num("DUSP_WAVE_MAX_WAVES", k.wave_max_waves);
     k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
+    k.wave_per_wave = num("DUSP_WAVE_PER_WAVE", k.wave_per_wave);
     return k;
 }
 
@@ -540,8 +542,8 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
-        std::snprintf(info->shape, sizeof info->shape, "%s, compiled circuit kernel (%d units in registers)", prog->P.feed_forward ? "feed-forward" : "feedback",
-                      (int)prog->P.ops.size());
+        std::snprintf(info->shape, sizeof info->shape, "%s, compiled kernel: %d units, %dx%d", prog->P.feed_forward ? "feed-forward" : "feedback",
+                      (int)prog->P.ops.size(), prog->jit_waves, prog->jit_per_wave);
     else if (prog->engine == DUSP_ENGINE_WAVE)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     return DUSP_OK;
@@ -632,32 +634,54 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
     }
     const size_t budget = 160 * 1024;
-    const size_t per_wave = prog->wave.has_filter ? dusp::jit_filter_tile_bytes(1) : 0;
-    if (opt.lds_table >= 0 && opt.table_bytes + per_wave > budget) opt.lds_table = -1, opt.table_bytes = 0;
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
     if (ctx->knobs.wave_max_waves > 0) most = std::max(1, std::min(most, ctx->knobs.wave_max_waves));
-    int waves = 1;
-    while (waves < most && (size_t)(waves * 2) * per_wave + opt.table_bytes <= budget && (unsigned)waves < want) waves *= 2;
+    int waves = 1, per_wave = 1;
+    const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
+    if (prog->wave.has_filter) {
+        // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has
+        // lanes, and every CU the same number of rounds — rows = instances per CU / rounds, spread over up to 16 wavefronts.
+        const uint64_t per_cu = (n_inst + (uint64_t)ctx->n_cus - 1) / (uint64_t)ctx->n_cus;
+        const uint64_t rounds = (per_cu + 63) / 64;
+        const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
+        waves = std::min(most, rows);
+        per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
+        opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget - opt.table_bytes);
+        if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
+            opt.lds_table = -1, opt.table_bytes = 0;
+            opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget);
+        }
+    } else {
+        while (waves < most && (unsigned)waves < want) waves *= 2;
+        // instances per wavefront (unsplit renders): as many as still leave every CU a workgroup — their independent unit blocks
+        // fill each other's latencies
+        if (a.n_seg == 1)
+            while (per_wave < per_wave_cap && (uint64_t)ctx->n_cus * waves * (per_wave + 1) <= n_inst) per_wave++;
+    }
 
     hipFunction_t render = nullptr;
     dusp::JitSource *src = nullptr;
-    for (;;) {  // a kernel that spills at this many wavefronts per workgroup (128 registers each at 16) is rebuilt for half as many
+    for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
-        auto it = prog->jit_src.find(waves);
+        opt.per_wave = per_wave;
+        auto it = prog->jit_src.find({waves, per_wave});
         if (it == prog->jit_src.end()) {
             dusp::JitSource gen;
             if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
-            it = prog->jit_src.emplace(waves, std::move(gen)).first;
+            it = prog->jit_src.emplace(std::make_pair(waves, per_wave), std::move(gen)).first;
         }
         src = &it->second;
         std::string err;
         int scratch = 0;
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
-        if (scratch == 0 || waves <= 4) break;
-        waves /= 2;
+        if (scratch <= 32) break;  // (a register or two spilled outside the hot path is cheaper than halving the instances in flight)
+        if (per_wave > 1) per_wave--;
+        else if (waves > 4) waves /= 2;
+        else break;
+        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget - opt.table_bytes);
     }
     if (!prog->jit_consts_uploaded) {
         HIP_TRY(ctx, prog->d_jit_fk.ensure(std::max<size_t>(1, src->fk.size())));
@@ -676,7 +700,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     a.fk = prog->d_jit_fk.p;
     a.dk = prog->d_jit_dk.p;
-    const unsigned grid = (unsigned)((n_virtual + (unsigned)waves - 1) / (unsigned)waves);
+    const unsigned per_block = (unsigned)(waves * per_wave);
+    const unsigned grid = (unsigned)((n_virtual + per_block - 1) / per_block);
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
     if (a.n_seg > 1 && !src->scans.empty()) {  // one accumulate pass + prefix per FM level that has scanned oscillators, then the render pass
         const size_t per = src->scans.size() * (size_t)n_inst * a.n_seg;
@@ -695,6 +720,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     HIP_TRY(ctx, dusp::jit_launch(render, a, grid, (unsigned)waves * 64, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+    prog->jit_waves = waves;
+    prog->jit_per_wave = per_wave;
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;
@@ -1212,14 +1239,14 @@ int dusp_last_kernel_ms(dusp_program *prog, float *ms) {
     return DUSP_OK;
 }
 
-int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int lds_table, int compile, char *text, size_t cap) {
+int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int per_wave, int lds_table, int compile, char *text, size_t cap) {
     return guarded(g_error, "dusp_circuit_kernel_source", [&]() -> int {
     if (!desc || (cap && !text)) {
         g_error = "dusp_circuit_kernel_source: NULL argument";
         return DUSP_ERR_ARG;
     }
-    if (waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16) {
-        g_error = "dusp_circuit_kernel_source: waves must be 1, 2, 4, 8 or 16";
+    if (waves < 1 || waves > 16 || per_wave < 1 || per_wave > 4) {
+        g_error = "dusp_circuit_kernel_source: waves must be 1 .. 16 and per_wave 1 .. 4";
         return DUSP_ERR_ARG;
     }
     dusp::Program P;
@@ -1241,10 +1268,17 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     }
     dusp::JitOptions opt;
     opt.waves = waves;
+    opt.per_wave = per_wave;
     if (lds_table && plan.lds_table_id >= 0 && P.g.sample_rate % 2 == 0) {
         opt.lds_table = plan.lds_table_id;
         opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
-        if (opt.table_bytes + (plan.has_filter ? dusp::jit_filter_tile_bytes(waves) : 0) > 160 * 1024) opt.lds_table = -1, opt.table_bytes = 0;
+    }
+    if (plan.has_filter) {
+        opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, 160 * 1024 - opt.table_bytes);
+        if (!opt.filter_sub) {
+            g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
+            return DUSP_ERR_ARG;
+        }
     }
     dusp::JitSource src;
     if (!dusp::jit_generate(P, plan, opt, src)) {

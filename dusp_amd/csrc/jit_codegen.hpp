@@ -26,7 +26,7 @@ namespace dusp {
 struct JitSource {
     bool ok = false;
     std::string why;            // when not ok: what keeps this program on the interpreter
-    std::string text;           // kernels: dusp_jit_render, dusp_jit_pass<L> for every L in pass_levels
+    std::string text;           // kernels: dusp_jit_render, dusp_jit_pass<L> for every L in pass_levels (per_wave == 1 only)
     std::vector<float> fk;      // values of the constants the text names k0, k1, ...
     std::vector<double> dk;     // ... and d0, d1, ...
     std::vector<int> pass_levels;                 // time-split rendering: FM levels that have scanned oscillators, ascending
@@ -38,16 +38,26 @@ struct JitSource {
 
 struct JitOptions {
     int waves = 16;          // wavefronts per workgroup (compile-time: launch bounds, the Filter stage's tile geometry)
+    int per_wave = 1;        // R: circuit instances per wavefront (unsplit renders only)
     int lds_table = -1;      // table id whose half image sits in LDS, or -1
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
+    int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
 };
 
-// LDS of one workgroup of the generated kernel: the table image, then the Filter stage's hand-over tiles.  Declared
-// statically in the kernel text (a static declaration may take all 160 KiB; dynamic LDS would need a function attribute
-// that module kernels do not have).
-inline size_t jit_filter_tile_bytes(int waves) { return (size_t)waves * (258 * 8 + 260 * 4 + 16); }
+// LDS of one workgroup of the generated kernel: the table image, then the Filter stage's tile — one 260-float row per
+// instance of the workgroup (the input chunk on the way in, the output chunk on the way out).  Declared statically in the
+// kernel text (a static declaration may take all 160 KiB; dynamic LDS would need a function attribute that module kernels
+// do not have).
+// Filter stage: one row of (sub-block + 2) doubles per instance of the workgroup; the sub-block (256, 128 or 64 samples) is the
+// largest that fits the LDS left over.
+inline size_t jit_filter_tile_bytes(int rows, int sub) { return (size_t)rows * (size_t)(sub + 2) * 8; }
+inline int jit_filter_sub(int rows, size_t lds_left) {
+    for (int sub : {256, 128, 64})
+        if (jit_filter_tile_bytes(rows, sub) <= lds_left) return sub;
+    return 0;
+}
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
-    return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) + (has_filter ? jit_filter_tile_bytes(opt.waves) : 0));
+    return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) + (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) : 0));
 }
 
 inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op); }
@@ -95,13 +105,16 @@ struct Emitter {
     const WavePlan &plan;
     JitOptions opt;
     JitSource &out;
+    int R = 1;
     std::vector<int> pos_of_op;    // execution position of op k
     std::vector<int> producer;     // buffer -> producing op (-1: none)
     std::vector<char> late;        // buffer is read by an op that ticks before its producer: keep last iteration's registers
+    std::vector<char> shared;      // op computes the same chunk for every instance (constants and time only): emitted once per wave
     std::vector<int> fconst_of;    // per (op, operand): index into fk, or -1
+    std::vector<long long> dconst_of;  // per op: index of its first f64 constant (Ramp: duration, y0, y1; Delay: ring base, length; maps / Timer: d[0])
     std::string s;
 
-    Emitter(const Program &P_, const WavePlan &plan_, JitOptions o, JitSource &out_) : P(P_), plan(plan_), opt(o), out(out_) {}
+    Emitter(const Program &P_, const WavePlan &plan_, JitOptions o, JitSource &out_) : P(P_), plan(plan_), opt(o), out(out_), R(std::max(1, o.per_wave)) {}
 
     void line(const std::string &t) { s += t; s += '\n'; }
     static std::string num(long long v) { return std::to_string(v); }
@@ -109,31 +122,46 @@ struct Emitter {
     int add_fk(float v) { out.fk.push_back(v); return (int)out.fk.size() - 1; }
     int add_dk(double v) { out.dk.push_back(v); return (int)out.dk.size() - 1; }
 
+    static bool operand_live(const DevOp &op, int j) {
+        switch (op.op) {
+        case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
+        case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
+        case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
+        default:
+            if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
+            return j < 2;
+        }
+    }
     bool reads_late(int consumer_pos, int buf) const {
         const int pr = producer[(size_t)buf];
         return pr < 0 || pos_of_op[(size_t)pr] >= consumer_pos;
     }
-    // text of operand j of op k at sample c ("c" may be a literal digit)
-    std::string opnd(int k, int j, const std::string &c) const {
+    // slot suffix of op k's variables for instance slot r: a shared op has one copy
+    std::string sfx(int k, int r) const { return "_" + num(shared[(size_t)k] ? 0 : r); }
+    std::string buf_name(int consumer_pos, int buf, int r) const {
+        return std::string(reads_late(consumer_pos, buf) ? "w" : "v") + num(buf) + sfx(producer[(size_t)buf], r);
+    }
+    // text of operand j of op k at sample c ("c" may be a literal digit), for instance slot r
+    std::string opnd(int k, int j, const std::string &c, int r) const {
         const DevOperand &o = P.ops[(size_t)k].in[j];
-        if (o.kind == SRC_BUF) return (reads_late(pos_of_op[(size_t)k], o.idx) ? "w" : "v") + num(o.idx) + "[" + c + "]";
-        if (o.kind == SRC_PARAM) return "p" + num(o.idx);
+        if (o.kind == SRC_BUF) return buf_name(pos_of_op[(size_t)k], o.idx, r) + "[" + c + "]";
+        if (o.kind == SRC_PARAM) return "p" + num(o.idx) + "_" + num(r);
         return "k" + num(fconst_of[(size_t)k * kMaxIn + j]);
     }
     // operand as a float[4] the unit functions can take by reference
-    std::string opnd_array(int k, int j, const std::string &tmp) {
+    std::string opnd_array(int k, int j, const std::string &tmp, int r) {
         const DevOperand &o = P.ops[(size_t)k].in[j];
-        if (o.kind == SRC_BUF) return (reads_late(pos_of_op[(size_t)k], o.idx) ? "w" : "v") + num(o.idx);
-        const std::string sc = opnd(k, j, "0");
+        if (o.kind == SRC_BUF) return buf_name(pos_of_op[(size_t)k], o.idx, r);
+        const std::string sc = opnd(k, j, "0", r);
         line("        const float " + tmp + "[4] = {" + sc + ", " + sc + ", " + sc + ", " + sc + "};");
         return tmp;
     }
-    std::string table_args(int table_id) const {  // <IN_LDS> and the global row
-        return std::string(opt.lds_table == table_id ? "true" : "false");
-    }
+    std::string in_lds(int table_id) const { return opt.lds_table == table_id ? "true" : "false"; }
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
+    std::string ctx(int r) const { return "X[" + num(r) + "]"; }
+    int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
 
-    // ops in the input cone of `roots` (execution positions), for the accumulate passes
+    // ops in the input cone of `roots`, for the accumulate passes
     std::vector<char> cone(const std::vector<int> &roots) const {
         std::vector<char> in(P.ops.size(), 0);
         std::vector<int> stack = roots;
@@ -144,7 +172,7 @@ struct Emitter {
             in[(size_t)k] = 1;
             for (int j = 0; j < kMaxIn; j++) {
                 const DevOperand &o = P.ops[(size_t)k].in[j];
-                if (o.kind == SRC_BUF && o.idx >= 0 && o.idx < P.n_bufs && producer[(size_t)o.idx] >= 0) stack.push_back(producer[(size_t)o.idx]);
+                if (operand_live(P.ops[(size_t)k], j) && o.kind == SRC_BUF && producer[(size_t)o.idx] >= 0) stack.push_back(producer[(size_t)o.idx]);
             }
         }
         return in;
@@ -161,14 +189,14 @@ struct Emitter {
                 if (sc.level == pass_level) roots.push_back(plan.order[(size_t)sc.op_pos]);
             used = cone(roots);
         }
-        const std::string W = num(opt.waves);
+        const std::string W = num(opt.waves), RR = num(R);
         line("extern \"C\" __global__ void __launch_bounds__(" + W + " * 64) " + (render ? std::string("dusp_jit_render") : "dusp_jit_pass" + num(pass_level)) + "(JitArgs A) {");
         line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, out.has_filter) / 4)) + "];");
-        line("    JitCtx X;");
-        line("    jit_begin<" + W + ", " + num(opt.lds_table) + ">(A, lds, X);");
-        if (out.has_filter) line("    char *tile = (char *)lds + " + num((long long)(opt.lds_table >= 0 ? opt.table_bytes : 0)) + ";");
+        line("    JitCtx X[" + RR + "];");
+        line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", " + RR + ">(A, lds, X);");
+        if (out.has_filter) line("    double *tile = (double *)(lds + " + num((long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4)) + ");");
         // constants and parameters the used ops name
-        std::vector<char> fk_used(out.fk.size(), 0), dk_used(out.dk.size(), 0);
+        std::vector<char> fk_used(out.fk.size(), 0);
         std::vector<int> params_used;
         for (size_t k = 0; k < P.ops.size(); k++) {
             if (!used[k]) continue;
@@ -180,163 +208,190 @@ struct Emitter {
             }
         }
         for (size_t i = 0; i < out.fk.size(); i++)
-            if (fk_used[i]) line("    const float k" + num((long long)i) + " = A.fk[" + num((long long)i) + "];");
-        for (int p : params_used) line("    const float p" + num(p) + " = jit_param(A, X, " + num(p) + ");");
+            if (fk_used[i]) line("    const float k" + num((long long)i) + " = jit_u(A.fk[" + num((long long)i) + "]);");
+        for (int p : params_used)
+            for (int r = 0; r < R; r++) line("    const float p" + num(p) + "_" + num(r) + " = jit_param(A, " + ctx(r) + ", " + num(p) + ");");
         // state of the units
+        std::string fast = "true";  // every constant-f oscillator of the wave qualifies for the 32.32 form
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int k = plan.order[at];
             if (!used[(size_t)k]) continue;
             const DevOp &op = P.ops[(size_t)k];
-            const std::string id = num(k);
-            switch (op.op) {
-            case OP_OSC:
-                if (op.in[0].kind != SRC_BUF) {
-                    line("    JitOscK o" + id + ";");
-                    line("    o" + id + ".begin(A, X, " + opnd(k, 0, "0") + ", " + num(op.state_slot) + ");");
-                } else {
-                    int scan_id = -1;
-                    for (size_t i = 0; i < out.scans.size(); i++)
-                        if (out.scans[i].op_pos == (int)at) scan_id = (int)i;
-                    const bool accumulating = !render && plan.osc_level[(size_t)k] >= pass_level;
-                    line("    JitOscS o" + id + ";");
-                    line("    o" + id + ".begin(A, X, " + num(op.state_slot) + ", " + num(scan_id) + ", " + (accumulating ? "true" : "false") + ");");
+            for (int r = 0; r < copies(k); r++) {
+                const std::string id = num(k) + "_" + num(r);
+                switch (op.op) {
+                case OP_OSC:
+                    if (op.in[0].kind != SRC_BUF) {
+                        line("    JitOscK o" + id + ";");
+                        line("    o" + id + ".begin(A, " + ctx(r) + ", " + opnd(k, 0, "0", r) + ", " + num(op.state_slot) + ");");
+                        fast += " && o" + id + ".fx32";
+                    } else {
+                        int scan_id = -1;
+                        for (size_t i = 0; i < out.scans.size(); i++)
+                            if (out.scans[i].op_pos == (int)at) scan_id = (int)i;
+                        const bool accumulating = !render && plan.osc_level[(size_t)k] >= pass_level;
+                        line("    JitOscS o" + id + ";");
+                        line("    o" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", " + num(scan_id) + ", " + (accumulating ? "true" : "false") + ");");
+                    }
+                    break;
+                case OP_DELAY:
+                    line("    JitDelayK y" + id + ";");
+                    line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
+                case OP_TIMER:
+                    line("    JitTimer c" + id + ";");
+                    line("    c" + id + ".begin(A, " + ctx(r) + ", d" + num(dconst_of[(size_t)k]) + ", " + num(op.state_slot) + ");");
+                    break;
+                default: break;
                 }
-                break;
-            case OP_FILTER:
-                line("    JitFilterK<" + W + "> f" + id + ";");
-                line("    f" + id + ".begin(A, X, tile, " + num(op.attr) + ", " + opnd(k, 1, "0") + ", " + num(op.state_slot) + ");");
-                break;
-            case OP_DELAY:
-                line("    JitDelayK y" + id + ";");
-                line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
-                break;
-            case OP_TIMER:
-                line("    JitTimer c" + id + ";");
-                line("    c" + id + ".begin(A, X, d" + num(dconst_of[(size_t)k]) + ", " + num(op.state_slot) + ");");
-                break;
-            default: break;
+            }
+            if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
+                const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
+                line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + "> f" + num(k) + ";");
+                line("    f" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
+                for (int r = 0; r < R; r++)
+                    line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
             }
         }
         // registers of late edges: the producer's previous chunk (outlets start as zeros, SignalChunk.js:7)
         for (int b = 0; b < P.n_bufs; b++)
-            if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]]) line("    float w" + num(b) + "[4] = {0.f, 0.f, 0.f, 0.f};");
-        line("    for (uint32_t g = X.g_begin; g < X.g_end; ++g) {");
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int k = plan.order[at];
-            if (!used[(size_t)k]) continue;
-            unit(k, (int)at, render, pass_level);
-        }
-        if (render)
-            for (size_t oc = 0; oc < P.out_bufs.size(); oc++) line("        jit_store(A, X, g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + ");");
-        for (int b = 0; b < P.n_bufs; b++)
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
-                line("        for (int c = 0; c < 4; ++c) w" + num(b) + "[c] = v" + num(b) + "[c];");
+                for (int r = 0; r < copies(producer[(size_t)b]); r++) line("    float w" + num(b) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
+        // the chunk loop, twice: with the constant-f oscillators in 32.32 fixed point, and in the general form
+        line("    if (" + fast + ") {");
+        loop(render, pass_level, used, true);
+        line("    } else {");
+        loop(render, pass_level, used, false);
         line("    }");
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
             for (size_t k = 0; k < P.ops.size(); k++)
-                if (P.ops[k].op == OP_FILTER) line("    f" + num((long long)k) + ".end(A, X, " + num(P.ops[k].state_slot) + ");");
-            line("    if (X.live && X.seg == X.n_seg - 1 && X.lane == 0) {");
-            for (size_t k = 0; k < P.ops.size(); k++) {
-                const DevOp &op = P.ops[k];
-                const std::string slot = "A.state[(size_t)" + num(op.state_slot) + " * A.n_pad + X.inst]";
-                if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) line("        " + slot + " = o" + num((long long)k) + ".end_phase(A, X);");
-                if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) line("        " + slot + " = o" + num((long long)k) + ".end_phase();");
-                if (op.op == OP_RAMP) line("        jit_ramp_end(A, X, d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
-                if (op.op == OP_TIMER)
-                    line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
-                if (op.op == OP_DELAY) line("        " + slot + " = y" + num((long long)k) + ".carried;");
+                if (P.ops[k].op == OP_FILTER) {
+                    line("    f" + num((long long)k) + ".end(A, X[0], " + num(P.ops[k].state_slot) + ");");
+                    for (int r = 0; r < R; r++) line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].state_slot) + ");");
+                }
+            for (int r = 0; r < R; r++) {
+                line("    if (" + ctx(r) + ".live && " + ctx(r) + ".seg == " + ctx(r) + ".n_seg - 1 && " + ctx(r) + ".lane == 0) {");
+                for (size_t k = 0; k < P.ops.size(); k++) {
+                    const DevOp &op = P.ops[k];
+                    const std::string slot = "A.state[(size_t)" + num(op.state_slot) + " * A.n_pad + " + ctx(r) + ".inst]", id = num((long long)k) + sfx((int)k, r);
+                    if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) line("        " + slot + " = o" + id + ".end_phase(A, " + ctx(r) + ");");
+                    if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) line("        " + slot + " = o" + id + ".end_phase();");
+                    if (op.op == OP_RAMP) line("        jit_ramp_end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_TIMER)
+                        line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
+                    if (op.op == OP_DELAY) line("        " + slot + " = y" + id + ".carried;");
+                }
+                line("    }");
             }
-            line("    }");
         } else {
-            line("    if (X.live && X.lane == 0) {");
+            line("    if (X[0].live && X[0].lane == 0) {");
             for (size_t i = 0; i < out.scans.size(); i++)
                 if (out.scans[i].level == pass_level)
-                    line("        A.seg_sum[((size_t)" + num((long long)i) + " * A.n_inst + X.inst) * X.n_seg + X.seg] = o" + num(plan.order[(size_t)out.scans[i].op_pos]) + ".packed();");
+                    line("        A.seg_sum[((size_t)" + num((long long)i) + " * A.n_inst + X[0].inst) * X[0].n_seg + X[0].seg] = o" + num(plan.order[(size_t)out.scans[i].op_pos]) + "_0.packed();");
             line("    }");
         }
         line("}");
         line("");
     }
 
-    std::vector<long long> dconst_of;  // per op: index of its first f64 constant (Ramp: duration, y0, y1; maps / Timer: d[0])
-
-    static bool operand_live(const DevOp &op, int j) {
-        switch (op.op) {
-        case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
-        case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
-        case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
-        default:
-            if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
-            return j < 2;
+    void loop(bool render, int pass_level, const std::vector<char> &used, bool fx) {
+        line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const int k = plan.order[at];
+            if (!used[(size_t)k]) continue;
+            unit(k, render, pass_level, fx);
         }
+        if (render)
+            for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
+                for (int r = 0; r < R; r++)
+                    line("        jit_store(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
+        for (int b = 0; b < P.n_bufs; b++)
+            if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
+                for (int r = 0; r < copies(producer[(size_t)b]); r++)
+                    line("        for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
+        line("    }");
     }
 
-    void unit(int k, int at, bool render, int pass_level) {
+    void unit(int k, bool render, int pass_level, bool fx) {
         const DevOp &op = P.ops[(size_t)k];
-        const std::string id = num(k), v = "v" + num(op.out_buf);
-        auto decl = [&]() { line("        float " + v + "[4];"); };
-        auto each = [&](const std::string &expr) {
-            decl();
-            line("        for (int c = 0; c < 4; ++c) " + v + "[c] = " + expr + ";");
-        };
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
-        switch (op.op) {
-        case OP_OSC:
-            decl();
-            if (op.in[0].kind != SRC_BUF)
-                line("        o" + id + ".tick<" + table_args(op.attr) + ">(X, " + table_row(op.attr) + ", " + v + ");");
-            else {
-                const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
-                const std::string f = opnd_array(k, 0, "t" + id);
-                line("        o" + id + ".tick<" + table_args(op.attr) + ", " + (lookup ? "true" : "false") + ">(X, " + table_row(op.attr) + ", " + f + ", " + v + ");");
-                if (!lookup) line("        for (int c = 0; c < 4; ++c) " + v + "[c] = 0.f;");
+        if (op.op == OP_FILTER) {  // feed-forward half per lane; then, sub-block by sub-block: park P, all recurrences on wave 0, pick y up
+            const std::string f = "f" + num(k);
+            std::vector<std::string> xs;
+            for (int r = 0; r < R; r++) {
+                xs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
+                line("        const auto e" + num(k) + "_" + num(r) + " = " + f + ".edge(" + ctx(r) + ", " + num(r) + ", " + xs.back() + ");");
+                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
             }
-            break;
-        case OP_RAMP:
-            decl();
-            line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(X, g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
-                 num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
-            break;
-        case OP_MULTIPLY: each(opnd(k, 0, "c") + " * " + opnd(k, 1, "c")); break;  // Multiply.js:23-34
-        case OP_SUM: each(opnd(k, 0, "c") + " + " + opnd(k, 1, "c")); break;       // Sum.js:33-44
-        case OP_REPEATER: each(opnd(k, 0, "c")); break;                             // Repeater.js:23-30
-        case OP_TIMER:
-            decl();
-            line("        c" + id + ".tick(X, " + dref + ", " + v + ");");
-            break;
-        case OP_INPUT:
-            decl();
-            line("        jit_input(A, X, g, " + num(op.attr) + ", " + v + ");");
-            break;
-        case OP_FILTER: {
-            decl();
-            const std::string x = opnd_array(k, 0, "t" + id);
-            line("        f" + id + ".tick(X, tile, " + x + ", " + v + ");");
-            break;
+            for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) {
+                for (int r = 0; r < R; r++)
+                    line("        " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ", e" + num(k) + "_" + num(r) + ");");
+                line("        jit_lds_barrier();");
+                line("        " + f + ".serial(X[0], tile);");
+                line("        jit_lds_barrier();");
+                for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+                // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
+            }
+            return;
         }
-        case OP_DELAY: {
-            decl();
-            const std::string x = opnd_array(k, 0, "t" + id);
-            line("        y" + id + ".tick(A, X, g, (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0") + ", " + x + ", " + v + ");");
-            break;
-        }
-        default:
-            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) {  // stateless maps of at most two operands (map_ops.hpp)
-                const std::string y = operand_live(op, 1) ? opnd(k, 1, "c") : std::string("0.f");
-                each("map_apply(" + num(op.op) + ", " + opnd(k, 0, "c") + ", " + y + ", " + dref + ")");
-            } else {  // Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude
+        for (int r = 0; r < copies(k); r++) {
+            const std::string id = num(k) + "_" + num(r), v = "v" + num(op.out_buf) + "_" + num(r), X_ = ctx(r);
+            auto decl = [&]() { line("        float " + v + "[4];"); };
+            auto each = [&](const std::string &expr) {
                 decl();
-                line("        for (int c = 0; c < 4; ++c) {");
-                std::string arr = "            const float in_[kMaxIn] = {";
-                for (int j = 0; j < kMaxIn; j++) arr += (j ? ", " : "") + (j < op.n_in ? opnd(k, j, "c") : opnd(k, 0, "c"));
-                line(arr + "};");
-                line("            " + v + "[c] = map_wide(" + num(op.op) + ", " + num(op.attr) + ", " + num(op.n_in) + ", in_, " + dref + ");");
-                line("        }");
+                line("        for (int c = 0; c < 4; ++c) " + v + "[c] = " + expr + ";");
+            };
+            switch (op.op) {
+            case OP_OSC:
+                decl();
+                if (op.in[0].kind != SRC_BUF)
+                    line("        o" + id + ".tick<" + in_lds(op.attr) + ", " + (fx ? "true" : "false") + ">(" + X_ + ", " + table_row(op.attr) + ", " + v + ");");
+                else {
+                    const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
+                    const std::string f = opnd_array(k, 0, "t" + id, r);
+                    line("        o" + id + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ">(" + X_ + ", " + table_row(op.attr) + ", " + f + ", " + v + ");");
+                    if (!lookup) line("        for (int c = 0; c < 4; ++c) " + v + "[c] = 0.f;");
+                }
+                break;
+            case OP_RAMP:
+                decl();
+                line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(" + X_ + ", g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
+                     num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
+                break;
+            case OP_MULTIPLY: each(opnd(k, 0, "c", r) + " * " + opnd(k, 1, "c", r)); break;  // Multiply.js:23-34
+            case OP_SUM: each(opnd(k, 0, "c", r) + " + " + opnd(k, 1, "c", r)); break;       // Sum.js:33-44
+            case OP_REPEATER: each(opnd(k, 0, "c", r)); break;                                // Repeater.js:23-30
+            case OP_TIMER:
+                decl();
+                line("        c" + id + ".tick(" + X_ + ", " + dref + ", " + v + ");");
+                break;
+            case OP_INPUT:
+                decl();
+                line("        jit_input(A, " + X_ + ", g, " + num(op.attr) + ", " + v + ");");
+                break;
+            case OP_DELAY: {
+                decl();
+                const std::string x = opnd_array(k, 0, "t" + id, r);
+                line("        y" + id + ".tick(A, " + X_ + ", g, (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ", " + x + ", " + v + ");");
+                break;
             }
-            break;
+            default:
+                if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) {  // stateless maps of at most two operands (map_ops.hpp)
+                    const std::string y = operand_live(op, 1) ? opnd(k, 1, "c", r) : std::string("0.f");
+                    each("map_apply(" + num(op.op) + ", " + opnd(k, 0, "c", r) + ", " + y + ", " + dref + ")");
+                } else {  // Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude
+                    decl();
+                    line("        for (int c = 0; c < 4; ++c) {");
+                    std::string arr = "            const float in_[kMaxIn] = {";
+                    for (int j = 0; j < kMaxIn; j++) arr += (j ? ", " : "") + (j < op.n_in ? opnd(k, j, "c", r) : opnd(k, 0, "c", r));
+                    line(arr + "};");
+                    line("            " + v + "[c] = map_wide(" + num(op.op) + ", " + num(op.attr) + ", " + num(op.n_in) + ", in_, " + dref + ");");
+                    line("        }");
+                }
+                break;
+            }
         }
-        (void)at;
     }
 
     bool run() {
@@ -355,7 +410,7 @@ struct Emitter {
                 if (!operand_live(op, j)) continue;
                 const DevOperand &o = op.in[j];
                 if (o.kind == SRC_BUF) {
-                    if (o.idx < 0 || o.idx >= P.n_bufs) { out.why = "operand out of range"; return false; }
+                    if (o.idx < 0 || o.idx >= P.n_bufs || producer[(size_t)o.idx] < 0) { out.why = "operand without a producer"; return false; }
                     if (reads_late(pos_of_op[k], o.idx)) late[(size_t)o.idx] = 1;
                 } else if (o.kind == SRC_CONST)
                     fconst_of[k * kMaxIn + j] = add_fk(o.cval);
@@ -373,6 +428,23 @@ struct Emitter {
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }
+        // Units that compute the same chunk for every instance — constants, closed forms of time, and whatever is built from
+        // those alone — are emitted once per wave and shared by its R instances (the fused kernels' "one Ramp evaluation per
+        // step for the block's voices", in general).  In execution order; an operand read late is not known yet: not shared.
+        shared.assign(P.ops.size(), 0);
+        for (size_t at = 0; at < plan.order.size() && R > 1; at++) {
+            const int k = plan.order[at];
+            const DevOp &op = P.ops[(size_t)k];
+            bool ok = op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_TIMER || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
+                      (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST);
+            for (int j = 0; ok && j < kMaxIn; j++) {
+                if (!operand_live(op, j)) continue;
+                const DevOperand &o = op.in[j];
+                if (o.kind == SRC_PARAM) ok = false;
+                if (o.kind == SRC_BUF) ok = !reads_late((int)at, o.idx) && shared[(size_t)producer[(size_t)o.idx]];
+            }
+            shared[(size_t)k] = ok ? 1 : 0;
+        }
         // scanned oscillators and the accumulate passes a time-split render needs
         for (size_t at = 0; at < plan.order.size(); at++) {
             const DevOp &op = P.ops[(size_t)plan.order[at]];
@@ -386,11 +458,11 @@ struct Emitter {
         line("// generated by dusp_amd/csrc/jit_codegen.hpp — one kernel per topologically sorted Circuit");
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
-        // f64 constants are read where they are used: declare them as macros over the array (loop-invariant scalar loads)
-        for (size_t i = 0; i < out.dk.size(); i++) line("#define d" + num((long long)i) + " (A.dk[" + num((long long)i) + "])");
+        // f64 constants are read where they are used (loop-invariant scalar loads)
+        for (size_t i = 0; i < out.dk.size(); i++) line("#define d" + num((long long)i) + " jit_u(A.dk[" + num((long long)i) + "])");
         line("");
         kernel(-1);
-        if (plan.splittable)
+        if (plan.splittable && R == 1)
             for (int L : out.pass_levels) kernel(L);
         out.text = s;
         out.ok = true;

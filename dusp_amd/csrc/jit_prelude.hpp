@@ -44,32 +44,51 @@ struct JitCtx {
     __device__ __forceinline__ uint64_t n0(uint32_t g) const { return (uint64_t)g * kChunk + lane * 4; }  // this lane's first sample of chunk g
 };
 
-template <int WAVES, int LDS_TABLE>
-__device__ __forceinline__ void jit_begin(const JitArgs &A, float *lds, JitCtx &X) {
-    X.sr = A.sample_rate;
-    X.srd = (double)X.sr;
-    X.S = (unsigned long long)X.sr << kJFrac;
-    X.inv_S = 1.0 / (double)X.S;
-    X.lift = X.S * ((1ull << 62) / X.S);  // multiple of S that makes any |x| < 2^62 non-negative before the modulo
-    X.table.g = nullptr;
-    X.table.h = lds;
-    X.table.N = X.sr + 1;
-    X.table.M = X.sr / 2;
-    if (LDS_TABLE >= 0) load_half_table<WAVES * 64>(lds, A.tables + (size_t)LDS_TABLE * A.table_stride, X.sr);
-    X.lane = threadIdx.x & 63u;
-    X.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    X.n_seg = A.n_seg;
+// R: circuit instances per wavefront (unsplit renders of many instances; a time-split render has R == 1).  A wave's R instances
+// are consecutive: workgroup b, wave w, slot r renders instance (b WAVES + w) R + r.  Their unit blocks stand next to each other
+// in the generated text, so the independent work of R instances fills each other's latencies, and the Filter stage gets
+// WAVES x R recurrences to run side by side.
+template <int WAVES, int LDS_TABLE, int R>
+__device__ __forceinline__ void jit_begin(const JitArgs &A, float *lds, JitCtx (&X)[R]) {
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (LDS_TABLE >= 0) load_half_table<WAVES * 64>(lds, A.tables + (size_t)LDS_TABLE * A.table_stride, A.sample_rate);
     const uint32_t n_virtual = A.n_inst * A.n_seg;  // a "virtual instance" is one time segment of an instance
-    const uint32_t v = blockIdx.x * WAVES + X.wave;
-    X.live = v < n_virtual;
-    const uint32_t vinst = X.live ? v : n_virtual - 1;
-    X.inst = vinst / A.n_seg;
-    X.seg = vinst - X.inst * A.n_seg;
-    X.g_begin = X.seg * A.seg_groups;
-    X.g_end = A.n_seg == 1 ? A.n_groups : min(X.g_begin + A.seg_groups, A.n_groups);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        JitCtx &x = X[r];
+        x.sr = A.sample_rate;
+        x.srd = (double)x.sr;
+        x.S = (unsigned long long)x.sr << kJFrac;
+        x.inv_S = 1.0 / (double)x.S;
+        x.lift = x.S * ((1ull << 62) / x.S);  // multiple of S that makes any |x| < 2^62 non-negative before the modulo
+        x.table.g = nullptr;
+        x.table.h = lds;
+        x.table.N = x.sr + 1;
+        x.table.M = x.sr / 2;
+        x.lane = lane;
+        x.wave = wave;
+        x.n_seg = A.n_seg;
+        const uint32_t v = (blockIdx.x * WAVES + wave) * R + r;
+        x.live = v < n_virtual;
+        const uint32_t vinst = x.live ? v : n_virtual - 1;
+        x.inst = vinst / A.n_seg;
+        x.seg = vinst - x.inst * A.n_seg;
+        x.g_begin = x.seg * A.seg_groups;
+        x.g_end = A.n_seg == 1 ? A.n_groups : min(x.g_begin + A.seg_groups, A.n_groups);
+    }
 }
 
-__device__ __forceinline__ float jit_param(const JitArgs &A, const JitCtx &X, uint32_t slot) { return A.params[(size_t)slot * A.n_inst + X.inst]; }
+// Values that are the same in every lane, made known as such: the compiler keeps them in scalar registers instead of one copy
+// per lane (a load through a plain pointer lands in vector registers even when its address is wave-uniform).
+__device__ __forceinline__ uint32_t jit_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }  // (the builtin returns int)
+__device__ __forceinline__ float jit_u(float v) { return __uint_as_float(jit_u(__float_as_uint(v))); }
+__device__ __forceinline__ unsigned long long jit_u(unsigned long long v) {
+    return ((unsigned long long)jit_u((uint32_t)(v >> 32)) << 32) | (unsigned long long)jit_u((uint32_t)v);
+}
+__device__ __forceinline__ double jit_u(double v) { return __longlong_as_double((long long)jit_u((unsigned long long)__double_as_longlong(v))); }
+__device__ __forceinline__ bool jit_u(bool v) { return jit_u(v ? 1u : 0u) != 0u; }
+
+__device__ __forceinline__ float jit_param(const JitArgs &A, const JitCtx &X, uint32_t slot) { return jit_u(A.params[(size_t)slot * A.n_inst + X.inst]); }
 
 // (a * n) mod S for a < S < 2^53 and n < 2^32, exactly: the product is cut into pieces that mod_u64 (x < 2^64) can take
 __device__ __forceinline__ unsigned long long jit_mulmod(unsigned long long a, unsigned long long n, unsigned long long S, double inv_S) {
@@ -126,19 +145,19 @@ __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uin
 // ---- Osc (src/components/Osc/Osc.js:35-47) with an unconnected f — a constant or a per-instance parameter.  Equal increments:
 // phase(n) = (phase0 + (n + 1) q) mod S in exact 2^-36 fixed point, so the lane jumps to its own samples and thereafter
 // advances by (256 q) mod S per chunk; nothing crosses lanes, nothing is carried but this lane's own phase.
-// Three wave-uniform forms of the same arithmetic:
-//   whole   f and the start phase are whole numbers: the fraction is 0, `out = table[phase]` (Osc.js:43-45 degenerate)
-//   fx32    every phase is a multiple of 2^-32 (any f32 f with |f| >= 2^-8, i.e. lsb(f) >= 2^-31, from a start phase on that
-//           grid): index and fraction are two u32, advanced by add-with-carry; the fraction converts to f64 in one step
-//   else    the general u64 form
-// All the lookups of a chunk are issued before the first lerp (the branch on the form sits outside the sample loop).
+// Two forms of the same arithmetic, chosen per KERNEL BODY (the generated kernel holds its chunk loop twice and takes the
+// fast copy when every such oscillator of the wave qualifies, so that no branch stands inside the loop):
+//   FX   every phase is a multiple of 2^-32 (any f32 f with |f| >= 2^-8, i.e. lsb(f) >= 2^-31, from a start phase on that
+//        grid): index and fraction are two u32, advanced by add-with-carry; the fraction converts to f64 in one step
+//   else the general u64 form
+// All the lookups of a chunk are issued before the first lerp.
 struct JitOscK {
-    uint32_t I, F;                 // fx32 / whole: index and 2^-32 fraction of this lane's first sample of the next chunk
+    uint32_t I, F;                 // FX: index and 2^-32 fraction of this lane's first sample of the next chunk
     uint32_t qI, qF, cI, cF;       // increment per sample / per chunk in the same form (wave-uniform)
     unsigned long long P;          // general form: phase of this lane's first sample of the next chunk
     unsigned long long q, q256;    // increment per sample / per chunk, mod S (wave-uniform)
     unsigned long long P_init;     // phase before the render's first sample (wave-uniform)
-    bool bad, whole, fx32;         // bad: f is NaN / Inf (every sample NaN)
+    bool bad, fx32;                // bad: f is NaN / Inf (every sample NaN); fx32: qualifies for the FX form
 
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float f, int state_slot) {
         double fd = (double)f;
@@ -151,7 +170,10 @@ struct JitOscK {
         P_init = (unsigned long long)(A.init_state[state_slot] * kJ36);
         q256 = jit_mulmod(q, kChunk, X.S, X.inv_S);
         P = addmod(P_init, jit_mulmod(q, X.n0(X.g_begin) + 1, X.S, X.inv_S), X.S);
-        whole = ((q | P_init) & kJMask) == 0ull;
+        q = jit_u(q);
+        q256 = jit_u(q256);
+        P_init = jit_u(P_init);
+        bad = jit_u(bad);
         fx32 = ((q | P_init) & 15ull) == 0ull;
         I = (uint32_t)(P >> kJFrac);
         F = (uint32_t)((P & kJMask) >> 4);
@@ -167,9 +189,10 @@ struct JitOscK {
         f = f2;
         i = i2;
     }
-    template <bool IN_LDS>
+    template <bool IN_LDS, bool FX>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
-        if (fx32) {
+        float ta[4], tb[4];
+        if (FX) {
             uint32_t iv[4], fv[4];
             iv[0] = I;
             fv[0] = F;
@@ -179,18 +202,12 @@ struct JitOscK {
                 fv[c] = fv[c - 1];
                 step32(iv[c], fv[c], qI, qF, X.sr);
             }
-            if (whole) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) out[c] = IN_LDS ? X.table.at(iv[c]) : gtab[iv[c]];
-            } else {
-                float ta[4], tb[4];
+            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, iv[c], ta[c], tb[c]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, iv[c], ta[c], tb[c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const double fraction = (double)fv[c] * (1.0 / 4294967296.0);
-                    out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
-                }
+            for (int c = 0; c < 4; ++c) {
+                const double fraction = (double)fv[c] * (1.0 / 4294967296.0);
+                out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
             }
             step32(I, F, cI, cF, X.sr);
         } else {
@@ -198,7 +215,6 @@ struct JitOscK {
             Pv[0] = P;
 #pragma unroll
             for (int c = 1; c < 4; ++c) Pv[c] = addmod(Pv[c - 1], q, X.S);
-            float ta[4], tb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
 #pragma unroll
@@ -208,10 +224,8 @@ struct JitOscK {
             }
             P = addmod(P, q256, X.S);
         }
-        if (bad) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[c] = __builtin_nanf("");
-        }
+        for (int c = 0; c < 4; ++c) out[c] = bad ? __builtin_nanf("") : out[c];
     }
     // the phase after ceil(n_samples / 256) ticks (state write-back)
     __device__ __forceinline__ double end_phase(const JitArgs &A, const JitCtx &X) const {
@@ -232,9 +246,9 @@ struct JitOscS {
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int op_index, bool accumulating) {
         carry = 0ull;
         poison = 0u;
-        if (X.n_seg == 1) carry = (unsigned long long)(A.init_state[state_slot] * kJ36);
+        if (X.n_seg == 1) carry = jit_u((unsigned long long)(A.init_state[state_slot] * kJ36));
         else if (!accumulating) {  // start phase known from the accumulate + prefix passes
-            const unsigned long long v = A.seg_start[((size_t)op_index * A.n_inst + X.inst) * X.n_seg + X.seg];
+            const unsigned long long v = jit_u(A.seg_start[((size_t)op_index * A.n_inst + X.inst) * X.n_seg + X.seg]);
             carry = v & ~(1ull << 63);
             poison = (uint32_t)(v >> 63);
         }
@@ -333,7 +347,7 @@ __device__ __forceinline__ void jit_ramp_end(const JitArgs &A, const JitCtx &X, 
 struct JitTimer {
     double t;  // value before the next chunk's first sample (uniform)
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double period, int state_slot) {
-        t = repeat_add(A.init_state[state_slot], period, (uint64_t)X.g_begin * kChunk);
+        t = jit_u(repeat_add(A.init_state[state_slot], period, (uint64_t)X.g_begin * kChunk));
     }
     __device__ __forceinline__ void tick(const JitCtx &X, double period, float (&out)[4]) {
         long long T, ce;
@@ -342,12 +356,12 @@ struct JitTimer {
             long long Tl = T + (long long)(X.lane * 4) * ce;
 #pragma unroll
             for (int c = 0; c < 4; ++c) out[c] = (float)ldexp((double)(Tl += ce), K - 52);
-            t = ldexp((double)(T + (long long)kChunk * ce), K - 52);
+            t = jit_u(ldexp((double)(T + (long long)kChunk * ce), K - 52));
         } else {
             double tt = repeat_add(t, period, (uint64_t)X.lane * 4);
 #pragma unroll
             for (int c = 0; c < 4; ++c) out[c] = (float)(tt = tt + period);
-            t = __shfl(tt, 63, 64);
+            t = jit_u(__shfl(tt, 63, 64));
         }
     }
 };
@@ -392,127 +406,157 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
     }
 }
 
-// ---- Filter (src/components/Filter.js:27-51) with an unconnected cutoff.  The feed-forward half (a0 x + a1 x1) + a2 x2 is
-// lane-parallel (neighbours by shuffle, the two samples before the chunk carried as scalars); the output recurrence
-// y = f32((P - b1 y1) - b2 y2) is serial, so the WAVES instances of a workgroup run theirs side by side: every wave parks
-// its P row in a shared LDS tile, wave 0 runs lane = instance over the rows (its lanes keep y1, y2 of "their" instance in
-// registers from chunk to chunk), every wave picks its Y row up again.  `tile` = Pt[WAVES][258] f64, then Yt[WAVES][260] f32,
-// then b[WAVES][2] f64 (per-instance b1, b2 for wave 0).
-template <int WAVES>
+// ---- Filter (src/components/Filter.js:27-51) with an unconnected cutoff.  y = f32((P - b1 y1) - b2 y2) with
+// P = (a0 x + a1 x1) + a2 x2 is a recurrence in y only.  P is lane-parallel (neighbours by shuffle, the two inputs before the
+// chunk carried as scalars); the recurrence is a dependent chain of five f64 operations per sample whatever the lane count,
+// so the WAVES x R instances of a workgroup run theirs side by side on the lanes of ONE wave: in sub-blocks of SUB samples
+// every wave parks its instances' P values (f64) in a shared LDS tile, wave 0 runs lane = instance over the rows — nothing
+// but the chain: P values pulled into registers 16 at a time, y written as f32 over the P values already consumed — and
+// every wave picks its rows up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of
+// "its" lane of wave 0 for the whole render.
+//   tile: rows of SUB + 2 doubles, row = wave R + r;  SUB = 256, 128 or 64 by what LDS holds next to the table image
+template <int WAVES, int R, int SUB>
 struct JitFilterK {
-    double k[5];      // a0 a1 a2 b1 b2 of THIS wave's instance (uniform)
-    double x1, x2;    // the two inputs before the chunk (uniform)
-    double y1, y2;    // wave 0: the recurrence's memory of instance `lane` of the workgroup; else unused
-    double b1r, b2r;  // wave 0: that instance's b1, b2
-    double lastF;
+    static constexpr int kPitch = SUB + 2;  // doubles per row
+    double a[R][3], x1[R], x2[R];           // this wave's instances: a0 a1 a2, the two inputs before the chunk (wave-uniform)
+    double k[5], y1, y2, lastF;             // wave 0, lane = row: that instance's coefficients and recurrence memory
 
-    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, char *tile, int kind, float f, int state_slot) {
+    // fr: the cutoff of the instance THIS LANE serves in wave 0 (a constant, or that instance's parameter: jit_row_param)
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int kind, float fr, int state_slot) {
         const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
-        const double ft = (double)f;
+        const double ft = (double)fr;
         if (is[0] == 0.0 || ft != is[1]) jit_filter_coefficients(kind, ft, X.srd, k);  // `if (this.f[t] != this.lastF)`
         else {
             k[0] = is[2]; k[1] = is[3]; k[2] = is[4]; k[3] = is[5]; k[4] = is[6];
         }
         lastF = ft;
-        x1 = is[7];
-        x2 = is[8];
         y1 = is[9];
         y2 = is[10];
-        double *bt = (double *)(tile + (size_t)WAVES * (258 * 8 + 260 * 4));
-        if (X.lane == 0) {
-            bt[X.wave * 2] = k[3];
-            bt[X.wave * 2 + 1] = k[4];
-        }
-        jit_lds_barrier();
-        b1r = bt[(X.lane < WAVES ? X.lane : 0) * 2];
-        b2r = bt[(X.lane < WAVES ? X.lane : 0) * 2 + 1];
-        jit_lds_barrier();  // (the next Filter's begin() reuses bt)
     }
-    __device__ __forceinline__ void tick(const JitCtx &X, char *tile, const float (&x)[4], float (&out)[4]) {
-        double *Pt = (double *)tile;
-        float *Yt = (float *)(Pt + WAVES * 258);
-        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
-        double xm1 = X.lane == 0 ? x1 : (double)xl1, xm2 = X.lane == 0 ? x2 : (double)xl2;
-        double *prow = Pt + X.wave * 258;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double xin = (double)x[c];
-            prow[X.lane * 4 + c] = (k[0] * xin + k[1] * jit_or0(xm1)) + k[2] * jit_or0(xm2);
-            xm2 = jit_or0(xm1);
-            xm1 = xin;
+    // f: the cutoff of the wave's instance in slot r
+    __device__ __forceinline__ void begin_slot(const JitArgs &A, const JitCtx &X, int r, int kind, float f, int state_slot) {
+        const double *is = A.init_state + state_slot;
+        double kk[5];
+        const double ft = (double)f;
+        if (is[0] == 0.0 || ft != is[1]) jit_filter_coefficients(kind, ft, X.srd, kk);
+        else {
+            kk[0] = is[2]; kk[1] = is[3]; kk[2] = is[4];
         }
-        // the chunk's last two inputs, for the next chunk's first lanes (lane 63 holds them)
-        x1 = __shfl(xm1, 63, 64);
-        x2 = __shfl(xm2, 63, 64);
-        jit_lds_barrier();
-        if (X.wave == 0 && X.lane < WAVES) {
-            const double *pr = Pt + X.lane * 258;
-            f32x4 *yr = (f32x4 *)(Yt + X.lane * 260);
-            // The `|| 0` selects of Filter.js:42-46 are speculated away: without them a NaN never leaves the recurrence, so testing
-            // a block's last outputs finds one anywhere in it (the block is then redone exactly); a -0 in place of +0 can only flip
-            // the sign of a later zero, which every consumer maps to +0 (see loop2_engine.hip).
-            constexpr int PB = 16;
-            for (int t0 = 0; t0 < kChunk; t0 += PB) {
-                double pv[PB];
+        a[r][0] = jit_u(kk[0]); a[r][1] = jit_u(kk[1]); a[r][2] = jit_u(kk[2]);
+        x1[r] = jit_u(is[7]);
+        x2[r] = jit_u(is[8]);
+    }
+    // once per chunk and slot: the two inputs before this lane's first sample (neighbour lanes, or the carried scalars)
+    struct Edge { float m1, m2; };
+    __device__ __forceinline__ Edge edge(const JitCtx &X, int r, const float (&x)[4]) {
+        Edge e;
+        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
+        // (the carried values are f32-valued: inputs are chunk samples, and `x2 || 0` only ever maps to +0)
+        e.m1 = X.lane == 0 ? (float)x1[r] : xl1;
+        e.m2 = X.lane == 0 ? (float)x2[r] : (float)jit_or0((double)xl2);
+        const double last1 = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        const double last2 = jit_or0((double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
+        x1[r] = last1;  // the chunk's last two inputs, for the next chunk's first lane: x1 as it is, x2 through `|| 0` (Filter.js:48-49)
+        x2[r] = last2;
+        return e;
+    }
+    // sub-block s: the lanes that own its samples compute the feed-forward half of theirs and park it
+    __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const float (&x)[4], const Edge &e) const {
+        const int first = s * (SUB / 4);
+        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+            double *row = tile + (size_t)(X.wave * R + r) * kPitch + ((int)X.lane - first) * 4;
+            double xm1 = (double)e.m1, xm2 = (double)e.m2;
 #pragma unroll
-                for (int i = 0; i < PB; ++i) pv[i] = pr[t0 + i];
-                __builtin_amdgcn_sched_barrier(0);
-                const double y1_in = y1, y2_in = y2;
-                double u1 = jit_or0(y1), u2 = jit_or0(y2);
-                f32x4 y4[PB / 4];
-#pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const float y = (float)((pv[i] - b1r * u1) - b2r * u2);
-                    y4[i >> 2][i & 3] = y;
-                    u2 = u1;
-                    u1 = (double)y;
-                }
-                if (u1 == u1 && u2 == u2) {
-                    y1 = u1;
-                    y2 = u2;
-                } else {
-                    y1 = y1_in;
-                    y2 = y2_in;
-#pragma unroll
-                    for (int i = 0; i < PB; ++i) {
-                        const float y = (float)((pv[i] - b1r * jit_or0(y1)) - b2r * jit_or0(y2));  // Filter.js:40-46
-                        y4[i >> 2][i & 3] = y;
-                        y2 = jit_or0(y1);
-                        y1 = (double)y;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
+            for (int c = 0; c < 4; ++c) {
+                const double xin = (double)x[c];
+                row[c] = (a[r][0] * xin + a[r][1] * jit_or0(xm1)) + a[r][2] * jit_or0(xm2);
+                xm2 = jit_or0(xm1);
+                xm1 = xin;
             }
         }
-        jit_lds_barrier();
-        const f32x4 yv = *(const f32x4 *)(Yt + X.wave * 260 + X.lane * 4);
-        out[0] = yv[0]; out[1] = yv[1]; out[2] = yv[2]; out[3] = yv[3];
     }
-    // state write-back: coefficients and input history by each wave's lane 0, the recurrence's memory by wave 0's lanes
-    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) {
-        if (X.live && X.lane == 0) {
-            double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
-            st[0] = 1.0;
-            st[A.n_pad] = lastF;
-            for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
-            st[(size_t)7 * A.n_pad] = x1;
-            st[(size_t)8 * A.n_pad] = x2;
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
+        const int first = s * (SUB / 4);
+        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+            const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
+            out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
         }
-        const uint32_t mine = blockIdx.x * WAVES + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
-        if (X.wave == 0 && X.lane < WAVES && mine < A.n_inst) {
-            double *st = A.state + (size_t)state_slot * A.n_pad + mine;
-            st[(size_t)9 * A.n_pad] = y1;
-            st[(size_t)10 * A.n_pad] = y2;
+    }
+    // between two barriers: SUB samples of the recurrence of every row
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile) {
+        if (X.wave != 0 || X.lane >= WAVES * R) return;
+        const double *pr = tile + (size_t)X.lane * kPitch;
+        f32x4 *yr = (f32x4 *)pr;
+        const double b1 = k[3], b2 = k[4];
+        // The `|| 0` selects of Filter.js:42-46 on y1 / y2 are speculated away: without them a NaN never leaves the recurrence, so
+        // testing a block's last outputs finds one anywhere in it (the block is then redone exactly); a -0 in place of +0 can only
+        // flip the sign of a later zero, which every consumer maps to +0 (see loop2_engine.hip).
+        constexpr int PB = 8;  // (registers: the kernel is built for 16 wavefronts of 128 VGPRs, several instances each)
+        for (int t0 = 0; t0 < SUB; t0 += PB) {
+            double pv[PB];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) pv[i] = pr[t0 + i];
+            __builtin_amdgcn_sched_barrier(0);
+            const double y1_in = y1, y2_in = y2;
+            double u1 = jit_or0(y1), u2 = jit_or0(y2);
+            f32x4 y4[PB / 4];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const float y = (float)((pv[i] - b1 * u1) - b2 * u2);
+                y4[i >> 2][i & 3] = y;
+                u2 = u1;
+                u1 = (double)y;
+            }
+            if (u1 == u1 && u2 == u2) {
+                y1 = u1;
+                y2 = u2;
+            } else {
+                y1 = y1_in;
+                y2 = y2_in;
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const float y = (float)((pv[i] - b1 * jit_or0(y1)) - b2 * jit_or0(y2));  // Filter.js:40-46
+                    y4[i >> 2][i & 3] = y;
+                    y2 = jit_or0(y1);
+                    y1 = (double)y;
+                }
+            }
+            // y of samples t0 .. t0+7 goes where P of samples t0/2 .. t0/2+3 stood: read already (this block's are in registers)
+#pragma unroll
+            for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
         }
+    }
+    // state write-back: the input history by each wave (slot r), coefficients and recurrence memory by the lanes that hold them
+    __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
+        if (!X.live || X.lane != 0) return;
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[(size_t)7 * A.n_pad] = x1[r];
+        st[(size_t)8 * A.n_pad] = x2[r];
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
+        if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst) return;
+        double *st = A.state + (size_t)state_slot * A.n_pad + inst;
+        st[0] = 1.0;
+        st[A.n_pad] = lastF;
+        for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
+        st[(size_t)9 * A.n_pad] = y1;
+        st[(size_t)10 * A.n_pad] = y2;
     }
 };
+// parameter `slot` of the instance lane `lane` of wave 0 serves in the Filter stage
+template <int WAVES, int R>
+__device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X, uint32_t slot) {
+    const uint32_t inst = min(blockIdx.x * (WAVES * R) + X.lane, A.n_inst - 1);
+    return A.params[(size_t)slot * A.n_inst + inst];
+}
+
 // ---- Delay (src/components/Delay.js:20-41) with a constant delay D + phi, 256 <= D <= len - 256: the chunk's 256 reads are one
 // coalesced load from the ring ([instance][slot] in HBM), reads and writes of one chunk never meet, and every slot's final
 // value (ceil tap of sample n-1, then floor tap of sample n, with the reference's two `+=` roundings) is written once.
 struct JitDelayK {
     double carried;  // the input sample before the chunk (uniform)
-    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { carried = A.init_state[state_slot]; }
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { carried = jit_u(A.init_state[state_slot]); }
     __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, int64_t ring_base, int64_t len, float delay, const float (&x)[4],
                                          float (&out)[4]) {
         double dconst = (double)delay;
@@ -546,7 +590,7 @@ struct JitDelayK {
             }
             if (X.live) ring[lo] = slot;
         }
-        carried = (double)__shfl(x[3], 63, 64);
+        carried = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
     }
 };
 

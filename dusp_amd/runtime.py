@@ -82,7 +82,7 @@ def load():
     L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
     L.dusp_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.dusp_host_free.argtypes = [vp, vp]
-    L.dusp_circuit_kernel_source.argtypes = [vp, sz, ci, ci, ci, ctypes.c_char_p, sz]
+    L.dusp_circuit_kernel_source.argtypes = [vp, sz, ci, ci, ci, ci, ctypes.c_char_p, sz]
     _lib = L
     return L
 
@@ -103,13 +103,13 @@ class _PinnedBlock:
             pass
 
 
-def circuit_kernel_source(words, waves=16, lds_table=True, compile=False):
+def circuit_kernel_source(words, waves=16, per_wave=1, lds_table=True, compile=False):
     """HIP text of the kernel the circuit compiler generates for a descriptor (dusp_circuit_kernel_source; needs no GPU).
     Raises DuspHipError(-2) for circuits that stay on the interpreter."""
     L = load()
     words = np.ascontiguousarray(words, dtype=np.float64)
     buf = ctypes.create_string_buffer(1 << 20)
-    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, int(lds_table), int(compile), buf, len(buf))
+    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, per_wave, int(lds_table), int(compile), buf, len(buf))
     if n < 0:
         raise DuspHipError(n, L.dusp_last_error(None).decode())
     return buf.value.decode()

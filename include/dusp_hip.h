@@ -206,13 +206,14 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
  * order, operands in registers — compiled for gfx950 in process (hiprtc) the first time a circuit structure is rendered and
  * cached afterwards.  This call returns that kernel's HIP text for a descriptor (for inspection, and so that the generator
  * and the run-time compiler can be tested without a GPU):
- *   waves      wavefronts per workgroup the text is generated for (1, 2, 4, 8, 16)
+ *   waves      wavefronts per workgroup the text is generated for (1 .. 16)
+ *   per_wave   circuit instances per wavefront (1 .. 4; renders that are split in time use 1)
  *   lds_table  non-zero: assume the oscillators' first wave table is antisymmetric (half image in LDS), as a context would find
  *   compile    non-zero: also compile the text for gfx950
  *   text, cap  receives at most cap - 1 characters, NUL-terminated (cap 0: nothing is copied)
  * Returns the length of the text, DUSP_ERR_UNSUPPORTED when the circuit stays on the interpreter (dusp_last_error(NULL) says
  * why), or another negative dusp_status. */
-int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int lds_table, int compile, char *text, size_t cap);
+int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int per_wave, int lds_table, int compile, char *text, size_t cap);
 
 /* Duration in milliseconds of the most recent render's kernel(s) on this
  * program, measured with HIP events on the launch stream (synchronises). */

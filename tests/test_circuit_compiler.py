@@ -26,8 +26,9 @@ def test_golden_circuits_compile_for_gfx950(name):
     assert "dusp_jit_render" in text and '#include "jit_prelude.hpp"' in text
     # one statement block per channel-expanded unit, in process order: every outlet buffer is declared exactly once per kernel
     render = text.split('extern "C"')[1]
-    bufs = re.findall(r"float (v\d+)\[4\];", render)
-    assert len(bufs) == len(set(bufs)) >= 1
+    # (the chunk loop stands twice in a kernel: constant-f oscillators in 32.32 fixed point / in the general form)
+    bufs = re.findall(r"float (v\d+_\d+)\[4\];", render)
+    assert len(bufs) == 2 * len(set(bufs)) >= 2
 
 
 def test_what_the_compiler_takes_and_what_stays_on_the_interpreter():
@@ -63,7 +64,7 @@ def test_kernel_text_depends_on_structure_not_on_constants():
     # a per-instance parameter instead of a constant is another structure too (pN instead of kN)
     uni = descriptor.unify([descriptor.extract(voice(f, 5, 40, 0.5, 48000)) for f in (220, 330)])
     p = source(uni.words)
-    assert p != a and "jit_param(A, X, 0)" in p
+    assert p != a and "jit_param(A, X[0], 0)" in p
 
 
 def test_fm_levels_get_their_accumulate_passes():
@@ -84,16 +85,31 @@ def test_fm_levels_get_their_accumulate_passes():
 def test_feedback_edges_read_last_iterations_registers():
     g = Golden("loop_220")
     text = source(g.desc, waves=8)
-    late = set(re.findall(r"float (w\d+)\[4\] = \{0\.f", text))
+    late = set(re.findall(r"float (w\d+_0)\[4\] = \{0\.f", text))
     assert len(late) == 1                                        # the loop's one back edge: the Filter's previous chunk
     w = late.pop()
     assert re.search(r"%s\[c\] = v%s\[c\]" % (w, w[1:]), text)   # carried over at the end of the iteration
-    assert "JitFilterK<8>" in text and "JitDelayK" in text
+    assert "JitFilterK<8, 1, 256>" in text and "JitDelayK" in text
+
+
+def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
+    """per_wave instances per wavefront: every unit block stands per_wave times — except units that compute the same chunk for
+    every instance (here the envelope: constants and time only), which are emitted once and read by all."""
+    d.configure(48000)
+    uni = descriptor.unify([descriptor.extract(d.Filter(d.Multiply(d.Osc(110 + k), d.Ramp(48000, 1, 0).trigger()), 800)) for k in (0, 8)])
+    text = source(uni.words, waves=16, per_wave=3, compile=True)
+    fast = text.split("} else {")[0]
+    assert fast.count("jit_ramp<") == 1 and fast.count(".tick<true, true>") == 3   # one envelope, three oscillators
+    # 48 recurrences side by side on wave 0, in two sub-blocks of 128 samples (what LDS holds next to the table image)
+    assert fast.count("f3.edge(") == 3 and fast.count("f3.park(") == 6 and fast.count("f3.serial(") == 2 and fast.count("f3.pick(") == 6
+    assert "JitFilterK<16, 3, 128>" in text and "dusp_jit_pass" not in text
+    with pytest.raises(runtime.DuspHipError, match="per_wave"):
+        source(uni.words, waves=16, per_wave=5)
 
 
 def test_bad_arguments_come_back_as_statuses():
     g = Golden("osc440_1s")
     with pytest.raises(runtime.DuspHipError, match="waves must be"):
-        source(g.desc, waves=3)
+        source(g.desc, waves=17)
     with pytest.raises(runtime.DuspHipError, match="magic"):
         source(np.zeros(40))

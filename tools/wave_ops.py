@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-unit cost on the wave engine: small graphs forced onto ENGINE_WAVE, 16384 instances x 1 s (time split off)."""
+"""Per-unit cost on the wave engine: small graphs forced onto ENGINE_WAVE, 16384 instances x 1 s (time split off).
+  python tools/wave_ops.py [--only=name,name]"""
 import os
 import sys
 
@@ -28,7 +29,10 @@ graphs = {
     "filter(osc)": lambda k: d.Filter(d.Osc(110 + k / 8), 800),
     "allpass(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.AllPass(0.0021, 0.6)),
 }
+only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 for name, g in graphs.items():
+    if only and name not in only[0].split(","):
+        continue
     full = descriptor.unify([descriptor.extract(g(k)) for k in (0, 8, 16)])
     base = full.params[:, 0].astype(np.float64)
     step = (full.params[:, 1].astype(np.float64) - base) / 8.0
@@ -45,6 +49,7 @@ for name, g in graphs.items():
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
+    prog._read_info()
     print("%-22s %8.3f ms  %8.1f Gsamples/s   [%s]" % (name, ms, V * n / ms / 1e6, prog.shape), flush=True)
     prog.close()
     del out
