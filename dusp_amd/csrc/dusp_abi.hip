@@ -628,11 +628,14 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
     dusp::JitOptions opt;
-    const int t = prog->wave.lds_table_id;
-    if (t >= 0 && ctx->table_antisym[t] && P.g.sample_rate % 2 == 0) {
-        opt.lds_table = t;
-        opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
-    }
+    for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
+    // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
+    for (const dusp::DevOp &op : P.ops)
+        if (op.op == dusp::OP_OSC && opt.lds_table < 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
+            !(ctx->table_form[op.attr] >= dusp::TABLE_FORM_SAW && ctx->table_form[op.attr] <= dusp::TABLE_FORM_TRIANGLE)) {
+            opt.lds_table = ctx->table_form[op.attr] == dusp::TABLE_FORM_8BIT && ctx->table_antisym[0] ? 0 : op.attr;  // (the sine image serves 8bit too)
+            opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
+        }
     const size_t budget = 160 * 1024;
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
@@ -678,7 +681,12 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
         if (scratch <= 32) break;  // (a register or two spilled outside the hot path is cheaper than halving the instances in flight)
-        if (per_wave > 1) per_wave--;
+        // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
+        // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
+        if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
+            waves /= 2;
+            per_wave *= 2;
+        } else if (per_wave > 1) per_wave--;
         else if (waves > 4) waves /= 2;
         else break;
         if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget - opt.table_bytes);
@@ -770,6 +778,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         L.table_antisym = ctx->table_antisym[prog->fused.table_id];
         L.table_finite = ctx->table_finite[prog->fused.table_id];
         L.table_fx32_ok = ctx->table_fx32_ok[prog->fused.table_id];
+        L.table_form = ctx->table_form[prog->fused.table_id];
         L.knobs = ctx->knobs;
         HIP_TRY(ctx, prog->d_recs.ensure(n_inst));
         L.recs = prog->d_recs.p;
@@ -1269,9 +1278,16 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     dusp::JitOptions opt;
     opt.waves = waves;
     opt.per_wave = per_wave;
-    if (lds_table && plan.lds_table_id >= 0 && P.g.sample_rate % 2 == 0) {
-        opt.lds_table = plan.lds_table_id;
-        opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
+    if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
+        opt.table_form[1] = dusp::TABLE_FORM_SAW;
+        opt.table_form[2] = dusp::TABLE_FORM_SQUARE;
+        if (P.g.sample_rate % 4 == 0) opt.table_form[3] = dusp::TABLE_FORM_TRIANGLE;
+        opt.table_form[4] = dusp::TABLE_FORM_8BIT;
+        for (const dusp::DevOp &op : P.ops)
+            if (op.op == dusp::OP_OSC && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
+                opt.lds_table = 0;
+                opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
+            }
     }
     if (plan.has_filter) {
         opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, 160 * 1024 - opt.table_bytes);

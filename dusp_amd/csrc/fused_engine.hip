@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
     table.h = lds_table;
     table.N = A.sample_rate + 1;
     table.M = A.sample_rate / 2;
+    table.form = make_table_form(A.table_form, A.sample_rate);
     if (TBL == 1) load_half_table<BLOCK>(lds_table, A.table, A.sample_rate);
     const uint32_t lane = threadIdx.x & 63u;
     constexpr uint32_t waves_per_block = BLOCK / 64;
@@ -406,8 +407,10 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     A.seg_major = L.knobs.fused_segmajor;
 
     int tbl = (L.table_antisym && L.sample_rate % 2 == 0) ? 1 : 0;
+    if (L.table_form >= TABLE_FORM_SAW && L.table_form <= TABLE_FORM_TRIANGLE) tbl = 2;  // no table at all: a closed form of the index
+    A.table_form = L.table_form;
     if (L.knobs.fused_table_global) tbl = 0;
-    const size_t lds_bytes = tbl ? half_table_lds_bytes(L.sample_rate) : 0;
+    const size_t lds_bytes = tbl == 1 ? half_table_lds_bytes(L.sample_rate) : 0;
     if (lds_bytes > 160 * 1024) tbl = 0;
 
     // R voices per item share one Ramp evaluation per step; without a Ramp there is nothing to share
@@ -415,8 +418,8 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     if (R != 1 && R != 4 && R != 8) R = 4;
     // Items: (voice block, segment).  Aim at `per_wave` equal items for every resident wave so that all
     // waves finish together; segments of at least 16 steps keep the per-item jump-ahead negligible.
-    const int block = tbl ? 1024 : 256;
-    const int grid = tbl ? L.n_cus : L.n_cus * 8;
+    const int block = tbl == 1 ? 1024 : 256;
+    const int grid = tbl == 1 ? L.n_cus : L.n_cus * 8;
     const uint64_t total_waves = (uint64_t)grid * (block / 64);
     const uint64_t n_blk = (A.n_inst + R - 1) / R;
     const uint64_t per_wave = (uint64_t)std::max(1, L.knobs.fused_items);
@@ -434,10 +437,12 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     if (e != hipSuccess) return e;
 
 #define DUSP_L3(KIND, RR, FD, FIN) \
-    return tbl ? launch_one<KIND, 1, RR, FD, FIN, 1024>(A, L.recs, grid, lds_bytes, stream) \
-               : launch_one<KIND, 0, RR, FD, FIN, 256>(A, L.recs, grid, 0, stream)
+    return tbl == 1 ? launch_one<KIND, 1, RR, FD, FIN, 1024>(A, L.recs, grid, lds_bytes, stream) \
+                    : launch_one<KIND, 0, RR, FD, FIN, 256>(A, L.recs, grid, 0, stream)
+    // (the closed-form variants exist for 4 voices per item only)
 #define DUSP_L2(KIND, FD, FIN) \
-    do { if (R == 8) { DUSP_L3(KIND, 8, FD, FIN); } if (R == 4) { DUSP_L3(KIND, 4, FD, FIN); } DUSP_L3(KIND, 1, FD, FIN); } while (0)
+    do { if (tbl == 2) return launch_one<KIND, 2, 4, FD, FIN, 256>(A, L.recs, grid, 0, stream); \
+         if (R == 8) { DUSP_L3(KIND, 8, FD, FIN); } if (R == 4) { DUSP_L3(KIND, 4, FD, FIN); } DUSP_L3(KIND, 1, FD, FIN); } while (0)
     switch (plan.kind) {
     case FUSED_OSC:
         if (finite) DUSP_L2(FUSED_OSC, false, true);

@@ -152,6 +152,7 @@ struct FusedLaunch {
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
     bool table_antisym, table_finite, table_fx32_ok;
+    int table_form;  // TABLE_FORM_* (device_util.hpp): saw / square / triangle are evaluated from the index instead of gathered
     Knobs knobs;
 };
 
@@ -171,7 +172,8 @@ struct FusedArgs {
     const float *s_table;  // row of the Shape's table
     double s_t0, s_c, s_left, s_right;  // edges as values of the 0..1 shape, unless they are "shape" (= the table's end values)
     float s_min, s_max;
-    int32_t s_playing, s_finished, shape_state_word, s_left_is_shape, s_right_is_shape, pad3;
+    int32_t s_playing, s_finished, shape_state_word, s_left_is_shape, s_right_is_shape;
+    int32_t table_form;  // TABLE_FORM_* of the Osc's table (kernels instantiated with TBL == 2 evaluate it)
 };
 
 // q' of Markstein's division-by-reciprocal: q = t*r; rem = fma(-q, d, t); q' = fma(rem, r, q).

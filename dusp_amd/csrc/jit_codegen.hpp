@@ -42,7 +42,18 @@ struct JitOptions {
     int lds_table = -1;      // table id whose half image sits in LDS, or -1
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
+    int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
 };
+
+// Where an oscillator's table comes from in a generated kernel (jit_prelude.hpp jit_pair): 1 the LDS half image, 2 a closed form
+// of the index, 3 8bit derived from the sine image, 0 a gather from L2.
+inline int jit_table_source(const JitOptions &opt, int table_id) {
+    if (opt.lds_table == table_id) return 1;
+    const int form = opt.table_form[table_id];
+    if (form == 1 || form == 2 || form == 3) return 2;  // TABLE_FORM_SAW / SQUARE / TRIANGLE
+    if (form == 4 && opt.lds_table == 0) return 3;       // TABLE_FORM_8BIT next to the sine image
+    return 0;
+}
 
 // LDS of one workgroup of the generated kernel: the table image, then the Filter stage's tile — one 260-float row per
 // instance of the workgroup (the input chunk on the way in, the output chunk on the way out).  Declared statically in the
@@ -156,7 +167,7 @@ struct Emitter {
         line("        const float " + tmp + "[4] = {" + sc + ", " + sc + ", " + sc + ", " + sc + "};");
         return tmp;
     }
-    std::string in_lds(int table_id) const { return opt.lds_table == table_id ? "true" : "false"; }
+    std::string in_lds(int table_id) const { return num(jit_table_source(opt, table_id)) + ", " + num(opt.table_form[table_id]); }
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }

@@ -132,11 +132,24 @@ __device__ __forceinline__ long long jit_fix36(float f) {
     return (bits >> 31) ? -(long long)mag : (long long)mag;
 }
 
-// One table lookup pair (T[idx], T[idx + 1]): from the LDS half-table image when the kernel carries this table, else from L2.
-template <bool IN_LDS>
+// One table lookup pair (T[idx], T[idx + 1]).  TF says where this oscillator's table comes from:
+//   0  gathered from L2 (a table that is neither antisymmetric nor a closed form)
+//   1  the LDS half-table image the kernel carries (antisymmetric tables: sine, 8bit)
+//   2  no table: saw / square / triangle evaluated from the index (FORM = TABLE_FORM_*; the host has checked every entry)
+//   3  8bit evaluated from the SINE image in LDS (circuits that mix sine and 8bit oscillators)
+template <int TF, int FORM>
 __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uint32_t idx, float &a, float &b) {
-    if (IN_LDS) X.table.pair(idx, a, b);
-    else {
+    if (TF == 1) X.table.pair(idx, a, b);
+    else if (TF == 2) {
+        const TableForm F = make_table_form(FORM, X.sr);
+        a = closed_table_entry(F, idx);
+        b = closed_table_entry(F, idx + 1 <= X.sr ? idx + 1 : X.sr);  // (the table's pad entry repeats its last one)
+    } else if (TF == 3) {
+        float sa, sb;
+        X.table.pair(idx, sa, sb);
+        a = eightbit_of_sine(sa);
+        b = eightbit_of_sine(sb);
+    } else {
         a = gtab[idx];
         b = gtab[idx + 1];
     }
@@ -189,7 +202,7 @@ struct JitOscK {
         f = f2;
         i = i2;
     }
-    template <bool IN_LDS, bool FX>
+    template <int TF, int FORM, bool FX>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
         float ta[4], tb[4];
         if (FX) {
@@ -203,7 +216,7 @@ struct JitOscK {
                 step32(iv[c], fv[c], qI, qF, X.sr);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, iv[c], ta[c], tb[c]);
+            for (int c = 0; c < 4; ++c) jit_pair<TF, FORM>(X, gtab, iv[c], ta[c], tb[c]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double fraction = (double)fv[c] * (1.0 / 4294967296.0);
@@ -216,7 +229,7 @@ struct JitOscK {
 #pragma unroll
             for (int c = 1; c < 4; ++c) Pv[c] = addmod(Pv[c - 1], q, X.S);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
+            for (int c = 0; c < 4; ++c) jit_pair<TF, FORM>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
@@ -253,7 +266,7 @@ struct JitOscS {
             poison = (uint32_t)(v >> 63);
         }
     }
-    template <bool IN_LDS, bool LOOKUP>
+    template <int TF, int FORM, bool LOOKUP>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, const float (&f)[4], float (&out)[4]) {
         long long qv[4];
         bool bad = false, big = false;
@@ -290,7 +303,7 @@ struct JitOscS {
         if (LOOKUP) {  // all the lookups of the chunk first, then the lerps
             float ta[4], tb[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) jit_pair<IN_LDS>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
+            for (int c = 0; c < 4; ++c) jit_pair<TF, FORM>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
@@ -496,7 +509,7 @@ struct JitFilterK {
             double pv[PB];
 #pragma unroll
             for (int i = 0; i < PB; ++i) pv[i] = pr[t0 + i];
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);  // (an LDS read left on the chain costs ~100 cycles: all of the block's first)
             const double y1_in = y1, y2_in = y2;
             double u1 = jit_or0(y1), u2 = jit_or0(y2);
             f32x4 y4[PB / 4];

@@ -99,7 +99,7 @@ def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     uni = descriptor.unify([descriptor.extract(d.Filter(d.Multiply(d.Osc(110 + k), d.Ramp(48000, 1, 0).trigger()), 800)) for k in (0, 8)])
     text = source(uni.words, waves=16, per_wave=3, compile=True)
     fast = text.split("} else {")[0]
-    assert fast.count("jit_ramp<") == 1 and fast.count(".tick<true, true>") == 3   # one envelope, three oscillators
+    assert fast.count("jit_ramp<") == 1 and fast.count(".tick<1, 0, true>") == 3   # one envelope, three oscillators
     # 48 recurrences side by side on wave 0, in two sub-blocks of 128 samples (what LDS holds next to the table image)
     assert fast.count("f3.edge(") == 3 and fast.count("f3.park(") == 6 and fast.count("f3.serial(") == 2 and fast.count("f3.pick(") == 6
     assert "JitFilterK<16, 3, 128>" in text and "dusp_jit_pass" not in text
@@ -113,3 +113,17 @@ def test_bad_arguments_come_back_as_statuses():
         source(g.desc, waves=17)
     with pytest.raises(runtime.DuspHipError, match="magic"):
         source(np.zeros(40))
+
+
+def test_saw_square_triangle_are_evaluated_not_looked_up():
+    """The reference's saw, square and triangle tables (waveTables.js:10-26) are functions of the index: kernels evaluate them
+    (table source 2) instead of gathering from a 192 KB table that does not fit LDS; sine and 8bit come from the LDS half image."""
+    d.configure(48000)
+    mix = d.Sum(d.Sum(d.Osc(110, "saw"), d.Osc(220, "square")), d.Sum(d.Osc(330, "triangle"), d.Sum(d.Osc(440), d.Osc(550, "8bit"))))
+    text = source(descriptor.extract(mix).words, waves=4, compile=True)
+    fast = text.split("} else {")[0]
+    for args in ("tick<2, 1, true>", "tick<2, 2, true>", "tick<2, 3, true>", "tick<1, 0, true>", "tick<3, 4, true>"):
+        assert fast.count(args) == 1, args
+    # without a context's verdict on the tables nothing is assumed: everything is gathered
+    plain = source(descriptor.extract(mix).words, waves=4, lds_table=False)
+    assert "tick<0, 0, true>" in plain and "tick<2," not in plain

@@ -50,14 +50,17 @@ def main():
     cfgs["cfg3b_sum1024"] = (lambda: uni_of([d.Sum.many([d.Osc(10 * k) for k in range(1, 1025)])]), T60, None)
     cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
                              (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
+    cfgs["cfg4_loop8192_compiled"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_WAVE)
     cfgs["cfg5_shard8192"] = (lambda: uni_of([d.Multiply(d.Osc(20 + k / 8), d.Ramp(T1, 1, 0).trigger()) for k in (0, 1)]), T1,
                               (20 + np.arange(8192) / 8.0).astype(np.float32).reshape(1, -1))
-    for name, (build, n, params) in cfgs.items():
+    for name, cfg in cfgs.items():
+        build, n, params = cfg[:3]
+        engine = cfg[3] if len(cfg) > 3 else runtime.ENGINE_AUTO
         if args.only and name not in args.only.split(","):
             continue
         t0 = time.time()
         uni = build()
-        prog = ctx.build(uni.words)
+        prog = ctx.build(uni.words, engine)
         n_inst = params.shape[1] if params is not None else 1
         dp = torch.from_numpy(params).cuda() if params is not None else None
         out = torch.empty((n_inst, prog.n_out_channels, n), dtype=torch.float32, device="cuda")
@@ -71,6 +74,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         ms = float(np.median(ts))
+        prog._read_info()
         samples = float(n_inst) * prog.n_out_channels * n
         print("%-16s engine=%-5s %-18s inst=%-6d n=%-8d  %10.3f ms  %12.1f Msamples/s out  %8.1f GB/s  (host build %.2fs)"
               % (name, prog.engine, prog.shape, n_inst, n, ms, samples / ms / 1e3, 4 * samples / ms / 1e6, host_s), flush=True)
