@@ -101,6 +101,9 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
         case OP_TIMER:
             if (!(P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300)) return no("a Timer outside the closed-form regime");
             break;
+        case OP_SHAPE:  // the running sum t += 1 / duration in closed form where it applies (the kernel checks, per instance)
+            if (op.in[0].kind == SRC_BUF) return no("a Shape with a connected duration");
+            break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
             return no("a unit the circuit compiler does not emit yet");
@@ -138,6 +141,7 @@ struct Emitter {
         case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
         case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
         case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
+        case OP_SHAPE: return j < 3;
         default:
             if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
             return j < 2;
@@ -253,6 +257,10 @@ struct Emitter {
                     line("    JitTimer c" + id + ";");
                     line("    c" + id + ".begin(A, " + ctx(r) + ", d" + num(dconst_of[(size_t)k]) + ", " + num(op.state_slot) + ");");
                     break;
+                case OP_SHAPE:
+                    line("    JitShape s" + id + ";");
+                    line("    s" + id + ".begin(A, " + ctx(r) + ", " + opnd(k, 0, "0", r) + ", " + num(op.state_slot) + ");");
+                    break;
                 default: break;
                 }
             }
@@ -292,6 +300,7 @@ struct Emitter {
                     if (op.op == OP_TIMER)
                         line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
                     if (op.op == OP_DELAY) line("        " + slot + " = y" + id + ".carried;");
+                    if (op.op == OP_SHAPE) line("        s" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                 }
                 line("    }");
             }
@@ -381,6 +390,12 @@ struct Emitter {
                 decl();
                 line("        jit_input(A, " + X_ + ", g, " + num(op.attr) + ", " + v + ");");
                 break;
+            case OP_SHAPE: {
+                decl();
+                const std::string mn = opnd_array(k, 1, "tn" + id, r), mx = opnd_array(k, 2, "tx" + id, r);
+                line("        s" + id + ".tick(" + X_ + ", " + table_row(op.attr & 255) + ", " + num(op.attr) + ", " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", " + mn + ", " + mx + ", " + v + ");");
+                break;
+            }
             case OP_DELAY: {
                 decl();
                 const std::string x = opnd_array(k, 0, "t" + id, r);
@@ -433,6 +448,9 @@ struct Emitter {
             } else if (op.op == OP_DELAY) {
                 dconst_of[k] = add_dk((double)op.ring_base);
                 add_dk((double)op.ring_len);
+            } else if (op.op == OP_SHAPE) {
+                dconst_of[k] = add_dk(op.d[0]);
+                add_dk(op.d[1]);
             } else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
                 dconst_of[k] = add_dk(op.d[0]);
             if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }
@@ -446,7 +464,7 @@ struct Emitter {
         for (size_t at = 0; at < plan.order.size() && R > 1; at++) {
             const int k = plan.order[at];
             const DevOp &op = P.ops[(size_t)k];
-            bool ok = op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_TIMER || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
+            bool ok = op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_TIMER || op.op == OP_SHAPE || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
                       (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST);
             for (int j = 0; ok && j < kMaxIn; j++) {
                 if (!operand_live(op, j)) continue;

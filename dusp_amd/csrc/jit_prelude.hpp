@@ -379,6 +379,76 @@ struct JitTimer {
     }
 };
 
+// ---- Shape (src/components/Shape/index.js:28-59) with an unconnected duration: while playing, t += 1 / duration is a running
+// f64 sum with a constant addend — closed form (repeat_add.hpp), like the Timer — then the 0..1 shape at t (a lerp in the
+// Shape's table, or an edge value outside 0..sampleRate) scaled into [min, max].  min / max may be signals.
+struct JitShape {
+    double t;       // value before the next chunk's first sample (uniform)
+    double c;       // 1 / duration (uniform)
+    bool playing, finished;
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float duration, int state_slot) {
+        c = jit_u(1.0 / (double)duration);
+        playing = jit_u(A.init_state[state_slot + 1] != 0.0);
+        finished = jit_u(A.init_state[state_slot + 2] != 0.0);
+        const double t0 = A.init_state[state_slot];
+        // (a render is only split in time when the duration is a constant inside the closed form's regime: fused_plan.hpp)
+        t = jit_u(playing && X.g_begin > 0 ? repeat_add(t0, c, (uint64_t)X.g_begin * kChunk) : t0);
+    }
+    // left / right: the edge values as numbers; attr bit 8 / 9: the edge is "shape" (= the table's first / last entry)
+    __device__ __forceinline__ void tick(const JitCtx &X, const float *data, int attr, double left_k, double right_k, const float (&mn)[4],
+                                         const float (&mx)[4], float (&out)[4]) {
+        double tt[4];
+        if (playing && !(c > 0.0 && c < 1.0e300 && t >= 0.0)) {
+            // outside the closed form's regime (a per-instance duration that is zero, negative or NaN): the reference's additions
+            // one by one, every lane up to its own samples
+            double tl = t;
+            for (uint32_t i = 0; i < X.lane * 4; ++i) tl += c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = tl = tl + c;
+            t = jit_u(__shfl(tl, 63, 64));
+        } else if (playing) {
+            long long T, ce;
+            int K;
+            if (linear_run(t, c, kChunk, T, ce, K)) {  // the whole chunk inside one binade: t_j = (T + j ce) 2^(K-52)
+                long long Tl = T + (long long)(X.lane * 4) * ce;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tt[k] = ldexp((double)(Tl += ce), K - 52);
+                t = jit_u(ldexp((double)(T + (long long)kChunk * ce), K - 52));
+            } else {
+                double tl = repeat_add(t, c, (uint64_t)X.lane * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tt[k] = tl = tl + c;
+                t = jit_u(__shfl(tl, 63, 64));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = t;
+        }
+        const double left = (attr & 256) ? (double)data[0] : left_k, right = (attr & 512) ? (double)data[X.sr] : right_k;
+        bool over = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double l = (double)mn[k], h = (double)mx[k], tk = tt[k];
+            if (tk <= 0.0) out[k] = (float)(left * (h - l) + l);
+            else if (tk > X.srd) {
+                over = true;
+                out[k] = (float)(right * (h - l) + l);
+            } else if (tk == tk) {
+                const double fl = floor(tk), frac = tk - fl;
+                out[k] = (float)(l + (h - l) * ((double)data[(int)ceil(tk)] * frac + (double)data[(int)fl] * (1.0 - frac)));
+            } else
+                out[k] = __builtin_nanf("");
+        }
+        if (__ballot(over)) finished = true;  // finish() (UnitOrPatch.js:77-84)
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = t;  // (written by the wave of the LAST segment: its running sum has reached the end of the render)
+        st[A.n_pad] = playing ? 1.0 : 0.0;
+        st[(size_t)2 * A.n_pad] = finished ? 1.0 : 0.0;
+    }
+};
+
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;
