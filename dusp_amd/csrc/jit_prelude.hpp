@@ -574,7 +574,7 @@ struct JitFilterK {
         // The `|| 0` selects of Filter.js:42-46 on y1 / y2 are speculated away: without them a NaN never leaves the recurrence, so
         // testing a block's last outputs finds one anywhere in it (the block is then redone exactly); a -0 in place of +0 can only
         // flip the sign of a later zero, which every consumer maps to +0 (see loop2_engine.hip).
-        constexpr int PB = 8;  // (registers: the kernel is built for 16 wavefronts of 128 VGPRs, several instances each)
+        constexpr int PB = R >= 2 ? 8 : 16;  // P values per block held in registers (with several instances per wave the kernel is at its 128 VGPRs)
         for (int t0 = 0; t0 < SUB; t0 += PB) {
             double pv[PB];
 #pragma unroll
@@ -604,7 +604,7 @@ struct JitFilterK {
                     y1 = (double)y;
                 }
             }
-            // y of samples t0 .. t0+7 goes where P of samples t0/2 .. t0/2+3 stood: read already (this block's are in registers)
+            // y of samples t0 .. t0+PB-1 goes where P of samples t0/2 .. stood: read already (this block's are in registers)
 #pragma unroll
             for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
         }
