@@ -651,10 +651,10 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
-        opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget - opt.table_bytes);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);
         if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
             opt.lds_table = -1, opt.table_bytes = 0;
-            opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget);
         }
     } else {
         while (waves < most && (unsigned)waves < want) waves *= 2;
@@ -686,10 +686,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
             waves /= 2;
             per_wave *= 2;
-        } else if (per_wave > 1) per_wave--;
+        } else if (prog->wave.has_filter && per_wave > 1) per_wave /= 2;  // (rows stay a power of two: whole rounds on every CU)
+        else if (per_wave > 1) per_wave--;
         else if (waves > 4) waves /= 2;
         else break;
-        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, budget - opt.table_bytes);
+        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);
     }
     if (!prog->jit_consts_uploaded) {
         HIP_TRY(ctx, prog->d_jit_fk.ensure(std::max<size_t>(1, src->fk.size())));
@@ -1290,7 +1291,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
             }
     }
     if (plan.has_filter) {
-        opt.filter_sub = dusp::jit_filter_sub(waves * per_wave, 160 * 1024 - opt.table_bytes);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, 160 * 1024 - opt.table_bytes);
         if (!opt.filter_sub) {
             g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
             return DUSP_ERR_ARG;

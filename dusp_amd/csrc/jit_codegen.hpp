@@ -62,13 +62,15 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // Filter stage: one row of (sub-block + 2) doubles per instance of the workgroup; the sub-block (256, 128 or 64 samples) is the
 // largest that fits the LDS left over.
 inline size_t jit_filter_tile_bytes(int rows, int sub) { return (size_t)rows * (size_t)(sub + 2) * 8; }
-inline int jit_filter_sub(int rows, size_t lds_left) {
+inline size_t jit_filter_scratch_bytes(int waves) { return (size_t)waves * 260 * 4; }  // one row of inputs per wavefront
+inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
     for (int sub : {256, 128, 64})
-        if (jit_filter_tile_bytes(rows, sub) <= lds_left) return sub;
+        if (jit_filter_tile_bytes(waves * per_wave, sub) + jit_filter_scratch_bytes(waves) <= lds_left) return sub;
     return 0;
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
-    return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) + (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) : 0));
+    return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves) : 0));
 }
 
 inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op); }
@@ -209,7 +211,11 @@ struct Emitter {
         line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, out.has_filter) / 4)) + "];");
         line("    JitCtx X[" + RR + "];");
         line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", " + RR + ">(A, lds, X);");
-        if (out.has_filter) line("    double *tile = (double *)(lds + " + num((long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4)) + ");");
+        if (out.has_filter) {
+            const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4);
+            line("    double *tile = (double *)(lds + " + num(at) + ");");
+            line("    float *xrow = lds + " + num(at + (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) / 4)) + " + X[0].wave * 260;");
+        }
         // constants and parameters the used ops name
         std::vector<char> fk_used(out.fk.size(), 0);
         std::vector<int> params_used;
@@ -341,18 +347,17 @@ struct Emitter {
             std::vector<std::string> xs;
             for (int r = 0; r < R; r++) {
                 xs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
-                line("        const auto e" + num(k) + "_" + num(r) + " = " + f + ".edge(" + ctx(r) + ", " + num(r) + ", " + xs.back() + ");");
                 line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
             }
             for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) {
-                for (int r = 0; r < R; r++)
-                    line("        " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ", e" + num(k) + "_" + num(r) + ");");
+                for (int r = 0; r < R; r++) line("        " + f + ".park(" + ctx(r) + ", tile, xrow, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ");");
                 line("        jit_lds_barrier();");
                 line("        " + f + ".serial(X[0], tile);");
                 line("        jit_lds_barrier();");
                 for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
                 // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
             }
+            for (int r = 0; r < R; r++) line("        " + f + ".carry(" + num(r) + ", " + xs[(size_t)r] + ");");
             return;
         }
         for (int r = 0; r < copies(k); r++) {

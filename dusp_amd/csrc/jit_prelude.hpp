@@ -498,6 +498,7 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 // every wave picks its rows up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of
 // "its" lane of wave 0 for the whole render.
 //   tile: rows of SUB + 2 doubles, row = wave R + r;  SUB = 256, 128 or 64 by what LDS holds next to the table image
+//   xrow: this wave's scratch row of 260 floats (the chunk's inputs of the slot being parked)
 template <int WAVES, int R, int SUB>
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
@@ -529,34 +530,29 @@ struct JitFilterK {
         x1[r] = jit_u(is[7]);
         x2[r] = jit_u(is[8]);
     }
-    // once per chunk and slot: the two inputs before this lane's first sample (neighbour lanes, or the carried scalars)
-    struct Edge { float m1, m2; };
-    __device__ __forceinline__ Edge edge(const JitCtx &X, int r, const float (&x)[4]) {
-        Edge e;
-        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
-        // (the carried values are f32-valued: inputs are chunk samples, and `x2 || 0` only ever maps to +0)
-        e.m1 = X.lane == 0 ? (float)x1[r] : xl1;
-        e.m2 = X.lane == 0 ? (float)x2[r] : (float)jit_or0((double)xl2);
-        const double last1 = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
-        const double last2 = jit_or0((double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
-        x1[r] = last1;  // the chunk's last two inputs, for the next chunk's first lane: x1 as it is, x2 through `|| 0` (Filter.js:48-49)
-        x2[r] = last2;
-        return e;
-    }
-    // sub-block s: the lanes that own its samples compute the feed-forward half of theirs and park it
-    __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const float (&x)[4], const Edge &e) const {
-        const int first = s * (SUB / 4);
-        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
-            double *row = tile + (size_t)(X.wave * R + r) * kPitch + ((int)X.lane - first) * 4;
-            double xm1 = (double)e.m1, xm2 = (double)e.m2;
+    // Sub-block s of slot r's chunk, parked with ALL 64 lanes at work: the wave stages the chunk's 256 inputs in its scratch row
+    // (lane l holds samples 4l .. 4l+3; the sub-block's samples belong to a quarter or half of the lanes), then lane l computes
+    // the feed-forward half of sample(s) s SUB + 64 q + l from the row — its own input and the two before it, the carried
+    // scalars in front of the chunk — and parks it.
+    __device__ __forceinline__ void park(const JitCtx &X, double *tile, float *xrow, int r, int s, const float (&x)[4]) const {
+        ((f32x4 *)xrow)[X.lane] = f32x4{x[0], x[1], x[2], x[3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double *row = tile + (size_t)(X.wave * R + r) * kPitch;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double xin = (double)x[c];
-                row[c] = (a[r][0] * xin + a[r][1] * jit_or0(xm1)) + a[r][2] * jit_or0(xm2);
-                xm2 = jit_or0(xm1);
-                xm1 = xin;
-            }
+        for (int q = 0; q < SUB / 64; ++q) {
+            const int j = s * SUB + q * 64 + (int)X.lane;
+            const double xin = (double)xrow[j];
+            const double xm1 = j >= 1 ? (double)xrow[j - 1] : x1[r];
+            const double xm2 = j >= 2 ? (double)xrow[j - 2] : (j == 1 ? jit_or0(x1[r]) : x2[r]);
+            row[q * 64 + (int)X.lane] = (a[r][0] * xin + a[r][1] * jit_or0(xm1)) + a[r][2] * jit_or0(xm2);
         }
+        __builtin_amdgcn_wave_barrier();  // (the next slot's stage may not overtake these reads)
+    }
+    // after the chunk's last sub-block: the chunk's last two inputs, for the next chunk's first lanes (x1 as it is, x2 through `|| 0`)
+    __device__ __forceinline__ void carry(int r, const float (&x)[4]) {
+        x1[r] = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        x2[r] = jit_or0((double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
     }
     static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
         const int first = s * (SUB / 4);
