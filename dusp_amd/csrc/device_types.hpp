@@ -50,7 +50,8 @@ struct Knobs {
     int loop_wide = 1;           // DUSP_LOOP_WIDE=0: narrow two-stage loop kernel
     int wave_segments = -1;      // DUSP_WAVE_SEGMENTS=n: force n time segments (0 / 1: off; -1: automatic)
     int wave_max_waves = 0;      // DUSP_WAVE_MAX_WAVES=n: cap the wavefronts per workgroup (0: no cap)
-    int wave_jit = 1;            // DUSP_WAVE_JIT=0: keep wave-engine programs on the interpreter (no per-circuit kernels)
+    int wave_jit = 1;            // DUSP_WAVE_JIT=0: keep wave-engine programs on the interpreter; 2: always wait for a circuit's kernel
+                                 // (1: a render the interpreter finishes sooner than a compile runs there while the kernel compiles in the background)
     int wave_per_wave = 0;       // DUSP_WAVE_PER_WAVE=n: circuit instances per wavefront in compiled kernels (0: automatic, up to 4)
 };
 

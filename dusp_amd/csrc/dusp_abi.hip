@@ -541,9 +541,11 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
-    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
+    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok && (prog->jit_waves || !prog->rendered))
         std::snprintf(info->shape, sizeof info->shape, "%s, compiled kernel: %d units, %dx%d", prog->P.feed_forward ? "feed-forward" : "feedback",
                       (int)prog->P.ops.size(), prog->jit_waves, prog->jit_per_wave);
+    else if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
+        std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS (kernel compiling)", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     else if (prog->engine == DUSP_ENGINE_WAVE)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     return DUSP_OK;
@@ -580,6 +582,8 @@ int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_s
     return render_device(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_);
 }
 
+constexpr int kJitLater = 1;  // render_jit: the kernel is being compiled in the background; render this one on the interpreter
+
 // WAVE programs the circuit compiler takes: ONE kernel generated for this circuit's structure (jit_codegen.hpp), compiled for
 // gfx950 in process the first time the structure is seen (jit_engine.hip), cached from then on.
 static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uint32_t n_chunks, const float *d_params, const float *d_inputs, float *d_out,
@@ -588,7 +592,6 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     const dusp::Program &P = prog->P;
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
-    HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
     if (prog->keep_memory) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: internal error: a continued program with device memory on the compiled path");
 
     dusp::JitArgs a{};
@@ -608,11 +611,6 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     a.table_stride = ctx->table_stride;
     a.vec4_ok = (n_samples % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
     a.n_out = (uint32_t)P.out_bufs.size();
-    if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
-        HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
-        HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
-    }
-    a.rings = prog->d_rings.p;
     // Few instances, long render: cut time into segments so that the whole chip works on it
     a.n_seg = 1;
     a.seg_groups = n_chunks;
@@ -676,6 +674,19 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             it = prog->jit_src.emplace(std::make_pair(waves, per_wave), std::move(gen)).first;
         }
         src = &it->second;
+        // A structure seen for the first time costs a compile of 0.3-0.8 s.  A render the interpreter kernel finishes sooner
+        // than that does not wait for it: the compile starts in a background thread, THIS render runs on the interpreter (same
+        // PCM, same state), and the next render of the structure — in this process, or in any with DUSP_JIT_CACHE set — finds
+        // its kernel.  DUSP_WAVE_JIT=2 always waits (tests, benchmarks).
+        if (ctx->knobs.wave_jit == 1 && !dusp::jit_code_ready(src->text)) {
+            // interpreter: ~0.7 ns per unit and chunk with the chip full, ~1 us per unit and chunk along one wavefront's serial path
+            const double units = (double)P.ops.size();
+            const double est_ms = std::max(units * (double)n_inst * n_chunks * 0.7e-6, units * (double)a.seg_groups * 1.0e-3);
+            if (est_ms < 400.0) {
+                dusp::jit_compile_in_background(src->text);
+                return kJitLater;
+            }
+        }
         std::string err;
         int scratch = 0;
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
@@ -692,6 +703,14 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         else break;
         if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);
     }
+    // (from here on the render happens on the compiled kernel: workspaces)
+    HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+    a.state = prog->d_state.p;
+    if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
+        HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
+        HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+    }
+    a.rings = prog->d_rings.p;
     if (!prog->jit_consts_uploaded) {
         HIP_TRY(ctx, prog->d_jit_fk.ensure(std::max<size_t>(1, src->fk.size())));
         HIP_TRY(ctx, prog->d_jit_dk.ensure(std::max<size_t>(1, src->dk.size())));
@@ -818,7 +837,11 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
 
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
-    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok) return render_jit(prog, n_inst, n_samples, n_chunks, d_params, d_inputs, d_out, stream);
+    prog->jit_waves = prog->jit_per_wave = 0;
+    if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok) {
+        const int rc = render_jit(prog, n_inst, n_samples, n_chunks, d_params, d_inputs, d_out, stream);
+        if (rc != kJitLater) return rc;
+    }
     if (prog->engine == DUSP_ENGINE_WAVE) {
         HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
         dusp::WaveArgs w{};

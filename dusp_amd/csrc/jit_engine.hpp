@@ -10,6 +10,10 @@ namespace dusp {
 
 // Compile generated kernel text for gfx950 (no device needed: used by the CPU test of the generator too).  Cached by text.
 bool jit_compile_only(const std::string &text, size_t *code_bytes, std::string &err);
+// Is the code object of `text` at hand (memory, or the DUSP_JIT_CACHE directory)?  If not, a render may start its compile in
+// a background thread and use the interpreter kernel meanwhile.
+bool jit_code_ready(const std::string &text);
+void jit_compile_in_background(const std::string &text);
 // The kernel `name` of that text, loaded on `device` (compiles / loads on first use).  scratch_bytes: private memory the
 // compiler had to spill into (0 when the kernel fits its registers).
 bool jit_get_kernel(int device, const std::string &text, const std::string &name, hipFunction_t *fn, int *scratch_bytes, std::string &err);

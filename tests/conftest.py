@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# Contexts of the test processes (and of the node processes they start) WAIT for a circuit's compiled kernel, so that every GPU
+# test that can runs on one; the product default lets a short first render run on the interpreter kernel while the circuit
+# compiles in the background (tests/test_gpu_batch.py::test_first_render_does_not_wait_for_the_compiler covers that).
+os.environ.setdefault("DUSP_WAVE_JIT", "2")
 
 
 def pytest_configure(config):

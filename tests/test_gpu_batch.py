@@ -430,3 +430,45 @@ def test_big_mix_down_fits_the_wave_engine_by_buffer_liveness():
     for a, b in zip(got_state, want_state):
         assert np.array_equal(a, b, equal_nan=True)
     assert kernel_ms < 50, kernel_ms
+
+
+def test_first_render_does_not_wait_for_the_compiler(oracle):
+    """Product default (DUSP_WAVE_JIT=1): the first render of a circuit structure this process has not seen is not held up by
+    the 0.3-0.8 s compile when the interpreter kernel finishes it sooner — the kernel compiles in a background thread and a
+    later render of the same structure runs on it.  Same PCM and state either way; and the interpreter (DUSP_WAVE_JIT=0) agrees."""
+    import time
+    d.configure(48000)
+    # (a structure no other test builds: 7 oscillators in a chain of FM pairs)
+    g = d.Osc(330.5)
+    for k in range(3):
+        g = d.Sum(d.Multiply(d.Osc(d.Sum(d.Multiply(g, 17.0 + k), 201.25 * (k + 1))), 0.5), d.Osc(77.0 + k))
+    ex = descriptor.extract(g)
+    n = 256 * 5 + 11
+    want = oracle.render(ex.words, n)
+    prog = knob_context(48000, DUSP_WAVE_JIT=1).build(ex.words, runtime.ENGINE_WAVE)
+    t0 = time.perf_counter()
+    first = prog.render(n)[0]
+    waited = time.perf_counter() - t0
+    prog._read_info()
+    assert "kernel compiling" in prog.shape and waited < 0.25, (prog.shape, waited)
+    assert np.array_equal(first, want)
+    state_first = [prog.state(u) for u in range(prog.n_units)]
+    prog.close()
+    deadline = time.perf_counter() + 60
+    while True:  # a fresh program of the same structure finds the kernel once the background compile is done
+        prog = knob_context(48000, DUSP_WAVE_JIT=1).build(ex.words, runtime.ENGINE_WAVE)
+        again = prog.render(n)[0]
+        prog._read_info()
+        shape = prog.shape
+        state_again = [prog.state(u) for u in range(prog.n_units)]
+        prog.close()
+        assert np.array_equal(again, want)
+        if "compiled kernel" in shape or time.perf_counter() > deadline:
+            break
+        time.sleep(0.1)
+    assert "compiled kernel" in shape, shape
+    for a, b in zip(state_first, state_again):
+        assert np.array_equal(a, b, equal_nan=True)
+    off = knob_context(48000, DUSP_WAVE_JIT=0).build(ex.words, runtime.ENGINE_WAVE)
+    assert np.array_equal(off.render(n)[0], want) and "chunk buffers in LDS" in off.shape
+    off.close()

@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("DUSP_WAVE_JIT", "2")  # wait for every circuit's compiled kernel
 
 
 def main():

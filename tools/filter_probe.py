@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DUSP_WAVE_SEGMENTS", "1")
+os.environ.setdefault("DUSP_WAVE_JIT", "2")  # wait for every circuit's compiled kernel (the default lets short renders run interpreted meanwhile)
 import torch  # noqa: E402
 import dusp_amd as d  # noqa: E402
 from dusp_amd import descriptor, runtime  # noqa: E402
