@@ -360,6 +360,28 @@ struct Emitter {
             for (int r = 0; r < R; r++) line("        " + f + ".carry(" + num(r) + ", " + xs[(size_t)r] + ");");
             return;
         }
+        if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) {
+            // A scanned oscillator: all the wave's instances are asked first whether this chunk needs the careful path (increments at
+            // or above the sample rate, NaN / Inf, a poisoned phase); then ONE straight-line block serves them all.
+            const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
+            std::vector<std::string> fs;
+            std::string rare = "false";
+            for (int r = 0; r < copies(k); r++) {
+                fs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
+                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
+                rare += " | o" + num(k) + "_" + num(r) + ".rare(" + ctx(r) + ", " + fs.back() + ")";
+            }
+            for (int careful = 0; careful < 2; careful++) {
+                line(careful ? "        } else {" : "        if (!(" + rare + ")) {");
+                for (int r = 0; r < copies(k); r++)
+                    line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
+                         table_row(op.attr) + ", " + fs[(size_t)r] + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+            }
+            line("        }");
+            if (!lookup)
+                for (int r = 0; r < copies(k); r++) line("        for (int c = 0; c < 4; ++c) v" + num(op.out_buf) + "_" + num(r) + "[c] = 0.f;");
+            return;
+        }
         for (int r = 0; r < copies(k); r++) {
             const std::string id = num(k) + "_" + num(r), v = "v" + num(op.out_buf) + "_" + num(r), X_ = ctx(r);
             auto decl = [&]() { line("        float " + v + "[4];"); };

@@ -266,61 +266,86 @@ struct JitOscS {
             poison = (uint32_t)(v >> 63);
         }
     }
-    template <int TF, int FORM, bool LOOKUP>
+    // Does this chunk need the careful path?  Wave-uniform: a poisoned oscillator, or an increment at or above the sample rate
+    // (the reference's `phase %= sampleRate` folds those) or NaN / Inf.  The generated kernel asks all the instances of a wave
+    // first and then runs ONE straight-line block for all of them, so that their independent work can interleave.
+    __device__ __forceinline__ bool rare(const JitCtx &X, const float (&f)[4]) const {
+        bool big = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) big = big || !(fabsf(f[c]) < (float)X.sr);
+        return poison != 0 || __any(big);
+    }
+    // RARE = false: every increment finite and below the sample rate in magnitude, the oscillator not poisoned (rare() said so).
+    // S = sr << 36 has a zero low word, so every "+- S" and every comparison with S touches the HIGH word of a phase only.
+    template <int TF, int FORM, bool LOOKUP, bool RARE>
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, const float (&f)[4], float (&out)[4]) {
         long long qv[4];
-        bool bad = false, big = false;
+        bool bad = false;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            qv[c] = jit_fix36(f[c]);
-            big = big || !(fabsf(f[c]) < (float)X.sr);  // at or above the sample rate, or NaN / Inf
-        }
-        if (__any(big)) {  // rare: the reference's `phase %= sampleRate` folds such increments ((a + b) % m == (a + b % m) % m)
+        for (int c = 0; c < 4; ++c) qv[c] = jit_fix36(f[c]);
+        if (RARE) {
+            bool big = false;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double fd = (double)f[c];
-                const bool fin = fabs(fd) <= 3.0e38;
-                bad = bad || !fin;
-                if (!fin) fd = 0.0;
-                if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);
-                qv[c] = (long long)(fd * kJ36);
+            for (int c = 0; c < 4; ++c) big = big || !(fabsf(f[c]) < (float)X.sr);
+            if (__any(big)) {  // (a + b) % m == (a + b % m) % m
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double fd = (double)f[c];
+                    const bool fin = fabs(fd) <= 3.0e38;
+                    bad = bad || !fin;
+                    if (!fin) fd = 0.0;
+                    if (fabs(fd) >= X.srd) fd = fmod(fd, X.srd);
+                    qv[c] = (long long)(fd * kJ36);
+                }
             }
         }
         const long long total = qv[0] + qv[1] + qv[2] + qv[3];  // |total| < 4 * 2^53
         const long long incl = jit_wave_scan(total);
-        const long long before = (long long)carry + (incl - total);
-        const unsigned long long bad_lanes = __ballot(bad);
-        bool dead = poison != 0 || (bad_lanes & ((1ull << X.lane) - 1ull)) != 0;
-        unsigned long long Pv[4];
-        Pv[0] = mod_u64((unsigned long long)(before + qv[0]) + X.lift, X.S, X.inv_S);
+        const long long x0 = (long long)carry + (incl - total) + qv[0];  // |x0| < 256 S: a small quotient
+        const uint32_t S_hi = X.sr << 4;
+        // x0 mod S: quotient from the high words in f32 (off by one at most), remainder fixed up — all on the high word
+        uint32_t hi[4], lo[4];
+        {
+            const int xh = (int)(x0 >> 32);
+            const int k = (int)floorf((float)xh * (1.0f / (float)S_hi));
+            int rh = xh - k * (int)S_hi;
+            rh = rh < 0 ? rh + (int)S_hi : rh;
+            rh = rh >= (int)S_hi ? rh - (int)S_hi : rh;
+            rh = rh < 0 ? rh + (int)S_hi : rh;
+            hi[0] = (uint32_t)rh;
+            lo[0] = (uint32_t)x0;
+        }
 #pragma unroll
-        for (int c = 1; c < 4; ++c) {
-            long long Pn = (long long)Pv[c - 1] + qv[c];
-            if (Pn < 0) Pn += (long long)X.S;
-            if (Pn >= (long long)X.S) Pn -= (long long)X.S;
-            Pv[c] = (unsigned long long)Pn;
+        for (int c = 1; c < 4; ++c) {  // + q (|q| < S): 64-bit add, then back into [0, S) by the high word
+            const unsigned long long sum = (((unsigned long long)hi[c - 1] << 32) | lo[c - 1]) + (unsigned long long)qv[c];
+            uint32_t t = (uint32_t)(sum >> 32) + S_hi;  // in (0, 3 S_hi)
+            t = min(t, t - S_hi);
+            t = min(t, t - S_hi);
+            hi[c] = t;
+            lo[c] = (uint32_t)sum;
         }
         if (LOOKUP) {  // all the lookups of the chunk first, then the lerps
             float ta[4], tb[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) jit_pair<TF, FORM>(X, gtab, (uint32_t)(Pv[c] >> kJFrac), ta[c], tb[c]);
+            for (int c = 0; c < 4; ++c) jit_pair<TF, FORM>(X, gtab, hi[c] >> 4, ta[c], tb[c]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double fraction = (double)(Pv[c] & kJMask) * (1.0 / kJ36);
+                // the 36 fraction bits as a double: mantissa of 2^16 + fraction (its last place is 2^-36), minus 2^16 — exact
+                const double fraction = __hiloint2double((int)(0x40F00000u | (hi[c] & 15u)), (int)lo[c]) - 65536.0;
                 out[c] = (float)((double)ta[c] * (1.0 - fraction) + (double)tb[c] * fraction);
             }
-            if (poison != 0 || bad_lanes != 0) {  // (uniform) from the first NaN / Inf increment on, every sample is NaN
+        }
+        const unsigned long long bad_lanes = RARE ? __ballot(bad) : 0ull;
+        if (RARE && LOOKUP && (poison != 0 || bad_lanes != 0)) {  // (uniform) from the first NaN / Inf increment on, every sample is NaN
+            bool dead = poison != 0 || (bad_lanes & ((1ull << X.lane) - 1ull)) != 0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    dead = dead || !(fabs((double)f[c]) <= 3.0e38);
-                    if (dead) out[c] = __builtin_nanf("");
-                }
+            for (int c = 0; c < 4; ++c) {
+                dead = dead || !(fabs((double)f[c]) <= 3.0e38);
+                if (dead) out[c] = __builtin_nanf("");
             }
         }
         // the chunk's last phase, as a scalar (lane 63 holds it)
-        const unsigned long long Pc = Pv[3];
-        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)Pc, 63), hi = __builtin_amdgcn_readlane((uint32_t)(Pc >> 32), 63);
-        carry = ((unsigned long long)hi << 32) | lo;
+        carry = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi[3], 63) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo[3], 63);
         if (bad_lanes) poison = 1u;
     }
     __device__ __forceinline__ double end_phase() const { return poison ? __builtin_nan("") : (double)carry * (1.0 / kJ36); }
