@@ -204,6 +204,7 @@ static dusp::Knobs read_knobs() {
     k.wave_max_waves = num("DUSP_WAVE_MAX_WAVES", k.wave_max_waves);
     k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
     k.wave_per_wave = num("DUSP_WAVE_PER_WAVE", k.wave_per_wave);
+    k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
     return k;
 }
 
@@ -626,6 +627,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
     dusp::JitOptions opt;
+    opt.profile = ctx->knobs.jit_profile != 0;
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
@@ -691,7 +693,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         int scratch = 0;
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
-        if (scratch <= 32) break;  // (a register or two spilled outside the hot path is cheaper than halving the instances in flight)
+        if (scratch <= 64) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
         if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
@@ -746,8 +748,24 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                                                  (int)src->scans.size(), level, n_inst, a.n_seg, a.sample_rate, stream));
         }
     }
+    DevBuf<unsigned long long> d_debug;
+    if (opt.profile) {
+        HIP_TRY(ctx, d_debug.ensure((size_t)grid * 4));
+        HIP_TRY(ctx, hipMemsetAsync(d_debug.p, 0, (size_t)grid * 4 * sizeof(unsigned long long), stream));
+        a.debug = d_debug.p;
+    }
     HIP_TRY(ctx, dusp::jit_launch(render, a, grid, (unsigned)waves * 64, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+    if (opt.profile) {  // diagnostic build: what wave 0 of the workgroups measured (mean over workgroups), to stderr
+        std::vector<unsigned long long> h((size_t)grid * 4);
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        HIP_TRY(ctx, hipMemcpy(h.data(), d_debug.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double loop = 0, serial = 0, chunks = 0;
+        for (unsigned b = 0; b < grid; b++) loop += (double)h[b * 4], serial += (double)h[b * 4 + 1], chunks += (double)h[b * 4 + 2];
+        std::fprintf(stderr, "[dusp jit profile] %ux%d waves x instances, %u workgroups: chunk loop %.0f cycles per chunk, of which Filter recurrences %.0f (%.1f per sample-step)\n",
+                     (unsigned)waves, per_wave, grid, loop / std::max(1.0, chunks), serial / std::max(1.0, chunks), serial / std::max(1.0, chunks) / 256.0);
+        d_debug.release();
+    }
     prog->jit_waves = waves;
     prog->jit_per_wave = per_wave;
     prog->last_n_inst = n_inst;

@@ -17,6 +17,7 @@ struct JitArgs {
     float *rings;              // [n_inst][ring_samples]
     // time-split rendering: [n_ops][n_inst][n_seg] phase totals / start phases of the scanned oscillators (2^-36 units, bit 63 = poisoned)
     unsigned long long *seg_sum, *seg_start;
+    unsigned long long *debug;  // diagnostic builds (DUSP_JIT_PROFILE=1): [workgroup][4] cycle counts of wave 0; NULL otherwise
     uint64_t n_samples, ring_samples, clock0;
     uint32_t n_inst, n_pad, n_groups, sample_rate, table_stride, vec4_ok, n_out, pad0;
     uint32_t n_seg, seg_groups;  // every instance is cut into n_seg segments of seg_groups chunks, one wavefront each (1: no split)

@@ -43,6 +43,8 @@ struct JitOptions {
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
+    bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
+                             // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
 };
 
 // Where an oscillator's table comes from in a generated kernel (jit_prelude.hpp jit_pair): 1 the LDS half image, 2 a closed form
@@ -283,11 +285,22 @@ struct Emitter {
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
                 for (int r = 0; r < copies(producer[(size_t)b]); r++) line("    float w" + num(b) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
         // the chunk loop, twice: with the constant-f oscillators in 32.32 fixed point, and in the general form
+        if (opt.profile) line("    const unsigned long long stamp_loop = __builtin_readcyclecounter();");
         line("    if (" + fast + ") {");
         loop(render, pass_level, used, true);
         line("    } else {");
         loop(render, pass_level, used, false);
         line("    }");
+        if (opt.profile && render) {
+            line("    if (A.debug && X[0].wave == 0 && X[0].lane == 0) {");
+            line("        A.debug[(size_t)blockIdx.x * 4 + 0] = __builtin_readcyclecounter() - stamp_loop;");
+            std::string ser = "0ull";
+            for (size_t k = 0; k < P.ops.size(); k++)
+                if (P.ops[k].op == OP_FILTER) ser += " + f" + num((long long)k) + ".cyc_serial";
+            line("        A.debug[(size_t)blockIdx.x * 4 + 1] = " + ser + ";");
+            line("        A.debug[(size_t)blockIdx.x * 4 + 2] = X[0].g_end - X[0].g_begin;");
+            line("    }");
+        }
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
             for (size_t k = 0; k < P.ops.size(); k++)
@@ -512,6 +525,7 @@ struct Emitter {
         }
         std::sort(out.pass_levels.begin(), out.pass_levels.end());
         line("// generated by dusp_amd/csrc/jit_codegen.hpp — one kernel per topologically sorted Circuit");
+        if (opt.profile) line("#define DUSP_JIT_PROFILE 1");
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
         // f64 constants are read where they are used (loop-invariant scalar loads)

@@ -529,6 +529,9 @@ struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
     double a[R][3], x1[R], x2[R];           // this wave's instances: a0 a1 a2, the two inputs before the chunk (wave-uniform)
     double k[5], y1, y2, lastF;             // wave 0, lane = row: that instance's coefficients and recurrence memory
+#ifdef DUSP_JIT_PROFILE
+    unsigned long long cyc_serial = 0;      // diagnostic build: cycles wave 0 spent inside serial()
+#endif
 
     // fr: the cutoff of the instance THIS LANE serves in wave 0 (a constant, or that instance's parameter: jit_row_param)
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int kind, float fr, int state_slot) {
@@ -589,6 +592,9 @@ struct JitFilterK {
     // between two barriers: SUB samples of the recurrence of every row
     __device__ __forceinline__ void serial(const JitCtx &X, double *tile) {
         if (X.wave != 0 || X.lane >= WAVES * R) return;
+#ifdef DUSP_JIT_PROFILE
+        const unsigned long long stamp0 = __builtin_readcyclecounter();
+#endif
         const double *pr = tile + (size_t)X.lane * kPitch;
         f32x4 *yr = (f32x4 *)pr;
         const double b1 = k[3], b2 = k[4];
@@ -629,6 +635,9 @@ struct JitFilterK {
 #pragma unroll
             for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
         }
+#ifdef DUSP_JIT_PROFILE
+        cyc_serial += __builtin_readcyclecounter() - stamp0;
+#endif
     }
     // state write-back: the input history by each wave (slot r), coefficients and recurrence memory by the lanes that hold them
     __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
