@@ -636,7 +636,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             opt.lds_table = ctx->table_form[op.attr] == dusp::TABLE_FORM_8BIT && ctx->table_antisym[0] ? 0 : op.attr;  // (the sine image serves 8bit too)
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
         }
-    const size_t budget = 160 * 1024;
+    opt.scratch_floats = dusp::jit_scratch_floats(P);
+    const size_t budget = 160 * 1024 - 16 * opt.scratch_floats * 4;  // (the sequential-stage units' scratch of up to 16 wavefronts comes first)
+    if (opt.lds_table >= 0 && opt.table_bytes > budget) opt.lds_table = -1, opt.table_bytes = 0;
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
@@ -1320,6 +1322,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     dusp::JitOptions opt;
     opt.waves = waves;
     opt.per_wave = per_wave;
+    opt.scratch_floats = dusp::jit_scratch_floats(P);
     if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
         opt.table_form[1] = dusp::TABLE_FORM_SAW;
         opt.table_form[2] = dusp::TABLE_FORM_SQUARE;
@@ -1332,7 +1335,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
             }
     }
     if (plan.has_filter) {
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, 160 * 1024 - opt.table_bytes);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4);
         if (!opt.filter_sub) {
             g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
             return DUSP_ERR_ARG;

@@ -43,6 +43,7 @@ struct JitOptions {
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
+    size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
                              // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
 };
@@ -70,9 +71,24 @@ inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
         if (jit_filter_tile_bytes(waves * per_wave, sub) + jit_filter_scratch_bytes(waves) <= lds_left) return sub;
     return 0;
 }
+// Units with a sequential stage (comb family, AHD, SampleRateRedux, MultiChannelOsc) walk their chunk out of a per-wave LDS scratch:
+// floats per wavefront the program's units ask for (rows of 256; the largest need).
+inline size_t jit_scratch_floats(const Program &P) {
+    size_t need = 0;
+    for (const DevOp &op : P.ops) {
+        size_t n = 0;
+        if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) n = 512 + (op.op != OP_FIXED_DELAY && op.in[1].kind == SRC_BUF ? 256 : 0);
+        if (op.op == OP_AHD) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF || op.in[2].kind == SRC_BUF) ? 1024 : 256;
+        if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
+        if (op.op == OP_MULTI_OSC) n = 512;
+        need = std::max(need, n);
+    }
+    return need;
+}
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves) : 0));
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves) : 0) +
+                                    (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
 inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op); }
@@ -108,6 +124,10 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
         case OP_SHAPE:  // the running sum t += 1 / duration in closed form where it applies (the kernel checks, per instance)
             if (op.in[0].kind == SRC_BUF) return no("a Shape with a connected duration");
             break;
+        case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:  // a private ring walked in rounds of its length
+            if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
+            break;
+        case OP_AHD: case OP_SAMPLE_RATE_REDUX: case OP_MULTI_OSC: break;  // serial stage on one lane out of the wave's LDS scratch
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
             return no("a unit the circuit compiler does not emit yet");
@@ -145,7 +165,8 @@ struct Emitter {
         case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
         case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
         case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
-        case OP_SHAPE: return j < 3;
+        case OP_SHAPE: case OP_AHD: return j < 3;
+        case OP_FIXED_DELAY: case OP_MULTI_OSC: return j < 1;
         default:
             if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
             return j < 2;
@@ -218,6 +239,11 @@ struct Emitter {
             line("    double *tile = (double *)(lds + " + num(at) + ");");
             line("    float *xrow = lds + " + num(at + (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) / 4)) + " + X[0].wave * 260;");
         }
+        if (opt.scratch_floats) {
+            const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
+                                 (out.has_filter ? (long long)((jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves)) / 4) : 0);
+            line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
+        }
         // constants and parameters the used ops name
         std::vector<char> fk_used(out.fk.size(), 0);
         std::vector<int> params_used;
@@ -268,6 +294,22 @@ struct Emitter {
                 case OP_SHAPE:
                     line("    JitShape s" + id + ";");
                     line("    s" + id + ".begin(A, " + ctx(r) + ", " + opnd(k, 0, "0", r) + ", " + num(op.state_slot) + ");");
+                    break;
+                case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:
+                    line("    JitComb b" + id + ";");
+                    line("    b" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
+                case OP_AHD:
+                    line("    JitAHD e" + id + ";");
+                    line("    e" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
+                case OP_SAMPLE_RATE_REDUX:
+                    line("    JitSRR h" + id + ";");
+                    line("    h" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
+                case OP_MULTI_OSC:
+                    line("    JitMultiOsc m" + id + ";");
+                    line("    m" + id + ".begin(A, " + num(op.state_slot) + ");");
                     break;
                 default: break;
                 }
@@ -320,6 +362,10 @@ struct Emitter {
                         line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
                     if (op.op == OP_DELAY) line("        " + slot + " = y" + id + ".carried;");
                     if (op.op == OP_SHAPE) line("        s" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) line("        " + slot + " = (double)b" + id + ".tb;");
+                    if (op.op == OP_AHD) line("        e" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_SAMPLE_RATE_REDUX) line("        h" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_MULTI_OSC) line("        " + slot + " = m" + id + ".phase;");
                 }
                 line("    }");
             }
@@ -430,6 +476,34 @@ struct Emitter {
                 decl();
                 line("        jit_input(A, " + X_ + ", g, " + num(op.attr) + ", " + v + ");");
                 break;
+            case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: {
+                decl();
+                const std::string x = opnd_array(k, 0, "t" + id, r);
+                const bool row = op.op != OP_FIXED_DELAY && op.in[1].kind == SRC_BUF;
+                const std::string gain = op.op == OP_FIXED_DELAY ? x : opnd_array(k, 1, "tg" + id, r);
+                line("        b" + id + ".tick<" + num(op.op) + ", " + (row ? "true" : "false") + ">(A, " + X_ + ", scr, (int64_t)" + dref + ", (uint32_t)d" + num(dconst_of[(size_t)k] + 1) +
+                     ", " + x + ", " + gain + ", " + v + ");");
+                break;
+            }
+            case OP_AHD: {
+                decl();
+                const std::string a0 = opnd_array(k, 0, "ta" + id, r), a1 = opnd_array(k, 1, "th" + id, r), a2 = opnd_array(k, 2, "td" + id, r);
+                auto is_row = [&](int j) { return std::string(op.in[j].kind == SRC_BUF ? "true" : "false"); };
+                line("        e" + id + ".tick<" + is_row(0) + ", " + is_row(1) + ", " + is_row(2) + ">(" + X_ + ", scr, " + dref + ", " + a0 + ", " + a1 + ", " + a2 + ", " + v + ");");
+                break;
+            }
+            case OP_SAMPLE_RATE_REDUX: {
+                decl();
+                const std::string a0 = opnd_array(k, 0, "ti" + id, r), a1 = opnd_array(k, 1, "tm" + id, r);
+                line("        h" + id + ".tick<" + (op.in[0].kind == SRC_BUF ? "true" : "false") + ", " + (op.in[1].kind == SRC_BUF ? "true" : "false") + ">(" + X_ + ", scr, " + a0 + ", " + a1 + ", " + v + ");");
+                break;
+            }
+            case OP_MULTI_OSC: {
+                decl();
+                const std::string f = opnd_array(k, 0, "t" + id, r);
+                line("        m" + id + ".tick(" + X_ + ", scr, " + table_row(op.attr) + ", " + f + ", " + v + ");");
+                break;
+            }
             case OP_SHAPE: {
                 decl();
                 const std::string mn = opnd_array(k, 1, "tn" + id, r), mx = opnd_array(k, 2, "tx" + id, r);
@@ -491,7 +565,11 @@ struct Emitter {
             } else if (op.op == OP_SHAPE) {
                 dconst_of[k] = add_dk(op.d[0]);
                 add_dk(op.d[1]);
-            } else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
+            } else if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) {
+                dconst_of[k] = add_dk((double)op.ring_base);
+                add_dk((double)op.ring_len);
+            } else if (op.op == OP_AHD)
+                dconst_of[k] = add_dk(op.d[0]); else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
                 dconst_of[k] = add_dk(op.d[0]);
             if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }
         }

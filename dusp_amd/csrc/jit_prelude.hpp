@@ -474,6 +474,238 @@ struct JitShape {
     }
 };
 
+// ---- Units with a sequential stage.  Their state evolves sample by sample with its own roundings, so one lane walks the chunk's
+// 256 samples out of a per-wave LDS scratch (`scr`: rows of 256 floats) while everything around it stays lane-parallel.
+__device__ __forceinline__ void jit_row_put(float *row, uint32_t lane, const float (&v)[4]) { ((f32x4 *)row)[lane] = f32x4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void jit_row_get(const float *row, uint32_t lane, float (&v)[4]) {
+    const f32x4 x = ((const f32x4 *)row)[lane];
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void jit_wave_sync() {  // LDS written by some lanes of this wave, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// FixedDelay / CombFilter / AllPass (FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15): a private ring of L slots read and
+// rewritten one slot per sample, so sample t depends on sample t - L only: the min(L, 256) slots a chunk touches are staged in
+// LDS and walked min(L, 64) independent samples at a time.  scr: row 0 input (output in place), row 1 the ring window, row 2 gain.
+struct JitComb {
+    uint32_t tb;  // tBuffer (uniform)
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { tb = jit_u((uint32_t)A.init_state[state_slot]); }
+    template <int KIND /*OP_FIXED_DELAY / OP_COMB_FILTER / OP_ALL_PASS*/, bool GAIN_ROW>
+    __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, float *scr, int64_t ring_base, uint32_t L, const float (&x)[4],
+                                         const float (&gain)[4], float (&out)[4]) {
+        float *Xr = scr, *R = scr + kChunk, *G = scr + 2 * kChunk;
+        jit_wave_sync();  // (the scratch's previous user is done)
+        jit_row_put(Xr, X.lane, x);
+        if (GAIN_ROW) jit_row_put(G, X.lane, gain);
+        const uint32_t first = (tb + 1u) % L, window = L < (uint32_t)kChunk ? L : (uint32_t)kChunk;
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        for (uint32_t p = X.lane; p < window; p += 64) {
+            uint32_t s_ = first + p;
+            if (s_ >= L) s_ -= L;
+            R[p] = ring[s_];
+        }
+        jit_wave_sync();
+        const uint32_t step = L < 64u ? L : 64u;
+        uint32_t p = X.lane;  // (base + lane) mod L, kept incrementally
+        for (uint32_t base = 0; base < (uint32_t)kChunk; base += step) {
+            const uint32_t t = base + X.lane;
+            if (X.lane < step && t < (uint32_t)kChunk) {
+                const float xin = Xr[t], was = R[p];
+                const double g = (double)(GAIN_ROW ? G[t] : gain[0]);
+                float now, y;
+                if (KIND == OP_FIXED_DELAY) { y = was; now = xin; }
+                else if (KIND == OP_COMB_FILTER) { y = was; now = (float)((double)xin + (double)was * g); }
+                else {
+                    now = (float)((double)xin + (double)was * g);
+                    y = (float)((double)was - (double)xin * g);
+                }
+                R[p] = now;
+                Xr[t] = y;
+            }
+            p += step;
+            if (p >= L) p -= L;
+            jit_wave_sync();
+        }
+        if (X.live)
+            for (uint32_t q = X.lane; q < window; q += 64) {
+                uint32_t s_ = first + q;
+                if (s_ >= L) s_ -= L;
+                ring[s_] = R[q];
+            }
+        tb = (tb + (uint32_t)kChunk) % L;
+        jit_row_get(Xr, X.lane, out);
+    }
+};
+
+// AHD (AHD.js:35-76): a per-sample state machine over three slopes, on lane 0.  scr: row 0 output, rows 1-3 attack / hold / decay
+// where they are signals.  A state outside 0..3 leaves the outlet's samples as the previous chunk had them.
+struct JitAHD {
+    int stage;
+    bool playing;
+    double t;
+    float prev[4];  // this lane's samples of the previous chunk
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
+        stage = (int)jit_u((uint32_t)(int)A.init_state[state_slot]);
+        playing = jit_u(A.init_state[state_slot + 1] != 0.0);
+        t = jit_u(A.init_state[state_slot + 2]);
+        prev[0] = prev[1] = prev[2] = prev[3] = 0.f;
+    }
+    template <bool ROW_A, bool ROW_H, bool ROW_D>
+    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, double period, const float (&att)[4], const float (&hold)[4], const float (&dec)[4],
+                                         float (&out)[4]) {
+        float *Y = scr;
+        jit_wave_sync();
+        jit_row_put(Y, X.lane, prev);
+        if (ROW_A) jit_row_put(scr + kChunk, X.lane, att);
+        if (ROW_H) jit_row_put(scr + 2 * kChunk, X.lane, hold);
+        if (ROW_D) jit_row_put(scr + 3 * kChunk, X.lane, dec);
+        jit_wave_sync();
+        if (X.lane == 0) {
+            int st = stage;
+            bool pl = playing;
+            double tt = t;
+            for (int k = 0; k < kChunk; ++k) {
+                if (st == 1) {
+                    Y[k] = (float)tt;
+                    if (pl) { tt += period / (double)(ROW_A ? scr[kChunk + k] : att[0]); if (tt >= 1.0) { ++st; tt -= 1.0; } }
+                } else if (st == 2) {
+                    Y[k] = 1.f;
+                    if (pl) { tt += period / (double)(ROW_H ? scr[2 * kChunk + k] : hold[0]); if (tt >= 1.0) { ++st; tt -= 1.0; } }
+                } else if (st == 3) {
+                    Y[k] = (float)(1.0 - tt);
+                    if (pl) { tt += period / (double)(ROW_D ? scr[3 * kChunk + k] : dec[0]); if (tt >= 1.0) { st = 0; pl = false; } }
+                } else if (st == 0)
+                    Y[k] = 0.f;
+            }
+            stage = st;
+            playing = pl;
+            t = tt;
+        }
+        stage = (int)jit_u((uint32_t)stage);
+        playing = jit_u(playing);
+        t = jit_u(t);
+        jit_wave_sync();
+        jit_row_get(Y, X.lane, out);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) prev[c] = out[c];
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = (double)stage;
+        st[A.n_pad] = playing ? 1.0 : 0.0;
+        st[(size_t)2 * A.n_pad] = t;
+    }
+};
+
+// SampleRateRedux (SampleRateRedux.js:21-38): sample & hold with a counter, on lane 0.  scr: row 0 output, row 1 input, row 2 amount.
+struct JitSRR {
+    double since;
+    float held;
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
+        since = jit_u(A.init_state[state_slot]);
+        held = jit_u((float)A.init_state[state_slot + 1]);
+    }
+    template <bool ROW_IN, bool ROW_AMT>
+    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, const float (&in)[4], const float (&amt)[4], float (&out)[4]) {
+        float *Y = scr;
+        jit_wave_sync();
+        if (ROW_IN) jit_row_put(scr + kChunk, X.lane, in);
+        if (ROW_AMT) jit_row_put(scr + 2 * kChunk, X.lane, amt);
+        jit_wave_sync();
+        if (X.lane == 0) {
+            double sn = since;
+            float hd = held;
+            for (int k = 0; k < kChunk; ++k) {
+                sn += 1.0;
+                if (sn > (double)(ROW_AMT ? scr[2 * kChunk + k] : amt[0])) { hd = ROW_IN ? scr[kChunk + k] : in[0]; sn = 0.0; }
+                Y[k] = hd;
+            }
+            since = sn;
+            held = hd;
+        }
+        since = jit_u(since);
+        held = jit_u(held);
+        jit_wave_sync();
+        jit_row_get(Y, X.lane, out);
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = since;
+        st[A.n_pad] = (double)held;
+    }
+};
+
+// MultiChannelOsc (MultiChannelOsc.js:21-38): `phase += f; phase %= sr` WITHOUT the Osc's `if (phase < 0) phase += sr`: the remainder
+// keeps the dividend's sign, so the phase is not a modular sum in general — while nothing is negative it is (every increment of the
+// chunk in [0, sr) on the 2^-36 grid, the start phase too: the Osc's exact fixed-point scan), else the 256 phases come from lane 0,
+// in f64 exactly as the reference adds them.  Lookups (from L2, like the interpreter kernel) are lane-parallel.  scr: 512 floats.
+struct JitMultiOsc {
+    double phase;  // uniform
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { phase = jit_u(A.init_state[state_slot]); }
+    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, const float *gtab, const float (&f)[4], float (&out)[4]) {
+        double ph0 = phase;
+        ph0 = (ph0 != ph0 || ph0 == 0.0) ? 0.0 : ph0;  // `this.phase[c] = this.phase[c] || 0`
+        bool grid = ph0 >= 0.0 && ph0 < X.srd && ph0 * kJ36 == floor(ph0 * kJ36);
+        long long q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double fd = (double)f[c];
+            grid = grid && fd >= 0.0 && fd < X.srd;  // (below sampleRate: phase + f stays under 2^17 + 2^17, exact in f64 on this grid)
+            if (!(fd >= 0.0 && fd < X.srd)) fd = 0.0;
+            const double scaled = fd * kJ36;
+            grid = grid && scaled == floor(scaled);
+            q[c] = (long long)scaled;
+        }
+        if (__all(grid)) {
+            const long long total = q[0] + q[1] + q[2] + q[3];
+            const long long incl = jit_wave_scan(total);
+            const long long before = (long long)(unsigned long long)(ph0 * kJ36) + (incl - total);
+            unsigned long long P = mod_u64((unsigned long long)(before + q[0]) + X.lift, X.S, X.inv_S);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c > 0) {
+                    P += (unsigned long long)q[c];
+                    if (P >= X.S) P -= X.S;
+                }
+                const uint32_t idx = (uint32_t)(P >> kJFrac);
+                const double fraction = (double)(P & kJMask) * (1.0 / kJ36);
+                out[c] = (float)((double)gtab[idx] * (1.0 - fraction) + (double)gtab[fraction != 0.0 ? idx + 1 : idx] * fraction);
+            }
+            const unsigned long long lastP = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(P >> 32), 63) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((uint32_t)P, 63);
+            phase = (double)lastP * (1.0 / kJ36);
+            return;
+        }
+        double *T = (double *)scr;
+        jit_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[X.lane * 4 + c] = (double)f[c];
+        jit_wave_sync();
+        if (X.lane == 0) {
+            double ph = ph0;
+            for (int k = 0; k < kChunk; ++k) {
+                double p = ph + T[k];
+                if (fabs(p) >= X.srd) p = (p > 0.0 && p < 2.0 * X.srd) ? p - X.srd : (p < 0.0 && p > -2.0 * X.srd) ? p + X.srd : fmod(p, X.srd);
+                T[k] = ph = p;
+            }
+            phase = ph;
+        }
+        phase = jit_u(phase);
+        jit_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double ph = T[X.lane * 4 + c];
+            if (!(ph >= 0.0 && ph <= X.srd)) { out[c] = __builtin_nanf(""); continue; }  // typed-array[NaN / negative] is undefined
+            const double lo = floor(ph), fraction = ph - lo;
+            const int idx = (int)lo;
+            out[c] = (float)((double)gtab[idx] * (1.0 - fraction) + (double)gtab[fraction != 0.0 ? idx + 1 : idx] * fraction);
+        }
+    }
+};
+
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;
