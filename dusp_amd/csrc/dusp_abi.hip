@@ -637,12 +637,18 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
         }
     opt.scratch_floats = dusp::jit_scratch_floats(P);
-    const size_t budget = 160 * 1024 - 16 * opt.scratch_floats * 4;  // (the sequential-stage units' scratch of up to 16 wavefronts comes first)
-    if (opt.lds_table >= 0 && opt.table_bytes > budget) opt.lds_table = -1, opt.table_bytes = 0;
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
     if (ctx->knobs.wave_max_waves > 0) most = std::max(1, std::min(most, ctx->knobs.wave_max_waves));
+    // the sequential-stage units' per-wave scratch comes out of the same 160 KiB: as many wavefronts as fit next to the table image
+    // (a power of two; the table image goes only when not even one wave's scratch fits beside it)
+    if (opt.scratch_floats) {
+        const size_t scratch = opt.scratch_floats * 4;
+        if (opt.table_bytes + scratch > 160 * 1024) opt.lds_table = -1, opt.table_bytes = 0;
+        while (most > 1 && opt.table_bytes + (size_t)most * scratch > 160 * 1024) most /= 2;
+    }
+    const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
     const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
     if (prog->wave.has_filter) {

@@ -81,6 +81,8 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_AHD) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF || op.in[2].kind == SRC_BUF) ? 1024 : 256;
         if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
         if (op.op == OP_MULTI_OSC) n = 512;
+        if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
+        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 1536;  // P, b1, b2 per sample (f64)
         need = std::max(need, n);
     }
     return need;
@@ -104,7 +106,6 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
     if (plan.ring_events) return no("delay lines that need ordered slot operations");
     if (P.ops.size() > 96) return no("more than 96 channel-expanded units: straight-line code would outgrow the instruction cache");
     if (P.out_bufs.size() > 16) return no("more than 16 output channels");
-    if (!P.g.rings.empty()) return no("CircleBuffers");
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];
         switch (op.op) {
@@ -112,22 +113,19 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
         case OP_RAMP:
             if (plan.op_state[k] >= 0) return no("a Ramp that a Retriggerer restarts");
             break;
-        case OP_FILTER:
-            if (op.in[1].kind == SRC_BUF) return no("a Filter with a connected cutoff");
-            break;
+        case OP_FILTER: break;  // (a connected cutoff: per-sample coefficients, the recurrence per wave out of its scratch)
         case OP_DELAY:
             if (!delay_write_once(op)) return no("a Delay outside the write-once regime");
             break;
         case OP_TIMER:
             if (!(P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300)) return no("a Timer outside the closed-form regime");
             break;
-        case OP_SHAPE:  // the running sum t += 1 / duration in closed form where it applies (the kernel checks, per instance)
-            if (op.in[0].kind == SRC_BUF) return no("a Shape with a connected duration");
-            break;
+        case OP_SHAPE: break;  // the running sum t += 1 / duration in closed form where it applies (the kernel checks, per instance), else on one lane
         case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:  // a private ring walked in rounds of its length
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("comb ring out of range");
             break;
         case OP_AHD: case OP_SAMPLE_RATE_REDUX: case OP_MULTI_OSC: break;  // serial stage on one lane out of the wave's LDS scratch
+        case OP_CB_READER: case OP_CB_WRITER: break;  // (an unconnected offset and a ring of at least a chunk: else plan.ring_events, above)
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
             return no("a unit the circuit compiler does not emit yet");
@@ -166,7 +164,8 @@ struct Emitter {
         case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
         case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
         case OP_SHAPE: case OP_AHD: return j < 3;
-        case OP_FIXED_DELAY: case OP_MULTI_OSC: return j < 1;
+        case OP_FIXED_DELAY: case OP_MULTI_OSC: case OP_CB_READER: return j < 1;
+        case OP_CB_WRITER: return j < ((op.attr & 2) ? 1 : 2);  // (attr bit 1: nothing to mix on this channel)
         default:
             if (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST) return j < op.n_in;
             return j < 2;
@@ -293,7 +292,7 @@ struct Emitter {
                     break;
                 case OP_SHAPE:
                     line("    JitShape s" + id + ";");
-                    line("    s" + id + ".begin(A, " + ctx(r) + ", " + opnd(k, 0, "0", r) + ", " + num(op.state_slot) + ");");
+                    line("    s" + id + ".begin(A, " + ctx(r) + ", " + (op.in[0].kind == SRC_BUF ? std::string("1.f") : opnd(k, 0, "0", r)) + ", " + num(op.state_slot) + ");");
                     break;
                 case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS:
                     line("    JitComb b" + id + ";");
@@ -311,10 +310,19 @@ struct Emitter {
                     line("    JitMultiOsc m" + id + ";");
                     line("    m" + id + ".begin(A, " + num(op.state_slot) + ");");
                     break;
+                case OP_CB_READER: case OP_CB_WRITER:
+                    line("    JitCBNode n" + id + ";");
+                    line("    n" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
                 default: break;
                 }
             }
-            if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
+            if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
+                for (int r = 0; r < R; r++) {
+                    line("    JitFilterM f" + num(k) + "_" + num(r) + ";");
+                    line("    f" + num(k) + "_" + num(r) + ".begin(A, " + num(op.state_slot) + ");");
+                }
+            } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
                 line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
@@ -338,7 +346,7 @@ struct Emitter {
             line("        A.debug[(size_t)blockIdx.x * 4 + 0] = __builtin_readcyclecounter() - stamp_loop;");
             std::string ser = "0ull";
             for (size_t k = 0; k < P.ops.size(); k++)
-                if (P.ops[k].op == OP_FILTER) ser += " + f" + num((long long)k) + ".cyc_serial";
+                if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind != SRC_BUF) ser += " + f" + num((long long)k) + ".cyc_serial";
             line("        A.debug[(size_t)blockIdx.x * 4 + 1] = " + ser + ";");
             line("        A.debug[(size_t)blockIdx.x * 4 + 2] = X[0].g_end - X[0].g_begin;");
             line("    }");
@@ -346,7 +354,10 @@ struct Emitter {
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
             for (size_t k = 0; k < P.ops.size(); k++)
-                if (P.ops[k].op == OP_FILTER) {
+                if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind == SRC_BUF) {
+                    for (int r = 0; r < R; r++)
+                        line("    if (" + ctx(r) + ".live && " + ctx(r) + ".lane == 0) f" + num((long long)k) + "_" + num(r) + ".end(A, " + ctx(r) + ", " + num(P.ops[k].state_slot) + ");");
+                } else if (P.ops[k].op == OP_FILTER) {
                     line("    f" + num((long long)k) + ".end(A, X[0], " + num(P.ops[k].state_slot) + ");");
                     for (int r = 0; r < R; r++) line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].state_slot) + ");");
                 }
@@ -366,6 +377,7 @@ struct Emitter {
                     if (op.op == OP_AHD) line("        e" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_SAMPLE_RATE_REDUX) line("        h" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_MULTI_OSC) line("        " + slot + " = m" + id + ".phase;");
+                    if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) line("        " + slot + " = n" + id + ".T;");
                 }
                 line("    }");
             }
@@ -401,6 +413,15 @@ struct Emitter {
     void unit(int k, bool render, int pass_level, bool fx) {
         const DevOp &op = P.ops[(size_t)k];
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
+        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
+            for (int r = 0; r < R; r++) {
+                const std::string id = num(k) + "_" + num(r);
+                const std::string x = opnd_array(k, 0, "t" + id, r), f = opnd_array(k, 1, "tf" + id, r);
+                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
+                line("        f" + id + ".tick(" + ctx(r) + ", scr, " + num(op.attr) + ", " + x + ", " + f + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+            }
+            return;
+        }
         if (op.op == OP_FILTER) {  // feed-forward half per lane; then, sub-block by sub-block: park P, all recurrences on wave 0, pick y up
             const std::string f = "f" + num(k);
             std::vector<std::string> xs;
@@ -498,6 +519,18 @@ struct Emitter {
                 line("        h" + id + ".tick<" + (op.in[0].kind == SRC_BUF ? "true" : "false") + ", " + (op.in[1].kind == SRC_BUF ? "true" : "false") + ">(" + X_ + ", scr, " + a0 + ", " + a1 + ", " + v + ");");
                 break;
             }
+            case OP_CB_READER:
+                decl();
+                line("        n" + id + ".read<" + ((op.attr & 1) ? "true" : "false") + ">(A, " + X_ + ", (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 0, "0", r) + ", " + v + ");");
+                break;
+            case OP_CB_WRITER: {  // no outlet
+                const bool mix = !(op.attr & 2);
+                const std::string x = mix ? opnd_array(k, 1, "t" + id, r) : std::string();
+                if (!mix) line("        const float t" + id + "[4] = {0.f, 0.f, 0.f, 0.f};");
+                line("        n" + id + ".write<" + ((op.attr & 1) ? "true" : "false") + ", " + (mix ? "true" : "false") + ">(A, " + X_ + ", (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " +
+                     opnd(k, 0, "0", r) + ", " + (mix ? x : "t" + id) + ");");
+                break;
+            }
             case OP_MULTI_OSC: {
                 decl();
                 const std::string f = opnd_array(k, 0, "t" + id, r);
@@ -507,6 +540,11 @@ struct Emitter {
             case OP_SHAPE: {
                 decl();
                 const std::string mn = opnd_array(k, 1, "tn" + id, r), mx = opnd_array(k, 2, "tx" + id, r);
+                if (op.in[0].kind == SRC_BUF) {
+                    const std::string du = opnd_array(k, 0, "tu" + id, r);
+                    line("        s" + id + ".tick_signal(" + X_ + ", scr, " + table_row(op.attr & 255) + ", " + num(op.attr) + ", " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", " + du + ", " + mn + ", " + mx + ", " + v + ");");
+                    break;
+                }
                 line("        s" + id + ".tick(" + X_ + ", " + table_row(op.attr & 255) + ", " + num(op.attr) + ", " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", " + mn + ", " + mx + ", " + v + ");");
                 break;
             }
@@ -565,13 +603,13 @@ struct Emitter {
             } else if (op.op == OP_SHAPE) {
                 dconst_of[k] = add_dk(op.d[0]);
                 add_dk(op.d[1]);
-            } else if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) {
+            } else if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS || op.op == OP_CB_READER || op.op == OP_CB_WRITER) {
                 dconst_of[k] = add_dk((double)op.ring_base);
                 add_dk((double)op.ring_len);
             } else if (op.op == OP_AHD)
                 dconst_of[k] = add_dk(op.d[0]); else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
                 dconst_of[k] = add_dk(op.d[0]);
-            if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }
+            if (op.op == OP_FILTER && op.in[1].kind != SRC_BUF) { out.has_filter = true; out.n_filters++; }  // (the workgroup-wide stage; a modulated Filter runs per wave)
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }

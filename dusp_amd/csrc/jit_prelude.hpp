@@ -88,6 +88,18 @@ __device__ __forceinline__ unsigned long long jit_u(unsigned long long v) {
 __device__ __forceinline__ double jit_u(double v) { return __longlong_as_double((long long)jit_u((unsigned long long)__double_as_longlong(v))); }
 __device__ __forceinline__ bool jit_u(bool v) { return jit_u(v ? 1u : 0u) != 0u; }
 
+// rows of 256 floats in a wave's LDS scratch: every lane its four samples
+__device__ __forceinline__ void jit_row_put(float *row, uint32_t lane, const float (&v)[4]) { ((f32x4 *)row)[lane] = f32x4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ void jit_row_get(const float *row, uint32_t lane, float (&v)[4]) {
+    const f32x4 x = ((const f32x4 *)row)[lane];
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void jit_wave_sync() {  // LDS written by some lanes of this wave, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float jit_param(const JitArgs &A, const JitCtx &X, uint32_t slot) { return jit_u(A.params[(size_t)slot * A.n_inst + X.inst]); }
 
 // (a * n) mod S for a < S < 2^53 and n < 2^32, exactly: the product is cut into pieces that mod_u64 (x < 2^64) can take
@@ -449,6 +461,11 @@ struct JitShape {
 #pragma unroll
             for (int k = 0; k < 4; ++k) tt[k] = t;
         }
+        values(X, data, attr, left_k, right_k, tt, mn, mx, out);
+    }
+    // the 0..1 shape at t (table lerp, or an edge value) scaled into [min, max] (Shape/index.js:33-58)
+    __device__ __forceinline__ void values(const JitCtx &X, const float *data, int attr, double left_k, double right_k, const double (&tt)[4], const float (&mn)[4],
+                                           const float (&mx)[4], float (&out)[4]) {
         const double left = (attr & 256) ? (double)data[0] : left_k, right = (attr & 512) ? (double)data[X.sr] : right_k;
         bool over = false;
 #pragma unroll
@@ -466,6 +483,35 @@ struct JitShape {
         }
         if (__ballot(over)) finished = true;  // finish() (UnitOrPatch.js:77-84)
     }
+    // A connected duration: t += 1 / duration[t] is a running f64 sum with a different addend every sample — lane 0 adds them up out
+    // of the wave's scratch (512 floats), the lookups and the scaling stay lane-parallel.
+    __device__ __forceinline__ void tick_signal(const JitCtx &X, float *scr, const float *data, int attr, double left_k, double right_k, const float (&dur)[4],
+                                                const float (&mn)[4], const float (&mx)[4], float (&out)[4]) {
+        double tt[4];
+        if (playing) {
+            double *T = (double *)scr;
+            jit_wave_sync();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) T[X.lane * 4 + k] = 1.0 / (double)dur[k];
+            jit_wave_sync();
+            if (X.lane == 0) {
+                double acc = t;
+                for (int k = 0; k < kChunk; ++k) {
+                    acc += T[k];
+                    T[k] = acc;
+                }
+                t = acc;
+            }
+            t = jit_u(t);
+            jit_wave_sync();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = T[X.lane * 4 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tt[k] = t;
+        }
+        values(X, data, attr, left_k, right_k, tt, mn, mx, out);
+    }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
         st[0] = t;  // (written by the wave of the LAST segment: its running sum has reached the end of the render)
@@ -476,17 +522,6 @@ struct JitShape {
 
 // ---- Units with a sequential stage.  Their state evolves sample by sample with its own roundings, so one lane walks the chunk's
 // 256 samples out of a per-wave LDS scratch (`scr`: rows of 256 floats) while everything around it stays lane-parallel.
-__device__ __forceinline__ void jit_row_put(float *row, uint32_t lane, const float (&v)[4]) { ((f32x4 *)row)[lane] = f32x4{v[0], v[1], v[2], v[3]}; }
-__device__ __forceinline__ void jit_row_get(const float *row, uint32_t lane, float (&v)[4]) {
-    const f32x4 x = ((const f32x4 *)row)[lane];
-    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-}
-__device__ __forceinline__ void jit_wave_sync() {  // LDS written by some lanes of this wave, read by others
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // FixedDelay / CombFilter / AllPass (FixedDelay.js:13-19, CombFilter.js:11-17, AllPass.js:8-15): a private ring of L slots read and
 // rewritten one slot per sample, so sample t depends on sample t - L only: the min(L, 256) slots a chunk touches are staged in
 // LDS and walked min(L, 64) independent samples at a time.  scr: row 0 input (output in place), row 1 the ring window, row 2 gain.
@@ -706,6 +741,60 @@ struct JitMultiOsc {
     }
 };
 
+// ---- CircleBuffer nodes with an unconnected offset (CircleBufferReader.js:12-25, CircleBufferWriter.js:12-25, CircleBuffer.js:15-34): the
+// node's 256 accesses of a chunk are 256 consecutive slots of the ring — index = floor((T + t -+ sr offset) % len), negatives
+// wrapped — one per sample, lane-parallel.  Several nodes share a ring and tick one after another, so each node first waits for
+// the wave's earlier ring traffic.  T: the node's private sample counter.
+struct JitCBNode {
+    double T;  // uniform
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { T = jit_u(A.init_state[state_slot]); }
+    __device__ __forceinline__ bool window(const JitCtx &X, bool reader, float off, int64_t len, int64_t &base) const {
+        const double origin = reader ? T - X.srd * (double)off : T + X.srd * (double)off;
+        const bool ok = fabs(origin) < 9.0e15;  // NaN / Inf offsets read `undefined` and write nowhere
+        base = 0;
+        if (ok) {
+            base = (int64_t)fmod(floor(origin), (double)len);
+            if (base < 0) base += len;
+        }
+        return ok;
+    }
+    template <bool WIPE>
+    __device__ __forceinline__ void read(const JitArgs &A, const JitCtx &X, int64_t ring_base, int64_t len, float off, float (&out)[4]) {
+        int64_t base;
+        const bool ok = window(X, true, off, len, base);
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int64_t idx = base + X.lane * 4 + c;
+            if (idx >= len) idx -= len;
+            out[c] = ok ? ring[idx] : __builtin_nanf("");
+            if (ok && WIPE && X.live) ring[idx] = 0.f;  // postWipe
+        }
+        T += (double)kChunk;
+    }
+    template <bool WIPE, bool MIX>
+    __device__ __forceinline__ void write(const JitArgs &A, const JitCtx &X, int64_t ring_base, int64_t len, float off, const float (&x)[4]) {
+        int64_t base;
+        const bool ok = window(X, false, off, len, base);
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (ok && X.live && (WIPE || MIX)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int64_t idx = base + X.lane * 4 + c;
+                if (idx >= len) idx -= len;
+                float v = WIPE ? 0.f : ring[idx];  // preWipe
+                if (MIX) v = v + x[c];
+                ring[idx] = v;
+            }
+        }
+        T += (double)kChunk;
+    }
+};
+
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;
@@ -895,6 +984,74 @@ __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X
     const uint32_t inst = min(blockIdx.x * (WAVES * R) + X.lane, A.n_inst - 1);
     return A.params[(size_t)slot * A.n_inst + inst];
 }
+
+// ---- Filter with a CONNECTED cutoff: `if (this.f[t] != this.lastF)` recomputes the coefficients — a pure function of f[t], so every lane
+// computes its four samples' own (a tan() each), parks b1 / b2 and the feed-forward half per sample in the wave's scratch (three
+// rows of 256 doubles), and lane 0 runs the recurrence with per-sample coefficients; y goes over the P values already consumed.
+struct JitFilterM {
+    double k[5], x1, x2, y1, y2, lastF;  // uniform: the last sample's coefficients, the inputs and outputs before the chunk
+    bool has_last;
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
+        const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
+        has_last = jit_u(is[0] != 0.0);
+        lastF = jit_u(is[1]);
+        for (int i = 0; i < 5; ++i) k[i] = jit_u(is[2 + i]);
+        x1 = jit_u(is[7]);
+        x2 = jit_u(is[8]);
+        y1 = jit_u(is[9]);
+        y2 = jit_u(is[10]);
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, int kind, const float (&x)[4], const float (&f)[4], float (&out)[4]) {
+        double *P = (double *)scr, *B1 = P + kChunk, *B2 = P + 2 * kChunk;
+        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
+        double xm1 = X.lane == 0 ? x1 : (double)xl1, xm2 = X.lane == 0 ? x2 : (double)xl2;
+        double kl[5];
+        jit_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            jit_filter_coefficients(kind, (double)f[c], X.srd, kl);
+            B1[X.lane * 4 + c] = kl[3];
+            B2[X.lane * 4 + c] = kl[4];
+            const double xin = (double)x[c];
+            P[X.lane * 4 + c] = (kl[0] * xin + kl[1] * jit_or0(xm1)) + kl[2] * jit_or0(xm2);
+            xm2 = jit_or0(xm1);
+            xm1 = xin;
+        }
+        jit_wave_sync();
+        if (X.lane == 0) {
+            double v1 = y1, v2 = y2;
+            float *Y = scr;
+            for (int t = 0; t < kChunk; ++t) {
+                const float y = (float)((P[t] - B1[t] * jit_or0(v1)) - B2[t] * jit_or0(v2));  // Filter.js:40-46
+                Y[t] = y;  // (over P[t / 2], read already)
+                v2 = jit_or0(v1);
+                v1 = (double)y;
+            }
+            y1 = v1;
+            y2 = v2;
+        }
+        y1 = jit_u(y1);
+        y2 = jit_u(y2);
+        // what the last sample left: its cutoff and coefficients, the chunk's last two inputs (lane 63 holds them)
+        lastF = jit_u(__shfl((double)f[3], 63, 64));
+        for (int i = 0; i < 5; ++i) k[i] = jit_u(__shfl(kl[i], 63, 64));
+        x1 = jit_u(__shfl(xm1, 63, 64));
+        x2 = jit_u(__shfl(xm2, 63, 64));
+        has_last = true;
+        jit_wave_sync();
+        jit_row_get(scr, X.lane, out);
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = has_last ? 1.0 : 0.0;
+        st[A.n_pad] = lastF;
+        for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
+        st[(size_t)7 * A.n_pad] = x1;
+        st[(size_t)8 * A.n_pad] = x2;
+        st[(size_t)9 * A.n_pad] = y1;
+        st[(size_t)10 * A.n_pad] = y2;
+    }
+};
 
 // ---- Delay (src/components/Delay.js:20-41) with a constant delay D + phi, 256 <= D <= len - 256: the chunk's 256 reads are one
 // coalesced load from the ring ([instance][slot] in HBM), reads and writes of one chunk never meet, and every slot's final

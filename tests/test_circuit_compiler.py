@@ -14,7 +14,8 @@ from dusp_amd import descriptor, runtime
 COMPILED = ["osc440_1s", "voice3_k7", "cfg2_sweep", "fm_mixed", "fm_sum", "mult_2ch", "loop_220", "filter_2ch", "filter_hp", "delay_default",
             "map_gain", "rest_crossfader", "rest_timer_fm", "osc_triangle",
             # units with a sequential stage (one lane walks the chunk out of the wave's LDS scratch)
-            "fam_allpass_series", "fam_comb_mod", "env_ahd_mod", "rest_srr_mod", "fam_multiosc_negative", "env_shape_semisine_amp"]
+            "fam_allpass_series", "fam_comb_mod", "env_ahd_mod", "rest_srr_mod", "fam_multiosc_negative", "env_shape_semisine_amp",
+            "env_shape_mod", "filter_lp_mod", "circlebuffer_taps", "circlebuffer_2ch"]
 
 
 def source(words, **kw):
@@ -42,11 +43,10 @@ def test_what_the_compiler_takes_and_what_stays_on_the_interpreter():
         except runtime.DuspHipError as e:
             assert e.status == -2, e
             refused[name] = e.message
-    assert taken >= 130 and len(refused) <= 29
-    assert "Filter with a connected cutoff" in refused["filter_lp_mod"]
-    assert "ordered slot operations" in refused["delay_mod"]
-    assert "CircleBuffers" in refused["circlebuffer_taps"]
-    assert "Shape with a connected duration" in refused["env_shape_mod"]
+    assert taken >= 139 and len(refused) <= 20
+    assert "ordered slot operations" in refused["delay_mod"] and "ordered slot operations" in refused["circlebuffer_moving_tap"]
+    assert "channel counts grow" in refused["patch_scary"]
+    assert "more than 96" in refused["summany_1024"]
 
 
 def test_kernel_text_depends_on_structure_not_on_constants():
