@@ -71,6 +71,12 @@ inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
         if (jit_filter_tile_bytes(waves * per_wave, sub) + jit_filter_scratch_bytes(waves) <= lds_left) return sub;
     return 0;
 }
+// units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
+inline bool jit_ring_ops(const DevOp &op) {
+    return (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
+           ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
+}
+
 // Units with a sequential stage (comb family, AHD, SampleRateRedux, MultiChannelOsc) walk their chunk out of a per-wave LDS scratch:
 // floats per wavefront the program's units ask for (rows of 256; the largest need).
 inline size_t jit_scratch_floats(const Program &P) {
@@ -83,6 +89,7 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_MULTI_OSC) n = 512;
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 1536;  // P, b1, b2 per sample (f64)
+        if (jit_ring_ops(op)) n = 1024;                                 // the slot-ownership table
         need = std::max(need, n);
     }
     return need;
@@ -95,6 +102,7 @@ inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
 
 inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op); }
 
+
 // Programs the compiler takes.  Everything else stays on the wave engine's interpreter (wave_engine.hip).
 inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_persistent, std::string &why) {
     auto no = [&](const char *w) {
@@ -103,7 +111,6 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
     };
     if (!plan.ok) return no("not a wave-engine program");
     if (resumable_persistent) return no("continued programs with delay lines / feedback park their chunk buffers between launches");
-    if (plan.ring_events) return no("delay lines that need ordered slot operations");
     if (P.ops.size() > 96) return no("more than 96 channel-expanded units: straight-line code would outgrow the instruction cache");
     if (P.out_bufs.size() > 16) return no("more than 16 output channels");
     for (size_t k = 0; k < P.ops.size(); k++) {
@@ -114,8 +121,8 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_
             if (plan.op_state[k] >= 0) return no("a Ramp that a Retriggerer restarts");
             break;
         case OP_FILTER: break;  // (a connected cutoff: per-sample coefficients, the recurrence per wave out of its scratch)
-        case OP_DELAY:
-            if (!delay_write_once(op)) return no("a Delay outside the write-once regime");
+        case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:  // write-once ring protocol, or ordered slot operations
+            if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("delay ring out of range");
             break;
         case OP_TIMER:
             if (!(P.init_state[(size_t)op.state_slot] >= 0 && op.d[0] > 0 && op.d[0] < 1e300)) return no("a Timer outside the closed-form regime");
@@ -282,9 +289,14 @@ struct Emitter {
                         line("    o" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", " + num(scan_id) + ", " + (accumulating ? "true" : "false") + ");");
                     }
                     break;
-                case OP_DELAY:
-                    line("    JitDelayK y" + id + ";");
-                    line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
+                case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:
+                    if (jit_ring_ops(op)) {
+                        line("    JitRingOps q" + id + ";");
+                        line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
+                    } else {
+                        line("    JitDelayK y" + id + ";");
+                        line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    }
                     break;
                 case OP_TIMER:
                     line("    JitTimer c" + id + ";");
@@ -311,8 +323,8 @@ struct Emitter {
                     line("    m" + id + ".begin(A, " + num(op.state_slot) + ");");
                     break;
                 case OP_CB_READER: case OP_CB_WRITER:
-                    line("    JitCBNode n" + id + ";");
-                    line("    n" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    line(std::string(jit_ring_ops(op) ? "    JitRingOps q" : "    JitCBNode n") + id + ";");
+                    line(std::string(jit_ring_ops(op) ? "    q" : "    n") + id + ".begin(A, " + num(op.state_slot) + ");");
                     break;
                 default: break;
                 }
@@ -371,6 +383,10 @@ struct Emitter {
                     if (op.op == OP_RAMP) line("        jit_ramp_end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_TIMER)
                         line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
+                    if (jit_ring_ops(op)) {
+                        if (op.op != OP_MONO_DELAY) line("        " + slot + " = q" + id + ".T;");
+                        continue;
+                    }
                     if (op.op == OP_DELAY) line("        " + slot + " = y" + id + ".carried;");
                     if (op.op == OP_SHAPE) line("        s" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) line("        " + slot + " = (double)b" + id + ".tb;");
@@ -469,6 +485,17 @@ struct Emitter {
                 decl();
                 line("        for (int c = 0; c < 4; ++c) " + v + "[c] = " + expr + ";");
             };
+            if (jit_ring_ops(op)) {  // ordered slot operations (JitRingOps): p0 the signal / the offset, p1 the delay / the writer's input
+                const bool has_out = op.out_buf >= 0;
+                if (has_out) decl();
+                else line("        float u" + id + "[4];");
+                const std::string p0 = opnd_array(k, 0, "t" + id, r);
+                std::string p1 = p0;
+                if (op.op != OP_CB_READER && !(op.op == OP_CB_WRITER && (op.attr & 2))) p1 = opnd_array(k, 1, "tz" + id, r);
+                line("        q" + id + ".tick<" + num(op.op) + ", " + num(op.attr) + ">(A, " + X_ + ", g, scr, (int64_t)" + dref + ", (uint32_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + p0 + ", " + p1 + ", " +
+                     (has_out ? v : "u" + id) + ");");
+                continue;
+            }
             switch (op.op) {
             case OP_OSC:
                 decl();
@@ -597,7 +624,7 @@ struct Emitter {
                 dconst_of[k] = add_dk(op.d[0]);
                 add_dk(op.d[1]);
                 add_dk(op.d[2]);
-            } else if (op.op == OP_DELAY) {
+            } else if (op.op == OP_DELAY || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY) {
                 dconst_of[k] = add_dk((double)op.ring_base);
                 add_dk((double)op.ring_len);
             } else if (op.op == OP_SHAPE) {

@@ -795,6 +795,141 @@ struct JitCBNode {
     }
 };
 
+// ---- Ordered slot operations: ring units whose accesses can land anywhere — a Delay with a signal-rate or sub-chunk delay
+// (Delay.js:26-40), MonoDelay (MonoDelay.js:16-30), ReadBackDelay (ReadBackDelay.js:24-44), CircleBuffer nodes with a signal-rate
+// offset or a ring shorter than a chunk.  The reference walks the chunk sample by sample — read (and clear) one slot, add a tap to
+// each of two others, ... — in f32, so the ORDER of the operations on one slot matters, while operations on different slots
+// commute.  Each lane owns four samples = up to twelve slot operations, keyed 3 t + j in the reference's order.  Rounds: every
+// pending operation bids for its slot with its key (ds_min_u32 on a 1024-entry table in the wave's scratch, indexed by
+// slot mod 1024: two slots sharing an entry only cost extra rounds), the lowest key of each entry performs its operation on the
+// ring in HBM, and so on until nothing is pending — three rounds for a steady delay; whatever the modulation does, the result is
+// the reference's.  KIND: the unit's opcode.  p0: the signal (delay lines) or the offset (CircleBuffer nodes); p1: the delay /
+// the writer's input.  T: carried state — Delay: the previous chunk's last input; the others: the unit's running sample count.
+struct JitRingOps {
+    double T;  // uniform
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { T = jit_u(A.init_state[state_slot]); }
+    enum : int { RO_NONE = 0, RO_READ, RO_READ_CLEAR, RO_ADD, RO_STORE };
+    template <int KIND, int ATTR>
+    __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, float *scr, int64_t ring_base, uint32_t len, const float (&p0)[4],
+                                         const float (&p1)[4], float (&out)[4]) {
+        constexpr bool is_delay = KIND == OP_DELAY, is_mono = KIND == OP_MONO_DELAY, is_readback = KIND == OP_READBACK_DELAY;
+        constexpr bool is_reader = KIND == OP_CB_READER, is_writer = KIND == OP_CB_WRITER;
+        constexpr bool writer_mixes = is_writer && !(ATTR & 2);
+        const double dlen = (double)len;
+        const uint32_t lane = X.lane;
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        uint32_t *own = (uint32_t *)scr;
+        constexpr uint32_t kOwnMask = 1023u, kFree = 0xffffffffu;
+        jit_wave_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
+        // what operation j of a sample does
+        constexpr int kind0 = is_delay ? RO_READ_CLEAR : is_mono ? RO_ADD : is_readback ? RO_STORE
+                              : is_reader ? ((ATTR & 1) ? RO_READ_CLEAR : RO_READ)
+                              : (ATTR & 1) ? RO_STORE : writer_mixes ? RO_ADD : RO_NONE;  // writer: preWipe then mix = store; mix alone = add
+        constexpr int kind1 = is_delay || is_mono ? RO_ADD : is_readback ? RO_READ : RO_NONE;
+        constexpr int kind2 = is_delay ? RO_ADD : is_mono ? RO_READ_CLEAR : RO_NONE;
+        const int kind[3] = {kind0, kind1, kind2};
+        const double T0 = T;
+        const uint32_t tb0 = is_readback ? (uint32_t)(int64_t)fmod(T0, dlen) : (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+        int32_t slot[4][3];
+        double val[4][3];
+        uint32_t pending = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t t = lane * 4 + c;
+            const uint32_t tb = (tb0 + t) % len;
+            out[c] = 0.f;
+            if (is_reader || is_writer) {  // CircleBuffer.js:16-18: floor(t % len), negatives wrapped; NaN / Inf go nowhere
+                const double at = is_reader ? T0 + (double)t - X.srd * (double)p0[c] : T0 + (double)t + X.srd * (double)p0[c];
+                double m = (at >= 0.0 && at < dlen) ? at : fmod(at, dlen);
+                m = floor(m);
+                if (m < 0.0) m += dlen;
+                const bool valid = m >= 0.0 && m < dlen;
+                slot[c][0] = valid ? (int32_t)m : -1; val[c][0] = writer_mixes ? (double)p1[c] : 0.0;
+                slot[c][1] = slot[c][2] = -1; val[c][1] = val[c][2] = 0.0;
+                if (is_reader && !valid) out[c] = __builtin_nanf("");
+            } else if (is_readback) {
+                double r = (T0 + (double)t) - (double)p1[c] + dlen;
+                r = (r >= 0.0 && r < dlen) ? r : fmod(r, dlen);
+                const bool valid = r >= 0.0 && r < dlen && r == floor(r);  // a fractional or negative index reads `undefined`
+                slot[c][0] = (int32_t)tb; val[c][0] = (double)p0[c];
+                slot[c][1] = valid ? (int32_t)r : -1; val[c][1] = 0.0;
+                slot[c][2] = -1; val[c][2] = 0.0;
+                if (!valid) out[c] = __builtin_nanf("");
+            } else {
+                const double xin = (double)p0[c];
+                double tWrite = (double)tb + (double)p1[c];
+                if (!(tWrite >= 0.0 && tWrite < dlen))
+                    tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
+                const double lo = floor(tWrite), frac = tWrite - trunc(tWrite);
+                double hi = ceil(tWrite);
+                if (is_mono && hi >= dlen) hi -= dlen;  // MonoDelay wraps the ceil tap, Delay drops it at index len
+                const int32_t slo = (lo >= 0.0 && lo < dlen) ? (int32_t)lo : -1, shi = (hi >= 0.0 && hi < dlen) ? (int32_t)hi : -1;
+                const double vlo = xin * (1.0 - frac), vhi = xin * frac;
+                slot[c][0] = is_delay ? (int32_t)tb : slo; val[c][0] = is_delay ? 0.0 : vlo;
+                slot[c][1] = is_delay ? slo : shi;          val[c][1] = is_delay ? vlo : vhi;
+                slot[c][2] = is_delay ? shi : (int32_t)tb;  val[c][2] = is_delay ? vhi : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (slot[c][j] >= 0 && kind[j] != RO_NONE) pending |= 1u << (c * 3 + j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nodes of one CircleBuffer tick one after another
+        __builtin_amdgcn_wave_barrier();
+        while (__any(pending != 0)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (pending & (1u << (c * 3 + j)))
+                        __hip_atomic_fetch_min(&own[(uint32_t)slot[c][j] & kOwnMask], (lane * 4 + c) * 3 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t won = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if ((pending & (1u << (c * 3 + j))) && own[(uint32_t)slot[c][j] & kOwnMask] == (lane * 4 + c) * 3 + j) won |= 1u << (c * 3 + j);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the winners' slots are distinct: all their loads first (up to twelve L2 round trips in flight per lane), then the stores
+            float was[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    was[c][j] = 0.f;
+                    if (!(won & (1u << (c * 3 + j)))) continue;
+                    own[(uint32_t)slot[c][j] & kOwnMask] = kFree;
+                    if (kind[j] != RO_STORE) was[c][j] = ring[slot[c][j]];
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (!(won & (1u << (c * 3 + j)))) continue;
+                    float *p = ring + slot[c][j];
+                    if (kind[j] == RO_READ || kind[j] == RO_READ_CLEAR) {
+                        out[c] = was[c][j];
+                        if (kind[j] == RO_READ_CLEAR && X.live) *p = 0.f;
+                    } else if (kind[j] == RO_STORE) {
+                        if (X.live) *p = (float)val[c][j];
+                    } else if (X.live)
+                        *p = (float)((double)was[c][j] + val[c][j]);
+                }
+            pending &= ~won;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this round's ring traffic has landed before the next one starts
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (is_delay) T = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p0[3]), 63));
+        else if (is_readback || is_reader || is_writer) T = T0 + (double)kChunk;
+    }
+};
+
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;

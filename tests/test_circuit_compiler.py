@@ -15,7 +15,9 @@ COMPILED = ["osc440_1s", "voice3_k7", "cfg2_sweep", "fm_mixed", "fm_sum", "mult_
             "map_gain", "rest_crossfader", "rest_timer_fm", "osc_triangle",
             # units with a sequential stage (one lane walks the chunk out of the wave's LDS scratch)
             "fam_allpass_series", "fam_comb_mod", "env_ahd_mod", "rest_srr_mod", "fam_multiosc_negative", "env_shape_semisine_amp",
-            "env_shape_mod", "filter_lp_mod", "circlebuffer_taps", "circlebuffer_2ch"]
+            "env_shape_mod", "filter_lp_mod", "circlebuffer_taps", "circlebuffer_2ch",
+            # ordered slot operations: delay lines and CircleBuffer nodes whose accesses can meet inside a chunk
+            "delay_mod", "fam_monodelay_mod", "fam_readback_frac", "circlebuffer_moving_tap", "circlebuffer_short_ring", "loop_110p5_short"]
 
 
 def source(words, **kw):
@@ -43,8 +45,7 @@ def test_what_the_compiler_takes_and_what_stays_on_the_interpreter():
         except runtime.DuspHipError as e:
             assert e.status == -2, e
             refused[name] = e.message
-    assert taken >= 139 and len(refused) <= 20
-    assert "ordered slot operations" in refused["delay_mod"] and "ordered slot operations" in refused["circlebuffer_moving_tap"]
+    assert taken >= 157 and len(refused) <= 2
     assert "channel counts grow" in refused["patch_scary"]
     assert "more than 96" in refused["summany_1024"]
 
