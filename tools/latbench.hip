@@ -1,5 +1,5 @@
 // latbench.hip — dependent-issue latency of the instructions on the biquad's critical path (gfx950), one wave.
-//   hipcc --offload-arch=gfx950 -O3 -o latbench latbench.hip && ./latbench
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o latbench latbench.hip && ./latbench   (no contraction: like the kernels)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
