@@ -205,6 +205,7 @@ static dusp::Knobs read_knobs() {
     k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
     k.wave_per_wave = num("DUSP_WAVE_PER_WAVE", k.wave_per_wave);
     k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
+    k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     return k;
 }
 
@@ -701,7 +702,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         int scratch = 0;
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
-        if (scratch <= 64) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
+        if (scratch <= ctx->knobs.jit_spill_bytes) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
         if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {

@@ -295,7 +295,7 @@ struct Emitter {
                         line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
                     } else {
                         line("    JitDelayK y" + id + ";");
-                        line("    y" + id + ".begin(A, " + num(op.state_slot) + ");");
+                        line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     }
                     break;
                 case OP_TIMER:
@@ -450,6 +450,12 @@ struct Emitter {
                 line("        jit_lds_barrier();");
                 line("        " + f + ".serial(X[0], tile);");
                 line("        jit_lds_barrier();");
+                line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
+                for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, xrow, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ");");
+                line("            jit_lds_barrier();");
+                line("            " + f + ".serial_exact(X[0], tile);");
+                line("            jit_lds_barrier();");
+                line("        }");
                 for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
                 // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
             }
@@ -578,7 +584,7 @@ struct Emitter {
             case OP_DELAY: {
                 decl();
                 const std::string x = opnd_array(k, 0, "t" + id, r);
-                line("        y" + id + ".tick(A, " + X_ + ", g, (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ", " + x + ", " + v + ");");
+                line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
                 break;
             }
             default:

@@ -1045,55 +1045,100 @@ struct JitFilterK {
             out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
         }
     }
-    // between two barriers: SUB samples of the recurrence of every row
+    // eight steps of the recurrence on P values held in registers, WITHOUT the `|| 0` selects of Filter.js:42-46
+    template <typename DST>
+    __device__ __forceinline__ void block8(const double (&pv)[8], double &u1, double &u2, DST *dst) const {
+        const double b1 = k[3], b2 = k[4];
+        f32x4 y4[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float y = (float)((pv[i] - b1 * u1) - b2 * u2);
+            y4[i >> 2][i & 3] = y;
+            u2 = u1;
+            u1 = (double)y;
+        }
+        dst[0] = y4[0];
+        dst[1] = y4[1];
+    }
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // a row's LDS address as a masked integer: known non-negative, so that element offsets fold into the ds instructions' immediates
+    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {
+        return ((uint32_t)(uintptr_t)(lds_double *)(tile + (size_t)row * kPitch)) & 0x3ffffu;
+    }
+    // Between two barriers: SUB samples of the recurrence of every row — one wave, up to 64 rows on its lanes.  A step's chain
+    // is mul, sub, sub, cvt, cvt (26-30 cycles by itself) and the wave issues in order, so whatever else sits in the loop adds
+    // its issue time (tools/serialbench.hip: an LDS read of two doubles 13 cycles, a 16-byte store 23, a test-and-branch per
+    // block 45): P comes from LDS in blocks of 8 whose reads are issued a block ahead (two register sets, no copies), offsets
+    // in the instructions' immediate fields; y overwrites P values that are in registers already; and the loop tests nothing.
+    //
+    // The `|| 0` selects of Filter.js:42-46 on y1 / y2 are speculated away.  Without them a NaN never leaves the recurrence (it
+    // comes back through b1 y1 whatever b1 is), so the LAST output of the sub-block tells whether any of its outputs was one;
+    // short of a NaN the selects only turn -0 into +0, which can only flip the sign of a later zero, and every consumer maps
+    // that to +0 (see loop2_engine.hip).  A sub-block that met a NaN in some row is given back: the word after row 0 says so,
+    // y1 / y2 stay as they were, every wave parks its rows again (failed()) and serial_exact() does the sub-block as written.
     __device__ __forceinline__ void serial(const JitCtx &X, double *tile) {
         if (X.wave != 0 || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
-        const double *pr = tile + (size_t)X.lane * kPitch;
-        f32x4 *yr = (f32x4 *)pr;
-        const double b1 = k[3], b2 = k[4];
-        // The `|| 0` selects of Filter.js:42-46 on y1 / y2 are speculated away: without them a NaN never leaves the recurrence, so
-        // testing a block's last outputs finds one anywhere in it (the block is then redone exactly); a -0 in place of +0 can only
-        // flip the sign of a later zero, which every consumer maps to +0 (see loop2_engine.hip).
-        constexpr int PB = R >= 2 ? 8 : 16;  // P values per block held in registers (with several instances per wave the kernel is at its 128 VGPRs)
-        for (int t0 = 0; t0 < SUB; t0 += PB) {
-            double pv[PB];
+        const uint32_t row = row_address(tile, X.lane);
+        const lds_double *pr = (const lds_double *)(uintptr_t)row;
+        lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
+        double u1 = jit_or0(y1), u2 = jit_or0(y2);
+        double pa[8], pb[8];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) pv[i] = pr[t0 + i];
-            __builtin_amdgcn_sched_barrier(0);  // (an LDS read left on the chain costs ~100 cycles: all of the block's first)
-            const double y1_in = y1, y2_in = y2;
-            double u1 = jit_or0(y1), u2 = jit_or0(y2);
-            f32x4 y4[PB / 4];
+        for (int i = 0; i < 8; ++i) pa[i] = pr[i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the loop is entered with its first block here, as every later iteration finds it
+        for (int t0 = 0; t0 < SUB; t0 += 16) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const float y = (float)((pv[i] - b1 * u1) - b2 * u2);
-                y4[i >> 2][i & 3] = y;
-                u2 = u1;
-                u1 = (double)y;
-            }
-            if (u1 == u1 && u2 == u2) {
-                y1 = u1;
-                y2 = u2;
-            } else {
-                y1 = y1_in;
-                y2 = y2_in;
+            for (int i = 0; i < 8; ++i) pb[i] = pr[8 + i];
+            __builtin_amdgcn_sched_barrier(0);
+            block8(pa, u1, u2, yr);  // y of samples t0 .. t0+7 goes where P of samples t0/2 .. t0/2+3 stood (P up to t0+15 is in registers)
+            const int next = t0 + 16 < SUB ? 16 : 0;  // (the last block reads itself again: a branch around the reads would make every wait conservative)
 #pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const float y = (float)((pv[i] - b1 * jit_or0(y1)) - b2 * jit_or0(y2));  // Filter.js:40-46
-                    y4[i >> 2][i & 3] = y;
-                    y2 = jit_or0(y1);
-                    y1 = (double)y;
-                }
-            }
-            // y of samples t0 .. t0+PB-1 goes where P of samples t0/2 .. stood: read already (this block's are in registers)
-#pragma unroll
-            for (int i = 0; i < PB / 4; ++i) yr[(t0 >> 2) + i] = y4[i];
+            for (int i = 0; i < 8; ++i) pa[i] = pr[next + i];
+            __builtin_amdgcn_sched_barrier(0);
+            block8(pb, u1, u2, yr + 2);
+            pr += 16;
+            yr += 4;
+        }
+        const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;  // (some row's: the sub-block is given back whole)
+        if (X.lane == 0) *(lds_u32 *)(uintptr_t)(row_address(tile, 0) + SUB * 8) = met_nan ? 1u : 0u;
+        if (!met_nan) {
+            y1 = u1;
+            y2 = u2;
         }
 #ifdef DUSP_JIT_PROFILE
         cyc_serial += __builtin_readcyclecounter() - stamp0;
 #endif
+    }
+    // after the barrier that ends serial(), every wave: was the sub-block given back?
+    static __device__ __forceinline__ bool failed(double *tile) {
+        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)(row_address(tile, 0) + SUB * 8)) != 0;
+    }
+    // the sub-block as Filter.js:40-46 writes it, on freshly parked rows
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile) {
+        if (X.wave != 0 || X.lane >= WAVES * R) return;
+        const uint32_t row = row_address(tile, X.lane);
+        const lds_double *pr = (const lds_double *)(uintptr_t)row;
+        lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
+        const double b1 = k[3], b2 = k[4];
+        for (int t0 = 0; t0 < SUB; t0 += 4) {
+            double pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = pr[t0 + i];
+            f32x4 y4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = (float)((pv[i] - b1 * jit_or0(y1)) - b2 * jit_or0(y2));
+                y4[i] = y;
+                y2 = jit_or0(y1);
+                y1 = (double)y;
+            }
+            yr[t0 >> 2] = y4;  // (over P of samples t0/2 and t0/2+1: read already)
+        }
     }
     // state write-back: the input history by each wave (slot r), coefficients and recurrence memory by the lanes that hold them
     __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
@@ -1191,29 +1236,42 @@ struct JitFilterM {
 // ---- Delay (src/components/Delay.js:20-41) with a constant delay D + phi, 256 <= D <= len - 256: the chunk's 256 reads are one
 // coalesced load from the ring ([instance][slot] in HBM), reads and writes of one chunk never meet, and every slot's final
 // value (ceil tap of sample n-1, then floor tap of sample n, with the reference's two `+=` roundings) is written once.
+// Everything a chunk reads was written before the chunk began (D >= 256), so the NEXT chunk's reads are issued right after
+// this chunk's writes and have the rest of the chunk — the Filter stage, usually — to arrive.
 struct JitDelayK {
-    double carried;  // the input sample before the chunk (uniform)
-    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { carried = jit_u(A.init_state[state_slot]); }
-    __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, int64_t ring_base, int64_t len, float delay, const float (&x)[4],
-                                         float (&out)[4]) {
+    double carried, phi;  // the input sample before the chunk; the delay's fraction (uniform)
+    float *ring;          // this instance's ring
+    uint32_t len, D, s0;  // ring length, whole delay, the chunk's first slot
+    float ahead[4];       // the coming chunk's reads
+    __device__ __forceinline__ void fetch(const JitCtx &X) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t s_ = s0 + X.lane * 4 + c;
+            if (s_ >= len) s_ -= len;
+            ahead[c] = ring[s_];
+        }
+    }
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_base, int64_t ring_len, float delay) {
+        carried = jit_u(A.init_state[state_slot]);
         double dconst = (double)delay;
-        if (dconst >= (double)len) dconst = fmod(dconst, (double)len);
-        const double Dfl = floor(dconst), phi = dconst - Dfl;
-        const int64_t D = (int64_t)Dfl;
-        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
-        const int64_t s0 = (int64_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+        if (dconst >= (double)ring_len) dconst = fmod(dconst, (double)ring_len);
+        const double Dfl = floor(dconst);
+        phi = dconst - Dfl;
+        D = (uint32_t)Dfl;
+        len = (uint32_t)ring_len;
+        ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        s0 = (uint32_t)((A.clock0 + (uint64_t)X.g_begin * kChunk) % (uint64_t)ring_len);
+        fetch(X);
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
         const float x_left = __shfl_up(x[3], 1, 64);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int64_t s_ = s0 + X.lane * 4 + c;
-            if (s_ >= len) s_ -= len;
-            out[c] = ring[s_];
-        }
+        for (int c = 0; c < 4; ++c) out[c] = ahead[c];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            int64_t s_ = s0 + X.lane * 4 + c;
-            if (s_ >= len) s_ -= len;
-            int64_t lo = s_ + D;
+            uint32_t lo = s0 + X.lane * 4 + c;
+            if (lo >= len) lo -= len;
+            lo += D;
             if (lo >= len) lo -= len;
             const double xin = (double)x[c];
             const double xprev = c == 0 ? (X.lane == 0 ? carried : (double)x_left) : (double)x[c - 1];
@@ -1228,6 +1286,9 @@ struct JitDelayK {
             if (X.live) ring[lo] = slot;
         }
         carried = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        s0 += kChunk;
+        if (s0 >= len) s0 -= len;  // (len >= 512 here)
+        fetch(X);  // (after this chunk's stores, in program order: a wave's accesses to one address stay in order)
     }
 };
 

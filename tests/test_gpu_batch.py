@@ -66,6 +66,31 @@ def test_feedback_loop_batch(engine, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("engine", [runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK])
+def test_filter_takes_nan_inputs_as_the_reference_does(engine, oracle):
+    """0/0 at the input of a Filter every 480 samples (some instances only): the recurrence reads `this.y1 || 0` (Filter.js:42-46), so it
+    recovers one sample later.  On the compiled kernel the recurrence runs without those selects and the sub-block that met the NaN is
+    given back and done over as written — the instances that share the workgroup must not notice."""
+    d.configure(48000)
+    def voice(k):
+        return d.Filter(d.Divide(d.Osc(100), d.Osc(100 + k)), 700 + k)
+    uni = descriptor.unify([descriptor.extract(voice(k)) for k in (0, 1, 0, 3, 0, 0, 7, 0, 2)])
+    n = 3000
+    prog = render.context(48000).build(uni.words, engine)
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    if engine == runtime.ENGINE_WAVE:
+        assert "compiled kernel" in prog.shape
+    met = 0
+    for i in range(uni.n_instances):
+        want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        # a NaN output sample reaches the PCM as 0 (renderChannelData.js:44): an exact zero between two samples that are far from it
+        w = want[0]
+        met += int(np.any((w[1:-1] == 0.0) & (np.abs(w[:-2]) > 0.1) & (np.abs(w[2:]) > 0.1)))
+        assert np.max(np.abs(pcm[i].astype(np.float64) - want)) <= 1e-5 * max(1.0, float(np.max(np.abs(want)))), i
+    assert met >= 5  # (the k = 0 instances divide 0 by 0 at every period's start)
+    prog.close()
+
+
 def test_headline_config_full_size(oracle):
     """BASELINE configs[2] at FULL size (1024 voices x 60 s @ 48 kHz, 11.8 GB of PCM resident in HBM):
     a spread of voices is compared with the oracle sample for sample over the whole minute, and a
