@@ -121,7 +121,7 @@ struct dusp_program {
     // WAVE programs the circuit compiler takes (jit_codegen.hpp): generated text per workgroup geometry, constants on the device
     bool jit_ok = false;
     std::string jit_why;
-    std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, instances per wavefront) -> kernel text (+ constants, scan list)
+    std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, 8 x instances per wavefront + Filter block) -> kernel text (+ constants, scan list)
     bool jit_consts_uploaded = false;
     int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
     DevBuf<float> d_jit_fk;
@@ -206,6 +206,7 @@ static dusp::Knobs read_knobs() {
     k.wave_per_wave = num("DUSP_WAVE_PER_WAVE", k.wave_per_wave);
     k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
+    k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     return k;
 }
 
@@ -377,8 +378,14 @@ static int finish_build(dusp_program *prog) {
         else if (engine == DUSP_ENGINE_AUTO)
             engine = wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
     }
+    // The feedback-voice shape with a write-once delay line has two kernels: the two-stage loop kernel and, since the circuit
+    // compiler knows all its units, a kernel compiled for the circuit — 17.7 against 20.2 ms on BASELINE configs[3].
+    std::string jit_why;
+    const bool compiled_loop = loopable && prog->loop_two_stage && wavable && !prog->wave.ring_events && ctx->knobs.wave_jit != 0 &&
+                               ctx->knobs.loop_compiled != 0 && dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, jit_why);
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
+                 : compiled_loop ? DUSP_ENGINE_WAVE
                  : (loopable && (prog->loop_two_stage || prog->wave.ring_events)) ? DUSP_ENGINE_LOOP  // (one lane per voice beats slot rounds)
                  : wavable ? DUSP_ENGINE_WAVE
                  : loopable ? DUSP_ENGINE_LOOP
@@ -678,11 +685,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
         opt.per_wave = per_wave;
-        auto it = prog->jit_src.find({waves, per_wave});
+        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8});
         if (it == prog->jit_src.end()) {
             dusp::JitSource gen;
             if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
-            it = prog->jit_src.emplace(std::make_pair(waves, per_wave), std::move(gen)).first;
+            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8), std::move(gen)).first;
         }
         src = &it->second;
         // A structure seen for the first time costs a compile of 0.3-0.8 s.  A render the interpreter kernel finishes sooner
@@ -705,6 +712,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (scratch <= ctx->knobs.jit_spill_bytes) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
+        if (prog->wave.has_filter && opt.filter_block == 8) {
+            opt.filter_block = 4;  // (first: the recurrence loop with half the P values in flight, 16 registers less)
+            continue;
+        }
+        opt.filter_block = 8;
         if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
             waves /= 2;
             per_wave *= 2;

@@ -42,6 +42,7 @@ struct JitOptions {
     int lds_table = -1;      // table id whose half image sits in LDS, or -1
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
+    int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
@@ -58,17 +59,16 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
     return 0;
 }
 
-// LDS of one workgroup of the generated kernel: the table image, then the Filter stage's tile — one 260-float row per
-// instance of the workgroup (the input chunk on the way in, the output chunk on the way out).  Declared statically in the
+// LDS of one workgroup of the generated kernel: the table image, then the Filter stage's tile, then the sequential-stage units'
+// per-wave scratch.  Declared statically in the
 // kernel text (a static declaration may take all 160 KiB; dynamic LDS would need a function attribute that module kernels
 // do not have).
 // Filter stage: one row of (sub-block + 2) doubles per instance of the workgroup; the sub-block (256, 128 or 64 samples) is the
 // largest that fits the LDS left over.
 inline size_t jit_filter_tile_bytes(int rows, int sub) { return (size_t)rows * (size_t)(sub + 2) * 8; }
-inline size_t jit_filter_scratch_bytes(int waves) { return (size_t)waves * 260 * 4; }  // one row of inputs per wavefront
 inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
     for (int sub : {256, 128, 64})
-        if (jit_filter_tile_bytes(waves * per_wave, sub) + jit_filter_scratch_bytes(waves) <= lds_left) return sub;
+        if (jit_filter_tile_bytes(waves * per_wave, sub) <= lds_left) return sub;
     return 0;
 }
 // units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
@@ -96,7 +96,7 @@ inline size_t jit_scratch_floats(const Program &P) {
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves) : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) : 0) +
                                     (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
@@ -243,11 +243,10 @@ struct Emitter {
         if (out.has_filter) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4);
             line("    double *tile = (double *)(lds + " + num(at) + ");");
-            line("    float *xrow = lds + " + num(at + (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) / 4)) + " + X[0].wave * 260;");
         }
         if (opt.scratch_floats) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
-                                 (out.has_filter ? (long long)((jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) + jit_filter_scratch_bytes(opt.waves)) / 4) : 0);
+                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) / 4) : 0);
             line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         }
         // constants and parameters the used ops name
@@ -445,13 +444,20 @@ struct Emitter {
                 xs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
                 line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
             }
+            for (int r = 0; r < R; r++) {
+                line("        double q" + num(k) + "_" + num(r) + "[4];");
+                line("        " + f + ".feed(" + ctx(r) + ", " + num(r) + ", " + xs[(size_t)r] + ", q" + num(k) + "_" + num(r) + ");");
+            }
             for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) {
-                for (int r = 0; r < R; r++) line("        " + f + ".park(" + ctx(r) + ", tile, xrow, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ");");
+                auto park = [&](const char *indent) {
+                    for (int r = 0; r < R; r++) line(std::string(indent) + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ");");
+                };
+                park("        ");
                 line("        jit_lds_barrier();");
-                line("        " + f + ".serial(X[0], tile);");
+                line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile);");
                 line("        jit_lds_barrier();");
                 line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
-                for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, xrow, " + num(r) + ", " + num(sb) + ", " + xs[(size_t)r] + ");");
+                park("            ");
                 line("            jit_lds_barrier();");
                 line("            " + f + ".serial_exact(X[0], tile);");
                 line("            jit_lds_barrier();");
@@ -459,7 +465,6 @@ struct Emitter {
                 for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
                 // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
             }
-            for (int r = 0; r < R; r++) line("        " + f + ".carry(" + num(r) + ", " + xs[(size_t)r] + ");");
             return;
         }
         if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) {

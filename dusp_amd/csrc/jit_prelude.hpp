@@ -971,19 +971,21 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 }
 
 // ---- Filter (src/components/Filter.js:27-51) with an unconnected cutoff.  y = f32((P - b1 y1) - b2 y2) with
-// P = (a0 x + a1 x1) + a2 x2 is a recurrence in y only.  P is lane-parallel (neighbours by shuffle, the two inputs before the
-// chunk carried as scalars); the recurrence is a dependent chain of five f64 operations per sample whatever the lane count,
-// so the WAVES x R instances of a workgroup run theirs side by side on the lanes of ONE wave: in sub-blocks of SUB samples
-// every wave parks its instances' P values (f64) in a shared LDS tile, wave 0 runs lane = instance over the rows — nothing
-// but the chain: P values pulled into registers 16 at a time, y written as f32 over the P values already consumed — and
-// every wave picks its rows up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of
-// "its" lane of wave 0 for the whole render.
+// P = (a0 x + a1 x1) + a2 x2 is a recurrence in y only.  P is lane-parallel: every lane computes its four samples' from its own
+// inputs and the last two of the lane before it (one DPP shift each; in front of the chunk, the two inputs carried as
+// scalars).  The recurrence is a dependent chain of five f64 operations per sample whatever the lane count, so the WAVES x R
+// instances of a workgroup run theirs side by side on the lanes of ONE wave: in sub-blocks of SUB samples every wave parks
+// its instances' P values (f64, out of the registers feed() left them in) in a shared LDS tile, wave 0 runs lane = instance
+// over the rows — nothing but the chain, y written as f32 over the P values already consumed — and every wave picks its rows
+// up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of "its" lane of wave 0 for
+// the whole render.
 //   tile: rows of SUB + 2 doubles, row = wave R + r;  SUB = 256, 128 or 64 by what LDS holds next to the table image
-//   xrow: this wave's scratch row of 260 floats (the chunk's inputs of the slot being parked)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int WAVES, int R, int SUB>
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
-    double a[R][3], x1[R], x2[R];           // this wave's instances: a0 a1 a2, the two inputs before the chunk (wave-uniform)
+    double a[R][3];                         // this wave's instances: a0 a1 a2 (wave-uniform)
+    float x1[R], x2[R];                     // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     double k[5], y1, y2, lastF;             // wave 0, lane = row: that instance's coefficients and recurrence memory
 #ifdef DUSP_JIT_PROFILE
     unsigned long long cyc_serial = 0;      // diagnostic build: cycles wave 0 spent inside serial()
@@ -1000,6 +1002,14 @@ struct JitFilterK {
         lastF = ft;
         y1 = is[9];
         y2 = is[10];
+        // (what the render leaves of these is known now: written here, the feed-forward coefficients need no registers through the loop)
+        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
+        if (X.wave == 0 && X.lane < WAVES * R && inst < A.n_inst) {
+            double *st = A.state + (size_t)state_slot * A.n_pad + inst;
+            st[0] = 1.0;
+            st[A.n_pad] = lastF;
+            for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
+        }
     }
     // f: the cutoff of the wave's instance in slot r
     __device__ __forceinline__ void begin_slot(const JitArgs &A, const JitCtx &X, int r, int kind, float f, int state_slot) {
@@ -1011,32 +1021,30 @@ struct JitFilterK {
             kk[0] = is[2]; kk[1] = is[3]; kk[2] = is[4];
         }
         a[r][0] = jit_u(kk[0]); a[r][1] = jit_u(kk[1]); a[r][2] = jit_u(kk[2]);
-        x1[r] = jit_u(is[7]);
-        x2[r] = jit_u(is[8]);
+        x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
+        x2[r] = jit_u((float)is[8]);
     }
-    // Sub-block s of slot r's chunk, parked with ALL 64 lanes at work: the wave stages the chunk's 256 inputs in its scratch row
-    // (lane l holds samples 4l .. 4l+3; the sub-block's samples belong to a quarter or half of the lanes), then lane l computes
-    // the feed-forward half of sample(s) s SUB + 64 q + l from the row — its own input and the two before it, the carried
-    // scalars in front of the chunk — and parks it.
-    __device__ __forceinline__ void park(const JitCtx &X, double *tile, float *xrow, int r, int s, const float (&x)[4]) const {
-        ((f32x4 *)xrow)[X.lane] = f32x4{x[0], x[1], x[2], x[3]};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double *row = tile + (size_t)(X.wave * R + r) * kPitch;
+    static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
+    // The feed-forward half of slot r's chunk, P[t] = (a0 x[t] + a1 (x[t-1] || 0)) + a2 (x[t-2] || 0) in f64 with the reference's
+    // order of roundings (Filter.js:40-42): lane l its samples 4l .. 4l+3.  Leaves the chunk's last two inputs for the next chunk.
+    __device__ __forceinline__ void feed(const JitCtx &X, int r, const float (&x)[4], double (&p)[4]) {
+        // the lane before this one's x[3] and x[2]; lane 0 gets the carried pair (DPP wave_shr:1, `old` stays where no lane shifts in)
+        const float l1 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x1[r]), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
+        const float l2 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x2[r]), __float_as_uint(x[2]), 0x138, 0xf, 0xf, false));
+        const double o[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
 #pragma unroll
-        for (int q = 0; q < SUB / 64; ++q) {
-            const int j = s * SUB + q * 64 + (int)X.lane;
-            const double xin = (double)xrow[j];
-            const double xm1 = j >= 1 ? (double)xrow[j - 1] : x1[r];
-            const double xm2 = j >= 2 ? (double)xrow[j - 2] : (j == 1 ? jit_or0(x1[r]) : x2[r]);
-            row[q * 64 + (int)X.lane] = (a[r][0] * xin + a[r][1] * jit_or0(xm1)) + a[r][2] * jit_or0(xm2);
-        }
-        __builtin_amdgcn_wave_barrier();  // (the next slot's stage may not overtake these reads)
+        for (int c = 0; c < 4; ++c) p[c] = (a[r][0] * (double)x[c] + a[r][1] * o[c + 1]) + a[r][2] * o[c];
+        x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
     }
-    // after the chunk's last sub-block: the chunk's last two inputs, for the next chunk's first lanes (x1 as it is, x2 through `|| 0`)
-    __device__ __forceinline__ void carry(int r, const float (&x)[4]) {
-        x1[r] = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
-        x2[r] = jit_or0((double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
+    // sub-block s of slot r: the lanes whose samples it holds put their four P values into the wave's row
+    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[4]) {
+        const int first = s * (SUB / 4);
+        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+            f64x2 *row = (f64x2 *)(tile + (size_t)(X.wave * R + r) * kPitch) + ((int)X.lane - first) * 2;
+            row[0] = f64x2{p[0], p[1]};
+            row[1] = f64x2{p[2], p[3]};
+        }
     }
     static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
         const int first = s * (SUB / 4);
@@ -1045,20 +1053,20 @@ struct JitFilterK {
             out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
         }
     }
-    // eight steps of the recurrence on P values held in registers, WITHOUT the `|| 0` selects of Filter.js:42-46
-    template <typename DST>
-    __device__ __forceinline__ void block8(const double (&pv)[8], double &u1, double &u2, DST *dst) const {
+    // PB (8 or 4) steps of the recurrence on P values held in registers, WITHOUT the `|| 0` selects of Filter.js:42-46
+    template <int PB, typename DST>
+    __device__ __forceinline__ void block(const double (&pv)[PB], double &u1, double &u2, DST *dst) const {
         const double b1 = k[3], b2 = k[4];
-        f32x4 y4[2];
+        f32x4 y4[PB / 4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < PB; ++i) {
             const float y = (float)((pv[i] - b1 * u1) - b2 * u2);
             y4[i >> 2][i & 3] = y;
             u2 = u1;
             u1 = (double)y;
         }
-        dst[0] = y4[0];
-        dst[1] = y4[1];
+#pragma unroll
+        for (int i = 0; i < PB / 4; ++i) dst[i] = y4[i];
     }
     typedef __attribute__((address_space(3))) double lds_double;
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
@@ -1078,6 +1086,7 @@ struct JitFilterK {
     // short of a NaN the selects only turn -0 into +0, which can only flip the sign of a later zero, and every consumer maps
     // that to +0 (see loop2_engine.hip).  A sub-block that met a NaN in some row is given back: the word after row 0 says so,
     // y1 / y2 stay as they were, every wave parks its rows again (failed()) and serial_exact() does the sub-block as written.
+    template <int PB>  // 8, or 4 where the kernel is short of registers (two sets of PB doubles)
     __device__ __forceinline__ void serial(const JitCtx &X, double *tile) {
         if (X.wave != 0 || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
@@ -1087,22 +1096,22 @@ struct JitFilterK {
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         double u1 = jit_or0(y1), u2 = jit_or0(y2);
-        double pa[8], pb[8];
+        double pa[PB], pb[PB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pa[i] = pr[i];
+        for (int i = 0; i < PB; ++i) pa[i] = pr[i];
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the loop is entered with its first block here, as every later iteration finds it
-        for (int t0 = 0; t0 < SUB; t0 += 16) {
+        for (int t0 = 0; t0 < SUB; t0 += 2 * PB) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pb[i] = pr[8 + i];
+            for (int i = 0; i < PB; ++i) pb[i] = pr[PB + i];
             __builtin_amdgcn_sched_barrier(0);
-            block8(pa, u1, u2, yr);  // y of samples t0 .. t0+7 goes where P of samples t0/2 .. t0/2+3 stood (P up to t0+15 is in registers)
-            const int next = t0 + 16 < SUB ? 16 : 0;  // (the last block reads itself again: a branch around the reads would make every wait conservative)
+            block<PB>(pa, u1, u2, yr);  // y of samples t0 .. t0+PB-1 goes where P of the samples from t0/2 on stood (P up to t0+2PB-1 is in registers)
+            const int next = t0 + 2 * PB < SUB ? 2 * PB : 0;  // (the last block reads itself again: a branch around the reads would make every wait conservative)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pa[i] = pr[next + i];
+            for (int i = 0; i < PB; ++i) pa[i] = pr[next + i];
             __builtin_amdgcn_sched_barrier(0);
-            block8(pb, u1, u2, yr + 2);
-            pr += 16;
-            yr += 4;
+            block<PB>(pb, u1, u2, yr + PB / 4);
+            pr += 2 * PB;
+            yr += PB / 2;
         }
         const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;  // (some row's: the sub-block is given back whole)
         if (X.lane == 0) *(lds_u32 *)(uintptr_t)(row_address(tile, 0) + SUB * 8) = met_nan ? 1u : 0u;
@@ -1144,16 +1153,13 @@ struct JitFilterK {
     __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
         if (!X.live || X.lane != 0) return;
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
-        st[(size_t)7 * A.n_pad] = x1[r];
-        st[(size_t)8 * A.n_pad] = x2[r];
+        st[(size_t)7 * A.n_pad] = (double)x1[r];
+        st[(size_t)8 * A.n_pad] = (double)x2[r];
     }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
         const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
         if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst) return;
         double *st = A.state + (size_t)state_slot * A.n_pad + inst;
-        st[0] = 1.0;
-        st[A.n_pad] = lastF;
-        for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
         st[(size_t)9 * A.n_pad] = y1;
         st[(size_t)10 * A.n_pad] = y2;
     }

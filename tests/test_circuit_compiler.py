@@ -103,11 +103,12 @@ def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     text = source(uni.words, waves=16, per_wave=3, compile=True)
     fast = text.split("} else {")[0]
     assert fast.count("jit_ramp<") == 1 and fast.count(".tick<1, 0, true>") == 3   # one envelope, three oscillators
-    # 48 recurrences side by side on wave 0, in four sub-blocks of 64 samples (what LDS holds next to the table image)
-    # (each sub-block followed by its give-back branch: parked again and done as written if a recurrence met a NaN)
-    assert fast.count("f3.park(") == 24 and fast.count("f3.serial(") == 4 and fast.count("f3.pick(") == 12 and fast.count("f3.carry(") == 3
-    assert fast.count("if (f3.failed(tile))") == 4 and fast.count("f3.serial_exact(") == 4
-    assert "JitFilterK<16, 3, 64>" in text and "dusp_jit_pass" not in text
+    # 48 recurrences side by side on wave 0, in two sub-blocks of 128 samples (what LDS holds next to the table image): the feed-forward
+    # half once per instance and chunk, into registers; each sub-block parked from there, followed by its give-back branch (parked again
+    # and done as written if a recurrence met a NaN)
+    assert fast.count("f3.feed(") == 3 and fast.count("f3.park(") == 12 and fast.count("f3.serial<8>(") == 2 and fast.count("f3.pick(") == 6
+    assert fast.count("if (f3.failed(tile))") == 2 and fast.count("f3.serial_exact(") == 2
+    assert "JitFilterK<16, 3, 128>" in text and "dusp_jit_pass" not in text
     with pytest.raises(runtime.DuspHipError, match="per_wave"):
         source(uni.words, waves=16, per_wave=5)
 

@@ -58,7 +58,7 @@ def test_feedback_loop_batch(engine, oracle):
     uni = descriptor.unify([descriptor.extract(loop(k)) for k in range(0, 8192, 97)])
     n = 2000
     prog = render.context(48000).build(uni.words, engine)
-    assert prog.engine == ("loop" if engine == runtime.ENGINE_AUTO else "chunk")
+    assert prog.engine == ("wave" if engine == runtime.ENGINE_AUTO else "chunk")  # (AUTO: a kernel compiled for the circuit)
     pcm = prog.render(n, uni.n_instances, uni.params)
     for i in range(0, uni.n_instances, 7):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
@@ -183,8 +183,10 @@ def test_config2_mixdown_full_size(oracle):
     prog.close()
 
 
-def test_config3_feedback_loops_full_size(oracle):
-    """configs[3]: 8192 instances of Osc->Sum->Delay->Filter->Multiply->(Sum), 10 s @ 48 kHz (15.7 GB of PCM)."""
+@pytest.mark.parametrize("engine", [runtime.ENGINE_AUTO, runtime.ENGINE_LOOP])
+def test_config3_feedback_loops_full_size(engine, oracle):
+    """configs[3]: 8192 instances of Osc->Sum->Delay->Filter->Multiply->(Sum), 10 s @ 48 kHz (15.7 GB of PCM): on the kernel compiled
+    for the circuit (what AUTO picks) and on the two-stage loop kernel."""
     import torch
     d.configure(48000)
     def loop(k):
@@ -195,8 +197,8 @@ def test_config3_feedback_loops_full_size(oracle):
     uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
     V, n = 8192, 480000
     params = (110 + np.arange(V) / 64.0).astype(np.float32).reshape(1, V)
-    prog = render.context(48000).build(uni.words)
-    assert prog.engine == "loop"
+    prog = render.context(48000).build(uni.words, engine)
+    assert prog.engine == ("wave" if engine == runtime.ENGINE_AUTO else "loop")
     out = torch.empty((V, 1, n), dtype=torch.float32, device="cuda")
     dp = torch.from_numpy(params).cuda()
     prog.render_device(n, V, dp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)

@@ -51,7 +51,7 @@ def main():
     cfgs["cfg3b_sum1024"] = (lambda: uni_of([d.Sum.many([d.Osc(10 * k) for k in range(1, 1025)])]), T60, None)
     cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
                              (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
-    cfgs["cfg4_loop8192_compiled"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_WAVE)
+    cfgs["cfg4_loop8192_loop_engine"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_LOOP)
     cfgs["cfg5_shard8192"] = (lambda: uni_of([d.Multiply(d.Osc(20 + k / 8), d.Ramp(T1, 1, 0).trigger()) for k in (0, 1)]), T1,
                               (20 + np.arange(8192) / 8.0).astype(np.float32).reshape(1, -1))
     for name, cfg in cfgs.items():
