@@ -682,6 +682,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
 
     hipFunction_t render = nullptr;
     dusp::JitSource *src = nullptr;
+    int jit_scratch = 0;
     for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
         opt.per_wave = per_wave;
@@ -709,6 +710,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         int scratch = 0;
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
+        jit_scratch = scratch;
         if (scratch <= ctx->knobs.jit_spill_bytes) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
@@ -783,8 +785,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         HIP_TRY(ctx, hipMemcpy(h.data(), d_debug.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double loop = 0, serial = 0, chunks = 0;
         for (unsigned b = 0; b < grid; b++) loop += (double)h[b * 4], serial += (double)h[b * 4 + 1], chunks += (double)h[b * 4 + 2];
-        std::fprintf(stderr, "[dusp jit profile] %ux%d waves x instances, %u workgroups: chunk loop %.0f cycles per chunk, of which Filter recurrences %.0f (%.1f per sample-step)\n",
-                     (unsigned)waves, per_wave, grid, loop / std::max(1.0, chunks), serial / std::max(1.0, chunks), serial / std::max(1.0, chunks) / 256.0);
+        std::fprintf(stderr, "[dusp jit profile] %ux%d waves x instances (%d B of scratch per lane), %u workgroups: chunk loop %.0f cycles per chunk, of which Filter recurrences %.0f (%.1f per sample-step)\n",
+                     (unsigned)waves, per_wave, jit_scratch, grid, loop / std::max(1.0, chunks), serial / std::max(1.0, chunks), serial / std::max(1.0, chunks) / 256.0);
         d_debug.release();
     }
     prog->jit_waves = waves;

@@ -335,7 +335,7 @@ struct Emitter {
                 }
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
-                line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + "> f" + num(k) + ";");
+                line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++)
                     line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");

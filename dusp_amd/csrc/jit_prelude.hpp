@@ -981,10 +981,10 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 // the whole render.
 //   tile: rows of SUB + 2 doubles, row = wave R + r;  SUB = 256, 128 or 64 by what LDS holds next to the table image
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-template <int WAVES, int R, int SUB>
+template <int WAVES, int R, int SUB, int NA>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
-    double a[R][3];                         // this wave's instances: a0 a1 a2 (wave-uniform)
+    double a[NA][3];                        // this wave's instances: a0 a1 a2 (wave-uniform)
     float x1[R], x2[R];                     // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     double k[5], y1, y2, lastF;             // wave 0, lane = row: that instance's coefficients and recurrence memory
 #ifdef DUSP_JIT_PROFILE
@@ -1020,7 +1020,9 @@ struct JitFilterK {
         else {
             kk[0] = is[2]; kk[1] = is[3]; kk[2] = is[4];
         }
-        a[r][0] = jit_u(kk[0]); a[r][1] = jit_u(kk[1]); a[r][2] = jit_u(kk[2]);
+        if (r < NA) {
+            a[r][0] = jit_u(kk[0]); a[r][1] = jit_u(kk[1]); a[r][2] = jit_u(kk[2]);
+        }
         x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
         x2[r] = jit_u((float)is[8]);
     }
@@ -1033,7 +1035,7 @@ struct JitFilterK {
         const float l2 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x2[r]), __float_as_uint(x[2]), 0x138, 0xf, 0xf, false));
         const double o[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = (a[r][0] * (double)x[c] + a[r][1] * o[c + 1]) + a[r][2] * o[c];
+        for (int c = 0; c < 4; ++c) p[c] = (a[r % NA][0] * (double)x[c] + a[r % NA][1] * o[c + 1]) + a[r % NA][2] * o[c];
         x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
         x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
     }
