@@ -1247,11 +1247,20 @@ struct JitFilterM {
 // Everything a chunk reads was written before the chunk began (D >= 256), so the NEXT chunk's reads are issued right after
 // this chunk's writes and have the rest of the chunk — the Filter stage, usually — to arrive.
 struct JitDelayK {
-    double carried, phi;  // the input sample before the chunk; the delay's fraction (uniform)
+    float carried;        // the input sample before the chunk (uniform)
+    double phi;           // the delay's fraction (uniform)
     float *ring;          // this instance's ring
     uint32_t len, D, s0;  // ring length, whole delay, the chunk's first slot
+    bool quad;            // ring length, delay and first slot are multiples of 4: a lane's four slots are ONE 16-byte access and wrap together
     float ahead[4];       // the coming chunk's reads
     __device__ __forceinline__ void fetch(const JitCtx &X) {
+        if (quad) {
+            uint32_t s_ = s0 + X.lane * 4;
+            if (s_ >= len) s_ -= len;
+            const f32x4 v = *(const f32x4 *)(ring + s_);
+            ahead[0] = v[0]; ahead[1] = v[1]; ahead[2] = v[2]; ahead[3] = v[3];
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t s_ = s0 + X.lane * 4 + c;
@@ -1260,7 +1269,7 @@ struct JitDelayK {
         }
     }
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_base, int64_t ring_len, float delay) {
-        carried = jit_u(A.init_state[state_slot]);
+        carried = jit_u((float)A.init_state[state_slot]);  // (an f32 sample: nothing is lost)
         double dconst = (double)delay;
         if (dconst >= (double)ring_len) dconst = fmod(dconst, (double)ring_len);
         const double Dfl = floor(dconst);
@@ -1269,31 +1278,49 @@ struct JitDelayK {
         len = (uint32_t)ring_len;
         ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
         s0 = (uint32_t)((A.clock0 + (uint64_t)X.g_begin * kChunk) % (uint64_t)ring_len);
+        quad = jit_u(((len | D | s0) & 3u) == 0u && ((uintptr_t)ring & 15u) == 0u);
         fetch(X);
     }
     __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
-        const float x_left = __shfl_up(x[3], 1, 64);
+        // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
+        const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = ahead[c];
+        float slot[4];
+        if (phi != 0.0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t lo = s0 + X.lane * 4 + c;
+            for (int c = 0; c < 4; ++c) {
+                uint32_t lo = s0 + X.lane * 4 + c;  // (only slot 0 of the ring drops the ceil tap: the test needs the slot)
+                if (lo >= len) lo -= len;
+                lo += D;
+                if (lo >= len) lo -= len;
+                const double xin = (double)x[c], xprev = (double)(c == 0 ? x_left : x[c - 1]);
+                const float tap = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
+                slot[c] = (float)((double)tap + xin * (1.0 - phi));            // floor tap of sample n
+            }
+        } else {
+            // (float)(0.0 + x * 1.0), then (float)(that + x * 0.0): x with -0 turned into +0, or NaN for a NaN / Inf — the same two
+            // steps in f32 give the same bits
+#pragma unroll
+            for (int c = 0; c < 4; ++c) slot[c] = (x[c] + 0.f) + x[c] * 0.f;
+        }
+        if (quad) {
+            uint32_t lo = s0 + X.lane * 4;
             if (lo >= len) lo -= len;
             lo += D;
             if (lo >= len) lo -= len;
-            const double xin = (double)x[c];
-            const double xprev = c == 0 ? (X.lane == 0 ? carried : (double)x_left) : (double)x[c - 1];
-            float slot;
-            if (phi != 0.0) {
-                slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
-                slot = (float)((double)slot + xin * (1.0 - phi));   // floor tap of sample n
-            } else {
-                slot = (float)(0.0 + xin * 1.0);
-                slot = (float)((double)slot + xin * 0.0);
+            if (X.live) *(f32x4 *)(ring + lo) = f32x4{slot[0], slot[1], slot[2], slot[3]};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t lo = s0 + X.lane * 4 + c;
+                if (lo >= len) lo -= len;
+                lo += D;
+                if (lo >= len) lo -= len;
+                if (X.live) ring[lo] = slot[c];
             }
-            if (X.live) ring[lo] = slot;
         }
-        carried = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
         s0 += kChunk;
         if (s0 >= len) s0 -= len;  // (len >= 512 here)
         fetch(X);  // (after this chunk's stores, in program order: a wave's accesses to one address stay in order)
