@@ -207,6 +207,7 @@ static dusp::Knobs read_knobs() {
     k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
+    k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
     return k;
 }
 
@@ -639,7 +640,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
-        if (op.op == dusp::OP_OSC && opt.lds_table < 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
+        if (op.op == dusp::OP_OSC && opt.lds_table < 0 && ctx->knobs.jit_lds_table != 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
             !(ctx->table_form[op.attr] >= dusp::TABLE_FORM_SAW && ctx->table_form[op.attr] <= dusp::TABLE_FORM_TRIANGLE)) {
             opt.lds_table = ctx->table_form[op.attr] == dusp::TABLE_FORM_8BIT && ctx->table_antisym[0] ? 0 : op.attr;  // (the sine image serves 8bit too)
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
@@ -674,10 +675,14 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         }
     } else {
         while (waves < most && (unsigned)waves < want) waves *= 2;
-        // instances per wavefront (unsplit renders): as many as still leave every CU a workgroup — their independent unit blocks
-        // fill each other's latencies
-        if (a.n_seg == 1)
-            while (per_wave < per_wave_cap && (uint64_t)ctx->n_cus * waves * (per_wave + 1) <= n_inst) per_wave++;
+        // instances per wavefront (unsplit renders of light circuits, jit_light): 4 or 2 while that leaves every CU a workgroup —
+        // their independent unit blocks fill each other's latencies
+        if (a.n_seg == 1 && (dusp::jit_light(P) || ctx->knobs.wave_per_wave > 1))
+            for (int r : {4, 2})
+                if (r <= per_wave_cap && (uint64_t)ctx->n_cus * waves * r <= n_inst) {
+                    per_wave = r;
+                    break;
+                }
     }
 
     hipFunction_t render = nullptr;
@@ -723,7 +728,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             waves /= 2;
             per_wave *= 2;
         } else if (prog->wave.has_filter && per_wave > 1) per_wave /= 2;  // (rows stay a power of two: whole rounds on every CU)
-        else if (per_wave > 1) per_wave--;
+        else if (per_wave > 1) per_wave /= 2;  // (4, 2, 1: an odd count leaves the last round of workgroups a third full at the usual batch sizes)
         else if (waves > 4) waves /= 2;
         else break;
         if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);

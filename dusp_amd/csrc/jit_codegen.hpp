@@ -71,6 +71,21 @@ inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
         if (jit_filter_tile_bytes(waves * per_wave, sub) <= lds_left) return sub;
     return 0;
 }
+// A circuit whose whole chunk body is a few dozen instructions (constant-f oscillators, Ramp, Timer, the elementwise maps; two units
+// at most): several instances per wavefront fill each other's latencies (osc(k): 4 % at four).  Anything heavier is bound by
+// VALU issue and by registers, and a second instance only adds to both (tools/wave_ops.py at 1 / 2 / 4 instances per wave:
+// Shape 1.67 / 1.84 / 1.95 ms, Multiply(Osc, Shape) 2.33 / 2.45 / 2.51, all-pass 1.93 / 1.88 / 2.04, FM pair 2.10 / 2.09 / 2.16).
+inline bool jit_light(const Program &P) {
+    int n = 0;
+    for (const DevOp &op : P.ops) {
+        if (op.op == OP_HOST_ONLY) continue;
+        n++;
+        const bool lean = (op.op == OP_OSC && op.in[0].kind != SRC_BUF) || op.op == OP_RAMP || op.op == OP_TIMER || op.op == OP_MULTIPLY || op.op == OP_SUM ||
+                          (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && op.op != OP_POW && op.op != OP_DECIBEL_TO_SCALER && op.op != OP_SEMITONE_TO_RATIO);
+        if (!lean) return false;
+    }
+    return n <= 2;
+}
 // units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
 inline bool jit_ring_ops(const DevOp &op) {
     return (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
