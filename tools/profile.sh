@@ -20,4 +20,4 @@ for P in "WRITE_SIZE" "FETCH_SIZE" \
 done
 # the other BASELINE configs (wave / sumchain / loop2 kernels): kernel-trace only
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/configs -- python3 $R/tools/configs_bench.py --rounds 2 > $O/configs.log 2>&1 || echo "configs pass failed"
-python3 $R/tools/profile_summary.py $O $R/profiles $TAG
+python3 $R/tools/profile_summary.py $O $R/profiles $TAG   # (on the GPU box this lands in the scratch copy: run it again here on the merged gpurun_out/)

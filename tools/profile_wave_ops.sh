@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r02}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-OUT=$R/profiles/${TAG}_wave_ops_pmc.md
+OUT=$R/gpurun_out/${TAG}_wave_ops_pmc.md   # (copy into profiles/ after the call: only gpurun_out/ comes back from the GPU box)
 echo "# rocprofv3 --pmc, circuit-compiler kernels ($TAG): tools/wave_ops.py, 16384 instances x 48000 samples per launch" > $OUT
 for G in "$@"; do
   K=$(echo "$G" | tr -c 'a-zA-Z0-9' '_')
