@@ -43,7 +43,7 @@ constexpr int kMaxWarmChunks = 8;  // chunks at the start of a render that may r
 struct Knobs {
     int fused_table_global = 0;  // DUSP_FUSED_TABLE=global: wave table from L2 even when the LDS half-table applies
     int fused_R = 4;             // DUSP_FUSED_R: voices per work item (1, 4, 8)
-    int fused_items = 4;         // DUSP_FUSED_ITEMS: work items per resident wave
+    int fused_items = 0;         // DUSP_FUSED_ITEMS: work items per resident wave (0: 4, or 2 when that would cut the render into items of under 64 chunks)
     int fused_fx32 = 1;          // DUSP_FUSED_FX32=0: no 32.32 fixed-point phase path
     int fused_segmajor = 0;      // DUSP_FUSED_SEGMAJOR=1: item order
     int loop2 = 1;               // DUSP_LOOP2=0: one-stage loop kernel

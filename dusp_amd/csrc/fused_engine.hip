@@ -422,10 +422,16 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
     const int grid = tbl == 1 ? L.n_cus : L.n_cus * 8;
     const uint64_t total_waves = (uint64_t)grid * (block / 64);
     const uint64_t n_blk = (A.n_inst + R - 1) / R;
-    const uint64_t per_wave = (uint64_t)std::max(1, L.knobs.fused_items);
-    uint64_t n_seg = (total_waves * per_wave + n_blk - 1) / n_blk;
-    if (n_seg < 1) n_seg = 1;
-    uint64_t seg = (A.n_groups + n_seg - 1) / n_seg;
+    // Four items per wave even the tail out on long renders; a short render (configs[4]'s shard: 8192 voices x 188 chunks) would
+    // be cut into items of a couple of dozen chunks each, and what an item costs before its first sample (the jump-ahead, the
+    // table image is per workgroup) shows: two items per wave there (0.398 -> 0.377 ms).
+    auto cut = [&](uint64_t per_wave, uint64_t &n_seg) {
+        n_seg = std::max<uint64_t>(1, (total_waves * per_wave + n_blk - 1) / n_blk);
+        return (A.n_groups + n_seg - 1) / n_seg;
+    };
+    uint64_t n_seg = 1, seg = 0;
+    if (L.knobs.fused_items > 0) seg = cut((uint64_t)L.knobs.fused_items, n_seg);
+    else if ((seg = cut(4, n_seg)) < 64) seg = cut(2, n_seg);
     if (seg < 16) seg = 16;
     if (seg > 4096) seg = 4096;
     A.seg_groups = (uint32_t)seg;

@@ -66,6 +66,23 @@ def test_feedback_loop_batch(engine, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("delay,ring", [(480, 4096), (257, 2048), (301.5, 2047), (1023, 1501), (700.25, 1000), (300, 1026)])
+def test_write_once_delay_geometries(delay, ring, oracle):
+    """Delay lines of at least a chunk on the compiled kernel: whole and fractional delays, ring lengths / delays / positions that are
+    and are not multiples of 4 (16-byte and 4-byte ring accesses), the ring wrapping inside a chunk; rendered past several ring
+    lengths, several instances per wavefront's worth of instances, against the oracle bit for bit (Delay.js:20-41)."""
+    d.configure(48000)
+    uni = descriptor.unify([descriptor.extract(d.Delay(d.Multiply(d.Osc(300 + 7 * k), 0.5 + k / 64), delay, ring)) for k in range(0, 40)])
+    n = 4 * 4096 + 300
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    assert "compiled kernel" in prog.shape
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    for i in range(0, uni.n_instances, 3):
+        want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        assert np.array_equal(pcm[i], want), (delay, ring, i)
+    prog.close()
+
+
 @pytest.mark.parametrize("engine", [runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK])
 def test_filter_takes_nan_inputs_as_the_reference_does(engine, oracle):
     """0/0 at the input of a Filter every 480 samples (some instances only): the recurrence reads `this.y1 || 0` (Filter.js:42-46), so it
