@@ -42,6 +42,7 @@ struct JitOptions {
     int lds_table = -1;      // table id whose half image sits in LDS, or -1
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
+    bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
@@ -171,6 +172,11 @@ struct Emitter {
     std::vector<int> fconst_of;    // per (op, operand): index into fk, or -1
     std::vector<long long> dconst_of;  // per op: index of its first f64 constant (Ramp: duration, y0, y1; Delay: ring base, length; maps / Timer: d[0])
     std::string s;
+    // The overlapped form of a Filter circuit's chunk (plan_overlap): which units go where, and what unit() is emitting right now
+    std::vector<char> grp_early, grp_side, grp_post, split_delay;
+    int slice = -1, n_slices = 1;  // unit(): only the instance slots r with r % n_slices == slice (shared units: slice 0)
+    bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
+    int delay_half = 0;            // unit(): 0 a write-once Delay's whole tick, 1 its reads only, 2 its writes only
 
     Emitter(const Program &P_, const WavePlan &plan_, JitOptions o, JitSource &out_) : P(P_), plan(plan_), opt(o), out(out_), R(std::max(1, o.per_wave)) {}
 
@@ -221,6 +227,73 @@ struct Emitter {
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
+    bool take(int k, int r) const { return slice < 0 || (copies(k) == 1 ? slice == 0 : r % n_slices == slice); }
+    bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind != SRC_BUF; }
+
+    // The Filter stage keeps ONE wave busy with the recurrences while the others wait; whatever the chunk holds that neither feeds a
+    // Filter nor hangs on one can run on those others meanwhile.  Units are sorted into
+    //   early: what a Filter's input needs of this chunk (its same-chunk ancestors).  A write-once Delay on the way contributes its
+    //          READS only — they were fetched a chunk ago and need nothing of this chunk — and the search stops there;
+    //   post:  what hangs on a Filter's output in this chunk;
+    //   side:  the rest, and the WRITES of those Delays: emitted as a block that waves 1.. run between the barriers of a sub-block
+    //          (next to wave 0's recurrences) and wave 0 runs after the last sub-block.
+    // Every consumer still follows its same-chunk producers, and edges the reference reads late (the `w` registers, copied at the end
+    // of the body) do not care about the order inside the body.  Not for circuits whose units share rings (CircleBuffer nodes, slot
+    // operations: their mutual order is their meaning) nor for a Filter that hangs on another one.
+    bool plan_overlap(const std::vector<char> &used) {
+        const size_t n = P.ops.size();
+        grp_early.assign(n, 0); grp_side.assign(n, 0); grp_post.assign(n, 0); split_delay.assign(n, 0);
+        std::vector<int> filters;
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const int k = plan.order[at];
+            if (!used[(size_t)k]) continue;
+            const DevOp &op = P.ops[(size_t)k];
+            if (op.op == OP_CB_READER || op.op == OP_CB_WRITER || jit_ring_ops(op)) return false;
+            if (is_filter_stage(k)) filters.push_back(k);
+        }
+        if (filters.empty()) return false;
+        auto same_chunk_producer = [&](int k, int j) -> int {
+            const DevOp &op = P.ops[(size_t)k];
+            const DevOperand &o = op.in[j];
+            if (!operand_live(op, j) || o.kind != SRC_BUF || reads_late(pos_of_op[(size_t)k], o.idx)) return -1;
+            return producer[(size_t)o.idx];
+        };
+        for (size_t at = 0; at < plan.order.size(); at++) {  // post: descendants of a Filter stage, in execution order
+            const int k = plan.order[at];
+            if (!used[(size_t)k]) continue;
+            for (int j = 0; j < kMaxIn; j++) {
+                const int pr = same_chunk_producer(k, j);
+                if (pr >= 0 && (is_filter_stage(pr) || grp_post[(size_t)pr])) grp_post[(size_t)k] = 1;
+            }
+            if (grp_post[(size_t)k] && is_filter_stage(k)) return false;
+        }
+        std::vector<int> stack;
+        for (int f : filters) {
+            const int pr = same_chunk_producer(f, 0);
+            if (pr >= 0) stack.push_back(pr);
+        }
+        while (!stack.empty()) {
+            const int k = stack.back();
+            stack.pop_back();
+            if (grp_early[(size_t)k]) continue;
+            grp_early[(size_t)k] = 1;
+            if (P.ops[(size_t)k].op == OP_DELAY) {  // (write-once: the other kind returned above)
+                split_delay[(size_t)k] = 1;
+                continue;
+            }
+            for (int j = 0; j < kMaxIn; j++) {
+                const int pr = same_chunk_producer(k, j);
+                if (pr >= 0) stack.push_back(pr);
+            }
+        }
+        bool any = false;
+        for (size_t k = 0; k < n; k++) {
+            if (!used[k] || is_filter_stage((int)k)) continue;
+            grp_side[k] = split_delay[k] || (!grp_early[k] && !grp_post[k]);
+            any = any || grp_side[k];
+        }
+        return any;
+    }
 
     // ops in the input cone of `roots`, for the accumulate passes
     std::vector<char> cone(const std::vector<int> &roots) const {
@@ -422,8 +495,88 @@ struct Emitter {
         line("");
     }
 
+    // the Filter stage of unit k: the feed-forward halves into registers ...
+    void filter_feed(int k) {
+        const DevOp &op = P.ops[(size_t)k];
+        for (int r = 0; r < R; r++) {
+            const std::string x = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
+            if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
+            line("        double q" + num(k) + "_" + num(r) + "[4];");
+            line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", q" + num(k) + "_" + num(r) + ");");
+        }
+    }
+    // ... then, sub-block by sub-block: park P, all recurrences on wave 0 (`beside`: what the other waves do meanwhile), pick y up
+    void filter_sub_block(int k, int sb, const std::string &beside) {
+        const DevOp &op = P.ops[(size_t)k];
+        const std::string f = "f" + num(k);
+        auto park = [&](const char *indent) {
+            for (int r = 0; r < R; r++) line(std::string(indent) + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ");");
+        };
+        park("        ");
+        line("        jit_lds_barrier();");
+        line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile);");
+        if (!beside.empty()) line("        " + beside);
+        line("        jit_lds_barrier();");
+        line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
+        park("            ");
+        line("            jit_lds_barrier();");
+        line("            " + f + ".serial_exact(X[0], tile);");
+        line("            jit_lds_barrier();");
+        line("        }");
+        for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+        // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
+    }
+
     void loop(bool render, int pass_level, const std::vector<char> &used, bool fx) {
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        if (render && opt.overlap && plan_overlap(used)) {
+            const int subs = kChunk / opt.filter_sub;
+            int windows = 0;
+            for (size_t at = 0; at < plan.order.size(); at++)
+                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) windows += subs;
+            for (size_t at = 0; at < plan.order.size(); at++) {  // every outlet's registers, visible to all the blocks below
+                const int k = plan.order[at];
+                if (used[(size_t)k] && P.ops[(size_t)k].out_buf >= 0)
+                    for (int r = 0; r < copies(k); r++) line("        float v" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
+            }
+            predeclared = true;
+            n_slices = std::max(1, std::min(windows, R));
+            for (slice = 0; slice < n_slices; slice++) {  // the side blocks: instance slots dealt over the sub-blocks' windows
+                line("        auto side" + num(slice) + " = [&]() __attribute__((always_inline)) {");
+                for (size_t at = 0; at < plan.order.size(); at++) {
+                    const int k = plan.order[at];
+                    if (!used[(size_t)k] || !grp_side[(size_t)k]) continue;
+                    delay_half = split_delay[(size_t)k] ? 2 : 0;
+                    unit(k, render, pass_level, fx);
+                }
+                line("        };");
+            }
+            slice = -1;
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (!used[(size_t)k] || !grp_early[(size_t)k]) continue;
+                delay_half = split_delay[(size_t)k] ? 1 : 0;
+                unit(k, render, pass_level, fx);
+            }
+            delay_half = 0;
+            for (size_t at = 0; at < plan.order.size(); at++)
+                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at]);
+            int window = 0;
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (!used[(size_t)k] || !is_filter_stage(k)) continue;
+                for (int sb = 0; sb < subs; sb++, window++)
+                    filter_sub_block(k, sb, window < n_slices ? "if (X[0].wave != 0) side" + num(window) + "();  // (beside wave 0's recurrences)" : std::string());
+            }
+            std::string own = "        if (X[0].wave == 0) {";
+            for (int i = 0; i < n_slices; i++) own += " side" + num(i) + "();";
+            line(own + " }  // (wave 0's own instances)");
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (used[(size_t)k] && grp_post[(size_t)k]) unit(k, render, pass_level, fx);
+            }
+            predeclared = false;
+        } else
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int k = plan.order[at];
             if (!used[(size_t)k]) continue;
@@ -445,68 +598,51 @@ struct Emitter {
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
             for (int r = 0; r < R; r++) {
+                if (!take(k, r)) continue;
                 const std::string id = num(k) + "_" + num(r);
                 const std::string x = opnd_array(k, 0, "t" + id, r), f = opnd_array(k, 1, "tf" + id, r);
-                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
+                if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
                 line("        f" + id + ".tick(" + ctx(r) + ", scr, " + num(op.attr) + ", " + x + ", " + f + ", v" + num(op.out_buf) + "_" + num(r) + ");");
             }
             return;
         }
-        if (op.op == OP_FILTER) {  // feed-forward half per lane; then, sub-block by sub-block: park P, all recurrences on wave 0, pick y up
-            const std::string f = "f" + num(k);
-            std::vector<std::string> xs;
-            for (int r = 0; r < R; r++) {
-                xs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
-                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-            }
-            for (int r = 0; r < R; r++) {
-                line("        double q" + num(k) + "_" + num(r) + "[4];");
-                line("        " + f + ".feed(" + ctx(r) + ", " + num(r) + ", " + xs[(size_t)r] + ", q" + num(k) + "_" + num(r) + ");");
-            }
-            for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) {
-                auto park = [&](const char *indent) {
-                    for (int r = 0; r < R; r++) line(std::string(indent) + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ");");
-                };
-                park("        ");
-                line("        jit_lds_barrier();");
-                line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile);");
-                line("        jit_lds_barrier();");
-                line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
-                park("            ");
-                line("            jit_lds_barrier();");
-                line("            " + f + ".serial_exact(X[0], tile);");
-                line("            jit_lds_barrier();");
-                line("        }");
-                for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
-                // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
-            }
+        if (op.op == OP_FILTER) {
+            filter_feed(k);
+            for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) filter_sub_block(k, sb, std::string());
             return;
         }
         if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) {
             // A scanned oscillator: all the wave's instances are asked first whether this chunk needs the careful path (increments at
             // or above the sample rate, NaN / Inf, a poisoned phase); then ONE straight-line block serves them all.
             const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
-            std::vector<std::string> fs;
+            std::vector<std::string> fs((size_t)copies(k));
             std::string rare = "false";
+            bool any = false;
             for (int r = 0; r < copies(k); r++) {
-                fs.push_back(opnd_array(k, 0, "t" + num(k) + "_" + num(r), r));
-                line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-                rare += " | o" + num(k) + "_" + num(r) + ".rare(" + ctx(r) + ", " + fs.back() + ")";
+                if (!take(k, r)) continue;
+                any = true;
+                fs[(size_t)r] = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
+                if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
+                rare += " | o" + num(k) + "_" + num(r) + ".rare(" + ctx(r) + ", " + fs[(size_t)r] + ")";
             }
+            if (!any) return;
             for (int careful = 0; careful < 2; careful++) {
                 line(careful ? "        } else {" : "        if (!(" + rare + ")) {");
                 for (int r = 0; r < copies(k); r++)
-                    line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
-                         table_row(op.attr) + ", " + fs[(size_t)r] + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+                    if (take(k, r))
+                        line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
+                             table_row(op.attr) + ", " + fs[(size_t)r] + ", v" + num(op.out_buf) + "_" + num(r) + ");");
             }
             line("        }");
             if (!lookup)
-                for (int r = 0; r < copies(k); r++) line("        for (int c = 0; c < 4; ++c) v" + num(op.out_buf) + "_" + num(r) + "[c] = 0.f;");
+                for (int r = 0; r < copies(k); r++)
+                    if (take(k, r)) line("        for (int c = 0; c < 4; ++c) v" + num(op.out_buf) + "_" + num(r) + "[c] = 0.f;");
             return;
         }
         for (int r = 0; r < copies(k); r++) {
+            if (!take(k, r)) continue;
             const std::string id = num(k) + "_" + num(r), v = "v" + num(op.out_buf) + "_" + num(r), X_ = ctx(r);
-            auto decl = [&]() { line("        float " + v + "[4];"); };
+            auto decl = [&]() { if (!predeclared) line("        float " + v + "[4];"); };
             auto each = [&](const std::string &expr) {
                 decl();
                 line("        for (int c = 0; c < 4; ++c) " + v + "[c] = " + expr + ";");
@@ -603,8 +739,13 @@ struct Emitter {
             }
             case OP_DELAY: {
                 decl();
+                if (delay_half == 1) {
+                    line("        y" + id + ".read(" + v + ");");
+                    break;
+                }
                 const std::string x = opnd_array(k, 0, "t" + id, r);
-                line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
+                if (delay_half == 2) line("        y" + id + ".write(" + X_ + ", " + x + ");");
+                else line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
                 break;
             }
             default:

@@ -1282,10 +1282,18 @@ struct JitDelayK {
         fetch(X);
     }
     __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
-        // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
-        const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
+        read(out);
+        write(X, x);
+    }
+    // The two halves of a tick.  What a chunk reads does not depend on what it writes, so a generated kernel may take the reads
+    // early (the Filter stage's input) and the writes late (behind the recurrences), see jit_codegen.hpp `plan_overlap`.
+    __device__ __forceinline__ void read(float (&out)[4]) const {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = ahead[c];
+    }
+    __device__ __forceinline__ void write(const JitCtx &X, const float (&x)[4]) {
+        // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
+        const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
         float slot[4];
         if (phi != 0.0) {
 #pragma unroll
