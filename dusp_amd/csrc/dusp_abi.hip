@@ -646,6 +646,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
         }
     opt.scratch_floats = dusp::jit_scratch_floats(P);
+    opt.filter_stages = dusp::jit_filter_stages(P);
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
@@ -668,10 +669,10 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
         if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
             opt.lds_table = -1, opt.table_bytes = 0;
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget);
         }
     } else {
         while (waves < most && (unsigned)waves < want) waves *= 2;
@@ -731,7 +732,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         else if (per_wave > 1) per_wave /= 2;  // (4, 2, 1: an odd count leaves the last round of workgroups a third full at the usual batch sizes)
         else if (waves > 4) waves /= 2;
         else break;
-        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, budget - opt.table_bytes);
+        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
     }
     // (from here on the render happens on the compiled kernel: workspaces)
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
@@ -789,7 +790,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         HIP_TRY(ctx, hipMemcpy(h.data(), d_debug.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double loop = 0, serial = 0, chunks = 0;
-        for (unsigned b = 0; b < grid; b++) loop += (double)h[b * 4], serial += (double)h[b * 4 + 1], chunks += (double)h[b * 4 + 2];
+        for (unsigned b = 0; b < grid; b++) loop += (double)h[b * 4], serial += (double)h[b * 4 + 1] + (double)h[b * 4 + 3], chunks += (double)h[b * 4 + 2];
         std::fprintf(stderr, "[dusp jit profile] %ux%d waves x instances (%d B of scratch per lane), %u workgroups: chunk loop %.0f cycles per chunk, of which Filter recurrences %.0f (%.1f per sample-step)\n",
                      (unsigned)waves, per_wave, jit_scratch, grid, loop / std::max(1.0, chunks), serial / std::max(1.0, chunks), serial / std::max(1.0, chunks) / 256.0);
         d_debug.release();
@@ -1360,8 +1361,9 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
                 opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
             }
     }
+    opt.filter_stages = dusp::jit_filter_stages(P);
     if (plan.has_filter) {
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4);
         if (!opt.filter_sub) {
             g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
             return DUSP_ERR_ARG;

@@ -42,6 +42,7 @@ struct JitOptions {
     int lds_table = -1;      // table id whose half image sits in LDS, or -1
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
+    int filter_stages = 0;   // Filter stages of the circuit (jit_filter_stages): each keeps its rows' y1 / y2 behind the tile
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
@@ -66,10 +67,17 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // do not have).
 // Filter stage: one row of (sub-block + 2) doubles per instance of the workgroup; the sub-block (256, 128 or 64 samples) is the
 // largest that fits the LDS left over.
-inline size_t jit_filter_tile_bytes(int rows, int sub) { return (size_t)rows * (size_t)(sub + 2) * 8; }
-inline int jit_filter_sub(int waves, int per_wave, size_t lds_left) {
+// Behind the rows: one word that says "given back", then y1 / y2 of every row of every Filter stage of the circuit (the stages share
+// the tile, one after the other, but each has its own recurrence memory).
+inline size_t jit_filter_tile_bytes(int rows, int sub, int stages) { return (size_t)rows * (size_t)(sub + 2) * 8 + 16 + (size_t)stages * (size_t)rows * 16; }
+inline int jit_filter_stages(const Program &P) {
+    int n = 0;
+    for (const DevOp &op : P.ops) n += op.op == OP_FILTER && op.in[1].kind != SRC_BUF;
+    return n;
+}
+inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left) {
     for (int sub : {256, 128, 64})
-        if (jit_filter_tile_bytes(waves * per_wave, sub) <= lds_left) return sub;
+        if (jit_filter_tile_bytes(waves * per_wave, sub, stages) <= lds_left) return sub;
     return 0;
 }
 // A circuit whose whole chunk body is a few dozen instructions (constant-f oscillators, Ramp, Timer, the elementwise maps; two units
@@ -112,7 +120,7 @@ inline size_t jit_scratch_floats(const Program &P) {
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages) : 0) +
                                     (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
@@ -334,7 +342,7 @@ struct Emitter {
         }
         if (opt.scratch_floats) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
-                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub) / 4) : 0);
+                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages) / 4) : 0);
             line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         }
         // constants and parameters the used ops name
@@ -355,6 +363,7 @@ struct Emitter {
             for (int r = 0; r < R; r++) line("    const float p" + num(p) + "_" + num(r) + " = jit_param(A, " + ctx(r) + ", " + num(p) + ");");
         // state of the units
         std::string fast = "true";  // every constant-f oscillator of the wave qualifies for the 32.32 form
+        int filter_ordinal = 0;
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int k = plan.order[at];
             if (!used[(size_t)k]) continue;
@@ -424,7 +433,7 @@ struct Emitter {
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
                 line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + "> f" + num(k) + ";");
-                line("    f" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
+                line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++)
                     line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
             }
@@ -449,6 +458,7 @@ struct Emitter {
             line("        A.debug[(size_t)blockIdx.x * 4 + 1] = " + ser + ";");
             line("        A.debug[(size_t)blockIdx.x * 4 + 2] = X[0].g_end - X[0].g_begin;");
             line("    }");
+            line("    if (A.debug && X[0].wave == 1 && X[0].lane == 0) A.debug[(size_t)blockIdx.x * 4 + 3] = " + ser + ";  // (the sub-blocks wave 1 served)");
         }
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
@@ -457,7 +467,7 @@ struct Emitter {
                     for (int r = 0; r < R; r++)
                         line("    if (" + ctx(r) + ".live && " + ctx(r) + ".lane == 0) f" + num((long long)k) + "_" + num(r) + ".end(A, " + ctx(r) + ", " + num(P.ops[k].state_slot) + ");");
                 } else if (P.ops[k].op == OP_FILTER) {
-                    line("    f" + num((long long)k) + ".end(A, X[0], " + num(P.ops[k].state_slot) + ");");
+                    line("    f" + num((long long)k) + ".end(A, X[0], tile, " + num(P.ops[k].state_slot) + ");");
                     for (int r = 0; r < R; r++) line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].state_slot) + ");");
                 }
             for (int r = 0; r < R; r++) {
@@ -506,7 +516,7 @@ struct Emitter {
         }
     }
     // ... then, sub-block by sub-block: park P, all recurrences on wave 0 (`beside`: what the other waves do meanwhile), pick y up
-    void filter_sub_block(int k, int sb, const std::string &beside) {
+    void filter_sub_block(int k, int sb, const std::string &beside, int who = 0) {
         const DevOp &op = P.ops[(size_t)k];
         const std::string f = "f" + num(k);
         auto park = [&](const char *indent) {
@@ -514,13 +524,13 @@ struct Emitter {
         };
         park("        ");
         line("        jit_lds_barrier();");
-        line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile);");
+        line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile, " + num(who) + ");");
         if (!beside.empty()) line("        " + beside);
         line("        jit_lds_barrier();");
         line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
         park("            ");
         line("            jit_lds_barrier();");
-        line("            " + f + ".serial_exact(X[0], tile);");
+        line("            " + f + ".serial_exact(X[0], tile, " + num(who) + ");");
         line("            jit_lds_barrier();");
         line("        }");
         for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
@@ -561,16 +571,27 @@ struct Emitter {
             delay_half = 0;
             for (size_t at = 0; at < plan.order.size(); at++)
                 if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at]);
+            // Waves 0 and 1 take turns at the recurrences (windows 0, 2, .. and 1, 3, ..): in a window the other waves run that window's
+            // side block, wave 1 runs ALL its side blocks in window 0 and wave 0 all its in window 1 — nobody is left with work of its
+            // own behind the last sub-block.  (One wavefront per workgroup, or one window per chunk: wave 0 serves and catches up after.)
+            const bool turns = opt.waves >= 2 && windows >= 2;
+            std::string all;
+            for (int i = 0; i < n_slices; i++) all += " side" + num(i) + "();";
             int window = 0;
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (!used[(size_t)k] || !is_filter_stage(k)) continue;
-                for (int sb = 0; sb < subs; sb++, window++)
-                    filter_sub_block(k, sb, window < n_slices ? "if (X[0].wave != 0) side" + num(window) + "();  // (beside wave 0's recurrences)" : std::string());
+                for (int sb = 0; sb < subs; sb++, window++) {
+                    std::string beside;
+                    const std::string one = window < n_slices ? " side" + num(window) + "();" : std::string();
+                    if (!turns) beside = one.empty() ? one : "if (X[0].wave != 0) {" + one + " }";
+                    else if (window == 0) beside = "if (X[0].wave > 1) {" + one + " } else if (X[0].wave == 1) {" + all + " }";
+                    else if (window == 1) beside = "if (X[0].wave > 1) {" + one + " } else if (X[0].wave == 0) {" + all + " }";
+                    else if (!one.empty()) beside = "if (X[0].wave > 1) {" + one + " }";
+                    filter_sub_block(k, sb, beside.empty() ? beside : beside + "  // (beside the recurrences)", turns ? (window & 1) : 0);
+                }
             }
-            std::string own = "        if (X[0].wave == 0) {";
-            for (int i = 0; i < n_slices; i++) own += " side" + num(i) + "();";
-            line(own + " }  // (wave 0's own instances)");
+            if (!turns) line("        if (X[0].wave == 0) {" + all + " }  // (wave 0's own instances)");
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (used[(size_t)k] && grp_post[(size_t)k]) unit(k, render, pass_level, fx);

@@ -979,20 +979,29 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 // over the rows — nothing but the chain, y written as f32 over the P values already consumed — and every wave picks its rows
 // up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of "its" lane of wave 0 for
 // the whole render.
-//   tile: rows of SUB + 2 doubles, row = wave R + r;  SUB = 256, 128 or 64 by what LDS holds next to the table image
+//   tile: rows of SUB + 2 doubles, row = wave R + r; then one word that says "given back"; then y1 / y2 of every row, stage by stage.
+//   SUB = 256, 128 or 64 by what LDS holds next to the table image
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int WAVES, int R, int SUB, int NA>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
     double a[NA][3];                        // this wave's instances: a0 a1 a2 (wave-uniform)
     float x1[R], x2[R];                     // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
-    double k[5], y1, y2, lastF;             // wave 0, lane = row: that instance's coefficients and recurrence memory
+    double k[5], lastF;                     // lane = row (the same in every wave): that instance's coefficients
+    int stage;                              // which of the circuit's Filter stages this is (they share the tile, not the memory)
+    // The recurrence's memory y1 / y2 lives in the row's two spare doubles of the tile, so that any wave can run a sub-block's
+    // recurrences (the generated kernel alternates between waves 0 and 1: each does its other work while the other one serves).
 #ifdef DUSP_JIT_PROFILE
     unsigned long long cyc_serial = 0;      // diagnostic build: cycles wave 0 spent inside serial()
 #endif
 
     // fr: the cutoff of the instance THIS LANE serves in wave 0 (a constant, or that instance's parameter: jit_row_param)
-    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int kind, float fr, int state_slot) {
+    // y1 / y2 of row `row` of this stage
+    __device__ __forceinline__ uint32_t memory_address(double *tile, uint32_t row) const {
+        return row_address(tile, WAVES * R) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
+    }
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double *tile, int stage_, int kind, float fr, int state_slot) {
+        stage = stage_;
         const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
         const double ft = (double)fr;
         if (is[0] == 0.0 || ft != is[1]) jit_filter_coefficients(kind, ft, X.srd, k);  // `if (this.f[t] != this.lastF)`
@@ -1000,8 +1009,11 @@ struct JitFilterK {
             k[0] = is[2]; k[1] = is[3]; k[2] = is[4]; k[3] = is[5]; k[4] = is[6];
         }
         lastF = ft;
-        y1 = is[9];
-        y2 = is[10];
+        if (X.wave == 0 && X.lane < WAVES * R) {  // (the first barrier of the chunk loop stands between this and the first reader)
+            lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+            mem[0] = is[9];
+            mem[1] = is[10];
+        }
         // (what the render leaves of these is known now: written here, the feed-forward coefficients need no registers through the loop)
         const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
         if (X.wave == 0 && X.lane < WAVES * R && inst < A.n_inst) {
@@ -1089,15 +1101,16 @@ struct JitFilterK {
     // that to +0 (see loop2_engine.hip).  A sub-block that met a NaN in some row is given back: the word after row 0 says so,
     // y1 / y2 stay as they were, every wave parks its rows again (failed()) and serial_exact() does the sub-block as written.
     template <int PB>  // 8, or 4 where the kernel is short of registers (two sets of PB doubles)
-    __device__ __forceinline__ void serial(const JitCtx &X, double *tile) {
-        if (X.wave != 0 || X.lane >= WAVES * R) return;
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
+        if (X.wave != who || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
         const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
-        double u1 = jit_or0(y1), u2 = jit_or0(y2);
+        lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+        double u1 = jit_or0(mem[0]), u2 = jit_or0(mem[1]);
         double pa[PB], pb[PB];
 #pragma unroll
         for (int i = 0; i < PB; ++i) pa[i] = pr[i];
@@ -1116,10 +1129,10 @@ struct JitFilterK {
             yr += PB / 2;
         }
         const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;  // (some row's: the sub-block is given back whole)
-        if (X.lane == 0) *(lds_u32 *)(uintptr_t)(row_address(tile, 0) + SUB * 8) = met_nan ? 1u : 0u;
+        if (X.lane == 0) *(lds_u32 *)(uintptr_t)row_address(tile, WAVES * R) = met_nan ? 1u : 0u;
         if (!met_nan) {
-            y1 = u1;
-            y2 = u2;
+            mem[0] = u1;
+            mem[1] = u2;
         }
 #ifdef DUSP_JIT_PROFILE
         cyc_serial += __builtin_readcyclecounter() - stamp0;
@@ -1127,15 +1140,17 @@ struct JitFilterK {
     }
     // after the barrier that ends serial(), every wave: was the sub-block given back?
     static __device__ __forceinline__ bool failed(double *tile) {
-        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)(row_address(tile, 0) + SUB * 8)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)row_address(tile, WAVES * R)) != 0;
     }
     // the sub-block as Filter.js:40-46 writes it, on freshly parked rows
-    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile) {
-        if (X.wave != 0 || X.lane >= WAVES * R) return;
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
+        if (X.wave != who || X.lane >= WAVES * R) return;
         const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         const double b1 = k[3], b2 = k[4];
+        lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+        double y1 = mem[0], y2 = mem[1];
         for (int t0 = 0; t0 < SUB; t0 += 4) {
             double pv[4];
 #pragma unroll
@@ -1150,6 +1165,8 @@ struct JitFilterK {
             }
             yr[t0 >> 2] = y4;  // (over P of samples t0/2 and t0/2+1: read already)
         }
+        mem[0] = y1;
+        mem[1] = y2;
     }
     // state write-back: the input history by each wave (slot r), coefficients and recurrence memory by the lanes that hold them
     __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
@@ -1158,12 +1175,13 @@ struct JitFilterK {
         st[(size_t)7 * A.n_pad] = (double)x1[r];
         st[(size_t)8 * A.n_pad] = (double)x2[r];
     }
-    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const double *tile, int state_slot) const {
         const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
         if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst) return;
         double *st = A.state + (size_t)state_slot * A.n_pad + inst;
-        st[(size_t)9 * A.n_pad] = y1;
-        st[(size_t)10 * A.n_pad] = y2;
+        const lds_double *mem = (const lds_double *)(uintptr_t)const_cast<JitFilterK *>(this)->memory_address(const_cast<double *>(tile), X.lane);  // (behind the chunk loop's last barrier)
+        st[(size_t)9 * A.n_pad] = mem[0];
+        st[(size_t)10 * A.n_pad] = mem[1];
     }
 };
 // parameter `slot` of the instance lane `lane` of wave 0 serves in the Filter stage
