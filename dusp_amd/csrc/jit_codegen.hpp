@@ -43,6 +43,7 @@ struct JitOptions {
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int filter_stages = 0;   // Filter stages of the circuit (jit_filter_stages): each keeps its rows' y1 / y2 behind the tile
+    bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
@@ -182,6 +183,7 @@ struct Emitter {
     std::string s;
     // The overlapped form of a Filter circuit's chunk (plan_overlap): which units go where, and what unit() is emitting right now
     std::vector<char> grp_early, grp_side, grp_post, split_delay;
+    bool any_side = false;         // plan_overlap: there are side units
     int slice = -1, n_slices = 1;  // unit(): only the instance slots r with r % n_slices == slice (shared units: slice 0)
     bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
     int delay_half = 0;            // unit(): 0 a write-once Delay's whole tick, 1 its reads only, 2 its writes only
@@ -294,13 +296,13 @@ struct Emitter {
                 if (pr >= 0) stack.push_back(pr);
             }
         }
-        bool any = false;
+        any_side = false;
         for (size_t k = 0; k < n; k++) {
             if (!used[k] || is_filter_stage((int)k)) continue;
             grp_side[k] = split_delay[k] || (!grp_early[k] && !grp_post[k]);
-            any = any || grp_side[k];
+            any_side = any_side || grp_side[k];
         }
-        return any;
+        return true;
     }
 
     // ops in the input cone of `roots`, for the accumulate passes
@@ -506,14 +508,40 @@ struct Emitter {
     }
 
     // the Filter stage of unit k: the feed-forward halves into registers ...
-    void filter_feed(int k) {
+    void filter_feed(int k, const char *into = "q", bool declare = true) {
         const DevOp &op = P.ops[(size_t)k];
         for (int r = 0; r < R; r++) {
             const std::string x = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
             if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-            line("        double q" + num(k) + "_" + num(r) + "[4];");
-            line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", q" + num(k) + "_" + num(r) + ");");
+            if (declare) line("        double " + std::string(into) + num(k) + "_" + num(r) + "[4];");
+            line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
         }
+    }
+    // May the early units and the feed-forward halves of chunk g+1 run inside chunk g (beside its recurrences)?  They may when
+    // nothing but they themselves and the Filter stages read what they produce, and they read nothing the reference reads late.
+    bool plan_rotate(const std::vector<char> &used) const {
+        for (size_t k = 0; k < P.ops.size(); k++) {
+            if (!used[k] || !grp_early[k]) continue;
+            const DevOp &op = P.ops[k];
+            if (!split_delay[k])
+                for (int j = 0; j < kMaxIn; j++)
+                    if (operand_live(op, j) && op.in[j].kind == SRC_BUF && reads_late(pos_of_op[k], op.in[j].idx)) return false;
+            const int b = op.out_buf;
+            if (b < 0) continue;
+            if (late[(size_t)b]) return false;
+            for (int ob : P.out_bufs)
+                if (ob == b) return false;
+            for (size_t c = 0; c < P.ops.size(); c++) {
+                if (!used[c]) continue;
+                for (int j = 0; j < kMaxIn; j++) {
+                    const DevOperand &o = P.ops[c].in[j];
+                    if (!operand_live(P.ops[c], j) || o.kind != SRC_BUF || o.idx != b) continue;
+                    const bool inside = (grp_early[c] && !split_delay[c]) || (is_filter_stage((int)c) && j == 0);
+                    if (!inside) return false;
+                }
+            }
+        }
+        return true;
     }
     // ... then, sub-block by sub-block: park P, all recurrences on wave 0 (`beside`: what the other waves do meanwhile), pick y up
     void filter_sub_block(int k, int sb, const std::string &beside, int who = 0) {
@@ -538,8 +566,15 @@ struct Emitter {
     }
 
     void loop(bool render, int pass_level, const std::vector<char> &used, bool fx) {
+        const bool sorted = render && opt.overlap && plan_overlap(used);
+        const bool rotate = sorted && opt.rotate && plan_rotate(used);
+        const bool overlapped = sorted && (any_side || rotate);
+        if (rotate)  // the next chunk's feed-forward halves, computed a chunk ahead
+            for (size_t at = 0; at < plan.order.size(); at++)
+                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]))
+                    for (int r = 0; r < R; r++) line("    double qn" + num(plan.order[at]) + "_" + num(r) + "[4];");
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
-        if (render && opt.overlap && plan_overlap(used)) {
+        if (overlapped) {
             const int subs = kChunk / opt.filter_sub;
             int windows = 0;
             for (size_t at = 0; at < plan.order.size(); at++)
@@ -550,7 +585,7 @@ struct Emitter {
                     for (int r = 0; r < copies(k); r++) line("        float v" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
             predeclared = true;
-            n_slices = std::max(1, std::min(windows, R));
+            n_slices = 1;  // (one side block: every wave runs all of its in one window)
             for (slice = 0; slice < n_slices; slice++) {  // the side blocks: instance slots dealt over the sub-blocks' windows
                 line("        auto side" + num(slice) + " = [&]() __attribute__((always_inline)) {");
                 for (size_t at = 0; at < plan.order.size(); at++) {
@@ -562,6 +597,7 @@ struct Emitter {
                 line("        };");
             }
             slice = -1;
+            if (rotate) line("        auto early = [&](uint32_t g) __attribute__((always_inline)) {  // (its own g: it works for the chunk after this one)");
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (!used[(size_t)k] || !grp_early[(size_t)k]) continue;
@@ -570,28 +606,36 @@ struct Emitter {
             }
             delay_half = 0;
             for (size_t at = 0; at < plan.order.size(); at++)
-                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at]);
-            // Waves 0 and 1 take turns at the recurrences (windows 0, 2, .. and 1, 3, ..): in a window the other waves run that window's
-            // side block, wave 1 runs ALL its side blocks in window 0 and wave 0 all its in window 1 — nobody is left with work of its
-            // own behind the last sub-block.  (One wavefront per workgroup, or one window per chunk: wave 0 serves and catches up after.)
+                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at], rotate ? "qn" : "q", !rotate);
+            if (rotate) {
+                line("        };");
+                line("        if (g == X[0].g_begin) early(g);");
+                for (size_t at = 0; at < plan.order.size(); at++)
+                    if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]))
+                        for (int r = 0; r < R; r++) {
+                            const std::string id = num(plan.order[at]) + "_" + num(r);
+                            line("        double q" + id + "[4];");
+                            line("        for (int c = 0; c < 4; ++c) q" + id + "[c] = qn" + id + "[c];");
+                        }
+            }
+            // Waves 0 and 1 take turns at the recurrences (windows 0, 2, .. and 1, 3, ..); wave i does all its other work — its side
+            // block, then the next chunk's early units — in window (i + 1) mod windows, which is never one it serves: the work is dealt
+            // evenly over the windows and nobody is left with any behind the last sub-block.  (One wavefront per workgroup, or one
+            // window per chunk: wave 0 serves, the others work beside it, wave 0 catches up after.)
             const bool turns = opt.waves >= 2 && windows >= 2;
-            std::string all;
-            for (int i = 0; i < n_slices; i++) all += " side" + num(i) + "();";
+            const std::string work = " side0();" + std::string(rotate ? " if (g + 1 < X[0].g_end) early(g + 1);" : "");
             int window = 0;
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (!used[(size_t)k] || !is_filter_stage(k)) continue;
                 for (int sb = 0; sb < subs; sb++, window++) {
                     std::string beside;
-                    const std::string one = window < n_slices ? " side" + num(window) + "();" : std::string();
-                    if (!turns) beside = one.empty() ? one : "if (X[0].wave != 0) {" + one + " }";
-                    else if (window == 0) beside = "if (X[0].wave > 1) {" + one + " } else if (X[0].wave == 1) {" + all + " }";
-                    else if (window == 1) beside = "if (X[0].wave > 1) {" + one + " } else if (X[0].wave == 0) {" + all + " }";
-                    else if (!one.empty()) beside = "if (X[0].wave > 1) {" + one + " }";
+                    if (turns) beside = "if ((X[0].wave + 1) % " + num(windows) + " == " + num(window) + ") {" + work + " }";
+                    else if (window == 0 && opt.waves >= 2) beside = "if (X[0].wave != 0) {" + work + " }";
                     filter_sub_block(k, sb, beside.empty() ? beside : beside + "  // (beside the recurrences)", turns ? (window & 1) : 0);
                 }
             }
-            if (!turns) line("        if (X[0].wave == 0) {" + all + " }  // (wave 0's own instances)");
+            if (!turns) line("        if (X[0].wave == 0) {" + work + " }  // (wave 0's own instances)");
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (used[(size_t)k] && grp_post[(size_t)k]) unit(k, render, pass_level, fx);
