@@ -521,6 +521,8 @@ struct Emitter {
     // nothing but they themselves and the Filter stages read what they produce, and they read nothing the reference reads late.
     bool plan_rotate(const std::vector<char> &used) const {
         for (size_t k = 0; k < P.ops.size(); k++) {
+            if (used[k] && is_filter_stage((int)k) && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx))
+                return false;  // (a Filter whose own input is last chunk's registers: they are this chunk's only when it ends)
             if (!used[k] || !grp_early[k]) continue;
             const DevOp &op = P.ops[k];
             if (!split_delay[k])

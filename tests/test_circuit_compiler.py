@@ -95,6 +95,34 @@ def test_feedback_edges_read_last_iterations_registers():
     assert "JitFilterK<8, 1, 256, 1>" in text and "JitDelayK" in text
 
 
+def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
+    """The Filter stage keeps one wave busy while the others would wait.  The generated chunk body therefore sorts its units: what the
+    Filter's input needs runs a chunk AHEAD (`early`, where nothing else reads it), what neither feeds a Filter nor hangs on one runs
+    in a `side` block, both between the barriers of a sub-block on the waves that do not serve it; waves 0 and 1 take turns serving."""
+    d.configure(48000)
+    def loop(k):   # BASELINE configs[3]: the Delay's reads feed the Filter, everything else only reaches the ring
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
+    fast = source(uni.words, waves=16, per_wave=2, compile=True).split("} else {")[0]
+    side = fast.split("auto side0 = [&]()")[1].split("};")[0]
+    assert ".tick<1, 0, true>" in side and side.count(".write(") == 2 and ".read(" not in side      # oscillators and the ring writes of both instances
+    early = fast.split("auto early = [&](uint32_t g)")[1].split("};")[0]
+    assert early.count(".read(") == 2 and early.count("f4.feed(") == 2 and ".write(" not in early     # ring reads and feed-forward halves, a chunk ahead
+    assert "if (g == X[0].g_begin) early(g);" in fast and fast.count("if (g + 1 < X[0].g_end) early(g + 1);") == 2
+    assert "f4.serial<8>(X[0], tile, 0);" in fast and "f4.serial<8>(X[0], tile, 1);" in fast         # two sub-blocks, two serving waves
+    assert "if ((X[0].wave + 1) % 2 == 0) { side0();" in fast and "if ((X[0].wave + 1) % 2 == 1) { side0();" in fast
+    # a voice whose oscillator also reaches the output: the oscillator cannot run ahead (the sum reads it), nothing is left for a side block
+    dry = descriptor.unify([descriptor.extract((lambda o: d.Sum(d.Filter(o, 900), o))(d.Osc(200 + k))) for k in (0, 8)])
+    text = source(dry.words, waves=16, per_wave=2)
+    assert "auto early" not in text and "auto side0" not in text
+    # Filters in series keep the plain form
+    text = source(descriptor.unify([descriptor.extract(d.Filter(d.Filter(d.Osc(200 + k), 900), 1200)) for k in (0, 8)]).words, waves=16, per_wave=2)
+    assert "auto early" not in text and "auto side0" not in text
+
+
 def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     """per_wave instances per wavefront: every unit block stands per_wave times — except units that compute the same chunk for
     every instance (here the envelope: constants and time only), which are emitted once and read by all."""
