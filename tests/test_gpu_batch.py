@@ -66,6 +66,47 @@ def test_feedback_loop_batch(engine, oracle):
     prog.close()
 
 
+def _filter_voice(kind, k):
+    o = d.Osc(110 + k / 4)
+    if kind == "env_after":      # a unit hanging on the Filter, a per-instance cutoff
+        return d.Multiply(d.Filter(o, 600 + k), d.Ramp(2500, 1, 0).trigger())
+    if kind == "dry_wet":        # the oscillator is read by the Filter AND behind it: it cannot run a chunk ahead
+        return d.Sum(d.Filter(o, 900), d.Multiply(o, 0.3))
+    if kind == "two_channels":   # two Filter stages sharing the tile, one after the other
+        return d.Filter(d.Multiply(o, [0.5, 0.25]), 1200)
+    if kind == "beside":         # a second oscillator that neither feeds the Filter nor hangs on it: a side block
+        return d.Sum(d.Filter(o, 1500, "HP"), d.Osc(330 + k / 8, "triangle"))
+    if kind == "late_input":     # the Filter ticks BEFORE the Delay it reads: last chunk's registers
+        s = d.Sum(o, 0)
+        dl = d.Delay(s, 300.25, 2048)
+        s.B = d.Multiply(d.Filter(dl, 3000), 0.5)
+        return dl
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["env_after", "dry_wet", "two_channels", "beside", "late_input"])
+def test_filter_circuits_in_full_workgroups(kind, oracle):
+    """Filter circuits at a batch size that fills workgroups of 16 wavefronts (several instances per wavefront, waves 0 and 1 taking
+    turns at the recurrences, the other units beside them or a chunk ahead where the circuit allows): sampled instances against the
+    oracle, within the Filter tolerance (device tan())."""
+    d.configure(48000)
+    V, n = 4096 + 17, 256 * 11 + 40
+    ks = np.arange(V)
+    uni = descriptor.unify([descriptor.extract(_filter_voice(kind, int(k))) for k in (0, 1, 2)])
+    base = uni.params[:, 0].astype(np.float64)
+    params = (base[:, None] + (uni.params[:, 1].astype(np.float64) - base)[:, None] * ks[None, :]).astype(np.float32)
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, V, params)
+    prog._read_info()
+    waves, per_wave = (int(t) for t in prog.shape.rsplit(" ", 1)[1].split("x"))
+    assert "compiled kernel" in prog.shape and waves >= 8 and waves * per_wave >= 17, prog.shape  # (several wavefronts: the turns are taken)
+    for i in (0, 1, 31, 32, 63, 64, 1000, 1023, 1024, 2047, 2048, 4095, 4096, V - 1):
+        want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)
+        err = np.max(np.abs(pcm[i].astype(np.float64) - want))
+        assert err <= 1e-5 * max(1.0, float(np.max(np.abs(want)))), (kind, i, err)
+    prog.close()
+
+
 @pytest.mark.parametrize("delay,ring", [(480, 4096), (257, 2048), (301.5, 2047), (1023, 1501), (700.25, 1000), (300, 1026)])
 def test_write_once_delay_geometries(delay, ring, oracle):
     """Delay lines of at least a chunk on the compiled kernel: whole and fractional delays, ring lengths / delays / positions that are
