@@ -184,6 +184,9 @@ struct Emitter {
     // The overlapped form of a Filter circuit's chunk (plan_overlap): which units go where, and what unit() is emitting right now
     std::vector<char> grp_early, grp_side, grp_post, split_delay;
     bool any_side = false;         // plan_overlap: there are side units
+    bool in_early = false;         // unit(): emitting the block that works a chunk ahead
+    std::vector<char> dbl;         // plan_rotate: buffers an early unit produces and something outside that block reads: written a chunk
+                                   // ahead as `vn`, copied into `v` at the top of the chunk they belong to
     int slice = -1, n_slices = 1;  // unit(): only the instance slots r with r % n_slices == slice (shared units: slice 0)
     bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
     int delay_half = 0;            // unit(): 0 a write-once Delay's whole tick, 1 its reads only, 2 its writes only
@@ -215,8 +218,10 @@ struct Emitter {
     }
     // slot suffix of op k's variables for instance slot r: a shared op has one copy
     std::string sfx(int k, int r) const { return "_" + num(shared[(size_t)k] ? 0 : r); }
+    std::string vout(int buf, int r) const { return std::string(in_early && !dbl.empty() && dbl[(size_t)buf] ? "vn" : "v") + num(buf) + "_" + num(r); }
     std::string buf_name(int consumer_pos, int buf, int r) const {
-        return std::string(reads_late(consumer_pos, buf) ? "w" : "v") + num(buf) + sfx(producer[(size_t)buf], r);
+        if (reads_late(consumer_pos, buf)) return "w" + num(buf) + sfx(producer[(size_t)buf], r);
+        return vout(buf, shared[(size_t)producer[(size_t)buf]] ? 0 : r);
     }
     // text of operand j of op k at sample c ("c" may be a literal digit), for instance slot r
     std::string opnd(int k, int j, const std::string &c, int r) const {
@@ -517,12 +522,14 @@ struct Emitter {
             line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
         }
     }
-    // May the early units and the feed-forward halves of chunk g+1 run inside chunk g (beside its recurrences)?  They may when
-    // nothing but they themselves and the Filter stages read what they produce, and they read nothing the reference reads late.
-    bool plan_rotate(const std::vector<char> &used) const {
+    // May the early units and the feed-forward halves of chunk g+1 run inside chunk g (beside its recurrences)?  They may when they
+    // read nothing the reference reads late (last chunk's registers become this chunk's only when it ends).  What they produce and
+    // something outside their block reads as well (a unit behind the Filter, a side unit, the PCM store, a late reader) is
+    // double-buffered: `dbl`.
+    bool plan_rotate(const std::vector<char> &used) {
+        dbl.assign((size_t)std::max(1, P.n_bufs), 0);
         for (size_t k = 0; k < P.ops.size(); k++) {
-            if (used[k] && is_filter_stage((int)k) && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx))
-                return false;  // (a Filter whose own input is last chunk's registers: they are this chunk's only when it ends)
+            if (used[k] && is_filter_stage((int)k) && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx)) return false;
             if (!used[k] || !grp_early[k]) continue;
             const DevOp &op = P.ops[k];
             if (!split_delay[k])
@@ -530,16 +537,16 @@ struct Emitter {
                     if (operand_live(op, j) && op.in[j].kind == SRC_BUF && reads_late(pos_of_op[k], op.in[j].idx)) return false;
             const int b = op.out_buf;
             if (b < 0) continue;
-            if (late[(size_t)b]) return false;
+            if (late[(size_t)b]) dbl[(size_t)b] = 1;
             for (int ob : P.out_bufs)
-                if (ob == b) return false;
+                if (ob == b) dbl[(size_t)b] = 1;
             for (size_t c = 0; c < P.ops.size(); c++) {
                 if (!used[c]) continue;
                 for (int j = 0; j < kMaxIn; j++) {
                     const DevOperand &o = P.ops[c].in[j];
                     if (!operand_live(P.ops[c], j) || o.kind != SRC_BUF || o.idx != b) continue;
                     const bool inside = (grp_early[c] && !split_delay[c]) || (is_filter_stage((int)c) && j == 0);
-                    if (!inside) return false;
+                    if (!inside) dbl[(size_t)b] = 1;
                 }
             }
         }
@@ -571,10 +578,15 @@ struct Emitter {
         const bool sorted = render && opt.overlap && plan_overlap(used);
         const bool rotate = sorted && opt.rotate && plan_rotate(used);
         const bool overlapped = sorted && (any_side || rotate);
-        if (rotate)  // the next chunk's feed-forward halves, computed a chunk ahead
-            for (size_t at = 0; at < plan.order.size(); at++)
-                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]))
-                    for (int r = 0; r < R; r++) line("    double qn" + num(plan.order[at]) + "_" + num(r) + "[4];");
+        if (!rotate) dbl.clear();
+        if (rotate)  // what is computed a chunk ahead: the feed-forward halves, and the early units' outlets that others read too
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (used[(size_t)k] && is_filter_stage(k))
+                    for (int r = 0; r < R; r++) line("    double qn" + num(k) + "_" + num(r) + "[4];");
+                if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
+                    for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
+            }
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
         if (overlapped) {
             const int subs = kChunk / opt.filter_sub;
@@ -600,6 +612,7 @@ struct Emitter {
             }
             slice = -1;
             if (rotate) line("        auto early = [&](uint32_t g) __attribute__((always_inline)) {  // (its own g: it works for the chunk after this one)");
+            in_early = rotate;
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (!used[(size_t)k] || !grp_early[(size_t)k]) continue;
@@ -609,9 +622,18 @@ struct Emitter {
             delay_half = 0;
             for (size_t at = 0; at < plan.order.size(); at++)
                 if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at], rotate ? "qn" : "q", !rotate);
+            in_early = false;
             if (rotate) {
                 line("        };");
                 line("        if (g == X[0].g_begin) early(g);");
+                for (size_t at = 0; at < plan.order.size(); at++) {
+                    const int k = plan.order[at];
+                    if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
+                        for (int r = 0; r < copies(k); r++) {
+                            const std::string id = num(P.ops[(size_t)k].out_buf) + "_" + num(r);
+                            line("        for (int c = 0; c < 4; ++c) v" + id + "[c] = vn" + id + "[c];");
+                        }
+                }
                 for (size_t at = 0; at < plan.order.size(); at++)
                     if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]))
                         for (int r = 0; r < R; r++) {
@@ -669,7 +691,7 @@ struct Emitter {
                 const std::string id = num(k) + "_" + num(r);
                 const std::string x = opnd_array(k, 0, "t" + id, r), f = opnd_array(k, 1, "tf" + id, r);
                 if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-                line("        f" + id + ".tick(" + ctx(r) + ", scr, " + num(op.attr) + ", " + x + ", " + f + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+                line("        f" + id + ".tick(" + ctx(r) + ", scr, " + num(op.attr) + ", " + x + ", " + f + ", " + vout(op.out_buf, r) + ");");
             }
             return;
         }
@@ -698,17 +720,17 @@ struct Emitter {
                 for (int r = 0; r < copies(k); r++)
                     if (take(k, r))
                         line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
-                             table_row(op.attr) + ", " + fs[(size_t)r] + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+                             table_row(op.attr) + ", " + fs[(size_t)r] + ", " + vout(op.out_buf, r) + ");");
             }
             line("        }");
             if (!lookup)
                 for (int r = 0; r < copies(k); r++)
-                    if (take(k, r)) line("        for (int c = 0; c < 4; ++c) v" + num(op.out_buf) + "_" + num(r) + "[c] = 0.f;");
+                    if (take(k, r)) line("        for (int c = 0; c < 4; ++c) " + vout(op.out_buf, r) + "[c] = 0.f;");
             return;
         }
         for (int r = 0; r < copies(k); r++) {
             if (!take(k, r)) continue;
-            const std::string id = num(k) + "_" + num(r), v = "v" + num(op.out_buf) + "_" + num(r), X_ = ctx(r);
+            const std::string id = num(k) + "_" + num(r), v = op.out_buf >= 0 ? vout(op.out_buf, r) : std::string("v_none"), X_ = ctx(r);
             auto decl = [&]() { if (!predeclared) line("        float " + v + "[4];"); };
             auto each = [&](const std::string &expr) {
                 decl();

@@ -114,10 +114,12 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
     assert "if (g == X[0].g_begin) early(g);" in fast and fast.count("if (g + 1 < X[0].g_end) early(g + 1);") == 2
     assert "f4.serial<8>(X[0], tile, 0);" in fast and "f4.serial<8>(X[0], tile, 1);" in fast         # two sub-blocks, two serving waves
     assert "if ((X[0].wave + 1) % 2 == 0) { side0();" in fast and "if ((X[0].wave + 1) % 2 == 1) { side0();" in fast
-    # a voice whose oscillator also reaches the output: the oscillator cannot run ahead (the sum reads it), nothing is left for a side block
+    # a voice whose oscillator also reaches the output: it still runs ahead, into registers of its own that become the chunk's at its top
     dry = descriptor.unify([descriptor.extract((lambda o: d.Sum(d.Filter(o, 900), o))(d.Osc(200 + k))) for k in (0, 8)])
-    text = source(dry.words, waves=16, per_wave=2)
-    assert "auto early" not in text and "auto side0" not in text
+    fast = source(dry.words, waves=16, per_wave=2, compile=True).split("} else {")[0]
+    early = fast.split("auto early = [&](uint32_t g)")[1].split("};")[0]
+    assert early.count(", vn0_") == 4 and "v0_0" not in early.replace("vn0_0", "")                   # written and fed to the Filter as vn
+    assert "for (int c = 0; c < 4; ++c) v0_0[c] = vn0_0[c];" in fast and "+ v0_0[c]" in fast                # ... and read by the sum as v
     # Filters in series keep the plain form
     text = source(descriptor.unify([descriptor.extract(d.Filter(d.Filter(d.Osc(200 + k), 900), 1200)) for k in (0, 8)]).words, waves=16, per_wave=2)
     assert "auto early" not in text and "auto side0" not in text
