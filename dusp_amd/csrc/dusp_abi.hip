@@ -779,20 +779,28 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     DevBuf<unsigned long long> d_debug;
     if (opt.profile) {
-        HIP_TRY(ctx, d_debug.ensure((size_t)grid * 4));
-        HIP_TRY(ctx, hipMemsetAsync(d_debug.p, 0, (size_t)grid * 4 * sizeof(unsigned long long), stream));
+        HIP_TRY(ctx, d_debug.ensure((size_t)grid * 16));
+        HIP_TRY(ctx, hipMemsetAsync(d_debug.p, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream));
         a.debug = d_debug.p;
     }
     HIP_TRY(ctx, dusp::jit_launch(render, a, grid, (unsigned)waves * 64, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
     if (opt.profile) {  // diagnostic build: what wave 0 of the workgroups measured (mean over workgroups), to stderr
-        std::vector<unsigned long long> h((size_t)grid * 4);
+        std::vector<unsigned long long> h((size_t)grid * 16);
         HIP_TRY(ctx, hipStreamSynchronize(stream));
         HIP_TRY(ctx, hipMemcpy(h.data(), d_debug.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double loop = 0, serial = 0, chunks = 0;
-        for (unsigned b = 0; b < grid; b++) loop += (double)h[b * 4], serial += (double)h[b * 4 + 1] + (double)h[b * 4 + 3], chunks += (double)h[b * 4 + 2];
+        double ph[12] = {0};
+        for (unsigned b = 0; b < grid; b++) {
+            loop += (double)h[b * 16], serial += (double)h[b * 16 + 1] + (double)h[b * 16 + 3], chunks += (double)h[b * 16 + 2];
+            for (int i = 0; i < 12; i++) ph[i] += (double)h[b * 16 + 4 + i];
+        }
         std::fprintf(stderr, "[dusp jit profile] %ux%d waves x instances (%d B of scratch per lane), %u workgroups: chunk loop %.0f cycles per chunk, of which Filter recurrences %.0f (%.1f per sample-step)\n",
                      (unsigned)waves, per_wave, jit_scratch, grid, loop / std::max(1.0, chunks), serial / std::max(1.0, chunks), serial / std::max(1.0, chunks) / 256.0);
+        std::fprintf(stderr, "[dusp jit profile]   barrier to barrier, as wave 0 sees them:");
+        for (int i = 0; i < 12; i++)
+            if (ph[i] > 0) std::fprintf(stderr, " %s%.0f", i == 11 ? "| tail " : "", ph[i] / std::max(1.0, chunks));
+        std::fprintf(stderr, "\n");
         d_debug.release();
     }
     prog->jit_waves = waves;

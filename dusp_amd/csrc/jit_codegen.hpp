@@ -184,6 +184,7 @@ struct Emitter {
     // The overlapped form of a Filter circuit's chunk (plan_overlap): which units go where, and what unit() is emitting right now
     std::vector<char> grp_early, grp_side, grp_post, split_delay;
     bool any_side = false;         // plan_overlap: there are side units
+    int phase = 0;                 // diagnostic build: the next barrier-to-barrier stamp of the chunk body
     bool in_early = false;         // unit(): emitting the block that works a chunk ahead
     std::vector<char> dbl;         // plan_rotate: buffers an early unit produces and something outside that block reads: written a chunk
                                    // ahead as `vn`, copied into `v` at the top of the chunk they belong to
@@ -451,6 +452,7 @@ struct Emitter {
                 for (int r = 0; r < copies(producer[(size_t)b]); r++) line("    float w" + num(b) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
         // the chunk loop, twice: with the constant-f oscillators in 32.32 fixed point, and in the general form
         if (opt.profile) line("    const unsigned long long stamp_loop = __builtin_readcyclecounter();");
+        if (opt.profile) line("    unsigned long long ph[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, ph_t = 0ull;  // (cycles from barrier to barrier, as wave 0 sees them)");
         line("    if (" + fast + ") {");
         loop(render, pass_level, used, true);
         line("    } else {");
@@ -458,14 +460,15 @@ struct Emitter {
         line("    }");
         if (opt.profile && render) {
             line("    if (A.debug && X[0].wave == 0 && X[0].lane == 0) {");
-            line("        A.debug[(size_t)blockIdx.x * 4 + 0] = __builtin_readcyclecounter() - stamp_loop;");
+            line("        A.debug[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter() - stamp_loop;");
             std::string ser = "0ull";
             for (size_t k = 0; k < P.ops.size(); k++)
                 if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind != SRC_BUF) ser += " + f" + num((long long)k) + ".cyc_serial";
-            line("        A.debug[(size_t)blockIdx.x * 4 + 1] = " + ser + ";");
-            line("        A.debug[(size_t)blockIdx.x * 4 + 2] = X[0].g_end - X[0].g_begin;");
+            line("        A.debug[(size_t)blockIdx.x * 16 + 1] = " + ser + ";");
+            line("        A.debug[(size_t)blockIdx.x * 16 + 2] = X[0].g_end - X[0].g_begin;");
             line("    }");
-            line("    if (A.debug && X[0].wave == 1 && X[0].lane == 0) A.debug[(size_t)blockIdx.x * 4 + 3] = " + ser + ";  // (the sub-blocks wave 1 served)");
+            line("    if (A.debug && X[0].wave == 0 && X[0].lane == 0) for (int i = 0; i < 12; ++i) A.debug[(size_t)blockIdx.x * 16 + 4 + i] = ph[i];");
+            line("    if (A.debug && X[0].wave == 1 && X[0].lane == 0) A.debug[(size_t)blockIdx.x * 16 + 3] = " + ser + ";  // (the sub-blocks wave 1 served)");
         }
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
@@ -559,11 +562,16 @@ struct Emitter {
         auto park = [&](const char *indent) {
             for (int r = 0; r < R; r++) line(std::string(indent) + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ");");
         };
+        auto stamp = [&]() {
+            if (opt.profile && phase < 11) line("        { const unsigned long long now_ = __builtin_readcyclecounter(); ph[" + num(phase++) + "] += now_ - ph_t; ph_t = now_; }");
+        };
         park("        ");
         line("        jit_lds_barrier();");
+        stamp();
         line("        " + f + ".serial<" + num(opt.filter_block) + ">(X[0], tile, " + num(who) + ");");
         if (!beside.empty()) line("        " + beside);
         line("        jit_lds_barrier();");
+        stamp();
         line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
         park("            ");
         line("            jit_lds_barrier();");
@@ -588,6 +596,8 @@ struct Emitter {
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        phase = 0;
+        if (opt.profile && render) line("        ph_t = __builtin_readcyclecounter();");
         if (overlapped) {
             const int subs = kChunk / opt.filter_sub;
             int windows = 0;
@@ -679,6 +689,7 @@ struct Emitter {
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
                 for (int r = 0; r < copies(producer[(size_t)b]); r++)
                     line("        for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
+        if (opt.profile && render) line("        ph[11] += __builtin_readcyclecounter() - ph_t;  // (behind the last barrier)");
         line("    }");
     }
 
