@@ -188,7 +188,12 @@ def test_random_circuit_wave_equals_chunk(seed):
         p.close()
 
 
-@pytest.mark.parametrize("seed,n_inst", [(17, 1100), (23, 2500), (29, 700), (31, 4200), (41, 300), (43, 900), (47, 600), (53, 1300), (59, 2100)])
+LARGE = [(17, 1100), (23, 2500), (29, 700), (31, 4200), (41, 300), (43, 900), (47, 600), (53, 1300), (59, 2100), (61, 4500), (67, 8192), (71, 5000)]
+# DUSP_FUZZ_BATCHES=n: n more structures at batch sizes that fill 16-wavefront workgroups (a soak run, not the default)
+LARGE += [(100 + s, 4096 + 37 * s) for s in range(int(__import__("os").environ.get("DUSP_FUZZ_BATCHES", "0")))]
+
+
+@pytest.mark.parametrize("seed,n_inst", LARGE)
 def test_random_large_batch_wave_equals_chunk(seed, n_inst):
     """Hundreds to thousands of instances: the wave engine packs 2-16 wavefronts per workgroup (shared table image,
     cooperative Filter stage, surplus waves in the last workgroup); still bit-identical to the chunk engine."""
