@@ -188,7 +188,6 @@ struct Emitter {
     bool in_early = false;         // unit(): emitting the block that works a chunk ahead
     std::vector<char> dbl;         // plan_rotate: buffers an early unit produces and something outside that block reads: written a chunk
                                    // ahead as `vn`, copied into `v` at the top of the chunk they belong to
-    int slice = -1, n_slices = 1;  // unit(): only the instance slots r with r % n_slices == slice (shared units: slice 0)
     bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
     int delay_half = 0;            // unit(): 0 a write-once Delay's whole tick, 1 its reads only, 2 its writes only
 
@@ -243,7 +242,6 @@ struct Emitter {
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
-    bool take(int k, int r) const { return slice < 0 || (copies(k) == 1 ? slice == 0 : r % n_slices == slice); }
     bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind != SRC_BUF; }
 
     // The Filter stage keeps ONE wave busy with the recurrences while the others wait; whatever the chunk holds that neither feeds a
@@ -609,18 +607,14 @@ struct Emitter {
                     for (int r = 0; r < copies(k); r++) line("        float v" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
             predeclared = true;
-            n_slices = 1;  // (one side block: every wave runs all of its in one window)
-            for (slice = 0; slice < n_slices; slice++) {  // the side blocks: instance slots dealt over the sub-blocks' windows
-                line("        auto side" + num(slice) + " = [&]() __attribute__((always_inline)) {");
-                for (size_t at = 0; at < plan.order.size(); at++) {
-                    const int k = plan.order[at];
-                    if (!used[(size_t)k] || !grp_side[(size_t)k]) continue;
-                    delay_half = split_delay[(size_t)k] ? 2 : 0;
-                    unit(k, render, pass_level, fx);
-                }
-                line("        };");
+            line("        auto side0 = [&]() __attribute__((always_inline)) {  // (a wave runs it whole, in one window it does not serve)");
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (!used[(size_t)k] || !grp_side[(size_t)k]) continue;
+                delay_half = split_delay[(size_t)k] ? 2 : 0;
+                unit(k, render, pass_level, fx);
             }
-            slice = -1;
+            line("        };");
             if (rotate) line("        auto early = [&](uint32_t g) __attribute__((always_inline)) {  // (its own g: it works for the chunk after this one)");
             in_early = rotate;
             for (size_t at = 0; at < plan.order.size(); at++) {
@@ -698,7 +692,6 @@ struct Emitter {
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
             for (int r = 0; r < R; r++) {
-                if (!take(k, r)) continue;
                 const std::string id = num(k) + "_" + num(r);
                 const std::string x = opnd_array(k, 0, "t" + id, r), f = opnd_array(k, 1, "tf" + id, r);
                 if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
@@ -717,30 +710,24 @@ struct Emitter {
             const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
             std::vector<std::string> fs((size_t)copies(k));
             std::string rare = "false";
-            bool any = false;
             for (int r = 0; r < copies(k); r++) {
-                if (!take(k, r)) continue;
-                any = true;
                 fs[(size_t)r] = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
                 if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
                 rare += " | o" + num(k) + "_" + num(r) + ".rare(" + ctx(r) + ", " + fs[(size_t)r] + ")";
             }
-            if (!any) return;
             for (int careful = 0; careful < 2; careful++) {
                 line(careful ? "        } else {" : "        if (!(" + rare + ")) {");
                 for (int r = 0; r < copies(k); r++)
-                    if (take(k, r))
-                        line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
+                    line("            o" + num(k) + "_" + num(r) + ".tick<" + in_lds(op.attr) + ", " + (lookup ? "true" : "false") + ", " + (careful ? "true" : "false") + ">(" + ctx(r) + ", " +
                              table_row(op.attr) + ", " + fs[(size_t)r] + ", " + vout(op.out_buf, r) + ");");
             }
             line("        }");
             if (!lookup)
                 for (int r = 0; r < copies(k); r++)
-                    if (take(k, r)) line("        for (int c = 0; c < 4; ++c) " + vout(op.out_buf, r) + "[c] = 0.f;");
+                    line("        for (int c = 0; c < 4; ++c) " + vout(op.out_buf, r) + "[c] = 0.f;");
             return;
         }
         for (int r = 0; r < copies(k); r++) {
-            if (!take(k, r)) continue;
             const std::string id = num(k) + "_" + num(r), v = op.out_buf >= 0 ? vout(op.out_buf, r) : std::string("v_none"), X_ = ctx(r);
             auto decl = [&]() { if (!predeclared) line("        float " + v + "[4];"); };
             auto each = [&](const std::string &expr) {
