@@ -63,19 +63,20 @@ typedef enum {
  *   FUSED — time-parallel fused kernels for recognised voice shapes (Osc, Osc x Ramp,
  *           Osc x gain, Sum.many chains): one lane per sample, time split across waves,
  *           16-byte coalesced PCM stores.
- *   WAVE  — one wavefront per instance, wavefront-wide phase accumulation.  Circuits of Osc / Ramp / Multiply / Sum / the
- *           stateless maps / Timer / Filter and Delay with constant controls (with or without feedback edges) get a kernel
- *           COMPILED FOR THAT CIRCUIT (units inlined in process order, operands in registers; dusp_circuit_kernel_source);
- *           the rest runs on an interpreter kernel with chunk buffers in LDS: every unit
- *           of the path (FM, Filters, feedback edges, envelopes, the comb family; delay lines and CircleBuffer
- *           nodes either lane-parallel or, where their accesses can meet inside a chunk, through ordered slot
- *           operations); few instances and a long render are split in time when the graph allows it.  Refuses
- *           by regime, not by unit: channel counts that grow during the first chunks, more chunk buffers than
- *           LDS holds, an oscillator phase outside [0, sampleRate).
+ *   WAVE  — one wavefront per instance (or a few), wavefront-wide phase accumulation.  A circuit gets a kernel COMPILED FOR IT
+ *           (units inlined in process order, operands in registers, the Filters' recurrences of a workgroup side by side on
+ *           one wave with the other units beside them; dusp_circuit_kernel_source) — every unit of the path: FM, Filters,
+ *           feedback edges, envelopes, the comb family, delay lines and CircleBuffer nodes lane-parallel or, where their
+ *           accesses can meet inside a chunk, through ordered slot operations.  What stays on the interpreter kernel
+ *           (chunk buffers in LDS) is decided by regime: continued programs with delay lines / feedback, circuits of more
+ *           than 96 units, and a structure's FIRST render while its kernel compiles in the background.  Few instances and
+ *           a long render are split in time when the graph allows it.  Refuses by regime, not by unit: channel counts that
+ *           grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
- * AUTO picks FUSED, else LOOP (two-stage), else WAVE, else LOOP, else CHUNK.
+ * AUTO picks FUSED, else WAVE for the feedback voice with a constant delay of at least a chunk (its compiled kernel beats
+ * the two-stage LOOP kernel), else LOOP for the other feedback voices, else WAVE, else CHUNK.
  *
  * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
  * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose
