@@ -661,7 +661,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
     const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
-    if (prog->wave.has_filter) {
+    const bool filter_stage = opt.filter_stages > 0;  // (a Filter with a connected cutoff runs per wave: no stage, no rows)
+    if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has
         // lanes, and every CU the same number of rounds — rows = instances per CU / rounds, spread over up to 16 wavefronts.
         const uint64_t per_cu = (n_inst + (uint64_t)ctx->n_cus - 1) / (uint64_t)ctx->n_cus;
@@ -720,19 +721,19 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (scratch <= ctx->knobs.jit_spill_bytes) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
-        if (prog->wave.has_filter && opt.filter_block == 8) {
+        if (filter_stage && opt.filter_block == 8) {
             opt.filter_block = 4;  // (first: the recurrence loop with half the P values in flight, 16 registers less)
             continue;
         }
         opt.filter_block = 8;
-        if (prog->wave.has_filter && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
+        if (filter_stage && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
             waves /= 2;
             per_wave *= 2;
-        } else if (prog->wave.has_filter && per_wave > 1) per_wave /= 2;  // (rows stay a power of two: whole rounds on every CU)
+        } else if (filter_stage && per_wave > 1) per_wave /= 2;  // (rows stay a power of two: whole rounds on every CU)
         else if (per_wave > 1) per_wave /= 2;  // (4, 2, 1: an odd count leaves the last round of workgroups a third full at the usual batch sizes)
         else if (waves > 4) waves /= 2;
         else break;
-        if (prog->wave.has_filter) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
+        if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
     }
     // (from here on the render happens on the compiled kernel: workspaces)
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));

@@ -1225,16 +1225,51 @@ struct JitFilterM {
         }
         jit_wave_sync();
         if (X.lane == 0) {
-            double v1 = y1, v2 = y2;
-            float *Y = scr;
-            for (int t = 0; t < kChunk; ++t) {
-                const float y = (float)((P[t] - B1[t] * jit_or0(v1)) - B2[t] * jit_or0(v2));  // Filter.js:40-46
-                Y[t] = y;  // (over P[t / 2], read already)
-                v2 = jit_or0(v1);
-                v1 = (double)y;
+            // One lane, 256 dependent steps: like the Filter stage's loop (JitFilterK::serial) the chain is kept free of everything
+            // else — P, b1, b2 of four steps in registers, the next four read while these run, the `|| 0` selects speculated away
+            // (a NaN cannot leave the recurrence without them, so the block's last output tells; the block is then redone as
+            // written).  y goes over the P values already consumed.
+            double v1 = jit_or0(y1), v2 = jit_or0(y2);
+            f32x4 *Y = (f32x4 *)scr;
+            double pa[4], ba[4], ca[4], pb[4], bb[4], cb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = P[i], ba[i] = B1[i], ca[i] = B2[i];
+            auto block = [&](const double (&p)[4], const double (&b1)[4], const double (&b2)[4], f32x4 *dst) __attribute__((always_inline)) {
+                const double in1 = v1, in2 = v2;
+                f32x4 y4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = (float)((p[i] - b1[i] * v1) - b2[i] * v2);
+                    y4[i] = y;
+                    v2 = v1;
+                    v1 = (double)y;
+                }
+                if (!(v1 == v1 && v2 == v2)) {  // Filter.js:40-46 as written
+                    v1 = in1;
+                    v2 = in2;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float y = (float)((p[i] - b1[i] * jit_or0(v1)) - b2[i] * jit_or0(v2));
+                        y4[i] = y;
+                        v2 = jit_or0(v1);
+                        v1 = (double)y;
+                    }  // (a NaN in v1 now fails the next block's test too: that block is done as written as well)
+                }
+                *dst = y4;
+            };
+            for (int t0 = 0; t0 < kChunk; t0 += 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pb[i] = P[t0 + 4 + i], bb[i] = B1[t0 + 4 + i], cb[i] = B2[t0 + 4 + i];
+                __builtin_amdgcn_sched_barrier(0);
+                block(pa, ba, ca, Y + (t0 >> 2));  // (y of samples t0 .. t0+3 over P of samples t0/2, t0/2+1: in registers up to t0+7)
+                const int next = t0 + 8 < kChunk ? t0 + 8 : t0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pa[i] = P[next + i], ba[i] = B1[next + i], ca[i] = B2[next + i];
+                __builtin_amdgcn_sched_barrier(0);
+                block(pb, bb, cb, Y + (t0 >> 2) + 1);
             }
             y1 = v1;
-            y2 = v2;
+            y2 = jit_or0(v2);  // (Filter.js:45: y2 = y1 || 0)
         }
         y1 = jit_u(y1);
         y2 = jit_u(y2);

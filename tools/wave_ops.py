@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-unit cost on the wave engine: small graphs forced onto ENGINE_WAVE, 16384 instances x 1 s (time split off).
-  python tools/wave_ops.py [--only=name,name]"""
+  python tools/wave_ops.py ["--only=name;name"]"""
 import os
 import sys
 
@@ -29,10 +29,14 @@ graphs = {
     "timer * k": lambda k: d.Multiply(d.Timer(), 1.0 + k / 1e4),
     "filter(osc)": lambda k: d.Filter(d.Osc(110 + k / 8), 800),
     "allpass(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.AllPass(0.0021, 0.6)),
+    "filter(osc) * ramp": lambda k: d.Multiply(d.Filter(d.Osc(110 + k / 8), 800 + k / 16), d.Ramp(sr, 1, 0).trigger()),
+    "filter(osc, lfo)": lambda k: d.Filter(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(5), 800), 1000)),
+    "delay(osc, 300.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 300.5, 2048),
+    "delay(osc, 30.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 30.5, 2048),
 }
 only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 for name, g in graphs.items():
-    if only and name not in only[0].split(","):
+    if only and name not in only[0].split(";"):
         continue
     full = descriptor.unify([descriptor.extract(g(k)) for k in (0, 8, 16)])
     base = full.params[:, 0].astype(np.float64)
