@@ -113,7 +113,7 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
         if (op.op == OP_MULTI_OSC) n = 512;
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
-        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 1536;  // P, b1, b2 per sample (f64)
+        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 768;   // P, b1, b2 per sample (f64) of half a chunk
         if (jit_ring_ops(op)) n = 1024;                                 // the slot-ownership table
         need = std::max(need, n);
     }

@@ -1208,66 +1208,81 @@ struct JitFilterM {
         y2 = jit_u(is[10]);
     }
     __device__ __forceinline__ void tick(const JitCtx &X, float *scr, int kind, const float (&x)[4], const float (&f)[4], float (&out)[4]) {
-        double *P = (double *)scr, *B1 = P + kChunk, *B2 = P + 2 * kChunk;
+        // The wave's scratch holds HALF a chunk of P, b1, b2 (3 KB: 16 wavefronts fit next to the table image, where a whole chunk
+        // let 8): every lane computes its four samples' values, lanes 0..31 hand theirs over first, then lanes 32..63.
+        constexpr int kHalf = kChunk / 2;
+        double *P = (double *)scr, *B1 = P + kHalf, *B2 = P + 2 * kHalf;
         const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
         double xm1 = X.lane == 0 ? x1 : (double)xl1, xm2 = X.lane == 0 ? x2 : (double)xl2;
-        double kl[5];
-        jit_wave_sync();
+        double kl[5], p4[4], b14[4], b24[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             jit_filter_coefficients(kind, (double)f[c], X.srd, kl);
-            B1[X.lane * 4 + c] = kl[3];
-            B2[X.lane * 4 + c] = kl[4];
+            b14[c] = kl[3];
+            b24[c] = kl[4];
             const double xin = (double)x[c];
-            P[X.lane * 4 + c] = (kl[0] * xin + kl[1] * jit_or0(xm1)) + kl[2] * jit_or0(xm2);
+            p4[c] = (kl[0] * xin + kl[1] * jit_or0(xm1)) + kl[2] * jit_or0(xm2);
             xm2 = jit_or0(xm1);
             xm1 = xin;
         }
-        jit_wave_sync();
-        if (X.lane == 0) {
-            // One lane, 256 dependent steps: like the Filter stage's loop (JitFilterK::serial) the chain is kept free of everything
-            // else — P, b1, b2 of four steps in registers, the next four read while these run, the `|| 0` selects speculated away
-            // (a NaN cannot leave the recurrence without them, so the block's last output tells; the block is then redone as
-            // written).  y goes over the P values already consumed.
-            double v1 = jit_or0(y1), v2 = jit_or0(y2);
-            f32x4 *Y = (f32x4 *)scr;
-            double pa[4], ba[4], ca[4], pb[4], bb[4], cb[4];
+        double v1 = jit_or0(y1), v2 = jit_or0(y2);  // (lane 0's)
+        for (int half = 0; half < 2; ++half) {
+            const bool mine = (int)(X.lane >> 5) == half;
+            const int at = (int)(X.lane & 31u) * 4;
+            jit_wave_sync();
+            if (mine) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pa[i] = P[i], ba[i] = B1[i], ca[i] = B2[i];
-            auto block = [&](const double (&p)[4], const double (&b1)[4], const double (&b2)[4], f32x4 *dst) __attribute__((always_inline)) {
-                const double in1 = v1, in2 = v2;
-                f32x4 y4;
+                for (int c = 0; c < 4; ++c) P[at + c] = p4[c], B1[at + c] = b14[c], B2[at + c] = b24[c];
+            }
+            jit_wave_sync();
+            if (X.lane == 0) {
+                // One lane, dependent steps: like the Filter stage's loop (JitFilterK::serial) the chain is kept free of everything
+                // else — P, b1, b2 of four steps in registers, the next four read while these run, the `|| 0` selects speculated
+                // away (a NaN cannot leave the recurrence without them, so the block's last output tells; the block is then redone
+                // as written).  y goes over the P values already consumed.
+                f32x4 *Y = (f32x4 *)scr;
+                double pa[4], ba[4], ca[4], pb[4], bb[4], cb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float y = (float)((p[i] - b1[i] * v1) - b2[i] * v2);
-                    y4[i] = y;
-                    v2 = v1;
-                    v1 = (double)y;
-                }
-                if (!(v1 == v1 && v2 == v2)) {  // Filter.js:40-46 as written
-                    v1 = in1;
-                    v2 = in2;
+                for (int i = 0; i < 4; ++i) pa[i] = P[i], ba[i] = B1[i], ca[i] = B2[i];
+                auto block = [&](const double (&p)[4], const double (&b1)[4], const double (&b2)[4], f32x4 *dst) __attribute__((always_inline)) {
+                    const double in1 = v1, in2 = v2;
+                    f32x4 y4;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float y = (float)((p[i] - b1[i] * jit_or0(v1)) - b2[i] * jit_or0(v2));
+                        const float y = (float)((p[i] - b1[i] * v1) - b2[i] * v2);
                         y4[i] = y;
-                        v2 = jit_or0(v1);
+                        v2 = v1;
                         v1 = (double)y;
-                    }  // (a NaN in v1 now fails the next block's test too: that block is done as written as well)
+                    }
+                    if (!(v1 == v1 && v2 == v2)) {  // Filter.js:40-46 as written
+                        v1 = in1;
+                        v2 = in2;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float y = (float)((p[i] - b1[i] * jit_or0(v1)) - b2[i] * jit_or0(v2));
+                            y4[i] = y;
+                            v2 = jit_or0(v1);
+                            v1 = (double)y;
+                        }  // (a NaN in v1 now fails the next block's test too: that block is done as written as well)
+                    }
+                    *dst = y4;
+                };
+                for (int t0 = 0; t0 < kHalf; t0 += 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pb[i] = P[t0 + 4 + i], bb[i] = B1[t0 + 4 + i], cb[i] = B2[t0 + 4 + i];
+                    __builtin_amdgcn_sched_barrier(0);
+                    block(pa, ba, ca, Y + (t0 >> 2));  // (y of samples t0 .. t0+3 over P of samples t0/2, t0/2+1: in registers up to t0+7)
+                    const int next = t0 + 8 < kHalf ? t0 + 8 : t0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pa[i] = P[next + i], ba[i] = B1[next + i], ca[i] = B2[next + i];
+                    __builtin_amdgcn_sched_barrier(0);
+                    block(pb, bb, cb, Y + (t0 >> 2) + 1);
                 }
-                *dst = y4;
-            };
-            for (int t0 = 0; t0 < kChunk; t0 += 8) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pb[i] = P[t0 + 4 + i], bb[i] = B1[t0 + 4 + i], cb[i] = B2[t0 + 4 + i];
-                __builtin_amdgcn_sched_barrier(0);
-                block(pa, ba, ca, Y + (t0 >> 2));  // (y of samples t0 .. t0+3 over P of samples t0/2, t0/2+1: in registers up to t0+7)
-                const int next = t0 + 8 < kChunk ? t0 + 8 : t0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pa[i] = P[next + i], ba[i] = B1[next + i], ca[i] = B2[next + i];
-                __builtin_amdgcn_sched_barrier(0);
-                block(pb, bb, cb, Y + (t0 >> 2) + 1);
             }
+            jit_wave_sync();
+            if (mine) jit_row_get(scr, X.lane & 31u, out);
+        }
+        if (X.lane == 0) {
             y1 = v1;
             y2 = jit_or0(v2);  // (Filter.js:45: y2 = y1 || 0)
         }
@@ -1279,8 +1294,6 @@ struct JitFilterM {
         x1 = jit_u(__shfl(xm1, 63, 64));
         x2 = jit_u(__shfl(xm2, 63, 64));
         has_last = true;
-        jit_wave_sync();
-        jit_row_get(scr, X.lane, out);
     }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
