@@ -96,9 +96,15 @@ inline bool jit_light(const Program &P) {
     }
     return n <= 2;
 }
+// A Delay with a constant delay of less than a chunk reads what two known input samples left in its slot: no ring (JitDelayShort)
+inline bool jit_delay_short(const DevOp &op) {
+    if (op.op != OP_DELAY || op.in[1].kind != SRC_CONST) return false;
+    const double d = (double)op.in[1].cval;
+    return d >= 1.0 && d < (double)kChunk && op.ring_len >= 2 * kChunk;  // (a ring of two chunks at least: a chunk's slots wrap once at most)
+}
 // units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
 inline bool jit_ring_ops(const DevOp &op) {
-    return (op.op == OP_DELAY && !delay_write_once(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
+    return (op.op == OP_DELAY && !delay_write_once(op) && !jit_delay_short(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
 }
 
@@ -115,6 +121,7 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 768;   // P, b1, b2 per sample (f64) of half a chunk
         if (jit_ring_ops(op)) n = 1024;                                 // the slot-ownership table
+        if (jit_delay_short(op)) n = 512;                               // the chunk before and this one, side by side
         need = std::max(need, n);
     }
     return need;
@@ -291,7 +298,7 @@ struct Emitter {
             stack.pop_back();
             if (grp_early[(size_t)k]) continue;
             grp_early[(size_t)k] = 1;
-            if (P.ops[(size_t)k].op == OP_DELAY) {  // (write-once: the other kind returned above)
+            if (P.ops[(size_t)k].op == OP_DELAY && !jit_delay_short(P.ops[(size_t)k])) {  // (write-once: the slot-operation kind returned above)
                 split_delay[(size_t)k] = 1;
                 continue;
             }
@@ -395,6 +402,9 @@ struct Emitter {
                     if (jit_ring_ops(op)) {
                         line("    JitRingOps q" + id + ";");
                         line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
+                    } else if (jit_delay_short(op)) {
+                        line("    JitDelayShort z" + id + ";");
+                        line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     } else {
                         line("    JitDelayK y" + id + ";");
                         line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
@@ -492,7 +502,7 @@ struct Emitter {
                         if (op.op != OP_MONO_DELAY) line("        " + slot + " = q" + id + ".T;");
                         continue;
                     }
-                    if (op.op == OP_DELAY) line("        " + slot + " = y" + id + ".carried;");
+                    if (op.op == OP_DELAY) line("        " + slot + " = " + (jit_delay_short(op) ? "z" : "y") + id + ".carried;");
                     if (op.op == OP_SHAPE) line("        s" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) line("        " + slot + " = (double)b" + id + ".tb;");
                     if (op.op == OP_AHD) line("        e" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
@@ -826,6 +836,11 @@ struct Emitter {
             }
             case OP_DELAY: {
                 decl();
+                if (jit_delay_short(op)) {
+                    const std::string x = opnd_array(k, 0, "t" + id, r);
+                    line("        z" + id + ".tick(" + X_ + ", scr, " + x + ", " + v + ");");
+                    break;
+                }
                 if (delay_half == 1) {
                     line("        y" + id + ".read(" + v + ");");
                     break;

@@ -1401,5 +1401,57 @@ struct JitDelayK {
     }
 };
 
+// ---- Delay with a constant delay D + phi of LESS than a chunk, 1 <= D <= 255 (Delay.js:20-41).  Sample t reads its slot and clears
+// it, then adds its floor tap D slots ahead and its ceil tap D + 1 ahead; so what sample t reads is what samples t-D-1 (ceil tap,
+// first) and t-D (floor tap) left there, each `+=` rounded to f32 — a function of two INPUT samples, and no ring is needed at
+// all: the wave keeps the chunk before this one in registers, lays both out in its scratch row and every lane picks the
+// two samples each of its four needs.  (The tap that would land on slot 0 by way of index `length` is dropped by the
+// reference's Float32Array: slot 0 gets no ceil tap.)  The ring in HBM stays untouched: nothing reads it after the render.
+struct JitDelayShort {
+    float carried;     // the input sample before the chunk (uniform; what the unit's state holds)
+    float before[4];   // this lane's four samples of the chunk before
+    double phi;        // the delay's fraction (uniform)
+    uint32_t len, D, s0;
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_len, float delay) {
+        carried = jit_u((float)A.init_state[state_slot]);
+        const double dconst = (double)delay, Dfl = floor(dconst);
+        phi = dconst - Dfl;
+        D = (uint32_t)Dfl;
+        len = (uint32_t)ring_len;
+        s0 = (uint32_t)((A.clock0 + (uint64_t)X.g_begin * kChunk) % (uint64_t)ring_len);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) before[c] = 0.f;  // (a fresh ring: zeros — Delay.js:14)
+        if (X.lane == 63) before[3] = carried;
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, const float (&x)[4], float (&out)[4]) {
+        jit_wave_sync();
+        jit_row_put(scr, X.lane, before);
+        jit_row_put(scr + kChunk, X.lane, x);
+        jit_wave_sync();
+        const int j0 = kChunk + (int)X.lane * 4 - (int)D;  // this lane's first sample, D ago: 1 .. 511 - 3
+        float h[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) h[i] = scr[j0 - 1 + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t slot = s0 + X.lane * 4 + c;
+            if (slot >= len) slot -= len;
+            const double xin = (double)h[c + 1], xprev = (double)h[c];
+            if (phi != 0.0) {
+                const float tap = slot != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of the sample before (dropped at slot 0)
+                out[c] = (float)((double)tap + xin * (1.0 - phi));               // floor tap
+            } else {
+                const float tap = (float)(0.0 + xin * 1.0);  // floor(tWrite) == ceil(tWrite): both `+=` of one sample
+                out[c] = (float)((double)tap + xin * 0.0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) before[c] = x[c];
+        carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        s0 += kChunk;
+        if (s0 >= len) s0 -= len;  // (len >= 512 here: jit_delay_short)
+    }
+};
+
 }  // namespace
 }  // namespace dusp

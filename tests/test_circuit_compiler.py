@@ -125,6 +125,16 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
     assert "auto early" not in text and "auto side0" not in text
 
 
+def test_constant_delays_need_no_slot_operations():
+    d.configure(48000)
+    short = source(descriptor.extract(d.Delay(d.Osc(500), 30.5, 2048)).words)
+    assert "JitDelayShort" in short and "JitRingOps" not in short and "JitDelayK" not in short   # two input samples per output sample: no ring
+    long_ = source(descriptor.extract(d.Delay(d.Osc(500), 300.5, 2048)).words)
+    assert "JitDelayK" in long_ and "JitRingOps" not in long_                                      # write-once ring
+    moving = source(descriptor.extract(d.Delay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200), 1024)).words)
+    assert "JitRingOps" in moving                                                                   # taps can meet: ordered slot operations
+
+
 def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     """per_wave instances per wavefront: every unit block stands per_wave times — except units that compute the same chunk for
     every instance (here the envelope: constants and time only), which are emitted once and read by all."""

@@ -124,6 +124,25 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("delay,ring", [(1, 512), (1.5, 700), (30.5, 2048), (64, 1000), (255, 512), (255.75, 513), (100.25, 4410), (30.5, 300)])
+def test_delays_shorter_than_a_chunk(delay, ring, oracle):
+    """A constant delay of less than a chunk on the compiled kernel: what a sample reads is what two known input samples left in its
+    slot, so the kernel needs no ring (JitDelayShort) — whole and fractional delays, the slot-0 rule of the reference's ceil tap,
+    rings that wrap inside a chunk, several ring lengths into the render; the last case (a ring shorter than two chunks) stays on
+    the ordered slot operations.  Against the oracle bit for bit (Delay.js:20-41)."""
+    d.configure(48000)
+    uni = descriptor.unify([descriptor.extract(d.Delay(d.Multiply(d.Osc(300 + 7 * k), 0.5 + k / 64), delay, ring)) for k in range(0, 40)])
+    n = 3 * 4410 + 300
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    prog._read_info()
+    assert "compiled kernel" in prog.shape
+    for i in range(0, uni.n_instances, 3):
+        want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        assert np.array_equal(pcm[i], want), (delay, ring, i)
+    prog.close()
+
+
 @pytest.mark.parametrize("engine", [runtime.ENGINE_WAVE, runtime.ENGINE_CHUNK])
 def test_filter_takes_nan_inputs_as_the_reference_does(engine, oracle):
     """0/0 at the input of a Filter every 480 samples (some instances only): the recurrence reads `this.y1 || 0` (Filter.js:42-46), so it
