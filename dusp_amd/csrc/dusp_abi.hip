@@ -379,11 +379,13 @@ static int finish_build(dusp_program *prog) {
         else if (engine == DUSP_ENGINE_AUTO)
             engine = wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
     }
-    // The feedback-voice shape with a write-once delay line has two kernels: the two-stage loop kernel and, since the circuit
-    // compiler knows all its units, a kernel compiled for the circuit — 17.7 against 20.2 ms on BASELINE configs[3].
+    // The feedback-voice shape with a CONSTANT delay has the loop kernels and, since the circuit compiler knows all its units, a
+    // kernel compiled for the circuit: 12.3 against 20.2 ms (two-stage loop kernel) on BASELINE configs[3]; with a delay of less than
+    // a chunk (a plucked-string voice) 3.7 against 43.8 ms (one-stage loop kernel) for 8192 voices x 2 s.
     std::string jit_why;
-    const bool compiled_loop = loopable && prog->loop_two_stage && wavable && !prog->wave.ring_events && ctx->knobs.wave_jit != 0 &&
-                               ctx->knobs.loop_compiled != 0 && dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, jit_why);
+    const bool compiled_loop = loopable && wavable && (prog->loop_two_stage ? !prog->wave.ring_events : dusp::jit_delay_short(prog->loop.delay)) &&
+                               ctx->knobs.wave_jit != 0 && ctx->knobs.loop_compiled != 0 &&
+                               dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, jit_why);
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
                  : compiled_loop ? DUSP_ENGINE_WAVE

@@ -75,8 +75,8 @@ typedef enum {
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
- * AUTO picks FUSED, else WAVE for the feedback voice with a constant delay of at least a chunk (its compiled kernel beats
- * the two-stage LOOP kernel), else LOOP for the other feedback voices, else WAVE, else CHUNK.
+ * AUTO picks FUSED, else WAVE for the feedback voice with a constant delay (its compiled kernel beats the LOOP kernels), else
+ * LOOP for the other feedback voices (per-instance or modulated delays), else WAVE, else CHUNK.
  *
  * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
  * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose

@@ -38,7 +38,7 @@ ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": r
 # what AUTO must pick for a few cases (fused voice shapes / feed-forward wave engine / universal chunk engine)
 EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
                    "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
-                   "loop_220": "wave", "loop_110p5_short": "loop", "loop_frac_delay": "wave", "loop_220_sr44100": "wave",  # (write-once delay: a compiled kernel; else the loop engine)
+                   "loop_220": "wave", "loop_110p5_short": "wave", "loop_frac_delay": "wave", "loop_220_sr44100": "wave",  # (a constant delay: a compiled kernel; per-instance / modulated delays: the loop engine)
                    "delay_mod": "wave", "delay_2ch": "wave", "circlebuffer_taps": "wave", "circlebuffer_2ch": "wave", "circlebuffer_moving_tap": "wave", "circlebuffer_moving_writer": "wave", "circlebuffer_short_ring": "wave",
                    "rest_crossfader": "wave", "rest_rescale_2ch": "wave", "rest_vecmag": "wave", "rest_concat": "wave", "rest_pick": "wave",
                    "rest_timer_fm": "wave", "rest_srr_mod": "wave", "env_shape_mod": "wave", "env_ahd_mod": "wave", "fam_comb": "wave", "fam_allpass_loop": "wave", "fam_multiosc_fm": "wave", "fam_multiosc_negative": "wave", "fam_monodelay": "wave", "fam_readback": "wave",
