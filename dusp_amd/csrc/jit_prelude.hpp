@@ -591,6 +591,43 @@ struct JitAHD {
     template <bool ROW_A, bool ROW_H, bool ROW_D>
     __device__ __forceinline__ void tick(const JitCtx &X, float *scr, double period, const float (&att)[4], const float (&hold)[4], const float (&dec)[4],
                                          float (&out)[4]) {
+        // Constant times (the usual envelope): the whole chunk in closed form unless a stage ends inside it.  `t += c` rounds at
+        // every sample; repeat_add / linear_run take any number of those steps at once, bit for bit (repeat_add.hpp), and t only
+        // grows, so "t after 256 steps is still below 1" says that no sample of the chunk leaves the stage.
+        if (!ROW_A && !ROW_H && !ROW_D) {
+            bool closed = stage == 0 || !playing;
+            double c = 0.0, t_end = t;
+            if (!closed) {
+                c = period / (double)(stage == 1 ? att[0] : stage == 2 ? hold[0] : dec[0]);
+                if (c > 0.0 && c < 1.0e300 && t >= 0.0) {
+                    t_end = repeat_add(t, c, kChunk);
+                    closed = t_end < 1.0;
+                }
+            }
+            if (closed) {
+                double tk[4];
+                if (stage == 0 || !playing) tk[0] = tk[1] = tk[2] = tk[3] = t;
+                else {
+                    long long T, ce;
+                    int K;
+                    if (linear_run(t, c, kChunk, T, ce, K)) {
+                        long long Tl = T + (long long)(X.lane * 4) * ce;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i, Tl += ce) tk[i] = ldexp((double)Tl, K - 52);
+                    } else {
+                        double tt = repeat_add(t, c, (uint64_t)X.lane * 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i, tt = tt + c) tk[i] = tt;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[i] = stage == 1 ? (float)tk[i] : stage == 2 ? 1.f : stage == 3 ? (float)(1.0 - tk[i]) : 0.f;
+                t = jit_u(t_end);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) prev[i] = out[i];
+                return;
+            }
+        }
         float *Y = scr;
         jit_wave_sync();
         jit_row_put(Y, X.lane, prev);
