@@ -410,6 +410,10 @@ struct Emitter {
                         line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     }
                     break;
+                case OP_PAN:  // (a pan position that is not a signal: its pow() once, here)
+                    if (op.in[1].kind != SRC_BUF)
+                        line("    const double g" + id + " = map_pan_compensation(" + opnd(k, 1, "0", r) + ", " + (dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0")) + ");");
+                    break;
                 case OP_TIMER:
                     line("    JitTimer c" + id + ";");
                     line("    c" + id + ".begin(A, " + ctx(r) + ", d" + num(dconst_of[(size_t)k]) + ", " + num(op.state_slot) + ");");
@@ -854,6 +858,8 @@ struct Emitter {
                 if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) {  // stateless maps of at most two operands (map_ops.hpp)
                     const std::string y = operand_live(op, 1) ? opnd(k, 1, "c", r) : std::string("0.f");
                     each("map_apply(" + num(op.op) + ", " + opnd(k, 0, "c", r) + ", " + y + ", " + dref + ")");
+                } else if (op.op == OP_PAN && op.in[1].kind != SRC_BUF) {
+                    each("map_pan(" + opnd(k, 0, "c", r) + ", " + opnd(k, 1, "c", r) + ", " + num(op.attr) + ", g" + id + ")");
                 } else {  // Pan, MidiToFrequency, Rescale, CrossFader, VectorMagnitude
                     decl();
                     line("        for (int c = 0; c < 4; ++c) {");

@@ -38,13 +38,15 @@ __device__ __forceinline__ float map_apply(int op, float x, float y, double d0) 
 
 // Stateless maps with more operands or an output-channel attribute: Pan, MidiToFrequency, Rescale, CrossFader,
 // VectorMagnitude.  v[k] = operand k of this sample (unused operands are whatever the caller loaded).
+// Pan.js:19-29 in two steps: the centre compensation is a pow() of the pan position alone, so a kernel generated for a circuit
+// whose pan is not a signal takes it once per instance instead of once per sample and channel.
+__device__ __forceinline__ double map_pan_compensation(float pan, double d0) { return js_pow(10.0, ((1.0 - fabs((double)pan)) * d0) / 20.0); }
+__device__ __forceinline__ float map_pan(float in, float pan, int attr, double compensation) {
+    return (float)((double)in * (attr ? 1.0 + (double)pan : 1.0 - (double)pan) / 2.0 * compensation);
+}
 __device__ __forceinline__ float map_wide(int op, int attr, int n_in, const float (&v)[kMaxIn], double d0) {
     switch (op) {
-    case OP_PAN: {                                                             // Pan.js:19-29
-        const double in = (double)v[0], pan = (double)v[1];
-        const double compensation = js_pow(10.0, ((1.0 - fabs(pan)) * d0) / 20.0);
-        return (float)(in * (attr ? 1.0 + pan : 1.0 - pan) / 2.0 * compensation);
-    }
+    case OP_PAN: return map_pan(v[0], v[1], attr, map_pan_compensation(v[1], d0));  // Pan.js:19-29
     case OP_MIDI_TO_FREQUENCY: return (float)(js_pow(2.0, ((double)v[0] - 69.0) / 12.0) * 440.0);  // MidiToFrequency.js:20
     case OP_RESCALE:                                                           // Rescale.js:34-35
         return (float)(((double)v[0] - (double)v[1]) / ((double)v[2] - (double)v[1]) * ((double)v[4] - (double)v[3]) + (double)v[3]);
