@@ -642,7 +642,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
-        if (op.op == dusp::OP_OSC && opt.lds_table < 0 && ctx->knobs.jit_lds_table != 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
+        if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && ctx->knobs.jit_lds_table != 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
             !(ctx->table_form[op.attr] >= dusp::TABLE_FORM_SAW && ctx->table_form[op.attr] <= dusp::TABLE_FORM_TRIANGLE)) {
             opt.lds_table = ctx->table_form[op.attr] == dusp::TABLE_FORM_8BIT && ctx->table_antisym[0] ? 0 : op.attr;  // (the sine image serves 8bit too)
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
@@ -1367,7 +1367,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         if (P.g.sample_rate % 4 == 0) opt.table_form[3] = dusp::TABLE_FORM_TRIANGLE;
         opt.table_form[4] = dusp::TABLE_FORM_8BIT;
         for (const dusp::DevOp &op : P.ops)
-            if (op.op == dusp::OP_OSC && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
+            if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
                 opt.lds_table = 0;
                 opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
             }

@@ -824,7 +824,7 @@ struct Emitter {
             case OP_MULTI_OSC: {
                 decl();
                 const std::string f = opnd_array(k, 0, "t" + id, r);
-                line("        m" + id + ".tick(" + X_ + ", scr, " + table_row(op.attr) + ", " + f + ", " + v + ");");
+                line("        m" + id + ".tick<" + in_lds(op.attr) + ">(" + X_ + ", scr, " + table_row(op.attr) + ", " + f + ", " + v + ");");
                 break;
             }
             case OP_SHAPE: {

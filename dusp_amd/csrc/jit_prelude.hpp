@@ -717,6 +717,7 @@ struct JitSRR {
 struct JitMultiOsc {
     double phase;  // uniform
     __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { phase = jit_u(A.init_state[state_slot]); }
+    template <int TF, int FORM>  // where the table comes from on the exact path (jit_pair)
     __device__ __forceinline__ void tick(const JitCtx &X, float *scr, const float *gtab, const float (&f)[4], float (&out)[4]) {
         double ph0 = phase;
         ph0 = (ph0 != ph0 || ph0 == 0.0) ? 0.0 : ph0;  // `this.phase[c] = this.phase[c] || 0`
@@ -744,7 +745,9 @@ struct JitMultiOsc {
                 }
                 const uint32_t idx = (uint32_t)(P >> kJFrac);
                 const double fraction = (double)(P & kJMask) * (1.0 / kJ36);
-                out[c] = (float)((double)gtab[idx] * (1.0 - fraction) + (double)gtab[fraction != 0.0 ? idx + 1 : idx] * fraction);
+                float ta, tb;
+                jit_pair<TF, FORM>(X, gtab, idx, ta, tb);  // (idx < sampleRate: the entry after it exists; times a zero fraction it adds +0 like T[idx] would)
+                out[c] = (float)((double)ta * (1.0 - fraction) + (double)tb * fraction);
             }
             const unsigned long long lastP = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(P >> 32), 63) << 32) |
                                              (uint32_t)__builtin_amdgcn_readlane((uint32_t)P, 63);
