@@ -190,6 +190,8 @@ struct Emitter {
     std::string s;
     // The overlapped form of a Filter circuit's chunk (plan_overlap): which units go where, and what unit() is emitting right now
     std::vector<char> grp_early, grp_side, grp_post, split_delay;
+    std::vector<char> chained;     // a Filter stage whose input hangs on another stage (a 4-pole filter): fed in place, behind that stage
+    std::vector<char> in_chain;    // post units on the way from one stage to the next: emitted between the two
     bool any_side = false;         // plan_overlap: there are side units
     int phase = 0;                 // diagnostic build: the next barrier-to-barrier stamp of the chunk body
     bool in_early = false;         // unit(): emitting the block that works a chunk ahead
@@ -264,6 +266,7 @@ struct Emitter {
     bool plan_overlap(const std::vector<char> &used) {
         const size_t n = P.ops.size();
         grp_early.assign(n, 0); grp_side.assign(n, 0); grp_post.assign(n, 0); split_delay.assign(n, 0);
+        chained.assign(n, 0); in_chain.assign(n, 0);
         std::vector<int> filters;
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int k = plan.order[at];
@@ -286,10 +289,27 @@ struct Emitter {
                 const int pr = same_chunk_producer(k, j);
                 if (pr >= 0 && (is_filter_stage(pr) || grp_post[(size_t)pr])) grp_post[(size_t)k] = 1;
             }
-            if (grp_post[(size_t)k] && is_filter_stage(k)) return false;
+            if (grp_post[(size_t)k] && is_filter_stage(k)) chained[(size_t)k] = 1;
         }
         std::vector<int> stack;
+        for (int f : filters) {  // a chained stage's input may pass through post units only (they are emitted right in front of it)
+            if (!chained[(size_t)f]) continue;
+            const int first = same_chunk_producer(f, 0);
+            if (first >= 0) stack.push_back(first);
+            while (!stack.empty()) {
+                const int k = stack.back();
+                stack.pop_back();
+                if (is_filter_stage(k) || in_chain[(size_t)k]) continue;
+                if (!grp_post[(size_t)k]) return false;
+                in_chain[(size_t)k] = 1;
+                for (int j = 0; j < kMaxIn; j++) {
+                    const int pr = same_chunk_producer(k, j);
+                    if (pr >= 0) stack.push_back(pr);
+                }
+            }
+        }
         for (int f : filters) {
+            if (chained[(size_t)f]) continue;
             const int pr = same_chunk_producer(f, 0);
             if (pr >= 0) stack.push_back(pr);
         }
@@ -544,7 +564,7 @@ struct Emitter {
     bool plan_rotate(const std::vector<char> &used) {
         dbl.assign((size_t)std::max(1, P.n_bufs), 0);
         for (size_t k = 0; k < P.ops.size(); k++) {
-            if (used[k] && is_filter_stage((int)k) && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx)) return false;
+            if (used[k] && is_filter_stage((int)k) && !chained[k] && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx)) return false;
             if (!used[k] || !grp_early[k]) continue;
             const DevOp &op = P.ops[k];
             if (!split_delay[k])
@@ -602,7 +622,7 @@ struct Emitter {
         if (rotate)  // what is computed a chunk ahead: the feed-forward halves, and the early units' outlets that others read too
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
-                if (used[(size_t)k] && is_filter_stage(k))
+                if (used[(size_t)k] && is_filter_stage(k) && !chained[(size_t)k])
                     for (int r = 0; r < R; r++) line("    double qn" + num(k) + "_" + num(r) + "[4];");
                 if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
@@ -639,7 +659,8 @@ struct Emitter {
             }
             delay_half = 0;
             for (size_t at = 0; at < plan.order.size(); at++)
-                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) filter_feed(plan.order[at], rotate ? "qn" : "q", !rotate);
+                if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]) && !chained[(size_t)plan.order[at]])
+                    filter_feed(plan.order[at], rotate ? "qn" : "q", !rotate);
             in_early = false;
             if (rotate) {
                 line("        };");
@@ -653,7 +674,7 @@ struct Emitter {
                         }
                 }
                 for (size_t at = 0; at < plan.order.size(); at++)
-                    if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]))
+                    if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]) && !chained[(size_t)plan.order[at]])
                         for (int r = 0; r < R; r++) {
                             const std::string id = num(plan.order[at]) + "_" + num(r);
                             line("        double q" + id + "[4];");
@@ -666,13 +687,25 @@ struct Emitter {
             // window per chunk: wave 0 serves, the others work beside it, wave 0 catches up after.)
             const bool turns = opt.waves >= 2 && windows >= 2;
             const std::string work = " side0();" + std::string(rotate ? " if (g + 1 < X[0].g_end) early(g + 1);" : "");
+            // Which window a wave works in (turns): never one it serves, and — wavefront i of a workgroup sits on SIMD i mod 4 — as
+            // few as possible on the SIMD of the window's serving wave (it leaves a quarter of the issue slots) and no more than
+            // two on any other: waves of SIMD 0 in odd windows, of SIMD 1 in even ones, the rest dealt round.
+            std::vector<unsigned> workers((size_t)std::max(1, windows), 0u);
+            for (int i = 0; turns && i < opt.waves; i++) {
+                const int simd = i & 3, group = i >> 2, half = std::max(1, windows / 2);
+                const int w = simd == 0 ? (2 * (group % half) + 1) % windows : simd == 1 ? 2 * (group % half) : (group + simd) % windows;
+                workers[(size_t)w] |= 1u << i;
+            }
             int window = 0;
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
-                if (!used[(size_t)k] || !is_filter_stage(k)) continue;
+                if (!used[(size_t)k]) continue;
+                if (in_chain[(size_t)k]) unit(k, render, pass_level, fx);  // (on the way from one stage to the next)
+                if (!is_filter_stage(k)) continue;
+                if (chained[(size_t)k]) filter_feed(k);
                 for (int sb = 0; sb < subs; sb++, window++) {
                     std::string beside;
-                    if (turns) beside = "if ((X[0].wave + 1) % " + num(windows) + " == " + num(window) + ") {" + work + " }";
+                    if (turns && workers[(size_t)window]) beside = "if ((" + num((long long)workers[(size_t)window]) + "u >> X[0].wave) & 1u) {" + work + " }";
                     else if (window == 0 && opt.waves >= 2) beside = "if (X[0].wave != 0) {" + work + " }";
                     filter_sub_block(k, sb, beside.empty() ? beside : beside + "  // (beside the recurrences)", turns ? (window & 1) : 0);
                 }
@@ -680,7 +713,7 @@ struct Emitter {
             if (!turns) line("        if (X[0].wave == 0) {" + work + " }  // (wave 0's own instances)");
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
-                if (used[(size_t)k] && grp_post[(size_t)k]) unit(k, render, pass_level, fx);
+                if (used[(size_t)k] && grp_post[(size_t)k] && !in_chain[(size_t)k] && !is_filter_stage(k)) unit(k, render, pass_level, fx);
             }
             predeclared = false;
         } else

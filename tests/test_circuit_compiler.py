@@ -113,16 +113,22 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
     assert early.count(".read(") == 2 and early.count("f4.feed(") == 2 and ".write(" not in early     # ring reads and feed-forward halves, a chunk ahead
     assert "if (g == X[0].g_begin) early(g);" in fast and fast.count("if (g + 1 < X[0].g_end) early(g + 1);") == 2
     assert "f4.serial<8>(X[0], tile, 0);" in fast and "f4.serial<8>(X[0], tile, 1);" in fast         # two sub-blocks, two serving waves
-    assert "if ((X[0].wave + 1) % 2 == 0) { side0();" in fast and "if ((X[0].wave + 1) % 2 == 1) { side0();" in fast
+    assert fast.count("u >> X[0].wave) & 1u) { side0();") == 2  # (each wave works in one window it does not serve)
     # a voice whose oscillator also reaches the output: it still runs ahead, into registers of its own that become the chunk's at its top
     dry = descriptor.unify([descriptor.extract((lambda o: d.Sum(d.Filter(o, 900), o))(d.Osc(200 + k))) for k in (0, 8)])
     fast = source(dry.words, waves=16, per_wave=2, compile=True).split("} else {")[0]
     early = fast.split("auto early = [&](uint32_t g)")[1].split("};")[0]
     assert early.count(", vn0_") == 4 and "v0_0" not in early.replace("vn0_0", "")                   # written and fed to the Filter as vn
     assert "for (int c = 0; c < 4; ++c) v0_0[c] = vn0_0[c];" in fast and "+ v0_0[c]" in fast                # ... and read by the sum as v
-    # Filters in series keep the plain form
-    text = source(descriptor.unify([descriptor.extract(d.Filter(d.Filter(d.Osc(200 + k), 900), 1200)) for k in (0, 8)]).words, waves=16, per_wave=2)
-    assert "auto early" not in text and "auto side0" not in text
+    # Filters in series (a 4-pole filter): the second stage is fed in place, behind the first one's last sub-block, with whatever stands
+    # between the two; the oscillator and the first stage's feed-forward half still run a chunk ahead, dealt over all four windows
+    fast = source(descriptor.unify([descriptor.extract(d.Filter(d.Multiply(d.Filter(d.Osc(200 + k), 900), 0.8), 1200)) for k in (0, 8)]).words,
+                  waves=16, per_wave=2, compile=True).split("} else {")[0]
+    early = fast.split("auto early = [&](uint32_t g)")[1].split("};")[0]
+    assert early.count("f1.feed(") == 2 and "f3.feed(" not in early
+    tail = fast.split("};")[-1]
+    assert tail.index("f1.serial<8>(X[0], tile, 1)") < tail.index("* k1") < tail.index("f3.feed(") < tail.index("f3.serial<8>(X[0], tile, 0)")
+    assert fast.count("u >> X[0].wave) & 1u) { side0();") == 4
 
 
 def test_constant_delays_need_no_slot_operations():

@@ -33,6 +33,13 @@ graphs = {
     "filter(osc, lfo)": lambda k: d.Filter(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(5), 800), 1000)),
     "delay(osc, 300.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 300.5, 2048),
     "delay(osc, 30.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 30.5, 2048),
+    "delay(osc, lfo)": lambda k: d.Delay(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(2), 40), 200), 1024),
+    "comb(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.CombFilter(0.004, 0.7)),
+    "osc * ahd": lambda k: d.Multiply(d.Osc(110 + k / 8), d.AHD(0.01, 0.1, 0.5).trigger()),
+    "pan(osc, 0.25)": lambda k: d.Pan(d.Osc(110 + k / 8), 0.25),
+    "multiosc(2 channels)": lambda k: d.MultiChannelOsc([220 + k / 8, 330]),
+    "srr(osc, 5)": lambda k: d.SampleRateRedux(d.Osc(110 + k / 8), 5),
+    "filter(filter(osc))": lambda k: d.Filter(d.Filter(d.Osc(110 + k / 8), 900), 1200),
 }
 only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
 for name, g in graphs.items():
