@@ -687,6 +687,31 @@ struct JitSRR {
         if (ROW_IN) jit_row_put(scr + kChunk, X.lane, in);
         if (ROW_AMT) jit_row_put(scr + 2 * kChunk, X.lane, amt);
         jit_wave_sync();
+        // A constant amount A: the counter runs 1, 2, .. and the input is taken whenever it exceeds A, i.e. every P = floor(A) + 1
+        // samples — every lane finds the sample its four outputs hold, nobody walks.  (A counter that is not a whole number, or
+        // a period beyond the integers f64 counts exactly, takes the walk below.)
+        if (!ROW_AMT) {
+            const double A = (double)amt[0], P = A >= 1.0 ? floor(A) + 1.0 : 1.0;
+            if (since >= 0.0 && since == floor(since) && since < 4.0e15 && (A != A || P < 4.0e15)) {
+                // first sample of the chunk that takes the input: the counter there is since + t + 1
+                const double first = A != A ? 1.0e9 : fmax(0.0, floor(A) - since);  // (`x > NaN` never holds)
+                const int t1 = first < (double)kChunk ? (int)first : kChunk, period = P < (double)kChunk ? (int)P : kChunk;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int t = (int)X.lane * 4 + c;
+                    const int src = t < t1 ? -1 : t1 + ((t - t1) / period) * period;
+                    out[c] = src < 0 ? held : (ROW_IN ? scr[kChunk + src] : in[0]);
+                }
+                if (t1 < kChunk) {
+                    const int last = t1 + ((kChunk - 1 - t1) / period) * period;
+                    held = jit_u(ROW_IN ? scr[kChunk + last] : in[0]);
+                    since = jit_u((double)(kChunk - 1 - last));
+                } else
+                    since = jit_u(since + (double)kChunk);
+                jit_wave_sync();  // (the next tick's rows may not overtake these reads)
+                return;
+            }
+        }
         if (X.lane == 0) {
             double sn = since;
             float hd = held;

@@ -124,6 +124,24 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     prog.close()
 
 
+def test_sample_rate_redux_periods(oracle):
+    """SampleRateRedux with a constant amount takes its input every floor(amount) + 1 samples (SampleRateRedux.js:24-35): the compiled
+    kernel finds each output's source sample in closed form.  Amounts below one, whole, fractional, around and beyond a chunk, per
+    instance; against the oracle bit for bit."""
+    d.configure(48000)
+    amounts = [0.0, 0.5, 1.0, 2.5, 5.0, 17.25, 255.0, 255.5, 256.0, 300.7, 1000.0, 47.0]
+    uni = descriptor.unify([descriptor.extract(d.SampleRateRedux(d.Osc(300 + 11 * i), a)) for i, a in enumerate(amounts)])
+    n = 256 * 14 + 33
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    prog._read_info()
+    assert "compiled kernel" in prog.shape
+    for i in range(uni.n_instances):
+        want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        assert np.array_equal(pcm[i], want), (amounts[i], i)
+    prog.close()
+
+
 @pytest.mark.parametrize("delay,ring", [(1, 512), (1.5, 700), (30.5, 2048), (64, 1000), (255, 512), (255.75, 513), (100.25, 4410), (30.5, 300)])
 def test_delays_shorter_than_a_chunk(delay, ring, oracle):
     """A constant delay of less than a chunk on the compiled kernel: what a sample reads is what two known input samples left in its
