@@ -98,13 +98,13 @@ inline bool jit_light(const Program &P) {
 }
 // A Delay with a constant delay of less than a chunk reads what two known input samples left in its slot: no ring (JitDelayShort)
 inline bool jit_delay_short(const DevOp &op) {
-    if (op.op != OP_DELAY || op.in[1].kind != SRC_CONST) return false;
-    const double d = (double)op.in[1].cval;
-    return d >= 1.0 && d < (double)kChunk && op.ring_len >= 2 * kChunk;  // (a ring of two chunks at least: a chunk's slots wrap once at most)
+    if ((op.op != OP_DELAY && op.op != OP_MONO_DELAY) || op.in[1].kind != SRC_CONST) return false;
+    const double d = (double)op.in[1].cval;  // (MonoDelay writes before it reads: a delay below one sample is a delay)
+    return d >= (op.op == OP_MONO_DELAY ? 0.0 : 1.0) && d < (double)(kChunk - 1) && op.ring_len >= 2 * kChunk;  // (a chunk's slots wrap once at most)
 }
 // units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
 inline bool jit_ring_ops(const DevOp &op) {
-    return (op.op == OP_DELAY && !delay_write_once(op) && !jit_delay_short(op)) || op.op == OP_MONO_DELAY || op.op == OP_READBACK_DELAY ||
+    return (op.op == OP_DELAY && !delay_write_once(op) && !jit_delay_short(op)) || (op.op == OP_MONO_DELAY && !jit_delay_short(op)) || op.op == OP_READBACK_DELAY ||
            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
 }
 
@@ -423,8 +423,8 @@ struct Emitter {
                         line("    JitRingOps q" + id + ";");
                         line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
                     } else if (jit_delay_short(op)) {
-                        line("    JitDelayShort z" + id + ";");
-                        line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
+                        line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
+                        line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     } else {
                         line("    JitDelayK y" + id + ";");
                         line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
@@ -871,7 +871,7 @@ struct Emitter {
                 line("        s" + id + ".tick(" + X_ + ", " + table_row(op.attr & 255) + ", " + num(op.attr) + ", " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", " + mn + ", " + mx + ", " + v + ");");
                 break;
             }
-            case OP_DELAY: {
+            case OP_DELAY: case OP_MONO_DELAY: {  // (a MonoDelay gets here with a constant delay below a chunk only: else the slot operations above)
                 decl();
                 if (jit_delay_short(op)) {
                     const std::string x = opnd_array(k, 0, "t" + id, r);

@@ -1472,13 +1472,16 @@ struct JitDelayK {
 // all: the wave keeps the chunk before this one in registers, lays both out in its scratch row and every lane picks the
 // two samples each of its four needs.  (The tap that would land on slot 0 by way of index `length` is dropped by the
 // reference's Float32Array: slot 0 gets no ceil tap.)  The ring in HBM stays untouched: nothing reads it after the render.
+// MONO: MonoDelay (MonoDelay.js:16-28) — taps first, then the read; the ceil tap wraps instead of being dropped; a delay of 0 reads
+// the sample's own floor tap; no state (fresh ring: the sample before the render left nothing).
+template <bool MONO>
 struct JitDelayShort {
     float carried;     // the input sample before the chunk (uniform; what the unit's state holds)
     float before[4];   // this lane's four samples of the chunk before
     double phi;        // the delay's fraction (uniform)
     uint32_t len, D, s0;
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_len, float delay) {
-        carried = jit_u((float)A.init_state[state_slot]);
+        carried = MONO ? 0.f : jit_u((float)A.init_state[state_slot]);
         const double dconst = (double)delay, Dfl = floor(dconst);
         phi = dconst - Dfl;
         D = (uint32_t)Dfl;
@@ -1503,7 +1506,7 @@ struct JitDelayShort {
             if (slot >= len) slot -= len;
             const double xin = (double)h[c + 1], xprev = (double)h[c];
             if (phi != 0.0) {
-                const float tap = slot != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of the sample before (dropped at slot 0)
+                const float tap = (MONO || slot != 0) ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of the sample before (Delay: dropped at slot 0)
                 out[c] = (float)((double)tap + xin * (1.0 - phi));               // floor tap
             } else {
                 const float tap = (float)(0.0 + xin * 1.0);  // floor(tWrite) == ceil(tWrite): both `+=` of one sample

@@ -124,6 +124,21 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("delay", [0, 0.25, 1, 30.5, 200, 254.5, 300.5])
+def test_mono_delay_constant_delays(delay, oracle):
+    """MonoDelay (taps first, then the read: a delay of 0 reads the sample's own tap; MonoDelay.js:16-28) with a constant delay: below a
+    chunk on the ring-less path of the compiled kernel, the last case on the ordered slot operations.  Bit for bit against the oracle."""
+    d.configure(48000)
+    uni = descriptor.unify([descriptor.extract(d.MonoDelay(d.Multiply(d.Osc(300 + 7 * k), 0.5 + k / 64), delay)) for k in range(0, 24)])
+    n = 256 * 9 + 77
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    for i in range(0, uni.n_instances, 3):
+        want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        assert np.array_equal(pcm[i], want), (delay, i)
+    prog.close()
+
+
 def test_sample_rate_redux_periods(oracle):
     """SampleRateRedux with a constant amount takes its input every floor(amount) + 1 samples (SampleRateRedux.js:24-35): the compiled
     kernel finds each output's source sample in closed form.  Amounts below one, whole, fractional, around and beyond a chunk, per
