@@ -102,9 +102,16 @@ inline bool jit_delay_short(const DevOp &op) {
     const double d = (double)op.in[1].cval;  // (MonoDelay writes before it reads: a delay below one sample is a delay)
     return d >= (op.op == OP_MONO_DELAY ? 0.0 : 1.0) && d < (double)(kChunk - 1) && op.ring_len >= 2 * kChunk;  // (a chunk's slots wrap once at most)
 }
+// A MonoDelay with a constant delay of a chunk at least: the write-once ring of the Delay (JitDelayK<true>)
+inline bool jit_mono_write_once(const DevOp &op) {
+    if (op.op != OP_MONO_DELAY || op.in[1].kind != SRC_CONST) return false;
+    const double d = (double)op.in[1].cval, len = (double)op.ring_len;
+    return d >= (double)kChunk && std::floor(d) + (double)kChunk <= len;
+}
 // units whose ring accesses can meet inside a chunk: ordered slot operations (the same rule as plan_wave's ring_events)
 inline bool jit_ring_ops(const DevOp &op) {
-    return (op.op == OP_DELAY && !delay_write_once(op) && !jit_delay_short(op)) || (op.op == OP_MONO_DELAY && !jit_delay_short(op)) || op.op == OP_READBACK_DELAY ||
+    return (op.op == OP_DELAY && !delay_write_once(op) && !jit_delay_short(op)) ||
+           (op.op == OP_MONO_DELAY && !jit_delay_short(op) && !jit_mono_write_once(op)) || op.op == OP_READBACK_DELAY ||
            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
 }
 
@@ -318,7 +325,7 @@ struct Emitter {
             stack.pop_back();
             if (grp_early[(size_t)k]) continue;
             grp_early[(size_t)k] = 1;
-            if (P.ops[(size_t)k].op == OP_DELAY && !jit_delay_short(P.ops[(size_t)k])) {  // (write-once: the slot-operation kind returned above)
+            if ((P.ops[(size_t)k].op == OP_DELAY || P.ops[(size_t)k].op == OP_MONO_DELAY) && !jit_delay_short(P.ops[(size_t)k])) {  // (write-once: the slot-operation kind returned above)
                 split_delay[(size_t)k] = 1;
                 continue;
             }
@@ -426,8 +433,8 @@ struct Emitter {
                         line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
                         line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     } else {
-                        line("    JitDelayK y" + id + ";");
-                        line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
+                        line(std::string("    JitDelayK<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> y" + id + ";");
+                        line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     }
                     break;
                 case OP_PAN:  // (a pan position that is not a signal: its pow() once, here)

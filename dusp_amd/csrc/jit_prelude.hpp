@@ -1377,6 +1377,8 @@ struct JitFilterM {
 // value (ceil tap of sample n-1, then floor tap of sample n, with the reference's two `+=` roundings) is written once.
 // Everything a chunk reads was written before the chunk began (D >= 256), so the NEXT chunk's reads are issued right after
 // this chunk's writes and have the rest of the chunk — the Filter stage, usually — to arrive.
+// MONO: MonoDelay — the same ring protocol (its taps and its read never meet inside a chunk either), no dropped ceil tap, no state.
+template <bool MONO>
 struct JitDelayK {
     float carried;        // the input sample before the chunk (uniform)
     double phi;           // the delay's fraction (uniform)
@@ -1400,7 +1402,7 @@ struct JitDelayK {
         }
     }
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_base, int64_t ring_len, float delay) {
-        carried = jit_u((float)A.init_state[state_slot]);  // (an f32 sample: nothing is lost)
+        carried = MONO ? 0.f : jit_u((float)A.init_state[state_slot]);  // (an f32 sample: nothing is lost)
         double dconst = (double)delay;
         if (dconst >= (double)ring_len) dconst = fmod(dconst, (double)ring_len);
         const double Dfl = floor(dconst);
@@ -1434,7 +1436,7 @@ struct JitDelayK {
                 lo += D;
                 if (lo >= len) lo -= len;
                 const double xin = (double)x[c], xprev = (double)(c == 0 ? x_left : x[c - 1]);
-                const float tap = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (dropped at slot 0)
+                const float tap = (MONO || lo != 0) ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of sample n-1 (Delay: dropped at slot 0)
                 slot[c] = (float)((double)tap + xin * (1.0 - phi));            // floor tap of sample n
             }
         } else {

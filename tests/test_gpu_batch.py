@@ -124,13 +124,14 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     prog.close()
 
 
-@pytest.mark.parametrize("delay", [0, 0.25, 1, 30.5, 200, 254.5, 300.5])
+@pytest.mark.parametrize("delay", [0, 0.25, 1, 30.5, 200, 254.5, 255.5, 256, 300.5, 4410])
 def test_mono_delay_constant_delays(delay, oracle):
     """MonoDelay (taps first, then the read: a delay of 0 reads the sample's own tap; MonoDelay.js:16-28) with a constant delay: below a
-    chunk on the ring-less path of the compiled kernel, the last case on the ordered slot operations.  Bit for bit against the oracle."""
+    chunk on the ring-less path of the compiled kernel, from a chunk on on the write-once ring, in between (255.5) on the ordered slot
+    operations.  Bit for bit against the oracle."""
     d.configure(48000)
     uni = descriptor.unify([descriptor.extract(d.MonoDelay(d.Multiply(d.Osc(300 + 7 * k), 0.5 + k / 64), delay)) for k in range(0, 24)])
-    n = 256 * 9 + 77
+    n = 256 * 24 + 77
     prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
     pcm = prog.render(n, uni.n_instances, uni.params)
     for i in range(0, uni.n_instances, 3):
