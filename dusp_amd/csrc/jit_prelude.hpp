@@ -1040,10 +1040,10 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 // inputs and the last two of the lane before it (one DPP shift each; in front of the chunk, the two inputs carried as
 // scalars).  The recurrence is a dependent chain of five f64 operations per sample whatever the lane count, so the WAVES x R
 // instances of a workgroup run theirs side by side on the lanes of ONE wave: in sub-blocks of SUB samples every wave parks
-// its instances' P values (f64, out of the registers feed() left them in) in a shared LDS tile, wave 0 runs lane = instance
+// its instances' P values (f64, out of the registers feed() left them in) in a shared LDS tile, ONE wave (`who`: the generated kernel lets waves 0 and 1 take turns) runs lane = instance
 // over the rows — nothing but the chain, y written as f32 over the P values already consumed — and every wave picks its rows
-// up again.  A Filter's coefficients and the two outputs before the chunk live in the registers of "its" lane of wave 0 for
-// the whole render.
+// up again.  A row's coefficients live in "its" lane of EVERY wave (a function of the lane's instance alone), the two outputs before
+// the sub-block in LDS behind the tile.
 //   tile: rows of SUB + 2 doubles, row = wave R + r; then one word that says "given back"; then y1 / y2 of every row, stage by stage.
 //   SUB = 256, 128 or 64 by what LDS holds next to the table image
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -1057,10 +1057,10 @@ struct JitFilterK {
     // The recurrence's memory y1 / y2 lives in the row's two spare doubles of the tile, so that any wave can run a sub-block's
     // recurrences (the generated kernel alternates between waves 0 and 1: each does its other work while the other one serves).
 #ifdef DUSP_JIT_PROFILE
-    unsigned long long cyc_serial = 0;      // diagnostic build: cycles wave 0 spent inside serial()
+    unsigned long long cyc_serial = 0;      // diagnostic build: cycles this wave spent inside serial()
 #endif
 
-    // fr: the cutoff of the instance THIS LANE serves in wave 0 (a constant, or that instance's parameter: jit_row_param)
+    // fr: the cutoff of the instance THIS LANE serves when its wave runs the recurrences (a constant, or that instance's parameter: jit_row_param)
     // y1 / y2 of row `row` of this stage
     __device__ __forceinline__ uint32_t memory_address(double *tile, uint32_t row) const {
         return row_address(tile, WAVES * R) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
@@ -1249,7 +1249,7 @@ struct JitFilterK {
         st[(size_t)10 * A.n_pad] = mem[1];
     }
 };
-// parameter `slot` of the instance lane `lane` of wave 0 serves in the Filter stage
+// parameter `slot` of the instance lane `lane` serves in the Filter stage
 template <int WAVES, int R>
 __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X, uint32_t slot) {
     const uint32_t inst = min(blockIdx.x * (WAVES * R) + X.lane, A.n_inst - 1);
