@@ -55,12 +55,34 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT loading the HIP runtime (no torch.cuda call, no HIP call): the KFD topology
+    lists every compute node (`simd_count` > 0 = a GPU, 0 = a CPU), narrowed by the *_VISIBLE_DEVICES lists a launcher may have set."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for name in os.listdir(nodes):
+            try:
+                with open(os.path.join(nodes, name, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue  # (a node this user may not read is not one it can use)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of a process that has not
-    initialised the GPU (importing torch and counting devices does not), wait, pass rank 0's line through."""
+    loaded the HIP runtime at all (devices are counted from the KFD topology in sysfs), wait, pass rank 0's line through."""
     import socket
-    import torch
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box" % (args.gpus, have))
     with socket.socket() as s:
@@ -167,6 +189,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gather:
+        # one rank: the same gather code runs (the root's own shard is a device copy, no peer), so that its timing and its
+        # report are exercised on a one-GPU box too
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     sr = args.sample_rate
     cfg5 = args.config == "cfg5"
@@ -231,7 +262,7 @@ def main():
         raise SystemExit("bench: rendered buffer is empty or non-finite")
 
     gather_info = None
-    if args.gather and world > 1 and not mixdown:
+    if args.gather and not mixdown:
         # the north star's "trivial RCCL gather of rendered PCM over xGMI": render + gather, tile-pipelined (tile k+1 renders
         # while round k is on the wire), timed on its own and never part of `value`
         tile = args.gather_tile or max(1, n_voices // 8)
@@ -258,10 +289,12 @@ def main():
             inbound = 4.0 * (n_total - n_voices) * prog.n_out_channels * n_samples
             ok = bool(torch.equal(full[lo:hi], d_out)) and bool(torch.isfinite(full[-1, 0, :4096]).all()) and float(full[-1].abs().max()) > 0
             gather_info = {"render_plus_gather_ms": round(gdt * 1e3, 3), "render_only_ms": round(float(np.mean(kernel_ms)), 4),
-                           "inbound_GBps": round(inbound / gdt / 1e9, 1), "per_link_GBps": round(inbound / gdt / 1e9 / (world - 1), 1),
+                           "inbound_GBps": round(inbound / gdt / 1e9, 1) if world > 1 else None,
+                           "per_link_GBps": round(inbound / gdt / 1e9 / (world - 1), 1) if world > 1 else None,
                            "link_peak_GBps": XGMI_LINK_GBS, "tile_voices": tile, "rounds": (n_voices + tile - 1) // tile,
                            "Msamples_per_s_with_gather": round(float(n_total) * n_samples / gdt / 1e6, 1), "checked": ok,
-                           "note": "%d peers -> rank 0, one receive per peer and round posted together; round k overlaps the render of tile k+1" % (world - 1)}
+                           "note": ("%d peers -> rank 0, one receive per peer and round posted together; round k overlaps the render of tile k+1" % (world - 1))
+                                   if world > 1 else "one rank: no peer, the root's own shard is a device copy per tile (the gather's code path, not a link measurement)"}
         del full
 
     # The write ceiling of THIS box, for scale: a fill kernel (16-byte coalesced stores and nothing else) over the same
@@ -294,8 +327,11 @@ def main():
                 traffic = rec.get("write_bytes_per_launch")
                 traffic_source = "profiles/%s: %s" % (name, rec.get("source", "rocprofv3 --pmc WRITE_SIZE, own pass on an earlier box; not measured in this run"))
                 break
-        what = ("%d voices/GPU x Multiply(Osc(10k), Ramp(T,1,0) triggered)" % n_voices if not cfg5 else
-                "%d voices in total x Multiply(Osc(20+k/8), Ramp(T,1,0) triggered)" % n_total)
+        if mixdown:  # (mixdown_program: bare constant-f oscillators through Sum.many — no envelope)
+            what = ("%d voices/GPU x Osc(10k)" % n_voices if not cfg5 else "%d voices in total x Osc(20+k/8)" % n_total)
+        else:
+            what = ("%d voices/GPU x Multiply(Osc(10k), Ramp(T,1,0) triggered)" % n_voices if not cfg5 else
+                    "%d voices in total x Multiply(Osc(20+k/8), Ramp(T,1,0) triggered)" % n_total)
         line = {
             "metric": "rendered Msamples/sec (whole node) + HBM GB/s fraction, 1024-voice 48kHz",
             "value": round(total_samples * args.steps / elapsed / 1e6, 1),
@@ -322,11 +358,14 @@ def main():
                                                           "what": "dusp_fill_device over the same buffer on this box, best of 3"}
         if world == 1 and args.cpu_seconds > 0 and not mixdown:
             line["cpu_baseline"] = cpu_baseline(words, params, n_samples, args.cpu_seconds)
-        if gather_info:
-            line["gather"] = gather_info
+        # (fixed schema: the gather's fields are always there; null where --gather was not asked for)
+        line["gather"] = gather_info or {"render_plus_gather_ms": None, "render_only_ms": None, "inbound_GBps": None, "per_link_GBps": None,
+                                          "link_peak_GBps": XGMI_LINK_GBS, "tile_voices": None, "rounds": None,
+                                          "Msamples_per_s_with_gather": None, "checked": None, "note": "not measured: run with --gather"}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

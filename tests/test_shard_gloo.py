@@ -3,6 +3,7 @@
 The GPU box runs the same host logic with backend 'nccl' (RCCL); here the renderer is the CPU oracle
 (test infrastructure) so that the gathered PCM can be checked against a single-process render.  The HIP
 renderer goes through the very same code at world_size 1 in test_sharded_render_on_the_gpu (-m gpu)."""
+import json
 import os
 import socket
 import subprocess
@@ -137,3 +138,30 @@ def test_sharded_render_on_the_gpu(oracle):
                            capture_output=True, text=True, timeout=300,
                            env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
         assert r.returncode != 0 and "only 1 GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_the_launcher_counts_gpus_without_the_hip_runtime():
+    """bench.py's device count reads the KFD topology from sysfs: no torch import, no HIP call in the parent of the ranks."""
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpus(); "
+            "assert 'torch' not in sys.modules, 'the launcher imported torch'; print(n)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout.strip()) >= 0
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0 and int(r.stdout.strip()) == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gather_runs_at_one_rank():
+    """`bench.py --gpus 1 --config cfg5 --gather`: the gather's timing and report code on a one-GPU box (self-copy, no peer);
+    and the sysfs device count agrees with what the HIP runtime sees."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "cfg5", "--voices", "4096", "--seconds", "0.25",
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--gather"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["gather"]["checked"] is True and line["gather"]["render_plus_gather_ms"] > 0 and line["gather"]["rounds"] == 8
+    assert line["n_gpus"] == 1 and line["config"]["voices_total"] == 4096
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.visible_gpus() == torch.cuda.device_count()
