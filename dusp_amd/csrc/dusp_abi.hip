@@ -8,6 +8,7 @@
 #include <exception>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <algorithm>
 #include <string>
@@ -58,7 +59,27 @@ struct dusp_ctx {
     // pinned host buffers handed out by dusp_host_alloc (in_use) or waiting for reuse
     struct HostBuf { void *p; size_t bytes; bool in_use; };
     std::vector<HostBuf> host_pool;
+    std::mutex host_pool_mutex;  // dusp_host_free may come from a finalizer thread (a garbage collector) while the owner allocates
+    // bumped by every dusp_table_upload: compiled kernels are generated against what the context knows about its tables
+    // (closed forms, antisymmetry, the LDS image's table), so a program's generated text is dropped when this has moved on
+    uint64_t table_generation = 0;
+    bool tables_guarded = false;
 };
+
+// DUSP_GUARD=1 (tests): every device allocation of the library carries guard bytes behind its end, filled with a pattern and
+// checked after each render — a kernel that writes past the end of a workspace (state, rings, parked chunks, staging PCM, the
+// tables) fails THAT render with a message instead of corrupting whatever the allocator placed next to it.
+static size_t g_guard_bytes = 0;
+constexpr unsigned char kGuardPattern = 0xA5;
+
+static bool guard_intact(const void *end_of_payload) {
+    unsigned char tail[4096];
+    const size_t n = std::min(g_guard_bytes, sizeof tail);
+    if (hipMemcpy(tail, end_of_payload, n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (size_t i = 0; i < n; i++)
+        if (tail[i] != kGuardPattern) return false;
+    return true;
+}
 
 template <class T>
 struct DevBuf {  // grow-only device allocation
@@ -69,10 +90,12 @@ struct DevBuf {  // grow-only device allocation
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T) + g_guard_bytes);
+        if (e == hipSuccess && g_guard_bytes) e = hipMemset((char *)p + n * sizeof(T), kGuardPattern, g_guard_bytes);
         if (e == hipSuccess) cap = n;
         return e;
     }
+    bool intact() const { return !p || !g_guard_bytes || guard_intact((const char *)p + cap * sizeof(T)); }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -123,6 +146,7 @@ struct dusp_program {
     std::string jit_why;
     std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, 8 x instances per wavefront + Filter block) -> kernel text (+ constants, scan list)
     bool jit_consts_uploaded = false;
+    uint64_t jit_table_generation = 0;  // ctx->table_generation the texts in jit_src were generated against
     int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
@@ -208,6 +232,10 @@ static dusp::Knobs read_knobs() {
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
+    if (const char *f = getenv("DUSP_JIT_FORCE")) {
+        int w = 0, r = 0;
+        if (std::sscanf(f, "%dx%d", &w, &r) == 2 && w >= 1 && w <= 16 && r >= 1 && r <= 4) k.jit_force_waves = w, k.jit_force_per_wave = r;
+    }
     return k;
 }
 
@@ -253,6 +281,9 @@ int dusp_ctx_create(int device, dusp_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cus = prop.multiProcessorCount;
     ctx->knobs = read_knobs();
+    if (const char *g = getenv("DUSP_GUARD"))  // (process-wide, set by the first context: allocations made before keep their size)
+        if (atoi(g) > 0 && !g_guard_bytes) g_guard_bytes = 4096;
+    dusp::jit_configure();  // (the code-object cache directory: read once per process)
     *out = ctx.release();
     return DUSP_OK;
     });
@@ -279,8 +310,10 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     if (!ctx->d_tables) {
         ctx->table_len = (uint32_t)n;
         ctx->table_stride = (uint32_t)((n + 1 + 3) & ~(size_t)3);  // >= n+1 entries (one pad for idx+1), 16-byte rows
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tables, sizeof(float) * dusp::kNumTables * ctx->table_stride));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tables, sizeof(float) * dusp::kNumTables * ctx->table_stride + g_guard_bytes));
         HIP_TRY(ctx, hipMemset(ctx->d_tables, 0, sizeof(float) * dusp::kNumTables * ctx->table_stride));
+        if (g_guard_bytes) HIP_TRY(ctx, hipMemset((char *)ctx->d_tables + sizeof(float) * dusp::kNumTables * ctx->table_stride, kGuardPattern, g_guard_bytes));
+        ctx->tables_guarded = g_guard_bytes != 0;
     } else if (n != ctx->table_len) {
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_table_upload: all tables of a context must have the same length");
     }
@@ -300,6 +333,7 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     for (size_t t = 0; big && t < n; t++) big = table[t] == 0.f || std::fabs(table[t]) >= 9.5367431640625e-07f;
     ctx->table_fx32_ok[table_id] = big;
     ctx->table_set[table_id] = true;
+    ctx->table_generation++;
     // closed forms (device_util.hpp): every entry has to match, sign of zero included
     auto same_bits = [](float a, float b) { return std::memcmp(&a, &b, sizeof a) == 0; };
     const uint32_t sr = (uint32_t)n - 1;
@@ -605,6 +639,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
     if (prog->keep_memory) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: internal error: a continued program with device memory on the compiled path");
+    if (prog->jit_table_generation != ctx->table_generation) {  // a table was uploaded since: forms / the LDS image may have changed
+        prog->jit_src.clear();
+        prog->jit_consts_uploaded = false;
+        prog->jit_table_generation = ctx->table_generation;
+    }
 
     dusp::JitArgs a{};
     a.params = d_params;
@@ -626,7 +665,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // Few instances, long render: cut time into segments so that the whole chip works on it
     a.n_seg = 1;
     a.seg_groups = n_chunks;
-    if (prog->wave.splittable) {
+    if (prog->wave.splittable && !ctx->knobs.jit_force_waves) {
         const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
         uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
         if (ctx->knobs.wave_segments >= 0) n_seg = (uint64_t)ctx->knobs.wave_segments;
@@ -689,6 +728,15 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                 }
     }
 
+    if (ctx->knobs.jit_force_waves) {  // tests: this geometry, whatever the batch
+        waves = std::min(most, ctx->knobs.jit_force_waves);
+        per_wave = ctx->knobs.jit_force_per_wave;
+        if (filter_stage) {
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
+            if (!opt.filter_sub) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: DUSP_JIT_FORCE: the Filter stage's rows do not fit LDS at this geometry");
+        }
+    }
+
     hipFunction_t render = nullptr;
     dusp::JitSource *src = nullptr;
     int jit_scratch = 0;
@@ -720,7 +768,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
         jit_scratch = scratch;
-        if (scratch <= ctx->knobs.jit_spill_bytes) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
+        if (scratch <= ctx->knobs.jit_spill_bytes || ctx->knobs.jit_force_waves) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
         if (filter_stage && opt.filter_block == 8) {
@@ -819,9 +867,38 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
 static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
                                    float *d_out, void *stream_);
 
+// DUSP_GUARD=1: wait for the render and look at the guard bytes behind every workspace it could have touched
+static int check_guards(dusp_program *prog, hipStream_t stream) {
+    dusp_ctx *ctx = prog->ctx;
+    if (!g_guard_bytes) return DUSP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    const char *hit = nullptr;
+    if (!prog->d_scratch.intact()) hit = "chunk buffers";
+    else if (!prog->d_rings.intact()) hit = "rings";
+    else if (!prog->d_state.intact()) hit = "unit state";
+    else if (!prog->d_seg.intact()) hit = "segment phases";
+    else if (!prog->d_fused_state.intact()) hit = "fused end state";
+    else if (!prog->d_recs.intact()) hit = "voice records";
+    else if (!prog->d_sum_voices.intact()) hit = "sum-chain records";
+    else if (!prog->d_saved_bufs.intact()) hit = "parked chunks";
+    else if (!prog->d_rings_wave.intact()) hit = "parked rings";
+    else if (!prog->d_host_out.intact()) hit = "staging PCM";
+    else if (!prog->d_host_frames.intact()) hit = "staging frames";
+    else if (!prog->d_host_par.intact()) hit = "staging parameters";
+    else if (!prog->d_host_in.intact()) hit = "staging inputs";
+    else if (!prog->d_ops.intact() || !prog->d_out_bufs.intact() || !prog->d_init.intact()) hit = "program constants";
+    else if (!prog->d_jit_fk.intact() || !prog->d_jit_dk.intact() || !prog->d_jit_scan.intact()) hit = "compiled kernel's constants";
+    else if (ctx->tables_guarded && ctx->d_tables && !guard_intact((const char *)ctx->d_tables + sizeof(float) * dusp::kNumTables * ctx->table_stride)) hit = "lookup tables";
+    if (hit) CTX_FAIL(ctx, DUSP_ERR_HIP, std::string("render: a kernel wrote past the end of a device buffer (") + hit + "): guard bytes overwritten");
+    return DUSP_OK;
+}
+
 static int render_device(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
                          float *d_out, void *stream_) {
-    return guarded(prog->ctx->err, "render", [&]() -> int { return render_device_unguarded(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_); });
+    return guarded(prog->ctx->err, "render", [&]() -> int {
+        if (int rc = render_device_unguarded(prog, n_instances, n_samples, d_params, d_inputs, d_out, stream_)) return rc;
+        return check_guards(prog, stream_ ? (hipStream_t)stream_ : prog->ctx->stream);
+    });
 }
 
 static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
@@ -1182,6 +1259,7 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
         HIP_TRY(ctx, hipMemcpyAsync(d_in, h_inputs, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     if (int rc = render_device_unguarded(prog, n_instances, n_samples, d_par, d_in, d_out, ctx->stream)) return rc;
+    if (int rc = check_guards(prog, ctx->stream)) return rc;
     const size_t n_ch = prog->P.out_bufs.size();
     if (interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
         HIP_TRY(ctx, prog->d_host_frames.ensure(n_out));
@@ -1206,6 +1284,7 @@ int dusp_host_alloc(dusp_ctx *ctx, size_t n_bytes, void **out) {
     *out = nullptr;
     if (n_bytes < 1 || n_bytes > ((size_t)1 << 40)) CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_host_alloc: size out of range");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> pool_lock(ctx->host_pool_mutex);
     // smallest free buffer that fits and is not wastefully large; pinning fresh pages is the slow part, so buffers are kept
     dusp_ctx::HostBuf *best = nullptr;
     for (auto &b : ctx->host_pool)
@@ -1235,11 +1314,14 @@ int dusp_host_alloc(dusp_ctx *ctx, size_t n_bytes, void **out) {
 int dusp_host_free(dusp_ctx *ctx, void *p) {
     if (!ctx) return DUSP_ERR_ARG;
     if (!p) return DUSP_OK;
-    for (auto &b : ctx->host_pool)
-        if (b.p == p && b.in_use) {
-            b.in_use = false;  // stays pinned for the next render of that size (dusp_ctx_destroy releases the pool)
-            return DUSP_OK;
-        }
+    {
+        std::lock_guard<std::mutex> pool_lock(ctx->host_pool_mutex);  // (nothing else of the context is touched on this path: a finalizer thread may call it)
+        for (auto &b : ctx->host_pool)
+            if (b.p == p && b.in_use) {
+                b.in_use = false;  // stays pinned for the next render of that size (dusp_ctx_destroy releases the pool)
+                return DUSP_OK;
+            }
+    }
     CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_host_free: not a live buffer of this context");
 }
 
@@ -1397,6 +1479,8 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     return (int)std::min<size_t>(src.text.size(), 0x7fffffff);
     });
 }
+
+const char *dusp_jit_cache_dir(void) { return dusp::jit_cache_directory(); }
 
 int dusp_fill_device(dusp_ctx *ctx, float *d_out, size_t n_floats, float value, void *stream_) {
     if (!ctx) return DUSP_ERR_ARG;

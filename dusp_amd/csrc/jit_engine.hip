@@ -5,17 +5,29 @@
 // Caches.  Code objects are kept process-wide, keyed by the generated text (constants are not part of it, jit_codegen.hpp);
 // modules are loaded per device (a hipModule_t belongs to the device it was loaded on).  A render that finds its kernel
 // costs a map lookup; a new structure costs one hiprtc compile (0.3-0.8 s) — in the foreground when the render is worth
-// waiting for, else in a background thread while the interpreter kernel renders this once (dusp_abi.hip decides).
-// DUSP_JIT_CACHE=<directory> additionally keeps code objects on disk across processes (off unless set).
+// waiting for, else on the compile worker while the interpreter kernel renders this once (dusp_abi.hip decides).
+// Code objects are also kept ON DISK across processes, by default under $XDG_CACHE_HOME/dusp-hip (~/.cache/dusp-hip);
+// DUSP_JIT_CACHE=<directory> moves the cache, DUSP_JIT_CACHE=0 turns it off (read once per process, with the first
+// context).  A cache file is keyed by everything the code object depends on — the text, the embedded device library's
+// text, the compile options, the target and the hiprtc version — and carries its length and a hash of its payload: a
+// truncated or damaged file is deleted and the kernel compiled again.
 //
-// No fallback hides a failure here: if hiprtc or the module load fails the render call fails with the compiler's log.
+// One compile at a time per text: whoever needs a text that somebody is compiling waits for that compile (foreground) or
+// leaves it to the worker (background).  Compiles run OUTSIDE the lock, so lookups of finished kernels never wait for one.
+//
+// No fallback hides a failure here: if hiprtc or the module load fails the render call fails with the compiler's log — a
+// failed background compile is remembered with its log and fails the next render of that structure.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <set>
@@ -35,51 +47,107 @@ namespace dusp {
 namespace {
 
 std::mutex g_mutex;
+std::condition_variable g_cv;                     // a compile has finished (either outcome), or the worker has work / must leave
 std::map<std::string, std::vector<char>> g_code;  // generated text -> code object
-std::set<std::string> g_compiling;                // texts a background thread is compiling right now
-std::vector<std::thread> g_threads;
-std::atomic<bool> g_exit_hook{false};
+std::map<std::string, std::string> g_failed;      // generated text -> the compiler's log of a compile that failed
+std::set<std::string> g_compiling;                // texts somebody is compiling right now (worker or a foreground caller)
+std::deque<std::string> g_queue;                  // texts waiting for the worker
+std::thread g_worker;
+bool g_worker_started = false, g_leaving = false;
+std::string g_cache_dir;                          // "" = no disk cache
+std::once_flag g_configured;
+
+// the numerics contract of every kernel in this library: no contraction, no fast-math, correctly rounded division
+const char *const kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                                       "-fhip-fp32-correctly-rounded-divide-sqrt"};
+constexpr int kNumCompileOptions = (int)(sizeof kCompileOptions / sizeof kCompileOptions[0]);
 
 uint64_t fnv1a(const char *p, size_t n, uint64_t h = 1469598103934665603ull) {
     for (size_t i = 0; i < n; i++) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
     return h;
 }
-// file of the disk cache for a text: the key covers the device library's text too (a rebuilt library invalidates the cache)
-std::string disk_path(const std::string &text) {
-    const char *dir = getenv("DUSP_JIT_CACHE");
-    if (!dir || !*dir) return std::string();
+
+bool make_dirs(const std::string &path) {
+    for (size_t i = 1; i <= path.size(); i++)
+        if (i == path.size() || path[i] == '/') {
+            const std::string part = path.substr(0, i);
+            if (::mkdir(part.c_str(), 0700) != 0 && errno != EEXIST) return false;
+        }
+    struct stat st;
+    return ::stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+// Where code objects are kept across processes.  Read ONCE (std::call_once from jit_configure / first use).
+void configure_once() {
+    const char *e = getenv("DUSP_JIT_CACHE");
+    std::string dir;
+    if (e && *e) {
+        if (!std::strcmp(e, "0") || !std::strcmp(e, "off")) return;
+        dir = e;
+    } else {
+        const char *xdg = getenv("XDG_CACHE_HOME"), *home = getenv("HOME");
+        if (xdg && *xdg) dir = std::string(xdg) + "/dusp-hip";
+        else if (home && *home) dir = std::string(home) + "/.cache/dusp-hip";
+        else return;
+    }
+    if (make_dirs(dir)) g_cache_dir = dir;  // (a directory that cannot be made: no disk cache, nothing fails)
+}
+
+// key of the disk cache: everything a code object depends on
+uint64_t cache_key(const std::string &text) {
     uint64_t h = fnv1a(text.data(), text.size());
     for (const char *src : {dusp_src_device_types, dusp_src_device_util, dusp_src_map_ops, dusp_src_repeat_add, dusp_src_jit_args, dusp_src_jit_prelude})
-        h = fnv1a(src, std::strlen(src), h);
-    char name[64];
-    std::snprintf(name, sizeof name, "/dusp_%016llx_%zu.hsaco", (unsigned long long)h, text.size());
-    return std::string(dir) + name;
+        h = fnv1a(src, std::strlen(src) + 1, h);
+    for (const char *o : kCompileOptions) h = fnv1a(o, std::strlen(o) + 1, h);
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    const int version[3] = {major, minor, HIP_VERSION_PATCH};
+    return fnv1a((const char *)version, sizeof version, h);
 }
+std::string disk_path(const std::string &text) {
+    if (g_cache_dir.empty()) return std::string();
+    char name[64];
+    std::snprintf(name, sizeof name, "/dusp_%016llx_%zu.hsaco", (unsigned long long)cache_key(text), text.size());
+    return g_cache_dir + name;
+}
+struct DiskHeader {
+    char magic[8];  // "DUSPHSA1"
+    uint64_t bytes, hash;
+};
 bool disk_load(const std::string &text, std::vector<char> &code) {
     const std::string path = disk_path(text);
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
-    std::fseek(f, 0, SEEK_END);
-    const long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    bool ok = n > 0 && n < (64 << 20);
+    DiskHeader h{};
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "DUSPHSA1", 8) && h.bytes > 0 && h.bytes < ((uint64_t)64 << 20);
     if (ok) {
-        code.resize((size_t)n);
-        ok = std::fread(code.data(), 1, (size_t)n, f) == (size_t)n;
+        code.resize((size_t)h.bytes);
+        ok = std::fread(code.data(), 1, code.size(), f) == code.size() && std::fgetc(f) == EOF && fnv1a(code.data(), code.size()) == h.hash;
     }
     std::fclose(f);
+    if (!ok) {  // truncated, damaged or from another format: gone, the kernel is compiled again
+        code.clear();
+        std::remove(path.c_str());
+    }
     return ok;
 }
 void disk_store(const std::string &text, const std::vector<char> &code) {
     const std::string path = disk_path(text);
     if (path.empty()) return;
-    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)fnv1a((const char *)&code, sizeof(void *)));
+    const std::string tmp = path + ".tmp" + std::to_string((long long)::getpid()) + "_" + std::to_string((unsigned long long)fnv1a((const char *)&code, sizeof(void *)));
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return;
-    const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-    std::fclose(f);
-    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+    DiskHeader h{};
+    std::memcpy(h.magic, "DUSPHSA1", 8);
+    h.bytes = code.size();
+    h.hash = fnv1a(code.data(), code.size());
+    const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+void disk_forget(const std::string &text) {
+    const std::string path = disk_path(text);
+    if (!path.empty()) std::remove(path.c_str());
 }
 
 struct Loaded {
@@ -98,9 +166,7 @@ bool compile_text(const std::string &text, std::vector<char> &code, std::string 
         err = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
         return false;
     }
-    // the numerics contract of every kernel in this library: no contraction, no fast-math, correctly rounded division
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt"};
-    r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    r = hiprtcCompileProgram(prog, kNumCompileOptions, const_cast<const char **>(kCompileOptions));
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -115,83 +181,170 @@ bool compile_text(const std::string &text, std::vector<char> &code, std::string 
     code.resize(n);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    if (n == 0) err = "hiprtc: empty code object";
     return n > 0;
+}
+// compile_text behind a firewall: nothing thrown in there (bad_alloc ...) may leave a thread of this library
+bool compile_guarded(const std::string &text, std::vector<char> &code, std::string &err) noexcept {
+    try {
+        return compile_text(text, code, err);
+    } catch (const std::exception &e) {
+        try { err = std::string("circuit compiler: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        try { err = "circuit compiler: unknown internal error"; } catch (...) {}
+    }
+    return false;
+}
+
+// The code object of `text`, whoever gets it first: memory, the disk cache, a compile by this thread, or a compile somebody
+// else is running (waited for).  Called with `lock` held; the compile itself runs with it released.  use_disk = false: skip
+// the disk cache (its file has just failed to load as a module).
+bool obtain_code(std::unique_lock<std::mutex> &lock, const std::string &text, bool use_disk, std::string &err) {
+    for (;;) {
+        if (g_code.count(text)) return true;
+        auto bad = g_failed.find(text);
+        if (bad != g_failed.end()) {
+            err = bad->second;
+            return false;
+        }
+        if (!g_compiling.count(text)) break;
+        g_cv.wait(lock);  // the worker (or another caller) is at it
+    }
+    g_compiling.insert(text);
+    for (auto q = g_queue.begin(); q != g_queue.end(); ++q)  // (the worker need not pick it up any more)
+        if (*q == text) { g_queue.erase(q); break; }
+    lock.unlock();
+    std::vector<char> code;
+    std::string log;
+    bool ok = false;
+    try {
+        ok = use_disk && disk_load(text, code);
+        if (!ok) {
+            ok = compile_guarded(text, code, log);
+            if (ok) disk_store(text, code);
+        }
+    } catch (...) {
+        ok = false;
+        if (log.empty()) log = "circuit compiler: out of memory";
+    }
+    lock.lock();
+    g_compiling.erase(text);
+    try {
+        if (ok) g_code.emplace(text, std::move(code));
+        else g_failed[text] = log;
+    } catch (...) {
+        ok = false;
+    }
+    g_cv.notify_all();
+    if (!ok) err = log;
+    return ok;
+}
+
+void worker_main() noexcept {
+    std::unique_lock<std::mutex> lock(g_mutex);
+    for (;;) {
+        while (g_queue.empty() && !g_leaving) g_cv.wait(lock);
+        if (g_leaving) return;
+        std::string text;
+        try {
+            text = g_queue.front();
+        } catch (...) {
+            g_queue.pop_front();
+            continue;
+        }
+        g_queue.pop_front();
+        if (g_code.count(text) || g_failed.count(text) || g_compiling.count(text)) continue;
+        std::string err;
+        try {
+            (void)obtain_code(lock, text, true, err);  // (a failure stays in g_failed: the next render of that structure reports it)
+        } catch (...) {
+            if (!lock.owns_lock()) lock.lock();
+            g_compiling.erase(text);
+            g_cv.notify_all();
+        }
+    }
 }
 
 }  // namespace
 
-// the code object of `text`: from memory, from the disk cache, or compiled now (g_mutex held by the caller)
-static bool code_for(const std::string &text, const std::vector<char> **out, std::string &err) {
-    auto it = g_code.find(text);
-    if (it == g_code.end()) {
-        std::vector<char> code;
-        if (!disk_load(text, code)) {
-            if (!compile_text(text, code, err)) return false;
-            disk_store(text, code);
-        }
-        it = g_code.emplace(text, std::move(code)).first;
-    }
-    *out = &it->second;
-    return true;
+void jit_configure() { std::call_once(g_configured, configure_once); }
+
+const char *jit_cache_directory() {
+    jit_configure();
+    return g_cache_dir.c_str();
 }
 
 bool jit_compile_only(const std::string &text, size_t *code_bytes, std::string &err) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    const std::vector<char> *code = nullptr;
-    if (!code_for(text, &code, err)) return false;
-    if (code_bytes) *code_bytes = code->size();
+    jit_configure();
+    std::unique_lock<std::mutex> lock(g_mutex);
+    if (!obtain_code(lock, text, true, err)) return false;
+    if (code_bytes) *code_bytes = g_code[text].size();
     return true;
 }
 
 bool jit_code_ready(const std::string &text) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (g_code.count(text)) return true;
+    jit_configure();
+    std::unique_lock<std::mutex> lock(g_mutex);
+    if (g_code.count(text) || g_failed.count(text)) return true;  // (a failed text is "ready" to fail the render with its log)
+    if (g_compiling.count(text)) return false;
+    lock.unlock();
     std::vector<char> code;
     if (!disk_load(text, code)) return false;
+    lock.lock();
     g_code.emplace(text, std::move(code));
     return true;
 }
 
 void jit_compile_in_background(const std::string &text) {
+    jit_configure();
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (g_code.count(text) || g_compiling.count(text) || g_threads.size() >= 256) return;
-    if (!g_exit_hook.exchange(true))  // the process does not leave while a compile is running in one of these threads
-        std::atexit([] {
-            std::vector<std::thread> threads;
+    if (g_code.count(text) || g_failed.count(text) || g_compiling.count(text)) return;
+    for (const std::string &q : g_queue)
+        if (q == text) return;
+    if (g_queue.size() >= 4096) g_queue.pop_front();  // (a bound that recovers: the oldest waiting structure is simply asked for again later)
+    g_queue.push_back(text);
+    if (!g_worker_started) {  // ONE worker: compiles are -O3 hiprtc runs of 0.3-0.8 s each, side by side they only slow each other
+        g_worker_started = true;
+        g_worker = std::thread(worker_main);
+        std::atexit([] {  // the process does not leave while the worker is inside a compile
             {
                 std::lock_guard<std::mutex> l(g_mutex);
-                threads.swap(g_threads);
+                g_leaving = true;
+                g_queue.clear();
             }
-            for (auto &t : threads)
-                if (t.joinable()) t.join();
+            g_cv.notify_all();
+            if (g_worker.joinable()) g_worker.join();
         });
-    g_compiling.insert(text);
-    g_threads.emplace_back([text] {
-        std::vector<char> code;
-        std::string err;
-        const bool ok = compile_text(text, code, err);  // (outside the lock: renders go on meanwhile)
-        std::lock_guard<std::mutex> l(g_mutex);
-        if (ok) {
-            disk_store(text, code);
-            g_code.emplace(text, std::move(code));
-        }
-        g_compiling.erase(text);  // (a failed compile is retried, and reported, by the next render that waits for it)
-    });
+    }
+    g_cv.notify_all();
 }
 
 bool jit_get_kernel(int device, const std::string &text, const std::string &name, hipFunction_t *fn, int *scratch_bytes, std::string &err) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    Loaded &L = g_loaded[{device, text}];
-    if (!L.module) {
-        const std::vector<char> *code = nullptr;
-        if (!code_for(text, &code, err)) return false;
-        hipError_t e = hipModuleLoadData(&L.module, code->data());
-        if (e != hipSuccess) {
-            L.module = nullptr;
+    jit_configure();
+    std::unique_lock<std::mutex> lock(g_mutex);
+    for (int attempt = 0;; attempt++) {
+        {
+            auto it = g_loaded.find({device, text});
+            if (it != g_loaded.end() && it->second.module) break;
+        }
+        if (!obtain_code(lock, text, attempt == 0, err)) return false;
+        hipModule_t module = nullptr;
+        const hipError_t e = hipModuleLoadData(&module, g_code[text].data());
+        if (e == hipSuccess) {
+            g_loaded[{device, text}].module = module;
+            break;
+        }
+        (void)hipGetLastError();
+        // A code object the device does not take: if it came from the disk cache it may be stale in a way the key does not see
+        // (or damaged in a way the hash cannot, i.e. written wrong): forget file and blob, compile once, then give up.
+        g_code.erase(text);
+        disk_forget(text);
+        if (attempt >= 1) {
             err = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
             return false;
         }
     }
+    Loaded &L = g_loaded[{device, text}];
     auto k = L.kernels.find(name);
     if (k == L.kernels.end()) {
         hipFunction_t f = nullptr;

@@ -8,10 +8,13 @@
 
 namespace dusp {
 
+// Reads DUSP_JIT_CACHE / XDG_CACHE_HOME once per process (called when a context is created) and makes the cache directory.
+void jit_configure();
+const char *jit_cache_directory();  // "" when there is no disk cache
 // Compile generated kernel text for gfx950 (no device needed: used by the CPU test of the generator too).  Cached by text.
 bool jit_compile_only(const std::string &text, size_t *code_bytes, std::string &err);
-// Is the code object of `text` at hand (memory, or the DUSP_JIT_CACHE directory)?  If not, a render may start its compile in
-// a background thread and use the interpreter kernel meanwhile.
+// Is the code object of `text` at hand (memory, or the disk cache) — or known to fail?  If not, a render may leave its compile
+// to the background worker and use the interpreter kernel meanwhile.
 bool jit_code_ready(const std::string &text);
 void jit_compile_in_background(const std::string &text);
 // The kernel `name` of that text, loaded on `device` (compiles / loads on first use).  scratch_bytes: private memory the

@@ -4,6 +4,7 @@ There is deliberately no CPU fallback here: if the HIP library is missing or no
 GPU is usable, every entry point raises.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -22,7 +23,7 @@ EXPORTS = [
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
     "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
-    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source",
+    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source", "dusp_jit_cache_dir",
 ]
 
 
@@ -82,23 +83,28 @@ def load():
     L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
     L.dusp_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.dusp_host_free.argtypes = [vp, vp]
+    L.dusp_jit_cache_dir.restype = ctypes.c_char_p
+    L.dusp_jit_cache_dir.argtypes = []
     L.dusp_circuit_kernel_source.argtypes = [vp, sz, ci, ci, ci, ci, ctypes.c_char_p, sz]
     _lib = L
     return L
 
 
 PINNED_MIN_BYTES = 1 << 20  # results of at least 1 MiB are delivered in pinned memory (dusp_host_alloc): one DMA, no staging
+# Page-locked memory is a machine-wide resource: results a caller keeps alive stay pinned, so beyond this many bytes in use per
+# context new results are ordinary (pageable) numpy arrays again (the staged download).  `render(..., pinned=False)` opts out per call.
+PINNED_MAX_LIVE_BYTES = 8 << 30
 
 
 class _PinnedBlock:
     """Owner of one dusp_host_alloc buffer: handed back to the context's pool when the last array over it goes."""
 
-    def __init__(self, ctx, ptr):
-        self.ctx, self.ptr = ctx, ptr
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
 
-    def __del__(self):
+    def __del__(self):  # (whatever thread the garbage collector runs on: _host_release takes the context's lock)
         try:
-            self.ctx._host_release(self.ptr)
+            self.ctx._host_release(self.ptr, self.nbytes)
         except Exception:
             pass
 
@@ -126,6 +132,8 @@ class Context:
             raise DuspHipError(rc, self._L.dusp_last_error(None).decode())
         self._h = h
         self._host_live = 0       # pinned result buffers some numpy array still looks at
+        self._host_live_bytes = 0
+        self._host_lock = threading.Lock()  # pool calls may come from a finalizer on another thread
         self._close_pending = False
         self.sample_rate = None
         if sample_rate is not None:
@@ -137,22 +145,28 @@ class Context:
         the array (and every view of it) has been collected."""
         n = int(np.prod(shape))
         if pinned is None:
-            pinned = n * 4 >= PINNED_MIN_BYTES
+            pinned = n * 4 >= PINNED_MIN_BYTES and self._host_live_bytes + n * 4 <= PINNED_MAX_LIVE_BYTES
         if not pinned or n == 0:
             return np.empty(shape, dtype=np.float32)
         p = ctypes.c_void_p()
-        self._check(self._L.dusp_host_alloc(self._h, n * 4, ctypes.byref(p)))
-        self._host_live += 1
+        with self._host_lock:
+            self._check(self._L.dusp_host_alloc(self._h, n * 4, ctypes.byref(p)))
+            self._host_live += 1
+            self._host_live_bytes += n * 4
         buf = (ctypes.c_float * n).from_address(p.value)
-        buf._dusp_owner = _PinnedBlock(self, p.value)
+        buf._dusp_owner = _PinnedBlock(self, p.value, n * 4)
         return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
-    def _host_release(self, ptr):
-        self._host_live -= 1
-        if self._h:
-            self._L.dusp_host_free(self._h, ptr)
-            if self._close_pending and self._host_live == 0:
-                self.close()
+    def _host_release(self, ptr, nbytes=0):
+        with self._host_lock:
+            self._host_live -= 1
+            self._host_live_bytes -= nbytes
+            close_now = False
+            if self._h:
+                self._L.dusp_host_free(self._h, ptr)
+                close_now = self._close_pending and self._host_live == 0
+        if close_now:
+            self.close()
 
     def _check(self, rc):
         if rc < 0:
@@ -217,6 +231,11 @@ class Program:
         self.engine = ENGINE_NAMES.get(info.engine, str(info.engine))
         self.shape = info.shape.decode()
         self.n_device_ops = info.n_device_ops
+
+    def read_shape(self):
+        """The program's shape string as of now (after a render it names the kernel that ran: "compiled kernel: ..." or not)."""
+        self._read_info()
+        return self.shape
 
     def continue_with(self, words):
         """dusp_program_continue: re-arm this rendered program from a later extraction of the same circuit

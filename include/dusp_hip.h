@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 4
+#define DUSP_ABI_VERSION 5
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -215,6 +215,13 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
  * Returns the length of the text, DUSP_ERR_UNSUPPORTED when the circuit stays on the interpreter (dusp_last_error(NULL) says
  * why), or another negative dusp_status. */
 int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, int per_wave, int lds_table, int compile, char *text, size_t cap);
+
+/* ABI v5.  Where compiled circuit kernels (code objects) are kept across processes: $DUSP_JIT_CACHE if set ("0" / "off": no
+ * disk cache), else $XDG_CACHE_HOME/dusp-hip, else $HOME/.cache/dusp-hip — read once per process.  Files are keyed by the
+ * kernel text, the device library's text, the compile options, the target and the hiprtc version, and carry their length and
+ * a hash of their payload; a damaged file is deleted and the kernel compiled again.  Returns "" when there is no disk cache.
+ * The string lives as long as the library. */
+const char *dusp_jit_cache_dir(void);
 
 /* Duration in milliseconds of the most recent render's kernel(s) on this
  * program, measured with HIP events on the launch stream (synchronises). */

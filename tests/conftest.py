@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # test that can runs on one; the product default lets a short first render run on the interpreter kernel while the circuit
 # compiles in the background (tests/test_gpu_batch.py::test_first_render_does_not_wait_for_the_compiler covers that).
 os.environ.setdefault("DUSP_WAVE_JIT", "2")
+os.environ.setdefault("DUSP_GUARD", "1")  # guard bytes behind every device workspace, checked after each render (dusp_abi.hip)
 
 
 def pytest_configure(config):

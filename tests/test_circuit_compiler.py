@@ -179,3 +179,53 @@ def test_saw_square_triangle_are_evaluated_not_looked_up():
     # without a context's verdict on the tables nothing is assumed: everything is gathered
     plain = source(descriptor.extract(mix).words, waves=4, lds_table=False)
     assert "tick<0, 0, true>" in plain and "tick<2," not in plain
+
+
+def _compile_in_a_fresh_process(cache, name="fm_sum"):
+    """One process: compile the kernel of a golden circuit, report seconds and the cache directory the library uses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys, time, json; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests');\n"
+            "from conftest import Golden; from dusp_amd import runtime; runtime.load()\n"
+            "t0 = time.perf_counter(); runtime.circuit_kernel_source(Golden(%r).desc, waves=4, compile=True)\n"
+            "print(json.dumps({'s': time.perf_counter() - t0, 'dir': runtime.load().dusp_jit_cache_dir().decode()}))" % (ROOT, ROOT, name))
+    env = dict(os.environ)
+    env.pop("XDG_CACHE_HOME", None)
+    if cache is not None:
+        env["DUSP_JIT_CACHE"] = cache
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_code_objects_are_cached_on_disk_and_a_damaged_file_is_compiled_again(tmp_path):
+    """The code-object cache (jit_engine.hip): a second PROCESS finds the kernel on disk instead of compiling; a truncated or
+    altered cache file is noticed (length + hash in its header), deleted and replaced by a fresh compile; "0" turns the cache off."""
+    import os
+    cache = str(tmp_path / "cache")
+    first = _compile_in_a_fresh_process(cache)
+    assert first["dir"] == cache
+    files = [f for f in os.listdir(cache) if f.endswith(".hsaco")]
+    assert len(files) == 1
+    path = os.path.join(cache, files[0])
+    good = open(path, "rb").read()
+    assert good[:8] == b"DUSPHSA1" and len(good) > 4096
+    again = _compile_in_a_fresh_process(cache)
+    assert again["s"] < 0.5 * first["s"], (first, again)  # (no hiprtc run: generate the text, read the file)
+    assert open(path, "rb").read() == good
+    # truncated
+    open(path, "wb").write(good[: len(good) // 2])
+    _compile_in_a_fresh_process(cache)
+    assert open(path, "rb").read() == good
+    # same length, one byte of the payload changed
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x40
+    open(path, "wb").write(bytes(bad))
+    _compile_in_a_fresh_process(cache)
+    assert open(path, "rb").read() == good
+    # off
+    off = _compile_in_a_fresh_process("0")
+    assert off["dir"] == ""

@@ -34,7 +34,14 @@ def check(name, got, ref, engine=None):
         assert np.array_equal(got, ref), "first mismatch at %d" % int(np.argmax(got != ref))
 
 
-ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "loop": runtime.ENGINE_LOOP}
+# "interp": the wave engine's interpreter kernel (DUSP_WAVE_JIT=0) — what renders a new structure's short first renders under the
+# default knob and whatever the circuit compiler refuses; "wave" (with the suite's DUSP_WAVE_JIT=2) is the compiled kernels
+ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "loop": runtime.ENGINE_LOOP,
+           "interp": runtime.ENGINE_WAVE}
+
+
+def engine_context(sample_rate, engine):
+    return knob_context(sample_rate, DUSP_WAVE_JIT=0) if engine == "interp" else render.context(sample_rate)
 # what AUTO must pick for a few cases (fused voice shapes / feed-forward wave engine / universal chunk engine)
 EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
                    "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
@@ -45,20 +52,22 @@ EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "
                    "filter_2ch": "wave", "filter_lp_mod": "wave", "filter_hp": "wave", "delay_default": "wave", "delay_wrap": "wave"}
 
 
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop", "interp"])
 @pytest.mark.parametrize("name", ALL_GOLDEN)
 def test_render_matches_reference_golden(name, engine, oracle):
     g = Golden(name)
-    ctx = render.context(g.sample_rate)
+    ctx = engine_context(g.sample_rate, engine)
     try:
         prog = ctx.build(g.desc, ENGINES[engine])
     except runtime.DuspHipError as e:
-        assert engine in ("wave", "loop") and e.status == -2, e  # shape-specific engines refuse other graphs
+        assert engine in ("wave", "loop", "interp") and e.status == -2, e  # shape-specific engines refuse other graphs
         pytest.skip("graph shape not handled by this engine")
     if engine == "auto" and name in EXPECTED_ENGINE:
         assert prog.engine == EXPECTED_ENGINE[name]
     assert prog.n_out_channels == g.n_channels
     pcm = prog.render(g.n_samples)[0]
+    if engine == "interp":
+        assert "compiled kernel" not in prog.read_shape()
     check(name, g.windowed(pcm), g.pcm, engine)            # vs the JS reference's own output
     check(name, pcm, oracle.render(g.desc, g.n_samples), engine)  # vs the oracle, full length
     prog.close()
@@ -67,12 +76,12 @@ def test_render_matches_reference_golden(name, engine, oracle):
 @pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum",
                                   "rest_timer_fm", "rest_srr_mod", "rest_srr_nan", "rest_srr", "rest_vecmag_2d",
                                   "env_shape_mod", "env_shape_edges", "env_ahd_mod", "env_ahd_zero_hold", "env_ahd"])
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop", "interp"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
     n = min(g.n_samples, 5000)
     try:
-        prog = render.context(g.sample_rate).build(g.desc, ENGINES[engine])
+        prog = engine_context(g.sample_rate, engine).build(g.desc, ENGINES[engine])
     except runtime.DuspHipError:
         pytest.skip("not a feed-forward graph")
     prog.render(n)
