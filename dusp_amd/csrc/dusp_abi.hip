@@ -151,6 +151,7 @@ struct dusp_program {
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
+    DevBuf<int64_t> d_jit_regime;  // per-instance delays: [slot, ring length, mono] per unit, then the verdicts (render_jit)
 
     dusp_program() = default;
     dusp_program(const dusp_program &) = delete;
@@ -160,6 +161,7 @@ struct dusp_program {
         for (DevBuf<float> *b : {&d_scratch, &d_rings, &d_host_out, &d_host_par, &d_host_frames, &d_host_in, &d_saved_bufs, &d_rings_wave, &d_jit_fk}) b->release();
         for (DevBuf<double> *b : {&d_init, &d_state, &d_fused_state, &d_jit_dk}) b->release();
         d_jit_scan.release();
+        d_jit_regime.release();
         d_ops.release();
         d_out_bufs.release();
         d_seg.release();
@@ -405,6 +407,8 @@ static int finish_build(dusp_program *prog) {
     // kept for the whole chain (ring layouts differ) — except that a wave program that stops being plannable migrates to
     // the chunk engine.
     prog->persistent = prog->P.ring_samples != 0 || !prog->P.feed_forward;
+    for (dusp::DevOp &op : prog->P.ops)  // continued programs keep their rings in the reference's own state (jit_codegen.hpp kDelayExactRing)
+        if (op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) op.pad = (prog->resumable && prog->persistent) ? dusp::kDelayExactRing : 0;
     if (prog->resumable && prog->persistent) {
         if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_WAVE)
             CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: a resumable program with delay lines / feedback runs on DUSP_ENGINE_WAVE or DUSP_ENGINE_CHUNK");
@@ -417,9 +421,13 @@ static int finish_build(dusp_program *prog) {
     // kernel compiled for the circuit: 12.3 against 20.2 ms (two-stage loop kernel) on BASELINE configs[3]; with a delay of less than
     // a chunk (a plucked-string voice) 3.7 against 43.8 ms (one-stage loop kernel) for 8192 voices x 2 s.
     std::string jit_why;
-    const bool compiled_loop = loopable && wavable && (prog->loop_two_stage ? !prog->wave.ring_events : dusp::jit_delay_short(prog->loop.delay)) &&
+    // (a per-instance delay: the compiled kernel decides by the parameter column when it renders — write-once ring, no ring, or slot
+    // operations, all of which beat the one-stage loop kernel's one lane per voice)
+    const bool compiled_loop = loopable && wavable &&
+                               (prog->loop_two_stage ? !prog->wave.ring_events
+                                                     : (dusp::jit_delay_short(prog->loop.delay) || prog->loop.delay.in[1].kind == dusp::SRC_PARAM)) &&
                                ctx->knobs.wave_jit != 0 && ctx->knobs.loop_compiled != 0 &&
-                               dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, jit_why);
+                               dusp::jit_eligible(prog->P, prog->wave, jit_why);
     if (engine == DUSP_ENGINE_AUTO)
         engine = fusable ? DUSP_ENGINE_FUSED
                  : compiled_loop ? DUSP_ENGINE_WAVE
@@ -431,7 +439,7 @@ static int finish_build(dusp_program *prog) {
     prog->jit_src.clear();
     prog->jit_consts_uploaded = false;
     prog->jit_ok = engine == DUSP_ENGINE_WAVE && ctx->knobs.wave_jit != 0 &&
-                   dusp::jit_eligible(prog->P, prog->wave, prog->resumable && prog->persistent, prog->jit_why);
+                   dusp::jit_eligible(prog->P, prog->wave, prog->jit_why);
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const dusp::Program &P = prog->P;
@@ -638,7 +646,46 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     const dusp::Program &P = prog->P;
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
-    if (prog->keep_memory) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: internal error: a continued program with device memory on the compiled path");
+    const bool persistent = prog->resumable && prog->persistent;
+    const bool resume = prog->keep_memory;
+    if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
+    // Per-instance (parameter) delays: the kernel a Delay gets depends on where its instances' values lie — all of at least a chunk
+    // (write-once ring), all below a chunk (no ring), or neither (ordered slot operations) — so the column is looked at first
+    // (one small launch + a few bytes back; only programs with such a unit pay it).  The verdict lives in the operand's spare word.
+    {
+        std::vector<int64_t> entries;
+        std::vector<size_t> which;
+        for (size_t k = 0; k < prog->P.ops.size(); k++) {
+            const dusp::DevOp &op = prog->P.ops[k];
+            if ((op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) && op.in[1].kind == dusp::SRC_PARAM) {
+                entries.insert(entries.end(), {(int64_t)op.in[1].idx, op.ring_len, (int64_t)(op.op == dusp::OP_MONO_DELAY)});
+                which.push_back(k);
+            }
+        }
+        if (!which.empty()) {
+            const size_t n = which.size();
+            HIP_TRY(ctx, prog->d_jit_regime.ensure(4 * n));  // [3 n] entries as int64, then n verdicts as int (in one int64 slot each)
+            int64_t *d_entries = prog->d_jit_regime.p;
+            int *d_bits = (int *)(prog->d_jit_regime.p + 3 * n);
+            HIP_TRY(ctx, hipMemcpyAsync(d_entries, entries.data(), 3 * n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, n * sizeof(int64_t), stream));
+            HIP_TRY(ctx, dusp::jit_launch_classify_delays(d_params, n_inst, d_entries, (int)n, d_bits, stream));
+            std::vector<int> bits(n, 0);
+            HIP_TRY(ctx, hipMemcpyAsync(bits.data(), d_bits, n * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            bool changed = false;
+            for (size_t i = 0; i < n; i++) {
+                const int regime = bits[i] == dusp::DELAY_REGIME_LONG || bits[i] == dusp::DELAY_REGIME_SHORT ? bits[i] : dusp::DELAY_REGIME_OTHER;
+                int32_t &pad = prog->P.ops[which[i]].in[1].pad;
+                changed = changed || pad != regime;
+                pad = regime;
+            }
+            if (changed) {  // (another kernel text: the generated units differ)
+                prog->jit_src.clear();
+                prog->jit_consts_uploaded = false;
+            }
+        }
+    }
     if (prog->jit_table_generation != ctx->table_generation) {  // a table was uploaded since: forms / the LDS image may have changed
         prog->jit_src.clear();
         prog->jit_consts_uploaded = false;
@@ -677,6 +724,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
     dusp::JitOptions opt;
+    opt.persistent = persistent;
     opt.profile = ctx->knobs.jit_profile != 0;
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
@@ -788,11 +836,19 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // (from here on the render happens on the compiled kernel: workspaces)
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
     a.state = prog->d_state.p;
-    if (P.ring_samples) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
+    if (P.ring_samples && !resume) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
         HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
         HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
     }
     a.rings = prog->d_rings.p;
+    a.resume = resume ? 1u : 0u;
+    a.save_bufs = persistent ? 1u : 0u;
+    a.n_bufs = (uint32_t)std::max(1, P.n_bufs);
+    if (persistent) {  // every outlet's last chunk, parked between launches (the interpreter kernel's layout: either may continue the other)
+        HIP_TRY(ctx, prog->d_saved_bufs.ensure((size_t)a.n_bufs * dusp::kChunk * n_inst));
+        a.saved_bufs = prog->d_saved_bufs.p;
+    }
+    prog->keep_memory = false;
     if (!prog->jit_consts_uploaded) {
         HIP_TRY(ctx, prog->d_jit_fk.ensure(std::max<size_t>(1, src->fk.size())));
         HIP_TRY(ctx, prog->d_jit_dk.ensure(std::max<size_t>(1, src->dk.size())));
@@ -1428,20 +1484,26 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         g_error = "dusp_circuit_kernel_source: " + err;
         return DUSP_ERR_ARG;
     }
+    const bool continued = (lds_table & 2) != 0 && (P.ring_samples != 0 || !P.feed_forward);
+    lds_table &= 1;
+    if (continued)
+        for (dusp::DevOp &op : P.ops)
+            if (op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) op.pad = dusp::kDelayExactRing;
     dusp::WavePlan plan;
-    if (!dusp::plan_wave(P, plan, false)) {
+    if (!dusp::plan_wave(P, plan, continued)) {
         g_error = "dusp_circuit_kernel_source: the wave engine cannot run this graph (" + plan.why + ")";
         return DUSP_ERR_UNSUPPORTED;
     }
     for (size_t k = 0; k < plan.osc_level.size() && k < P.ops.size(); k++)
         if (plan.osc_level[k] >= 0) P.ops[k].d[0] = (double)plan.osc_level[k];
-    if (!dusp::jit_eligible(P, plan, false, err)) {
+    if (!dusp::jit_eligible(P, plan, err)) {
         g_error = "dusp_circuit_kernel_source: not a circuit the compiler takes (" + err + ")";
         return DUSP_ERR_UNSUPPORTED;
     }
     dusp::JitOptions opt;
     opt.waves = waves;
     opt.per_wave = per_wave;
+    opt.persistent = continued;
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
         opt.table_form[1] = dusp::TABLE_FORM_SAW;

@@ -411,9 +411,30 @@ inline void build_sum_voices(const FusedPlan &plan, uint32_t sample_rate, int gb
     }
 }
 
+// Regime of a per-instance (parameter) delay, found by looking at the parameter column when a render starts (dusp_abi.hip
+// classify_param_delays) and kept in the operand's spare word: every instance's delay of at least a chunk (and a chunk short of the
+// ring's length), every instance's below a chunk, or anything else (mixed, negative, NaN, within a sample of the chunk size).
+enum : int { DELAY_REGIME_UNKNOWN = 0, DELAY_REGIME_LONG = 1, DELAY_REGIME_SHORT = 2, DELAY_REGIME_OTHER = 4 };
+// one delay value's regime, as the compiled kernels' units will treat it (jit_prelude.hpp JitDelayK / JitDelayShort)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int delay_value_regime(float delay, int64_t ring_len, bool mono) {
+    double d = (double)delay;
+    if (!(d >= 0.0) || !(d < 4.0e9)) return DELAY_REGIME_OTHER;  // negative, NaN, absurd
+    const double len = (double)ring_len;
+    if (d >= (mono ? 0.0 : 1.0) && d < (double)(kChunk - 1) && ring_len >= 2 * kChunk) return DELAY_REGIME_SHORT;
+    if (d >= len) d = fmod(d, len);
+    const double fl = floor(d);
+    if (fl >= (double)kChunk && fl + (double)kChunk <= len) return DELAY_REGIME_LONG;
+    return DELAY_REGIME_OTHER;
+}
+
 // Delay with a constant delay of at least a chunk, and a chunk short of the ring's length: the wave engine's write-once
 // ring protocol (same predicate as delay_is_write_once in wave_engine.hip); other Delays go through ordered slot operations.
+// A per-instance delay qualifies once the renderer has found every instance's in that regime.
 inline bool delay_write_once(const DevOp &op) {
+    if (op.in[1].kind == SRC_PARAM) return op.in[1].pad == DELAY_REGIME_LONG;
     if (op.in[1].kind != SRC_CONST) return false;
     const double len = (double)op.ring_len;
     double dconst = (double)op.in[1].cval;

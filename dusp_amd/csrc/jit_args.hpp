@@ -20,6 +20,11 @@ struct JitArgs {
     unsigned long long *debug;  // diagnostic builds (DUSP_JIT_PROFILE=1): [workgroup][4] cycle counts of wave 0; NULL otherwise
     uint64_t n_samples, ring_samples, clock0;
     uint32_t n_inst, n_pad, n_groups, sample_rate, table_stride, vec4_ok, n_out, pad0;
+    // continued programs with delay lines / feedback (dusp_program_continue): every outlet's last chunk is parked in
+    // saved_bufs [n_inst][n_bufs][256] when a launch ends (save_bufs) and picked up by the next one (resume); Delay rings are kept in
+    // exactly the reference's state at launch boundaries
+    float *saved_bufs;
+    uint32_t resume, save_bufs, n_bufs, pad1;
     uint32_t n_seg, seg_groups;  // every instance is cut into n_seg segments of seg_groups chunks, one wavefront each (1: no split)
 };
 

@@ -48,6 +48,7 @@ struct JitOptions {
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
+    bool persistent = false; // a continued program with delay lines / feedback: outlets parked between launches, rings in the reference's state
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
                              // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
 };
@@ -97,13 +98,21 @@ inline bool jit_light(const Program &P) {
     return n <= 2;
 }
 // A Delay with a constant delay of less than a chunk reads what two known input samples left in its slot: no ring (JitDelayShort)
+// DevOp::pad of a Delay / MonoDelay: the program will be continued (dusp_program_continue) and its rings must be in the reference's own
+// state at every launch boundary: the ring-less form does not apply, and a MonoDelay stays on the slot operations
+constexpr int kDelayExactRing = 1;
 inline bool jit_delay_short(const DevOp &op) {
+    if ((op.op == OP_DELAY || op.op == OP_MONO_DELAY) && op.pad == kDelayExactRing) return false;
+    if ((op.op == OP_DELAY || op.op == OP_MONO_DELAY) && op.in[1].kind == SRC_PARAM)  // (every instance's delay looked at: fused_plan.hpp)
+        return op.in[1].pad == DELAY_REGIME_SHORT && op.ring_len >= 2 * kChunk;
     if ((op.op != OP_DELAY && op.op != OP_MONO_DELAY) || op.in[1].kind != SRC_CONST) return false;
     const double d = (double)op.in[1].cval;  // (MonoDelay writes before it reads: a delay below one sample is a delay)
     return d >= (op.op == OP_MONO_DELAY ? 0.0 : 1.0) && d < (double)(kChunk - 1) && op.ring_len >= 2 * kChunk;  // (a chunk's slots wrap once at most)
 }
 // A MonoDelay with a constant delay of a chunk at least: the write-once ring of the Delay (JitDelayK<true>)
 inline bool jit_mono_write_once(const DevOp &op) {
+    if (op.op == OP_MONO_DELAY && op.pad == kDelayExactRing) return false;
+    if (op.op == OP_MONO_DELAY && op.in[1].kind == SRC_PARAM) return op.in[1].pad == DELAY_REGIME_LONG;
     if (op.op != OP_MONO_DELAY || op.in[1].kind != SRC_CONST) return false;
     const double d = (double)op.in[1].cval, len = (double)op.ring_len;
     return d >= (double)kChunk && std::floor(d) + (double)kChunk <= len;
@@ -143,13 +152,12 @@ inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op);
 
 
 // Programs the compiler takes.  Everything else stays on the wave engine's interpreter (wave_engine.hip).
-inline bool jit_eligible(const Program &P, const WavePlan &plan, bool resumable_persistent, std::string &why) {
+inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &why) {
     auto no = [&](const char *w) {
         why = w;
         return false;
     };
     if (!plan.ok) return no("not a wave-engine program");
-    if (resumable_persistent) return no("continued programs with delay lines / feedback park their chunk buffers between launches");
     if (P.ops.size() > 96) return no("more than 96 channel-expanded units: straight-line code would outgrow the instruction cache");
     if (P.out_bufs.size() > 16) return no("more than 16 output channels");
     for (size_t k = 0; k < P.ops.size(); k++) {
@@ -428,12 +436,13 @@ struct Emitter {
                 case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:
                     if (jit_ring_ops(op)) {
                         line("    JitRingOps q" + id + ";");
-                        line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
+                        if (op.op == OP_DELAY) line("    q" + id + ".begin_delay(A, " + ctx(r) + ", " + num(op.state_slot) + ");");  // (a continued launch: the carried sample from the last one)
+                        else line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
                     } else if (jit_delay_short(op)) {
                         line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
                         line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     } else {
-                        line(std::string("    JitDelayK<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> y" + id + ";");
+                        line(std::string("    JitDelayK<") + (op.op == OP_MONO_DELAY ? "true" : "false") + ", " + (opt.persistent ? "true" : "false") + "> y" + id + ";");
                         line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
                     }
                     break;
@@ -456,6 +465,7 @@ struct Emitter {
                 case OP_AHD:
                     line("    JitAHD e" + id + ";");
                     line("    e" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    if (opt.persistent) line("    if (A.resume) jit_unpark(A, " + ctx(r) + ", " + num(op.out_buf) + ", e" + id + ".prev);");
                     break;
                 case OP_SAMPLE_RATE_REDUX:
                     line("    JitSRR h" + id + ";");
@@ -488,7 +498,10 @@ struct Emitter {
         // registers of late edges: the producer's previous chunk (outlets start as zeros, SignalChunk.js:7)
         for (int b = 0; b < P.n_bufs; b++)
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
-                for (int r = 0; r < copies(producer[(size_t)b]); r++) line("    float w" + num(b) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
+                for (int r = 0; r < copies(producer[(size_t)b]); r++) {
+                    line("    float w" + num(b) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
+                    if (opt.persistent && render) line("    if (A.resume) jit_unpark(A, " + ctx(r) + ", " + num(b) + ", w" + num(b) + "_" + num(r) + ");");
+                }
         // the chunk loop, twice: with the constant-f oscillators in 32.32 fixed point, and in the general form
         if (opt.profile) line("    const unsigned long long stamp_loop = __builtin_readcyclecounter();");
         if (opt.profile) line("    unsigned long long ph[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, ph_t = 0ull;  // (cycles from barrier to barrier, as wave 0 sees them)");
@@ -737,6 +750,13 @@ struct Emitter {
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
                 for (int r = 0; r < copies(producer[(size_t)b]); r++)
                     line("        for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
+        if (opt.persistent && render) {  // the launch's last chunk: every outlet's samples are parked for the launch that continues it
+            line("        if (A.save_bufs && g + 1 == X[0].g_end) {");
+            for (int b = 0; b < P.n_bufs; b++)
+                if (producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
+                    for (int r = 0; r < R; r++) line("            jit_park(A, " + ctx(r) + ", " + num(b) + ", v" + num(b) + sfx(producer[(size_t)b], r) + ");");
+            line("        }");
+        }
         if (opt.profile && render) line("        ph[11] += __builtin_readcyclecounter() - ph_t;  // (behind the last barrier)");
         line("    }");
     }
@@ -886,12 +906,12 @@ struct Emitter {
                     break;
                 }
                 if (delay_half == 1) {
-                    line("        y" + id + ".read(" + v + ");");
+                    line("        y" + id + ".read(" + X_ + ", " + v + ");");
                     break;
                 }
                 const std::string x = opnd_array(k, 0, "t" + id, r);
-                if (delay_half == 2) line("        y" + id + ".write(" + X_ + ", " + x + ");");
-                else line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
+                if (delay_half == 2) line("        y" + id + ".write(" + X_ + ", g, " + x + ");");
+                else line("        y" + id + ".tick(" + X_ + ", g, " + x + ", " + v + ");");
                 break;
             }
             default:

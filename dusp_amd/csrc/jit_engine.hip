@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 
+#include "fused_plan.hpp"
 #include "jit_args.hpp"
 #include "jit_engine.hpp"
 
@@ -368,6 +369,22 @@ hipError_t jit_launch(hipFunction_t fn, const JitArgs &A, unsigned grid, unsigne
     size_t size = sizeof args;
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     return hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, stream, nullptr, config);
+}
+
+// Per-instance (parameter) delays: which regime does every instance's value fall into?  One workgroup walks the parameter columns;
+// out[k] = OR of delay_value_regime over the instances, for entry k = (parameter slot, ring length, MonoDelay?).
+__global__ void dusp_classify_delays_kernel(const float *params, uint32_t n_inst, const int64_t *entries, int n_entries, int *out) {
+    for (int k = 0; k < n_entries; ++k) {
+        const int64_t slot = entries[3 * k], ring_len = entries[3 * k + 1];
+        const bool mono = entries[3 * k + 2] != 0;
+        int bits = 0;
+        for (uint32_t i = threadIdx.x; i < n_inst; i += blockDim.x) bits |= delay_value_regime(params[(size_t)slot * n_inst + i], ring_len, mono);
+        if (bits) atomicOr(&out[k], bits);
+    }
+}
+hipError_t jit_launch_classify_delays(const float *params, uint32_t n_inst, const int64_t *d_entries, int n_entries, int *d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(dusp_classify_delays_kernel, dim3(1), dim3(1024), 0, stream, params, n_inst, d_entries, n_entries, d_out);
+    return hipGetLastError();
 }
 
 // Start phase of every segment from the segments' phase totals: a serial modular prefix per (scanned oscillator, instance) —

@@ -102,6 +102,16 @@ __device__ __forceinline__ void jit_wave_sync() {  // LDS written by some lanes 
 
 __device__ __forceinline__ float jit_param(const JitArgs &A, const JitCtx &X, uint32_t slot) { return jit_u(A.params[(size_t)slot * A.n_inst + X.inst]); }
 
+// Continued programs (dusp_program_continue): an outlet's last chunk waits in saved_bufs [n_inst][n_bufs][256] between two launches —
+// what a feedback (or late) edge reads first in the next one, and what the chunk engine takes over if the chain migrates.
+__device__ __forceinline__ void jit_park(const JitArgs &A, const JitCtx &X, uint32_t buf, const float (&v)[4]) {
+    if (X.live) ((f32x4 *)(A.saved_bufs + ((size_t)X.inst * A.n_bufs + buf) * kChunk))[X.lane] = f32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void jit_unpark(const JitArgs &A, const JitCtx &X, uint32_t buf, float (&v)[4]) {
+    const f32x4 x = ((const f32x4 *)(A.saved_bufs + ((size_t)X.inst * A.n_bufs + buf) * kChunk))[X.lane];
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+
 // (a * n) mod S for a < S < 2^53 and n < 2^32, exactly: the product is cut into pieces that mod_u64 (x < 2^64) can take
 __device__ __forceinline__ unsigned long long jit_mulmod(unsigned long long a, unsigned long long n, unsigned long long S, double inv_S) {
     const unsigned long long ah = a >> 32, al = a & 0xffffffffull;  // ah < 2^21
@@ -873,6 +883,10 @@ struct JitCBNode {
 struct JitRingOps {
     double T;  // uniform
     __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { T = jit_u(A.init_state[state_slot]); }
+    // Delay: the carried input sample is engine-internal (no descriptor holds it): a continued launch takes it from where the last one left it
+    __device__ __forceinline__ void begin_delay(const JitArgs &A, const JitCtx &X, int state_slot) {
+        T = jit_u(A.resume ? A.state[(size_t)state_slot * A.n_pad + X.inst] : A.init_state[state_slot]);
+    }
     enum : int { RO_NONE = 0, RO_READ, RO_READ_CLEAR, RO_ADD, RO_STORE };
     template <int KIND, int ATTR>
     __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, float *scr, int64_t ring_base, uint32_t len, const float (&p0)[4],
@@ -1378,7 +1392,10 @@ struct JitFilterM {
 // Everything a chunk reads was written before the chunk began (D >= 256), so the NEXT chunk's reads are issued right after
 // this chunk's writes and have the rest of the chunk — the Filter stage, usually — to arrive.
 // MONO: MonoDelay — the same ring protocol (its taps and its read never meet inside a chunk either), no dropped ceil tap, no state.
-template <bool MONO>
+// EXACT: the program will be continued (dusp_program_continue), so the ring is kept in exactly the state the reference's has at a launch
+// boundary — slots zeroed once read (Delay.js:29), the launch's last ceil tap in place — so that the chain can move to the chunk
+// engine's read-modify-write protocol whenever an event changes the delay; the carried input sample comes from the last launch.
+template <bool MONO, bool EXACT = false>
 struct JitDelayK {
     float carried;        // the input sample before the chunk (uniform)
     double phi;           // the delay's fraction (uniform)
@@ -1403,28 +1420,43 @@ struct JitDelayK {
     }
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot, int64_t ring_base, int64_t ring_len, float delay) {
         carried = MONO ? 0.f : jit_u((float)A.init_state[state_slot]);  // (an f32 sample: nothing is lost)
+        if (EXACT && !MONO && A.resume) carried = jit_u((float)A.state[(size_t)state_slot * A.n_pad + X.inst]);
         double dconst = (double)delay;
         if (dconst >= (double)ring_len) dconst = fmod(dconst, (double)ring_len);
         const double Dfl = floor(dconst);
-        phi = dconst - Dfl;
-        D = (uint32_t)Dfl;
+        phi = jit_u(dconst - Dfl);
+        D = jit_u((uint32_t)Dfl);
         len = (uint32_t)ring_len;
         ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
         s0 = (uint32_t)((A.clock0 + (uint64_t)X.g_begin * kChunk) % (uint64_t)ring_len);
         quad = jit_u(((len | D | s0) & 3u) == 0u && ((uintptr_t)ring & 15u) == 0u);
         fetch(X);
     }
-    __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
-        read(out);
-        write(X, x);
+    __device__ __forceinline__ void tick(const JitCtx &X, uint32_t g, const float (&x)[4], float (&out)[4]) {
+        read(X, out);
+        write(X, g, x);
     }
     // The two halves of a tick.  What a chunk reads does not depend on what it writes, so a generated kernel may take the reads
     // early (the Filter stage's input) and the writes late (behind the recurrences), see jit_codegen.hpp `plan_overlap`.
-    __device__ __forceinline__ void read(float (&out)[4]) const {
+    __device__ __forceinline__ void read(const JitCtx &X, float (&out)[4]) const {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = ahead[c];
+        if (EXACT && X.live) {  // `buf[tB] = 0` (Delay.js:29): the slots this chunk has read
+            if (quad) {
+                uint32_t s_ = s0 + X.lane * 4;
+                if (s_ >= len) s_ -= len;
+                *(f32x4 *)(ring + s_) = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t s_ = s0 + X.lane * 4 + c;
+                    if (s_ >= len) s_ -= len;
+                    ring[s_] = 0.f;
+                }
+            }
+        }
     }
-    __device__ __forceinline__ void write(const JitCtx &X, const float (&x)[4]) {
+    __device__ __forceinline__ void write(const JitCtx &X, uint32_t g, const float (&x)[4]) {
         // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
         const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
         float slot[4];
@@ -1461,10 +1493,18 @@ struct JitDelayK {
                 if (X.live) ring[lo] = slot[c];
             }
         }
+        if (EXACT && !MONO && phi != 0.0 && g + 1 == X.g_end && X.lane == 63 && X.live) {
+            // the launch's last ceil tap, which the next chunk's first slot would fold in: in place, as the reference's ring has it
+            uint32_t lo = s0 + 255u;
+            if (lo >= len) lo -= len;
+            lo += D;
+            if (lo >= len) lo -= len;
+            if (lo + 1u < len) ring[lo + 1u] = (float)(0.0 + (double)x[3] * phi);  // (at index `length` the reference's store is dropped)
+        }
         carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
         s0 += kChunk;
         if (s0 >= len) s0 -= len;  // (len >= 512 here)
-        fetch(X);  // (after this chunk's stores, in program order: a wave's accesses to one address stay in order)
+        if (!EXACT || g + 1 != X.g_end) fetch(X);  // (after this chunk's stores, in program order: a wave's accesses to one address stay in order)
     }
 };
 

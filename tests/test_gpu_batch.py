@@ -66,6 +66,63 @@ def test_feedback_loop_batch(engine, oracle):
     prog.close()
 
 
+@pytest.mark.parametrize("regime,delay_of,expect", [
+    ("long", lambda k: 300 + k % 400, "compiled kernel"),                   # every instance >= one chunk: the write-once ring, per instance
+    ("long_frac", lambda k: 256 + (k % 97) * 3.25, "compiled kernel"),      # ... with fractions, some rings not 16-byte friendly
+    ("short", lambda k: 1 + (k % 250) + 0.5 * (k % 2), "compiled kernel"),  # every instance below a chunk: no ring
+    ("mixed", lambda k: 40 + 7 * (k % 90), "compiled kernel"),              # both sides of a chunk: ordered slot operations
+    ("edge", lambda k: 255.25 if k % 2 else 700, "compiled kernel"),        # within a sample of the chunk size: slot operations
+])
+def test_per_instance_delays_on_compiled_kernels(regime, delay_of, expect, oracle):
+    """A delay-time sweep of the configs[3] voice (Delay.js:20-41 with a different constant per instance): the compiled kernel looks at
+    the parameter column and takes the write-once ring / the ring-less form / the ordered slot operations; bit-equal to the chunk
+    engine on every instance, within the Filter tolerance of the oracle on a few."""
+    d.configure(48000)
+    def loop(k):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, delay_of(k), 4096), 2000)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    ks = list(range(0, 1200, 5)) + [1199]
+    uni = descriptor.unify([descriptor.extract(loop(k)) for k in ks])
+    assert uni.n_params == 2
+    n = 256 * 14 + 100
+    ctx = render.context(48000)
+    prog = ctx.build(uni.words)  # AUTO
+    assert prog.engine == "wave", prog.engine
+    pcm = prog.render(n, uni.n_instances, uni.params)
+    assert expect in prog.read_shape(), prog.read_shape()
+    ref = ctx.build(uni.words, runtime.ENGINE_CHUNK)
+    want = ref.render(n, uni.n_instances, uni.params)
+    assert np.array_equal(pcm, want), "instance %d differs from the chunk engine" % int(np.argmax((pcm != want).any(axis=(1, 2))))
+    for i in (0, 1, 17, uni.n_instances - 1):
+        w = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+        assert np.max(np.abs(pcm[i].astype(np.float64) - w)) <= 1e-5 * max(1.0, float(np.max(np.abs(w)))), (regime, i)
+    # the same program again with another column: the regime is looked at per render
+    other = uni.params.copy()
+    other[:] = uni.params[:, ::-1]
+    pcm2 = prog.render(n, uni.n_instances, other)
+    assert np.array_equal(pcm2, ref.render(n, uni.n_instances, other))
+    prog.close()
+    ref.close()
+
+
+def test_per_instance_mono_delays_on_compiled_kernels(oracle):
+    """MonoDelay with a per-instance delay (the Space patch's distance -> delay at batch scale): long, short and mixed columns."""
+    d.configure(48000)
+    for delays in ([300 + 3.5 * k for k in range(70)], [0.25 + 3.5 * k for k in range(70)], [100 + 9.75 * k for k in range(70)]):
+        uni = descriptor.unify([descriptor.extract(d.MonoDelay(d.Osc(200 + 3 * k), dl)) for k, dl in enumerate(delays)])
+        n = 256 * 6 + 17
+        ctx = render.context(48000)
+        prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
+        pcm = prog.render(n, uni.n_instances, uni.params)
+        assert "compiled kernel" in prog.read_shape()
+        for i in range(0, uni.n_instances, 3):
+            want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
+            assert np.array_equal(pcm[i], want), (delays[i], i)
+        prog.close()
+
+
 def _filter_voice(kind, k):
     o = d.Osc(110 + k / 4)
     if kind == "env_after":      # a unit hanging on the Filter, a per-instance cutoff

@@ -21,7 +21,7 @@ USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow",
 
 # |f| < 2^-13: the reference's own f64 phase accumulation rounds there (SURVEY.md §8a note ii), so the wave
 # engine's 2^-36 fixed-point scan is only within tolerance for it (the fused and chunk engines stay exact)
-BELOW_EXACT_REGIME = {("osc_f_tiny", "wave")}
+BELOW_EXACT_REGIME = {("osc_f_tiny", "wave"), ("osc_f_tiny", "interp")}
 
 
 def check(name, got, ref, engine=None):
