@@ -168,7 +168,6 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                 double lastF = st[NP], a0 = st[2 * NP], a1 = st[3 * NP], a2 = st[4 * NP], b1 = st[5 * NP],
                        b2 = st[6 * NP];
                 double x1 = st[7 * NP], x2 = st[8 * NP], y1 = st[9 * NP], y2 = st[10 * NP];
-                const double PI = 3.141592653589793;
                 for (int t0 = 0; t0 < kChunk; t0 += kBatch) {
                     float xv[kBatch], fv[kBatch], r[kBatch];
                     x.load(t0, xv);
@@ -180,7 +179,7 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                             has_lastF = true;
                             lastF = ft;
                             if (op.attr == 0) {  // LP
-                                const double lamda = 1.0 / tan(PI * ft / sr);
+                                const double lamda = filter_lamda(0, ft, sr);
                                 const double l2 = lamda * lamda;
                                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                                 a1 = 2.0 * a0;
@@ -188,7 +187,7 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                                 b1 = 2.0 * a0 * (1.0 - l2);
                                 b2 = a0 * (1.0 - 2.0 * lamda + l2);
                             } else {  // HP
-                                const double lamda = tan(PI * ft / sr);
+                                const double lamda = filter_lamda(1, ft, sr);
                                 const double l2 = lamda * lamda;
                                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                                 a1 = 0.0;
@@ -650,7 +649,6 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
     bool has_lastF = st[0] != 0.0;
     double lastF = st[NP], a0 = st[2 * NP], a1 = st[3 * NP], a2 = st[4 * NP], b1 = st[5 * NP], b2 = st[6 * NP];
     double x1 = st[7 * NP], x2 = st[8 * NP], y1 = st[9 * NP], y2 = st[10 * NP];
-    const double PI = 3.141592653589793;
     int64_t tBuffer = a.clock0 % len;
 
     for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
@@ -727,7 +725,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
                         has_lastF = true;
                         lastF = ft;
                         if (L.filter.attr == 0) {
-                            const double lamda = 1.0 / tan(PI * ft / sr);
+                            const double lamda = filter_lamda(0, ft, sr);
                             const double l2 = lamda * lamda;
                             a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                             a1 = 2.0 * a0;
@@ -735,7 +733,7 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
                             b1 = 2.0 * a0 * (1.0 - l2);
                             b2 = a0 * (1.0 - 2.0 * lamda + l2);
                         } else {
-                            const double lamda = tan(PI * ft / sr);
+                            const double lamda = filter_lamda(1, ft, sr);
                             const double l2 = lamda * lamda;
                             a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                             a1 = 0.0;

@@ -7,6 +7,7 @@
 #endif
 
 #include "device_types.hpp"
+#include "filter_lamda.hpp"
 
 namespace dusp {
 namespace {

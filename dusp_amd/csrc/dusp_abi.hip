@@ -736,6 +736,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         }
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     opt.filter_stages = dusp::jit_filter_stages(P);
+    opt.filter_mod = dusp::jit_filter_mod(P);
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
@@ -749,8 +750,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
-    const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
-    const bool filter_stage = opt.filter_stages > 0;  // (a Filter with a connected cutoff runs per wave: no stage, no rows)
+    // (a stage with a connected cutoff keeps twelve doubles per instance in registers: two instances per wavefront at most)
+    const int per_wave_cap = std::min(opt.filter_mod ? 2 : 4, ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4);
+    const bool filter_stage = opt.filter_stages > 0;
     if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has
         // lanes, and every CU the same number of rounds — rows = instances per CU / rounds, spread over up to 16 wavefronts.
@@ -759,10 +761,10 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
         if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
             opt.lds_table = -1, opt.table_bytes = 0;
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget, opt.filter_mod);
         }
     } else {
         while (waves < most && (unsigned)waves < want) waves *= 2;
@@ -780,7 +782,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         waves = std::min(most, ctx->knobs.jit_force_waves);
         per_wave = ctx->knobs.jit_force_per_wave;
         if (filter_stage) {
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
             if (!opt.filter_sub) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: DUSP_JIT_FORCE: the Filter stage's rows do not fit LDS at this geometry");
         }
     }
@@ -824,14 +826,14 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             continue;
         }
         opt.filter_block = 8;
-        if (filter_stage && waves > 4 && waves % 2 == 0 && per_wave * 2 <= 4) {
+        if (filter_stage && waves > 4 && waves % 2 == 0 && per_wave * 2 <= per_wave_cap) {
             waves /= 2;
             per_wave *= 2;
         } else if (filter_stage && per_wave > 1) per_wave /= 2;  // (rows stay a power of two: whole rounds on every CU)
         else if (per_wave > 1) per_wave /= 2;  // (4, 2, 1: an odd count leaves the last round of workgroups a third full at the usual batch sizes)
         else if (waves > 4) waves /= 2;
         else break;
-        if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes);
+        if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
     }
     // (from here on the render happens on the compiled kernel: workspaces)
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
@@ -1517,8 +1519,9 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
             }
     }
     opt.filter_stages = dusp::jit_filter_stages(P);
+    opt.filter_mod = dusp::jit_filter_mod(P);
     if (plan.has_filter) {
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4, opt.filter_mod);
         if (!opt.filter_sub) {
             g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
             return DUSP_ERR_ARG;

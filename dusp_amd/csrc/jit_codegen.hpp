@@ -43,6 +43,8 @@ struct JitOptions {
     size_t table_bytes = 0;  // size of that image (half_table_lds_bytes of the sample rate)
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int filter_stages = 0;   // Filter stages of the circuit (jit_filter_stages): each keeps its rows' y1 / y2 behind the tile
+    bool filter_mod = false; // one of them has a connected cutoff (jit_filter_mod): the tile's rows hold P, b1 and b2 of a sub-block
+    bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
@@ -71,15 +73,23 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // largest that fits the LDS left over.
 // Behind the rows: one word that says "given back", then y1 / y2 of every row of every Filter stage of the circuit (the stages share
 // the tile, one after the other, but each has its own recurrence memory).
-inline size_t jit_filter_tile_bytes(int rows, int sub, int stages) { return (size_t)rows * (size_t)(sub + 2) * 8 + 16 + (size_t)stages * (size_t)rows * 16; }
+// (mod: a stage with a connected cutoff shares the tile — rows of three arrays, P / b1 / b2 per sample: JitFilterKM)
+inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod) {
+    return (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8 + 16 + (size_t)stages * (size_t)rows * 16;
+}
 inline int jit_filter_stages(const Program &P) {
     int n = 0;
-    for (const DevOp &op : P.ops) n += op.op == OP_FILTER && op.in[1].kind != SRC_BUF;
+    for (const DevOp &op : P.ops) n += op.op == OP_FILTER;
     return n;
 }
-inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left) {
-    for (int sub : {256, 128, 64})
-        if (jit_filter_tile_bytes(waves * per_wave, sub, stages) <= lds_left) return sub;
+inline bool jit_filter_mod(const Program &P) {
+    for (const DevOp &op : P.ops)
+        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) return true;
+    return false;
+}
+inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left, bool mod) {
+    for (int sub : {256, 128, 64, 32})
+        if (jit_filter_tile_bytes(waves * per_wave, sub, stages, mod) <= lds_left) return sub;
     return 0;
 }
 // A circuit whose whole chunk body is a few dozen instructions (constant-f oscillators, Ramp, Timer, the elementwise maps; two units
@@ -135,7 +145,6 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
         if (op.op == OP_MULTI_OSC) n = 512;
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
-        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) n = 768;   // P, b1, b2 per sample (f64) of half a chunk
         if (jit_ring_ops(op)) n = 1024;                                 // the slot-ownership table
         if (jit_delay_short(op)) n = 512;                               // the chunk before and this one, side by side
         need = std::max(need, n);
@@ -144,7 +153,7 @@ inline size_t jit_scratch_floats(const Program &P) {
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages) : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod) : 0) +
                                     (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
@@ -167,7 +176,7 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &wh
         case OP_RAMP:
             if (plan.op_state[k] >= 0) return no("a Ramp that a Retriggerer restarts");
             break;
-        case OP_FILTER: break;  // (a connected cutoff: per-sample coefficients, the recurrence per wave out of its scratch)
+        case OP_FILTER: break;  // (a connected cutoff: per-sample coefficients next to P in the stage's tile)
         case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:  // write-once ring protocol, or ordered slot operations
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("delay ring out of range");
             break;
@@ -266,7 +275,8 @@ struct Emitter {
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
-    bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind != SRC_BUF; }
+    bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER; }
+    bool is_mod_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind == SRC_BUF; }  // a connected cutoff
 
     // The Filter stage keeps ONE wave busy with the recurrences while the others wait; whatever the chunk holds that neither feeds a
     // Filter nor hangs on one can run on those others meanwhile.  Units are sorted into
@@ -309,8 +319,10 @@ struct Emitter {
         std::vector<int> stack;
         for (int f : filters) {  // a chained stage's input may pass through post units only (they are emitted right in front of it)
             if (!chained[(size_t)f]) continue;
-            const int first = same_chunk_producer(f, 0);
-            if (first >= 0) stack.push_back(first);
+            for (int j = 0; j < 2; j++) {  // (the input, and a connected cutoff)
+                const int first = same_chunk_producer(f, j);
+                if (first >= 0) stack.push_back(first);
+            }
             while (!stack.empty()) {
                 const int k = stack.back();
                 stack.pop_back();
@@ -325,8 +337,10 @@ struct Emitter {
         }
         for (int f : filters) {
             if (chained[(size_t)f]) continue;
-            const int pr = same_chunk_producer(f, 0);
-            if (pr >= 0) stack.push_back(pr);
+            for (int j = 0; j < 2; j++) {
+                const int pr = same_chunk_producer(f, j);
+                if (pr >= 0) stack.push_back(pr);
+            }
         }
         while (!stack.empty()) {
             const int k = stack.back();
@@ -390,7 +404,7 @@ struct Emitter {
         }
         if (opt.scratch_floats) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
-                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages) / 4) : 0);
+                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod) / 4) : 0);
             line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         }
         // constants and parameters the used ops name
@@ -482,11 +496,10 @@ struct Emitter {
                 default: break;
                 }
             }
-            if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
-                for (int r = 0; r < R; r++) {
-                    line("    JitFilterM f" + num(k) + "_" + num(r) + ";");
-                    line("    f" + num(k) + "_" + num(r) + ".begin(A, " + num(op.state_slot) + ");");
-                }
+            if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
+                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + "> f" + num(k) + ";");
+                line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.state_slot) + ");");
+                for (int r = 0; r < R; r++) line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.state_slot) + ");");
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
                 line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + "> f" + num(k) + ";");
@@ -515,7 +528,7 @@ struct Emitter {
             line("        A.debug[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter() - stamp_loop;");
             std::string ser = "0ull";
             for (size_t k = 0; k < P.ops.size(); k++)
-                if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind != SRC_BUF) ser += " + f" + num((long long)k) + ".cyc_serial";
+                if (P.ops[k].op == OP_FILTER) ser += " + f" + num((long long)k) + ".cyc_serial";
             line("        A.debug[(size_t)blockIdx.x * 16 + 1] = " + ser + ";");
             line("        A.debug[(size_t)blockIdx.x * 16 + 2] = X[0].g_end - X[0].g_begin;");
             line("    }");
@@ -526,8 +539,9 @@ struct Emitter {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
             for (size_t k = 0; k < P.ops.size(); k++)
                 if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind == SRC_BUF) {
+                    line("    f" + num((long long)k) + ".end(A, X[0], tile, " + num(P.ops[k].state_slot) + ");");
                     for (int r = 0; r < R; r++)
-                        line("    if (" + ctx(r) + ".live && " + ctx(r) + ".lane == 0) f" + num((long long)k) + "_" + num(r) + ".end(A, " + ctx(r) + ", " + num(P.ops[k].state_slot) + ");");
+                        line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].attr) + ", " + num(P.ops[k].state_slot) + ");");
                 } else if (P.ops[k].op == OP_FILTER) {
                     line("    f" + num((long long)k) + ".end(A, X[0], tile, " + num(P.ops[k].state_slot) + ");");
                     for (int r = 0; r < R; r++) line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].state_slot) + ");");
@@ -570,11 +584,16 @@ struct Emitter {
     // the Filter stage of unit k: the feed-forward halves into registers ...
     void filter_feed(int k, const char *into = "q", bool declare = true) {
         const DevOp &op = P.ops[(size_t)k];
+        const bool mod = is_mod_stage(k);
         for (int r = 0; r < R; r++) {
             const std::string x = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
             if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-            if (declare) line("        double " + std::string(into) + num(k) + "_" + num(r) + "[4];");
-            line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
+            if (declare) line("        double " + std::string(into) + num(k) + "_" + num(r) + (mod ? "[12];" : "[4];"));
+            if (mod) {
+                const std::string f = opnd_array(k, 1, "tf" + num(k) + "_" + num(r), r);
+                line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + x + ", " + f + ", " + into + num(k) + "_" + num(r) + ");");
+            } else
+                line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
         }
     }
     // May the early units and the feed-forward halves of chunk g+1 run inside chunk g (beside its recurrences)?  They may when they
@@ -583,6 +602,8 @@ struct Emitter {
     // double-buffered: `dbl`.
     bool plan_rotate(const std::vector<char> &used) {
         dbl.assign((size_t)std::max(1, P.n_bufs), 0);
+        for (size_t k = 0; k < P.ops.size(); k++)  // (a connected cutoff: twelve doubles per instance and stage would have to be held twice)
+            if (used[k] && is_mod_stage((int)k) && !opt.rotate_mod) return false;
         for (size_t k = 0; k < P.ops.size(); k++) {
             if (used[k] && is_filter_stage((int)k) && !chained[k] && P.ops[k].in[0].kind == SRC_BUF && reads_late(pos_of_op[k], P.ops[k].in[0].idx)) return false;
             if (!used[k] || !grp_early[k]) continue;
@@ -643,7 +664,7 @@ struct Emitter {
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (used[(size_t)k] && is_filter_stage(k) && !chained[(size_t)k])
-                    for (int r = 0; r < R; r++) line("    double qn" + num(k) + "_" + num(r) + "[4];");
+                    for (int r = 0; r < R; r++) line("    double qn" + num(k) + "_" + num(r) + (is_mod_stage(k) ? "[12];" : "[4];"));
                 if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
@@ -696,9 +717,9 @@ struct Emitter {
                 for (size_t at = 0; at < plan.order.size(); at++)
                     if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at]) && !chained[(size_t)plan.order[at]])
                         for (int r = 0; r < R; r++) {
-                            const std::string id = num(plan.order[at]) + "_" + num(r);
-                            line("        double q" + id + "[4];");
-                            line("        for (int c = 0; c < 4; ++c) q" + id + "[c] = qn" + id + "[c];");
+                            const std::string id = num(plan.order[at]) + "_" + num(r), n_q = is_mod_stage(plan.order[at]) ? "12" : "4";
+                            line("        double q" + id + "[" + n_q + "];");
+                            line("        for (int c = 0; c < " + n_q + "; ++c) q" + id + "[c] = qn" + id + "[c];");
                         }
             }
             // Waves 0 and 1 take turns at the recurrences (windows 0, 2, .. and 1, 3, ..); wave i does all its other work — its side
@@ -764,15 +785,6 @@ struct Emitter {
     void unit(int k, bool render, int pass_level, bool fx) {
         const DevOp &op = P.ops[(size_t)k];
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
-        if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {
-            for (int r = 0; r < R; r++) {
-                const std::string id = num(k) + "_" + num(r);
-                const std::string x = opnd_array(k, 0, "t" + id, r), f = opnd_array(k, 1, "tf" + id, r);
-                if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-                line("        f" + id + ".tick(" + ctx(r) + ", scr, " + num(op.attr) + ", " + x + ", " + f + ", " + vout(op.out_buf, r) + ");");
-            }
-            return;
-        }
         if (op.op == OP_FILTER) {
             filter_feed(k);
             for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) filter_sub_block(k, sb, std::string());
@@ -971,7 +983,7 @@ struct Emitter {
             } else if (op.op == OP_AHD)
                 dconst_of[k] = add_dk(op.d[0]); else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
                 dconst_of[k] = add_dk(op.d[0]);
-            if (op.op == OP_FILTER && op.in[1].kind != SRC_BUF) { out.has_filter = true; out.n_filters++; }  // (the workgroup-wide stage; a modulated Filter runs per wave)
+            if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }  // (the workgroup-wide stage)
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }

@@ -8,6 +8,7 @@ sym: \
     .byte 0
 EMBED(dusp_src_device_types, "device_types.hpp")
 EMBED(dusp_src_device_util, "device_util.hpp")
+EMBED(dusp_src_filter_lamda, "filter_lamda.hpp")
 EMBED(dusp_src_map_ops, "map_ops.hpp")
 EMBED(dusp_src_repeat_add, "repeat_add.hpp")
 EMBED(dusp_src_jit_args, "jit_args.hpp")

@@ -40,8 +40,8 @@
 #include "jit_engine.hpp"
 
 // the device library's text, embedded by jit_embed.S (.incbin of the very files hipcc compiles into the AOT kernels)
-extern "C" const char dusp_src_device_types[], dusp_src_device_util[], dusp_src_map_ops[], dusp_src_repeat_add[], dusp_src_jit_args[],
-    dusp_src_jit_prelude[];
+extern "C" const char dusp_src_device_types[], dusp_src_device_util[], dusp_src_filter_lamda[], dusp_src_map_ops[], dusp_src_repeat_add[],
+    dusp_src_jit_args[], dusp_src_jit_prelude[];
 
 namespace dusp {
 
@@ -97,7 +97,8 @@ void configure_once() {
 // key of the disk cache: everything a code object depends on
 uint64_t cache_key(const std::string &text) {
     uint64_t h = fnv1a(text.data(), text.size());
-    for (const char *src : {dusp_src_device_types, dusp_src_device_util, dusp_src_map_ops, dusp_src_repeat_add, dusp_src_jit_args, dusp_src_jit_prelude})
+    for (const char *src : {dusp_src_device_types, dusp_src_device_util, dusp_src_filter_lamda, dusp_src_map_ops, dusp_src_repeat_add, dusp_src_jit_args,
+                            dusp_src_jit_prelude})
         h = fnv1a(src, std::strlen(src) + 1, h);
     for (const char *o : kCompileOptions) h = fnv1a(o, std::strlen(o) + 1, h);
     int major = 0, minor = 0;
@@ -159,10 +160,11 @@ struct Loaded {
 std::map<std::pair<int, std::string>, Loaded> g_loaded;  // (device, text) -> module on that device
 
 bool compile_text(const std::string &text, std::vector<char> &code, std::string &err) {
-    const char *headers[] = {dusp_src_device_types, dusp_src_device_util, dusp_src_map_ops, dusp_src_repeat_add, dusp_src_jit_args, dusp_src_jit_prelude};
-    const char *names[] = {"device_types.hpp", "device_util.hpp", "map_ops.hpp", "repeat_add.hpp", "jit_args.hpp", "jit_prelude.hpp"};
+    const char *headers[] = {dusp_src_device_types, dusp_src_device_util, dusp_src_filter_lamda, dusp_src_map_ops, dusp_src_repeat_add, dusp_src_jit_args,
+                             dusp_src_jit_prelude};
+    const char *names[] = {"device_types.hpp", "device_util.hpp", "filter_lamda.hpp", "map_ops.hpp", "repeat_add.hpp", "jit_args.hpp", "jit_prelude.hpp"};
     hiprtcProgram prog = nullptr;
-    hiprtcResult r = hiprtcCreateProgram(&prog, text.c_str(), "dusp_circuit.hip", 6, headers, names);
+    hiprtcResult r = hiprtcCreateProgram(&prog, text.c_str(), "dusp_circuit.hip", 7, headers, names);
     if (r != HIPRTC_SUCCESS) {
         err = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
         return false;

@@ -1029,9 +1029,8 @@ __device__ __forceinline__ void jit_input(const JitArgs &A, const JitCtx &X, uin
 
 // Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
 __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
-    const double PI = 3.141592653589793;
     if (kind == 0) {
-        const double lamda = 1.0 / tan(PI * f / sr);
+        const double lamda = filter_lamda(0, f, sr);
         const double l2 = lamda * lamda;
         k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
         k[1] = 2.0 * k[0];
@@ -1039,7 +1038,7 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
         k[3] = 2.0 * k[0] * (1.0 - l2);
         k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
     } else {
-        const double lamda = tan(PI * f / sr);
+        const double lamda = filter_lamda(1, f, sr);
         const double l2 = lamda * lamda;
         k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
         k[1] = 0.0;
@@ -1270,119 +1269,187 @@ __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X
     return A.params[(size_t)slot * A.n_inst + inst];
 }
 
-// ---- Filter with a CONNECTED cutoff: `if (this.f[t] != this.lastF)` recomputes the coefficients — a pure function of f[t], so every lane
-// computes its four samples' own (a tan() each), parks b1 / b2 and the feed-forward half per sample in the wave's scratch (three
-// rows of 256 doubles), and lane 0 runs the recurrence with per-sample coefficients; y goes over the P values already consumed.
-struct JitFilterM {
-    double k[5], x1, x2, y1, y2, lastF;  // uniform: the last sample's coefficients, the inputs and outputs before the chunk
-    bool has_last;
-    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
-        const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
-        has_last = jit_u(is[0] != 0.0);
-        lastF = jit_u(is[1]);
-        for (int i = 0; i < 5; ++i) k[i] = jit_u(is[2 + i]);
-        x1 = jit_u(is[7]);
-        x2 = jit_u(is[8]);
-        y1 = jit_u(is[9]);
-        y2 = jit_u(is[10]);
+// ---- Filter with a CONNECTED cutoff (an LFO or an envelope on the cutoff): `if (this.f[t] != this.lastF)` recomputes the coefficients
+// (Filter.js:34-37) — a pure function of f[t], so every lane computes its four samples' own (filter_lamda: two short polynomials and
+// a division, no argument reduction) together with the feed-forward half P[t] = (a0 x + a1 x1) + a2 x2, and the recurrence
+// y = f32((P - b1[t] y1) - b2[t] y2) runs like the constant-cutoff stage's: the WAVES x R instances of the workgroup side by side on
+// the lanes of ONE wave, out of a shared tile whose rows hold P, b1 and b2 of a sub-block (three arrays of SUB doubles; y goes
+// over the P values already consumed).  Same protocol as JitFilterK: park / serial / failed / serial_exact / pick, memory behind the tile.
+template <int WAVES, int R, int SUB>
+struct JitFilterKM {
+    static constexpr int kPitch = 3 * SUB + 2;  // doubles per row (even: rows stay 16-byte aligned)
+    float x1[R], x2[R];                         // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
+    float flast[R];                             // the cutoff of the last sample ticked (what `lastF` and the coefficients in the unit's state belong to)
+    bool ticked[R];
+    int stage;
+#ifdef DUSP_JIT_PROFILE
+    unsigned long long cyc_serial = 0;
+#endif
+    typedef __attribute__((address_space(3))) double lds_double;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {
+        return ((uint32_t)(uintptr_t)(lds_double *)(tile + (size_t)row * kPitch)) & 0x3ffffu;
     }
-    __device__ __forceinline__ void tick(const JitCtx &X, float *scr, int kind, const float (&x)[4], const float (&f)[4], float (&out)[4]) {
-        // The wave's scratch holds HALF a chunk of P, b1, b2 (3 KB: 16 wavefronts fit next to the table image, where a whole chunk
-        // let 8): every lane computes its four samples' values, lanes 0..31 hand theirs over first, then lanes 32..63.
-        constexpr int kHalf = kChunk / 2;
-        double *P = (double *)scr, *B1 = P + kHalf, *B2 = P + 2 * kHalf;
-        const float xl1 = __shfl_up(x[3], 1, 64), xl2 = __shfl_up(x[2], 1, 64);
-        double xm1 = X.lane == 0 ? x1 : (double)xl1, xm2 = X.lane == 0 ? x2 : (double)xl2;
-        double kl[5], p4[4], b14[4], b24[4];
+    __device__ __forceinline__ uint32_t memory_address(double *tile, uint32_t row) const {
+        return row_address(tile, WAVES * R) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
+    }
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double *tile, int stage_, int state_slot) {
+        stage = stage_;
+        const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
+        if (X.wave == 0 && X.lane < WAVES * R) {  // (the first barrier of the chunk loop stands between this and the first reader)
+            lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+            mem[0] = is[9];
+            mem[1] = is[10];
+        }
+    }
+    __device__ __forceinline__ void begin_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) {
+        const double *is = A.init_state + state_slot;
+        x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
+        x2[r] = jit_u((float)is[8]);
+        flast[r] = 0.f;
+        ticked[r] = false;
+    }
+    static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
+    // slot r's chunk: p[0..3] the feed-forward halves, p[4..7] b1, p[8..11] b2 of this lane's four samples
+    __device__ __forceinline__ void feed(const JitCtx &X, int r, int kind, const float (&x)[4], const float (&f)[4], double (&p)[12]) {
+        const float l1 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x1[r]), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
+        const float l2 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x2[r]), __float_as_uint(x[2]), 0x138, 0xf, 0xf, false));
+        const double o[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            jit_filter_coefficients(kind, (double)f[c], X.srd, kl);
-            b14[c] = kl[3];
-            b24[c] = kl[4];
-            const double xin = (double)x[c];
-            p4[c] = (kl[0] * xin + kl[1] * jit_or0(xm1)) + kl[2] * jit_or0(xm2);
-            xm2 = jit_or0(xm1);
-            xm1 = xin;
+            double k[5];
+            jit_filter_coefficients(kind, (double)f[c], X.srd, k);
+            p[c] = (k[0] * (double)x[c] + k[1] * o[c + 1]) + k[2] * o[c];
+            p[4 + c] = k[3];
+            p[8 + c] = k[4];
         }
-        double v1 = jit_or0(y1), v2 = jit_or0(y2);  // (lane 0's)
-        for (int half = 0; half < 2; ++half) {
-            const bool mine = (int)(X.lane >> 5) == half;
-            const int at = (int)(X.lane & 31u) * 4;
-            jit_wave_sync();
-            if (mine) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) P[at + c] = p4[c], B1[at + c] = b14[c], B2[at + c] = b24[c];
-            }
-            jit_wave_sync();
-            if (X.lane == 0) {
-                // One lane, dependent steps: like the Filter stage's loop (JitFilterK::serial) the chain is kept free of everything
-                // else — P, b1, b2 of four steps in registers, the next four read while these run, the `|| 0` selects speculated
-                // away (a NaN cannot leave the recurrence without them, so the block's last output tells; the block is then redone
-                // as written).  y goes over the P values already consumed.
-                f32x4 *Y = (f32x4 *)scr;
-                double pa[4], ba[4], ca[4], pb[4], bb[4], cb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pa[i] = P[i], ba[i] = B1[i], ca[i] = B2[i];
-                auto block = [&](const double (&p)[4], const double (&b1)[4], const double (&b2)[4], f32x4 *dst) __attribute__((always_inline)) {
-                    const double in1 = v1, in2 = v2;
-                    f32x4 y4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float y = (float)((p[i] - b1[i] * v1) - b2[i] * v2);
-                        y4[i] = y;
-                        v2 = v1;
-                        v1 = (double)y;
-                    }
-                    if (!(v1 == v1 && v2 == v2)) {  // Filter.js:40-46 as written
-                        v1 = in1;
-                        v2 = in2;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float y = (float)((p[i] - b1[i] * jit_or0(v1)) - b2[i] * jit_or0(v2));
-                            y4[i] = y;
-                            v2 = jit_or0(v1);
-                            v1 = (double)y;
-                        }  // (a NaN in v1 now fails the next block's test too: that block is done as written as well)
-                    }
-                    *dst = y4;
-                };
-                for (int t0 = 0; t0 < kHalf; t0 += 8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pb[i] = P[t0 + 4 + i], bb[i] = B1[t0 + 4 + i], cb[i] = B2[t0 + 4 + i];
-                    __builtin_amdgcn_sched_barrier(0);
-                    block(pa, ba, ca, Y + (t0 >> 2));  // (y of samples t0 .. t0+3 over P of samples t0/2, t0/2+1: in registers up to t0+7)
-                    const int next = t0 + 8 < kHalf ? t0 + 8 : t0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pa[i] = P[next + i], ba[i] = B1[next + i], ca[i] = B2[next + i];
-                    __builtin_amdgcn_sched_barrier(0);
-                    block(pb, bb, cb, Y + (t0 >> 2) + 1);
-                }
-            }
-            jit_wave_sync();
-            if (mine) jit_row_get(scr, X.lane & 31u, out);
-        }
-        if (X.lane == 0) {
-            y1 = v1;
-            y2 = jit_or0(v2);  // (Filter.js:45: y2 = y1 || 0)
-        }
-        y1 = jit_u(y1);
-        y2 = jit_u(y2);
-        // what the last sample left: its cutoff and coefficients, the chunk's last two inputs (lane 63 holds them)
-        lastF = jit_u(__shfl((double)f[3], 63, 64));
-        for (int i = 0; i < 5; ++i) k[i] = jit_u(__shfl(kl[i], 63, 64));
-        x1 = jit_u(__shfl(xm1, 63, 64));
-        x2 = jit_u(__shfl(xm2, 63, 64));
-        has_last = true;
+        x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
+        flast[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f[3]), 63));
+        ticked[r] = true;
     }
-    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, int state_slot) const {
+    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[12]) {
+        const int first = s * (SUB / 4);
+        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+            double *row = tile + (size_t)(X.wave * R + r) * kPitch + ((int)X.lane - first) * 4;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                f64x2 *at = (f64x2 *)(row + a * SUB);
+                at[0] = f64x2{p[4 * a], p[4 * a + 1]};
+                at[1] = f64x2{p[4 * a + 2], p[4 * a + 3]};
+            }
+        }
+    }
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
+        const int first = s * (SUB / 4);
+        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+            const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
+            out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
+        }
+    }
+    // PB steps with the coefficients of each step, WITHOUT the `|| 0` selects of Filter.js:42-46 (speculated away like JitFilterK::serial does)
+    template <int PB, typename DST>
+    static __device__ __forceinline__ void block(const double (&pv)[PB], const double (&b1)[PB], const double (&b2)[PB], double &u1, double &u2, DST *dst) {
+        f32x4 y4[PB / 4];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const float y = (float)((pv[i] - b1[i] * u1) - b2[i] * u2);
+            y4[i >> 2][i & 3] = y;
+            u2 = u1;
+            u1 = (double)y;
+        }
+#pragma unroll
+        for (int i = 0; i < PB / 4; ++i) dst[i] = y4[i];
+    }
+    template <int PB_>  // (the generated text passes the constant-cutoff stage's block size; three values per step: always blocks of 4 here)
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
+        constexpr int PB = 4;
+        if (X.wave != who || X.lane >= WAVES * R) return;
+#ifdef DUSP_JIT_PROFILE
+        const unsigned long long stamp0 = __builtin_readcyclecounter();
+#endif
+        const uint32_t row = row_address(tile, X.lane);
+        const lds_double *pr = (const lds_double *)(uintptr_t)row;
+        lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
+        lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+        double u1 = jit_or0(mem[0]), u2 = jit_or0(mem[1]);
+        double pa[PB], ba[PB], ca[PB], pb[PB], bb[PB], cb[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) pa[i] = pr[i], ba[i] = pr[SUB + i], ca[i] = pr[2 * SUB + i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        for (int t0 = 0; t0 < SUB; t0 += 2 * PB) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) pb[i] = pr[PB + i], bb[i] = pr[SUB + PB + i], cb[i] = pr[2 * SUB + PB + i];
+            __builtin_amdgcn_sched_barrier(0);
+            block<PB>(pa, ba, ca, u1, u2, yr);
+            const int next = t0 + 2 * PB < SUB ? 2 * PB : 0;  // (the last block reads itself again: no branch around the reads)
+#pragma unroll
+            for (int i = 0; i < PB; ++i) pa[i] = pr[next + i], ba[i] = pr[SUB + next + i], ca[i] = pr[2 * SUB + next + i];
+            __builtin_amdgcn_sched_barrier(0);
+            block<PB>(pb, bb, cb, u1, u2, yr + PB / 4);
+            pr += 2 * PB;
+            yr += PB / 2;
+        }
+        const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;
+        if (X.lane == 0) *(lds_u32 *)(uintptr_t)row_address(tile, WAVES * R) = met_nan ? 1u : 0u;
+        if (!met_nan) {
+            mem[0] = u1;
+            mem[1] = u2;
+        }
+#ifdef DUSP_JIT_PROFILE
+        cyc_serial += __builtin_readcyclecounter() - stamp0;
+#endif
+    }
+    static __device__ __forceinline__ bool failed(double *tile) {
+        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)row_address(tile, WAVES * R)) != 0;
+    }
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
+        if (X.wave != who || X.lane >= WAVES * R) return;
+        const uint32_t row = row_address(tile, X.lane);
+        const lds_double *pr = (const lds_double *)(uintptr_t)row;
+        lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
+        lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
+        double y1 = mem[0], y2 = mem[1];
+        for (int t0 = 0; t0 < SUB; t0 += 4) {
+            double pv[4], b1[4], b2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = pr[t0 + i], b1[i] = pr[SUB + t0 + i], b2[i] = pr[2 * SUB + t0 + i];
+            f32x4 y4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = (float)((pv[i] - b1[i] * jit_or0(y1)) - b2[i] * jit_or0(y2));
+                y4[i] = y;
+                y2 = jit_or0(y1);
+                y1 = (double)y;
+            }
+            yr[t0 >> 2] = y4;
+        }
+        mem[0] = y1;
+        mem[1] = y2;
+    }
+    __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int kind, int state_slot) const {
+        if (!X.live || X.lane != 0) return;
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
-        st[0] = has_last ? 1.0 : 0.0;
-        st[A.n_pad] = lastF;
-        for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
-        st[(size_t)7 * A.n_pad] = x1;
-        st[(size_t)8 * A.n_pad] = x2;
-        st[(size_t)9 * A.n_pad] = y1;
-        st[(size_t)10 * A.n_pad] = y2;
+        const double *is = A.init_state + state_slot;
+        if (ticked[r]) {
+            double k[5];
+            jit_filter_coefficients(kind, (double)flast[r], X.srd, k);
+            st[0] = 1.0;
+            st[A.n_pad] = (double)flast[r];
+            for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = k[i];
+        } else
+            for (int i = 0; i < 7; ++i) st[(size_t)i * A.n_pad] = is[i];
+        st[(size_t)7 * A.n_pad] = (double)x1[r];
+        st[(size_t)8 * A.n_pad] = (double)x2[r];
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const double *tile, int state_slot) const {
+        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
+        if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst) return;
+        double *st = A.state + (size_t)state_slot * A.n_pad + inst;
+        const lds_double *mem = (const lds_double *)(uintptr_t)const_cast<JitFilterKM *>(this)->memory_address(const_cast<double *>(tile), X.lane);
+        st[(size_t)9 * A.n_pad] = mem[0];
+        st[(size_t)10 * A.n_pad] = mem[1];
     }
 };
 

@@ -96,10 +96,9 @@ __global__ void __launch_bounds__(256) dusp_loop2_kernel(ChunkArgs a, LoopShape 
         b2 = st[6 * NP];
         lastF = st[NP];
         if (!has_lastF || ft != lastF) {
-            const double PI = 3.141592653589793;
             lastF = ft;
             if (L.filter.attr == 0) {  // LP (Filter.js:67-75)
-                const double lamda = 1.0 / tan(PI * ft / srd);
+                const double lamda = filter_lamda(0, ft, srd);
                 const double l2 = lamda * lamda;
                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                 a1 = 2.0 * a0;
@@ -107,7 +106,7 @@ __global__ void __launch_bounds__(256) dusp_loop2_kernel(ChunkArgs a, LoopShape 
                 b1 = 2.0 * a0 * (1.0 - l2);
                 b2 = a0 * (1.0 - 2.0 * lamda + l2);
             } else {  // HP (Filter.js:76-84)
-                const double lamda = tan(PI * ft / srd);
+                const double lamda = filter_lamda(1, ft, srd);
                 const double l2 = lamda * lamda;
                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                 a1 = 0.0;
@@ -367,10 +366,9 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
         b2 = st[6 * NP];
         lastF = st[NP];
         if (!has_lastF || ft != lastF) {
-            const double PI = 3.141592653589793;
             lastF = ft;
             if (L.filter.attr == 0) {  // LP (Filter.js:67-75)
-                const double lamda = 1.0 / tan(PI * ft / srd);
+                const double lamda = filter_lamda(0, ft, srd);
                 const double l2 = lamda * lamda;
                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                 a1 = 2.0 * a0;
@@ -378,7 +376,7 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
                 b1 = 2.0 * a0 * (1.0 - l2);
                 b2 = a0 * (1.0 - 2.0 * lamda + l2);
             } else {  // HP (Filter.js:76-84)
-                const double lamda = tan(PI * ft / srd);
+                const double lamda = filter_lamda(1, ft, srd);
                 const double l2 = lamda * lamda;
                 a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
                 a1 = 0.0;

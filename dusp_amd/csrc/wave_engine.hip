@@ -60,9 +60,8 @@ __device__ __forceinline__ double or0w(double v) { return (v != v || v == 0.0) ?
 
 // Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
 __device__ __forceinline__ void filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
-    const double PI = 3.141592653589793;
     if (kind == 0) {
-        const double lamda = 1.0 / tan(PI * f / sr);
+        const double lamda = filter_lamda(0, f, sr);
         const double l2 = lamda * lamda;
         k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
         k[1] = 2.0 * k[0];
@@ -70,7 +69,7 @@ __device__ __forceinline__ void filter_coefficients(int kind, double f, double s
         k[3] = 2.0 * k[0] * (1.0 - l2);
         k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
     } else {
-        const double lamda = tan(PI * f / sr);
+        const double lamda = filter_lamda(1, f, sr);
         const double l2 = lamda * lamda;
         k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
         k[1] = 0.0;

@@ -61,3 +61,15 @@ def test_descriptor_sizes_are_bounded_before_anything_is_allocated(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "compile_bounds_check.cpp")])
     rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
     assert rep["cases"] == 6 and rep["bad"] == 0
+
+
+def test_filter_lamda_is_within_a_few_ulp_of_the_reference_expression(tmp_path):
+    """dusp_amd/csrc/filter_lamda.hpp (what every engine computes 1 / tan(PI f / sr) and tan(PI f / sr) with, for cutoffs below Nyquist)
+    against the expression in extended precision: 4.8 million cutoffs; outside the range the math library's own value, bit for bit."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "filter_lamda_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "filter_lamda_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] > 4_000_000 and rep["bad_fallback"] == 0
+    assert rep["worst_ulp_lp"] <= 2.5 and rep["worst_ulp_hp"] <= 2.5, rep

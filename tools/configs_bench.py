@@ -7,6 +7,7 @@
   configs[4] cfg5   65536-voice sweep Multiply(Osc(20+k/8), Ramp): one GPU's shard = 8192 voices x 1 s
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -22,6 +23,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="scale durations (for quick runs)")
+    ap.add_argument("--json", default="", help="write one record per config (for tools/profile_summary.py)")
     args = ap.parse_args()
     import torch
     import dusp_amd as d
@@ -31,9 +33,9 @@ def main():
     ctx = runtime.Context(0, sr)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def loop(k):
+    def loop(k, delay=480):
         s = d.Sum(d.Osc(110 + k / 64), 0)
-        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        f = d.Filter(d.Delay(s, delay, 4096), 2000)
         s.B = d.Multiply(f, 0.5)
         return f
 
@@ -41,6 +43,7 @@ def main():
         return descriptor.unify([descriptor.extract(g) for g in graphs])
 
     cfgs = {}
+    records = []
     T10 = int(10 * sr * args.scale)
     T60 = int(60 * sr * args.scale)
     T1 = int(1 * sr * args.scale)
@@ -52,6 +55,8 @@ def main():
     cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
                              (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
     cfgs["cfg4_loop8192_loop_engine"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_LOOP)
+    # a delay-time sweep of the configs[3] voice: delay = 300 + k % 400 samples per instance (parameter rows: f, delay — in unit order)
+    cfgs["cfg4_delay_sweep"] = (lambda: uni_of([loop(k, 300 + k % 400) for k in (0, 65)]), T10, "delay_sweep")
     cfgs["cfg5_shard8192"] = (lambda: uni_of([d.Multiply(d.Osc(20 + k / 8), d.Ramp(T1, 1, 0).trigger()) for k in (0, 1)]), T1,
                               (20 + np.arange(8192) / 8.0).astype(np.float32).reshape(1, -1))
     for name, cfg in cfgs.items():
@@ -61,6 +66,12 @@ def main():
             continue
         t0 = time.time()
         uni = build()
+        if isinstance(params, str):  # delay sweep: which row is f, which the delay, is read off the two circuits
+            k = np.arange(8192)
+            rows = []
+            for p in range(uni.n_params):
+                rows.append((110 + k / 64.0) if abs(float(uni.params[p, 0]) - 110.0) < 1e-3 else (300 + k % 400).astype(np.float64))
+            params = np.ascontiguousarray(np.stack(rows).astype(np.float32))
         prog = ctx.build(uni.words, engine)
         n_inst = params.shape[1] if params is not None else 1
         dp = torch.from_numpy(params).cuda() if params is not None else None
@@ -79,8 +90,13 @@ def main():
         samples = float(n_inst) * prog.n_out_channels * n
         print("%-16s engine=%-5s %-18s inst=%-6d n=%-8d  %10.3f ms  %12.1f Msamples/s out  %8.1f GB/s  (host build %.2fs)"
               % (name, prog.engine, prog.shape, n_inst, n, ms, samples / ms / 1e3, 4 * samples / ms / 1e6, host_s), flush=True)
+        records.append({"config": name, "engine": prog.engine, "shape": prog.shape, "kernel": "dusp_jit_render" if "compiled kernel" in prog.shape else "dusp_%s_kernel" % prog.engine,
+                        "instances": n_inst, "channels": prog.n_out_channels, "n_samples": n, "avg_ms": round(ms, 4),
+                        "first_render_ms_compile_inclusive": round(ts[0], 3), "algorithmic_bytes": 4 * samples, "frac_of_8TBps": round(4 * samples / (ms * 1e-3) / 8e12, 4)})
         prog.close()
         del out
+    if args.json:
+        json.dump(records, open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

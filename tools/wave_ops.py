@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-unit cost on the wave engine: small graphs forced onto ENGINE_WAVE, 16384 instances x 1 s (time split off).
-  python tools/wave_ops.py ["--only=name;name"]"""
+"""Per-unit cost on the wave engine: small graphs forced onto ENGINE_WAVE, 16384 instances x 1 s (time split off), and patch
+topologies (descriptors extracted from the reference's own patch objects: tests/golden/patch_*) x 1024 instances.
+  python tools/wave_ops.py ["--only=name;name"] [--json=path]     (--json: one record per graph, for tools/profile_summary.py)"""
+import json
 import os
 import sys
 
@@ -42,26 +44,46 @@ graphs = {
     "filter(filter(osc))": lambda k: d.Filter(d.Filter(d.Osc(110 + k / 8), 900), 1200),
 }
 only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+json_path = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json=")] or [None])[0]
+records = []
+# patch topologies: the reference's own patches as extracted descriptors (constants only: every instance renders the same circuit)
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+PATCHES = ["patch_fm_osc", "patch_simple_delay", "patch_multitap", "patch_many_osc", "patch_stereo_detune", "patch_space"]
+for name in PATCHES:
+    graphs["%s x 1024" % name] = name
 for name, g in graphs.items():
     if only and name not in only[0].split(";"):
         continue
-    full = descriptor.unify([descriptor.extract(g(k)) for k in (0, 8, 16)])
-    base = full.params[:, 0].astype(np.float64)
-    step = (full.params[:, 1].astype(np.float64) - base) / 8.0
-    params = (base[:, None] + step[:, None] * np.arange(V)[None, :]).astype(np.float32)
-    dp = torch.from_numpy(np.ascontiguousarray(params)).cuda()
-    prog = ctx.build(full.words, runtime.ENGINE_WAVE)
-    out = torch.empty((V, prog.n_out_channels, n), dtype=torch.float32, device="cuda")
+    if isinstance(g, str):
+        words = np.fromfile(os.path.join(GOLDEN, g + ".desc.f64"), dtype=np.float64)
+        V_, dp, params = 1024, None, None
+        prog = ctx.build(words, runtime.ENGINE_AUTO)
+    else:
+        full = descriptor.unify([descriptor.extract(g(k)) for k in (0, 8, 16)])
+        base = full.params[:, 0].astype(np.float64)
+        step = (full.params[:, 1].astype(np.float64) - base) / 8.0
+        params = (base[:, None] + step[:, None] * np.arange(V)[None, :]).astype(np.float32)
+        dp = torch.from_numpy(np.ascontiguousarray(params)).cuda()
+        V_ = V
+        prog = ctx.build(full.words, runtime.ENGINE_WAVE)
+    out = torch.empty((V_, prog.n_out_channels, n), dtype=torch.float32, device="cuda")
     ts = []
     for r in range(3):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        prog.render_device(n, V, dp.data_ptr(), out.data_ptr(), stream)
+        prog.render_device(n, V_, dp.data_ptr() if dp is not None else None, out.data_ptr(), stream)
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
+    first_ms = ts[0]
     prog._read_info()
-    print("%-22s %8.3f ms  %8.1f Gsamples/s   [%s]" % (name, ms, V * n / ms / 1e6, prog.shape), flush=True)
+    algo = 4.0 * V_ * prog.n_out_channels * n
+    print("%-28s %8.3f ms  %8.1f Gsamples/s  %5.1f %% of 8 TB/s   [%s %s]" % (name, ms, V_ * prog.n_out_channels * n / ms / 1e6, 100 * algo / (ms * 1e-3) / 8e12, prog.engine, prog.shape), flush=True)
+    records.append({"graph": name, "kernel": "dusp_jit_render" if "compiled kernel" in prog.shape else prog.engine, "engine": prog.engine, "shape": prog.shape,
+                    "instances": V_, "channels": prog.n_out_channels, "n_samples": n, "avg_ms": round(ms, 4), "first_render_ms_compile_inclusive": round(first_ms, 3),
+                    "algorithmic_bytes": algo, "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4)})
     prog.close()
     del out
+if json_path:
+    json.dump(records, open(json_path, "w"), indent=1)
