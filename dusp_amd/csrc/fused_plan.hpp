@@ -39,6 +39,11 @@ struct FusedPlan {
     std::vector<double> sum_f, sum_phase0;
     std::vector<int> sum_units;
     bool sum_all_int = false;
+    // ... whose voices may be enveloped: every voice Multiply(Osc, k) (sum_env 1: sum_gain per voice) or every voice
+    // Multiply(Osc, Ramp) with Ramps that are equal in constants and state (sum_env 2: the r_* fields above describe them all)
+    int sum_env = 0;
+    std::vector<float> sum_gain;
+    std::vector<int> sum_ramp_units;
     // state write-back: words [first, first+count) of the end-state block belong to unit u
     int n_state_words = 0;
     std::vector<int> unit_state_first, unit_state_count;
@@ -58,6 +63,8 @@ struct OscRec {
 // phase of (block b, lane l, sample c) = (B0 + b*bs + l*step4 + c*Fm) mod (sampleRate << 32).
 struct SumVoice {
     uint64_t B0, bs, step4, step256, Fm;
+    float gain;  // enveloped chains of kind 1: the voice's Multiply constant
+    uint32_t pad;
 };
 
 struct SumArgs {
@@ -67,6 +74,8 @@ struct SumArgs {
     uint64_t n_samples, S;
     double inv_S, inv_sr;
     uint32_t n_voices, n_inst, n_groups, n_blocks, sample_rate, vec4_ok;
+    double r_d, r_y0, r_y1, r_t0;  // the voices' common Ramp (kernels instantiated with ENV == 2)
+    int32_t r_playing, r_fastdiv;
 };
 
 // The feedback voice of BASELINE configs[3] as the loop engine sees it (chunk_engine.hip).
@@ -276,7 +285,7 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
                 if (in.kind != IN_CONNECT) return no("Sum with a constant operand");
                 const UnitDesc &s = g.units[(size_t)in.src_unit];
                 if (s.op == OP_SUM && next < 0) next = in.src_unit;
-                else if (s.op == OP_OSC) oscs[k] = in.src_unit;
+                else if (s.op == OP_OSC || s.op == OP_MULTIPLY) oscs[k] = in.src_unit;  // (a voice: a bare oscillator, or an enveloped one — looked into below)
                 else return no("unsupported Sum operand");
             }
             if (next >= 0) {
@@ -293,10 +302,42 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
         plan.kind = FUSED_SUMCHAIN;
         plan.shape = "sumchain(osc(k) x " + std::to_string(rev.size()) + ")";
         plan.sum_all_int = true;
+        plan.sum_env = -1;
         for (auto it = rev.rbegin(); it != rev.rend(); ++it) {
-            const int ui = *it;
+            int ui = *it;
             if (ui < 0) return no("malformed chain");
+            int env = 0;
+            if (g.units[(size_t)ui].op == OP_MULTIPLY) {  // Multiply(Osc, k) or Multiply(Osc, Ramp), operands in either order
+                const UnitDesc &m = g.units[(size_t)ui];
+                used[(size_t)ui]++;
+                int osc = -1;
+                for (int k = 0; k < 2; k++) {
+                    const InletDesc &in = m.inlets[(size_t)k];
+                    if (in.kind == IN_CONNECT && g.units[(size_t)in.src_unit].op == OP_OSC && osc < 0) osc = in.src_unit;
+                    else if (in.kind == IN_CONNECT && g.units[(size_t)in.src_unit].op == OP_RAMP && env == 0) {
+                        env = 2;
+                        const UnitDesc &r = g.units[(size_t)in.src_unit];
+                        used[(size_t)in.src_unit]++;
+                        if (plan.sum_ramp_units.empty()) {
+                            plan.r_d = r.attrs[0]; plan.r_y0 = r.attrs[1]; plan.r_y1 = r.attrs[2];
+                            plan.r_t0 = r.state[0]; plan.r_playing = r.state[1] != 0;
+                        } else if (plan.r_d != r.attrs[0] || plan.r_y0 != r.attrs[1] || plan.r_y1 != r.attrs[2] || plan.r_t0 != r.state[0] ||
+                                   plan.r_playing != (r.state[1] != 0))
+                            return no("chain voices with different Ramps");
+                        plan.sum_ramp_units.push_back(in.src_unit);
+                    } else if (in.kind == IN_CONST && in.vals.size() == 1 && env == 0) {
+                        env = 1;
+                        plan.sum_gain.push_back((float)in.vals[0]);
+                    } else
+                        return no("unsupported voice in the chain");
+                }
+                if (osc < 0 || env == 0) return no("unsupported voice in the chain");
+                ui = osc;
+            }
+            if (plan.sum_env < 0) plan.sum_env = env;
+            else if (plan.sum_env != env) return no("chain voices of different kinds");
             const UnitDesc &o = g.units[(size_t)ui];
+            if (o.op != OP_OSC) return no("malformed chain");
             used[(size_t)ui]++;
             const InletDesc &fin = o.inlets[0];
             if (fin.kind != IN_CONST || fin.vals.size() != 1) return no("chain oscillator needs a constant f");
@@ -322,6 +363,19 @@ inline bool plan_fused(const Program &P, FusedPlan &plan) {
             plan.unit_state_first[(size_t)ui] = plan.n_state_words++;
             plan.unit_state_count[(size_t)ui] = 1;
         }
+        if (plan.sum_env == 2) {
+            if (!(plan.r_d > 0) || !std::isfinite(plan.r_d) || !std::isfinite(plan.r_t0) || plan.r_t0 > plan.r_d || (plan.r_playing && !(plan.r_t0 + 1 >= 0)))
+                return no("chain Ramp outside the closed-form regime");
+            plan.r_rcp = 1.0 / plan.r_d;
+            plan.r_fastdiv = ramp_fastdiv_ok(plan.r_t0, plan.r_d, plan.r_playing != 0) ? 1 : 0;
+            for (int ui : plan.sum_ramp_units) {  // [t, playing] per Ramp unit, behind the oscillators' phases
+                plan.unit_state_first[(size_t)ui] = plan.n_state_words;
+                plan.unit_state_count[(size_t)ui] = 2;
+                plan.n_state_words += 2;
+            }
+        }
+        if (plan.sum_env == 1) plan.shape = "sumchain(osc(k) * k x " + std::to_string(plan.sum_units.size()) + ")";
+        if (plan.sum_env == 2) plan.shape = "sumchain(osc(k) * ramp x " + std::to_string(plan.sum_units.size()) + ")";
         return true;
     } else
         return no("root is not an Osc, a Multiply or a Sum chain");
@@ -406,9 +460,17 @@ inline void build_sum_voices(const FusedPlan &plan, uint32_t sample_rate, int gb
         v.bs = (uint64_t)(((u128)Fm * (uint64_t)(gb * kChunk)) % S);
         v.step4 = (uint64_t)(((u128)Fm * 4) % S);
         v.step256 = (uint64_t)(((u128)Fm * kChunk) % S);
+        v.gain = plan.sum_env == 1 ? plan.sum_gain[j] : 1.f;
+        v.pad = 0;
         voices.push_back(v);
         end_phase.push_back(std::ldexp((double)(uint64_t)(((u128)P0 + (u128)Fm * T_end) % S), -32));
     }
+    if (plan.sum_env == 2)  // what every Ramp holds after T_end ticks (Ramp.js:27-36): behind the phases, [t, playing] per unit
+        for (size_t j = 0; j < plan.sum_ramp_units.size(); j++) {
+            const double since = (double)T_end;
+            end_phase.push_back(plan.r_playing ? std::fmin(plan.r_t0 + since, plan.r_d) : plan.r_t0);
+            end_phase.push_back((plan.r_playing && plan.r_t0 + since <= plan.r_d) ? 1.0 : 0.0);
+        }
 }
 
 // Regime of a per-instance (parameter) delay, found by looking at the parameter column when a render starts (dusp_abi.hip

@@ -1009,6 +1009,131 @@ struct JitRingOps {
     }
 };
 
+// ---- Delay with a signal-rate delay (an LFO on the delay time: SimpleDelay, chorus, flanger), Delay.js:26-40, WITHOUT slot rounds
+// where the taps allow it.  What the reference does to one ring slot during a chunk is a sequence in sample order: the read-and-clear
+// of the sample whose slot it is (slot s0 + t belongs to sample t), and the `+=` of every tap that lands there, each rounded to
+// f32.  When the tap positions t + delay[t] do not decrease along the chunk (a delay that falls by less than a sample per sample:
+// any audio-rate modulation short of a jump), the samples whose floor tap lands in one slot are CONSECUTIVE, so a slot's whole
+// sequence follows from two small groups of samples — those with floor(position) = slot (floor taps) and slot - 1 (ceil taps):
+// every lane takes slots of its own and replays their sequences out of the chunk's inputs in LDS, the ring is read and written once per
+// touched slot, nothing is bid for and nothing waits on another lane.  A chunk whose taps do decrease somewhere (or that holds a
+// negative / NaN delay, or spans more slots than the tables hold) takes the ordered slot operations (JitRingOps) instead —
+// whatever the modulation does, the result is the reference's.
+// scr: 1536 floats per wave — x (256 f32), the taps' fractions (256 f64), the groups' first / last samples (768 x 2 u16); the slot
+// operations' ownership table (1024 words) takes the same space when a chunk needs them.
+struct JitDelayGather {
+    JitRingOps rounds;  // (holds T: the previous chunk's last input, what the unit's state carries)
+    static constexpr int kTable = 768;
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot) { rounds.begin_delay(A, X, state_slot); }
+    __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, float *scr, int64_t ring_base, uint32_t len, const float (&x)[4],
+                                         const float (&dl)[4], float (&out)[4]) {
+        const double dlen = (double)len;
+        const uint32_t lane = X.lane;
+        const uint32_t tb0 = (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
+        // where every sample's taps land, exactly as Delay.js:33-36 computes it
+        int32_t rl[4];   // floor tap's slot, relative to the chunk's first slot (0 .. len - 1), or -1
+        double fr[4];
+        bool ok = len >= 2u * kChunk;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t t = lane * 4 + c;
+            uint32_t tb = tb0 + t;
+            if (tb >= len) tb -= len;
+            double tW = (double)tb + (double)dl[c];
+            if (!(tW >= 0.0 && tW < dlen)) tW = (tW >= dlen && tW < 2.0 * dlen) ? tW - dlen : fmod(tW, dlen);
+            const double lo = floor(tW);
+            fr[c] = tW - trunc(tW);
+            const bool valid = lo >= 0.0 && lo < dlen;
+            ok = ok && valid;
+            int32_t r = valid ? (int32_t)lo - (int32_t)tb0 : -1;
+            if (valid && r < 0) r += (int32_t)len;
+            rl[c] = r;
+        }
+        // non-decreasing along the chunk, and the span the tables can hold?
+        const int32_t before = __builtin_amdgcn_update_dpp(0, rl[3], 0x138, 0xf, 0xf, false);   // lane - 1's last (lane 0: 0)
+        const int32_t after = __builtin_amdgcn_update_dpp(0x7fffffff, rl[0], 0x130, 0xf, 0xf, false);  // lane + 1's first (lane 63: "more")
+        ok = ok && rl[0] >= before && rl[1] >= rl[0] && rl[2] >= rl[1] && rl[3] >= rl[2];
+        const int32_t base = __builtin_amdgcn_readlane(rl[0], 0), top = __builtin_amdgcn_readlane(rl[3], 63);
+        ok = ok && top - base + 2 <= kTable && (uint32_t)(top + 2) <= len;  // (every relative slot up to top + 1 is a ring slot of its own)
+        if (!__all(ok)) {
+            rounds.tick<OP_DELAY, 0>(A, X, g, scr, ring_base, len, x, dl, out);
+            return;
+        }
+        float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
+        float *Xr = scr;                       // [256]
+        double *Fr = (double *)(scr + 256);    // [256]
+        uint32_t *Gr = (uint32_t *)(scr + 768);  // [kTable]: first sample | last sample << 16 of the group whose floor taps land at base + index
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the last chunk's ring stores have landed (other lanes read those slots now)
+        // this lane's own slots (relative 4 lane + c: the chunk's read window), fetched while the tables are laid out
+        float old[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t a = tb0 + lane * 4 + c;
+            if (a >= len) a -= len;
+            old[c] = ring[a];
+        }
+        jit_wave_sync();  // (the scratch's previous user is done)
+        jit_row_put(Xr, lane, x);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Fr[lane * 4 + c] = fr[c];
+#pragma unroll
+        for (int k = 0; k < kTable / 256; ++k) ((uint4 *)Gr)[lane + 64 * k] = uint4{0xffffu, 0xffffu, 0xffffu, 0xffffu};  // first 65535, last 0: empty
+        jit_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int32_t prev = c == 0 ? (lane == 0 ? -2 : before) : rl[c - 1], next = c == 3 ? after : rl[c + 1];
+            unsigned short *e = (unsigned short *)(Gr + (rl[c] - base));
+            if (rl[c] != prev) e[0] = (unsigned short)(lane * 4 + c);
+            if (rl[c] != next) e[1] = (unsigned short)(lane * 4 + c);
+        }
+        jit_wave_sync();
+        // One slot's sequence.  r: relative slot; acc: what the ring holds there; returns what the slot's own sample reads (r < 256).
+        auto replay = [&](int32_t r, float &acc) __attribute__((always_inline)) -> float {
+            uint32_t a = tb0 + (uint32_t)r;
+            if (a >= len) a -= len;
+            const int32_t idx = r - base;
+            float seen = 0.f;
+            bool pending = r < kChunk;
+            for (int which = 0; which < 2; ++which) {  // ceil taps of the group below, then floor taps of the slot's own group
+                const int32_t gi = idx - 1 + which;
+                if (gi < 0 || gi > top - base) continue;
+                const uint32_t e = Gr[gi];
+                const int32_t first = (int32_t)(e & 0xffffu), last = (int32_t)(e >> 16);
+                for (int32_t t = first; t <= last; ++t) {
+                    if (pending && t >= r) { seen = acc; acc = 0.f; pending = false; }  // `out[t] = buf[tB]; buf[tB] = 0` (Delay.js:28-29)
+                    const double xin = (double)Xr[t], f = Fr[t];
+                    if (which == 0) {
+                        if (f != 0.0 && a != 0u) acc = (float)((double)acc + xin * f);  // ceil tap (at index `length` — slot 0 — it is dropped)
+                    } else {
+                        acc = (float)((double)acc + xin * (1.0 - f));                   // floor tap
+                        if (f == 0.0) acc = (float)((double)acc + xin * f);             // ... and a ceil tap that lands on the same slot
+                    }
+                }
+            }
+            if (pending) { seen = acc; acc = 0.f; }
+            return seen;
+        };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = old[c];
+            out[c] = replay((int32_t)(lane * 4 + c), acc);
+            uint32_t a = tb0 + lane * 4 + c;
+            if (a >= len) a -= len;
+            if (X.live) ring[a] = acc;
+        }
+        // slots beyond the read window that taps reach: read-modify-write, one lane each
+        for (int32_t r = (base > kChunk ? base : kChunk) + (int32_t)lane; r <= top + 1; r += 64) {
+            uint32_t a = tb0 + (uint32_t)r;
+            if (a >= len) a -= len;
+            float acc = ring[a];
+            (void)replay(r, acc);
+            if (X.live) ring[a] = acc;
+        }
+        rounds.T = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+    }
+};
+
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;

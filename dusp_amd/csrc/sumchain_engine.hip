@@ -13,6 +13,11 @@
 // phase of (block b, lane l, sample c) is (B0 + b*bs + l*step4 + c*Fm) mod S evaluated with exact
 // integer arithmetic (quotients estimated in f64 and corrected), then advanced by step256 per group
 // — the same INT / FX32 paths as fused_engine.hip.
+//
+// Enveloped voices (ENV): a chain of Multiply(Osc, k) voices multiplies every lookup by the voice's constant (ENV 1); a chain of
+// Multiply(Osc, Ramp) voices whose Ramps are equal — the usual mix of enveloped voices — evaluates the Ramp ONCE per work item
+// (a function of the sample index alone: 4 x GB values per lane) and multiplies every voice's lookups by it (ENV 2): each
+// product is one f32 rounding like the Multiply unit's (Multiply.js:23-34), then the Sum's.
 #include <hip/hip_runtime.h>
 
 #include "device_types.hpp"
@@ -21,7 +26,7 @@
 
 namespace dusp {
 
-template <int TBL, bool INT, int GB, bool FINITE, int BLOCK>
+template <int TBL, bool INT, int GB, bool FINITE, int BLOCK, int ENV>
 __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds_table[];
     Table<TBL> table;
@@ -46,6 +51,24 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
 #pragma unroll
         for (int g = 0; g < GB; ++g)
             for (int c = 0; c < 4; ++c) acc[g][c] = 0.f;  // 0 + v0 == v0: the chain starts at the first voice
+        float env[ENV == 2 ? GB : 1][4];
+        if (ENV == 2) {  // Ramp.js:25-40 in closed form: t(n) = min(t0 + n + 1, duration) while playing
+            const double dy = A.r_y1 - A.r_y0, rcp = 1.0 / A.r_d;
+#pragma unroll
+            for (int g = 0; g < (ENV == 2 ? GB : 1); ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint64_t n = (uint64_t)(g0 + g) * kChunk + lane * 4 + c;
+                    const double tt = A.r_playing ? fmin(A.r_t0 + (double)(n + 1), A.r_d) : A.r_t0;
+                    double q;
+                    if (A.r_fastdiv) {  // (the host has checked the refined reciprocal against the division on every t of this Ramp)
+                        q = tt * rcp;
+                        q = fma(fma(-q, A.r_d, tt), rcp, q);
+                    } else
+                        q = tt / A.r_d;
+                    env[g][c] = (float)(A.r_y0 + q * dy);
+                }
+        }
 
         for (uint32_t j = 0; j < A.n_voices; ++j) {
             const SumVoice rc = A.voices[j];
@@ -64,7 +87,10 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
                 for (int g = 0; g < GB; ++g)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[g][c] = acc[g][c] + table.at(idx[c]);  // f32 add, rounded per voice like the Sum units
+                        float v = table.at(idx[c]);
+                        if (ENV == 1) v = v * rc.gain;          // the voice's Multiply: one f32 rounding
+                        if (ENV == 2) v = v * env[g][c];
+                        acc[g][c] = acc[g][c] + v;  // f32 add, rounded per voice like the Sum units
                         idx[c] += s256;
                         idx[c] = min(idx[c], idx[c] - sr);
                     }
@@ -89,7 +115,10 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
                         const double wb = (double)F[c];
                         const double wa = 4294967296.0 - wb;
                         const float x = (float)((double)ta * wa + (double)tb * wb);  // see fused_engine.hip FX32
-                        acc[g][c] = acc[g][c] + ldexpf(x, -32);
+                        float v = ldexpf(x, -32);
+                        if (ENV == 1) v = v * rc.gain;
+                        if (ENV == 2) v = v * env[g][c];
+                        acc[g][c] = acc[g][c] + v;
                         const uint32_t f2 = F[c] + dF;
                         uint32_t i2 = I[c] + dI + (f2 < F[c] ? 1u : 0u);
                         i2 = min(i2, i2 - sr);
@@ -114,9 +143,9 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
     }
 }
 
-template <int TBL, bool INT, int GB, bool FINITE, int BLOCK>
+template <int TBL, bool INT, int GB, bool FINITE, int BLOCK, int ENV>
 static hipError_t launch_sum(const SumArgs &A, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = dusp_sumchain_kernel<TBL, INT, GB, FINITE, BLOCK>;
+    auto kernel = dusp_sumchain_kernel<TBL, INT, GB, FINITE, BLOCK, ENV>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -140,16 +169,24 @@ hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const Su
     A.n_blocks = (A.n_groups + gb - 1) / gb;
     A.sample_rate = L.sample_rate;
     A.vec4_ok = (L.n_samples % 4 == 0) && (((uintptr_t)L.out & 15) == 0);
+    A.r_d = plan.r_d;
+    A.r_y0 = plan.r_y0;
+    A.r_y1 = plan.r_y1;
+    A.r_t0 = plan.r_t0;
+    A.r_playing = plan.r_playing;
+    A.r_fastdiv = plan.r_fastdiv;
 
     const bool tbl = L.table_antisym && L.sample_rate % 2 == 0 && half_table_lds_bytes(L.sample_rate) <= 160 * 1024;
     const size_t lds_bytes = tbl ? half_table_lds_bytes(L.sample_rate) : 0;
     const int grid = tbl ? L.n_cus : L.n_cus * 8;
-    const bool finite = L.table_finite;
+    const bool finite = L.table_finite && plan.sum_env == 0;  // (enveloped voices: products may overflow, so the copy-out keeps the full `x || 0`)
     // INT needs blk * (bs >> 32) < 2^32
     const bool use_int = plan.sum_all_int && (uint64_t)A.n_blocks * L.sample_rate < (1ull << 32);
 
+#define DUSP_S5(TB, IN, G, FIN, EN) \
+    return TB ? launch_sum<1, IN, G, FIN, 1024, EN>(A, grid, lds_bytes, stream) : launch_sum<0, IN, G, FIN, 256, EN>(A, grid, 0, stream)
 #define DUSP_S4(TB, IN, G, FIN) \
-    return TB ? launch_sum<1, IN, G, FIN, 1024>(A, grid, lds_bytes, stream) : launch_sum<0, IN, G, FIN, 256>(A, grid, 0, stream)
+    do { if (plan.sum_env == 2) { DUSP_S5(TB, IN, G, FIN, 2); } if (plan.sum_env == 1) { DUSP_S5(TB, IN, G, FIN, 1); } DUSP_S5(TB, IN, G, FIN, 0); } while (0)
 #define DUSP_S3(IN, G) \
     do { if (finite) { DUSP_S4(tbl, IN, G, true); } DUSP_S4(tbl, IN, G, false); } while (0)
     if (gb == 8) {
@@ -160,6 +197,7 @@ hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const Su
     DUSP_S3(false, 4);
 #undef DUSP_S3
 #undef DUSP_S4
+#undef DUSP_S5
 }
 
 }  // namespace dusp

@@ -309,13 +309,65 @@ def test_sum_many_chain_fused_matches_oracle(fs, oracle):
         prog.close()
 
 
+@pytest.mark.parametrize("kind", ["ramp_int", "ramp_frac", "ramp_idle", "gain", "gain_first_operand"])
+def test_sum_many_chain_of_enveloped_voices_matches_oracle(kind, oracle):
+    """Sum.many over Multiply(Osc, Ramp) / Multiply(Osc, k) voices (Sum.js:18-29, Multiply.js:23-34): the mix of enveloped voices on the
+    fused sum chain — one f32 rounding per product, one per add, in chain order; PCM and every unit's state against the oracle."""
+    d.configure(48000)
+    n = 256 * 29 + 77
+    if kind == "ramp_int":
+        voices = [d.Multiply(d.Osc(10.0 * k), d.Ramp(5000, 1, 0).trigger()) for k in range(1, 38)]
+    elif kind == "ramp_frac":
+        voices = [d.Multiply(d.Ramp(7000.5, 0.25, 1.5).trigger(), d.Osc(20 + k / 8)) for k in range(33)]
+    elif kind == "ramp_idle":
+        voices = [d.Multiply(d.Osc(100.5 * k), d.Ramp(300, 0.5, 2)) for k in range(1, 9)]  # never triggered: a constant y0
+    elif kind == "gain":
+        voices = [d.Multiply(d.Osc(30.0 * k), 1.0 / k) for k in range(1, 50)]
+    else:
+        voices = [d.Multiply(0.5 + k / 7, d.Osc(55.25 * k)) for k in range(1, 20)]
+    ex = descriptor.extract(d.Sum.many(voices))
+    want, states = oracle.render(ex.words, n, return_state=True)
+    for engine in (runtime.ENGINE_AUTO, runtime.ENGINE_CHUNK):
+        prog = render.context(48000).build(ex.words, engine)
+        if engine == runtime.ENGINE_AUTO:
+            assert prog.engine == "fused" and prog.shape.startswith("sumchain(osc(k) * "), (prog.engine, prog.shape)
+        got = prog.render(n)[0]
+        assert np.array_equal(got, want), "first mismatch at %d" % int(np.argmax(got != want))
+        for u, st in enumerate(states):
+            assert np.array_equal(prog.state(u), st), u
+        prog.close()
+
+
+def test_config2_enveloped_mixdown_full_size(oracle):
+    """1024 x Multiply(Osc(10k), Ramp(T, 1, 0) triggered) through Sum.many, 60 s: the head against the oracle, the rest by properties —
+    the un-enveloped mix repeats every 4800 samples, so sample n of this one is that mix's sample (n mod 4800) scaled voice by voice by
+    the same envelope: bounded by 1024 x env(n), and zero wherever the plain mix's period has all voices at a zero crossing (n = 0 mod 4800)."""
+    d.configure(48000)
+    n = 2880000
+    ex = descriptor.extract(d.Sum.many([d.Multiply(d.Osc(10 * k), d.Ramp(n, 1, 0).trigger()) for k in range(1, 1025)]))
+    prog = render.context(48000).build(ex.words)
+    assert prog.engine == "fused" and prog.shape == "sumchain(osc(k) * ramp x 1024)", (prog.engine, prog.shape)
+    got = prog.render(n)[0, 0]
+    head = oracle.render(ex.words, 2048)[0]
+    assert np.array_equal(got[:2048], head)
+    env = 1.0 - (np.arange(n, dtype=np.float64) + 1) / n
+    assert np.all(np.abs(got.astype(np.float64)) <= 1024 * env + 1e-3)
+    assert got[4799::4800].tolist() == [0.0] * (n // 4800)  # phase(n) = 10k (n + 1) mod 48000 = 0 for every voice there
+    assert float(np.abs(got[:48000]).max()) > 10.0
+    ms = prog.last_kernel_ms()
+    assert ms < 30.0, ms  # (a guard against falling off the fused path, not a benchmark)
+    prog.close()
+
+
 def test_sum_chain_shapes_that_must_not_fuse():
     d.configure(48000)
     ctx = render.context(48000)
     for g in (d.Sum(d.Osc(100), 0.5),                                    # constant operand
               d.Sum(d.Sum(d.Osc(1), d.Osc(2)), d.Sum(d.Osc(3), d.Osc(4))),  # a tree, not a chain
               d.Sum.many([d.Osc(100), d.Osc(200, "saw"), d.Osc(300)]),      # mixed waveforms
-              d.Sum.many([d.Osc(100), d.Osc(2.0 ** -40)])):                 # f finer than 2^-32
+              d.Sum.many([d.Osc(100), d.Osc(2.0 ** -40)]),                  # f finer than 2^-32
+              d.Sum.many([d.Multiply(d.Osc(100), d.Ramp(500, 1, 0).trigger()), d.Multiply(d.Osc(200), d.Ramp(600, 1, 0).trigger())]),  # different Ramps
+              d.Sum.many([d.Multiply(d.Osc(100), 0.5), d.Osc(200)])):       # voices of different kinds
         prog = ctx.build(descriptor.extract(g).words)
         assert prog.engine == "wave"  # feed-forward, but not a Sum.many chain of constant oscillators
         prog.close()
