@@ -750,8 +750,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
-    // (a stage with a connected cutoff keeps twelve doubles per instance in registers: two instances per wavefront at most)
-    const int per_wave_cap = std::min(opt.filter_mod ? 2 : 4, ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4);
+    const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
     const bool filter_stage = opt.filter_stages > 0;
     if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has

@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -89,7 +90,7 @@ inline bool jit_filter_mod(const Program &P) {
 }
 inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left, bool mod) {
     for (int sub : {256, 128, 64, 32})
-        if (jit_filter_tile_bytes(waves * per_wave, sub, stages, mod) <= lds_left) return sub;
+        if ((!mod || sub <= 64) && jit_filter_tile_bytes(waves * per_wave, sub, stages, mod) <= lds_left) return sub;  // (a connected cutoff: one sample per lane and sub-block)
     return 0;
 }
 // A circuit whose whole chunk body is a few dozen instructions (constant-f oscillators, Ramp, Timer, the elementwise maps; two units
@@ -219,6 +220,7 @@ struct Emitter {
     bool any_side = false;         // plan_overlap: there are side units
     int phase = 0;                 // diagnostic build: the next barrier-to-barrier stamp of the chunk body
     bool in_early = false;         // unit(): emitting the block that works a chunk ahead
+    std::map<std::pair<int, int>, std::string> mod_x, mod_f;  // (Filter stage with a connected cutoff, instance slot) -> its input / cutoff registers
     std::vector<char> dbl;         // plan_rotate: buffers an early unit produces and something outside that block reads: written a chunk
                                    // ahead as `vn`, copied into `v` at the top of the chunk they belong to
     bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
@@ -592,12 +594,13 @@ struct Emitter {
         for (int r = 0; r < R; r++) {
             const std::string x = opnd_array(k, 0, "t" + num(k) + "_" + num(r), r);
             if (!predeclared) line("        float v" + num(op.out_buf) + "_" + num(r) + "[4];");
-            if (declare) line("        double " + std::string(into) + num(k) + "_" + num(r) + (mod ? "[12];" : "[4];"));
-            if (mod) {
-                const std::string f = opnd_array(k, 1, "tf" + num(k) + "_" + num(r), r);
-                line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + x + ", " + f + ", " + into + num(k) + "_" + num(r) + ");");
-            } else
-                line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
+            if (mod) {  // a connected cutoff: nothing is computed ahead — every sub-block's coefficients and feed-forward halves are made when it is parked (JitFilterKM::parkm)
+                mod_x[{k, r}] = x;
+                mod_f[{k, r}] = opnd_array(k, 1, "tf" + num(k) + "_" + num(r), r);
+                continue;
+            }
+            if (declare) line("        double " + std::string(into) + num(k) + "_" + num(r) + "[4];");
+            line("        f" + num(k) + ".feed(" + ctx(r) + ", " + num(r) + ", " + x + ", " + into + num(k) + "_" + num(r) + ");");
         }
     }
     // May the early units and the feed-forward halves of chunk g+1 run inside chunk g (beside its recurrences)?  They may when they
@@ -637,6 +640,15 @@ struct Emitter {
         const DevOp &op = P.ops[(size_t)k];
         const std::string f = "f" + num(k);
         auto park = [&](const char *indent) {
+            if (is_mod_stage(k)) {  // one sample per lane: 64 / sub-block instances side by side per pass
+                const int per = std::max(1, std::min(R, 64 / opt.filter_sub));
+                for (int r0 = 0; r0 < R; r0 += per) {
+                    const int r1 = std::min(R - 1, r0 + 1);
+                    line(std::string(indent) + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", " + num(sb) + ", " + num(op.attr) + ", " + mod_x[{k, r0}] + ", " +
+                         mod_f[{k, r0}] + ", " + mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
+                }
+                return;
+            }
             for (int r = 0; r < R; r++) line(std::string(indent) + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ");");
         };
         auto stamp = [&]() {
@@ -656,6 +668,8 @@ struct Emitter {
         line("            jit_lds_barrier();");
         line("        }");
         for (int r = 0; r < R; r++) line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", v" + num(op.out_buf) + "_" + num(r) + ");");
+        if (is_mod_stage(k))
+            for (int r = 0; r < R; r++) line("        " + f + ".carry(" + num(r) + ", " + num(sb) + ", " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
         // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
     }
 

@@ -1063,15 +1063,28 @@ struct JitDelayGather {
         float *Xr = scr;                       // [256]
         double *Fr = (double *)(scr + 256);    // [256]
         uint32_t *Gr = (uint32_t *)(scr + 768);  // [kTable]: first sample | last sample << 16 of the group whose floor taps land at base + index
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the last chunk's ring stores have landed (other lanes read those slots now)
-        // this lane's own slots (relative 4 lane + c: the chunk's read window), fetched while the tables are laid out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the last chunk's ring stores stay in front of these loads: a wave's accesses to one address keep their order)
+        // this lane's own slots (relative 4 lane + c: the chunk's read window) and the slots beyond it that taps reach, fetched while the
+        // tables are laid out
         float old[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t a = tb0 + lane * 4 + c;
             if (a >= len) a -= len;
             old[c] = ring[a];
+        }
+        const int32_t beyond = base > kChunk ? base : kChunk;  // first slot behind the read window that may be touched
+        constexpr int kAhead = 5;                              // passes of 64 slots fetched ahead (a steady delay below 256 + 64 needs 5 at most)
+        float far_[kAhead];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const int32_t r = beyond + (int32_t)lane + 64 * i;
+            far_[i] = 0.f;
+            if (r <= top + 1) {
+                uint32_t a = tb0 + (uint32_t)r;
+                if (a >= len) a -= len;
+                far_[i] = ring[a];
+            }
         }
         jit_wave_sync();  // (the scratch's previous user is done)
         jit_row_put(Xr, lane, x);
@@ -1123,7 +1136,18 @@ struct JitDelayGather {
             if (X.live) ring[a] = acc;
         }
         // slots beyond the read window that taps reach: read-modify-write, one lane each
-        for (int32_t r = (base > kChunk ? base : kChunk) + (int32_t)lane; r <= top + 1; r += 64) {
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const int32_t r = beyond + (int32_t)lane + 64 * i;
+            if (r <= top + 1) {
+                uint32_t a = tb0 + (uint32_t)r;
+                if (a >= len) a -= len;
+                float acc = far_[i];
+                (void)replay(r, acc);
+                if (X.live) ring[a] = acc;
+            }
+        }
+        for (int32_t r = beyond + (int32_t)lane + 64 * kAhead; r <= top + 1; r += 64) {  // (a span wider than that: fetched as they come)
             uint32_t a = tb0 + (uint32_t)r;
             if (a >= len) a -= len;
             float acc = ring[a];
@@ -1436,35 +1460,62 @@ struct JitFilterKM {
         ticked[r] = false;
     }
     static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
-    // slot r's chunk: p[0..3] the feed-forward halves, p[4..7] b1, p[8..11] b2 of this lane's four samples
-    __device__ __forceinline__ void feed(const JitCtx &X, int r, int kind, const float (&x)[4], const float (&f)[4], double (&p)[12]) {
-        const float l1 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x1[r]), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
-        const float l2 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x2[r]), __float_as_uint(x[2]), 0x138, 0xf, 0xf, false));
-        const double o[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double k[5];
-            jit_filter_coefficients(kind, (double)f[c], X.srd, k);
-            p[c] = (k[0] * (double)x[c] + k[1] * o[c + 1]) + k[2] * o[c];
-            p[4 + c] = k[3];
-            p[8 + c] = k[4];
-        }
-        x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
-        x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
-        flast[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f[3]), 63));
-        ticked[r] = true;
-    }
-    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[12]) {
+    // Sub-block s of the wave's instances r0 .. r0 + PER - 1 (PER = 64 / SUB of them side by side on the wave's lanes): every lane
+    // takes ONE sample — lane l: instance r0 + l / SUB, sample s SUB + l % SUB — computes its coefficients and feed-forward half and
+    // parks P, b1, b2 in the instance's tile row.  The samples come out of the owning lanes' registers (lane 4 j' holds samples
+    // 4 j' .. 4 j' + 3) through the row itself: the owners lay the sub-block's inputs and cutoffs out there as floats, everybody reads
+    // theirs (and the two inputs before it; in front of the sub-block, the carried pair), then the doubles go over them.
+    // xa / fa: input and cutoff registers of instance r0, xb / fb of instance r0 + 1 (PER == 2).
+    template <int PER>
+    __device__ __forceinline__ void parkm(const JitCtx &X, double *tile, int r0, int s, int kind, const float (&xa)[4], const float (&fa)[4],
+                                          const float (&xb)[4], const float (&fb)[4]) const {
+        static_assert(PER * SUB <= 64 && (PER == 1 || PER == 2), "one or two instances per pass");
+        const int mine = PER == 2 ? (int)(X.lane / SUB) : 0;          // which of the pass's instances this lane works for
+        const int j = (int)(X.lane % SUB);
+        const bool active = (int)X.lane < PER * SUB && r0 + mine < R;
         const int first = s * (SUB / 4);
-        if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
-            double *row = tile + (size_t)(X.wave * R + r) * kPitch + ((int)X.lane - first) * 4;
+        jit_wave_sync();  // (the rows' previous readers — pick — are done)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                f64x2 *at = (f64x2 *)(row + a * SUB);
-                at[0] = f64x2{p[4 * a], p[4 * a + 1]};
-                at[1] = f64x2{p[4 * a + 2], p[4 * a + 3]};
+        for (int q = 0; q < PER; ++q) {  // the owners of the sub-block's samples: four inputs and four cutoffs each
+            if (r0 + q >= R) break;
+            if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
+                float *row = (float *)(tile + (size_t)(X.wave * R + r0 + q) * kPitch);
+                const float (&x)[4] = q == 0 ? xa : xb;
+                const float (&f)[4] = q == 0 ? fa : fb;
+                ((f32x4 *)row)[(int)X.lane - first] = f32x4{x[0], x[1], x[2], x[3]};
+                ((f32x4 *)(row + SUB))[(int)X.lane - first] = f32x4{f[0], f[1], f[2], f[3]};
             }
         }
+        jit_wave_sync();
+        double p = 0.0, b1 = 0.0, b2 = 0.0;
+        double *drow = tile + (size_t)(X.wave * R + (active ? r0 + mine : r0)) * kPitch;
+        if (active) {
+            const float *row = (const float *)drow;
+            const float xin = row[j], fc = row[SUB + j];
+            // the two inputs before this one: earlier samples of the sub-block, else what the instance carries
+            const float c1 = mine == 0 ? x1[r0] : x1[(r0 + 1) % R], c2 = mine == 0 ? x2[r0] : x2[(r0 + 1) % R];
+            const float m1 = j >= 1 ? row[j - 1] : c1;
+            const float m2 = j >= 2 ? row[j - 2] : (j == 1 ? c1 : c2);
+            double k[5];
+            jit_filter_coefficients(kind, (double)fc, X.srd, k);
+            p = (k[0] * (double)xin + k[1] * (double)or0f(m1)) + k[2] * (double)or0f(m2);  // Filter.js:40-42, in its order of roundings
+            b1 = k[3];
+            b2 = k[4];
+        }
+        jit_wave_sync();  // (everybody has read the floats: the doubles go over them)
+        if (active) {
+            drow[j] = p;
+            drow[SUB + j] = b1;
+            drow[2 * SUB + j] = b2;
+        }
+    }
+    // behind sub-block s of slot r: the instance's carried inputs and cutoff are now the sub-block's last (its owners' last lane holds them)
+    __device__ __forceinline__ void carry(int r, int s, const float (&x)[4], const float (&f)[4]) {
+        const int last = (s + 1) * (SUB / 4) - 1;
+        x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), last));
+        x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), last)));
+        flast[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f[3]), last));
+        ticked[r] = true;
     }
     static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
         const int first = s * (SUB / 4);
