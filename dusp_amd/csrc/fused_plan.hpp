@@ -176,7 +176,7 @@ struct FusedArgs {
     DevOperand f, gain;
     double phase0;
     double r_d, r_y0, r_y1, r_t0, r_rcp;
-    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok, seg_major, pad2;
+    int32_t r_playing, r_fastdiv, vec4_ok, osc_state_word, ramp_state_word, fx32_ok, seg_major, r_scale_ok;
     // FUSED_OSC_SHAPE
     const float *s_table;  // row of the Shape's table
     double s_t0, s_c, s_left, s_right;  // edges as values of the 0..1 shape, unless they are "shape" (= the table's end values)

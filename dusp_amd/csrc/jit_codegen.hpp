@@ -300,6 +300,7 @@ struct Emitter {
             if (!used[(size_t)k]) continue;
             const DevOp &op = P.ops[(size_t)k];
             if (op.op == OP_CB_READER || op.op == OP_CB_WRITER || jit_ring_ops(op)) return false;
+            if (is_mod_stage(k)) return false;  // (a connected cutoff: its sub-blocks run in a loop of their own, unit())
             if (is_filter_stage(k)) filters.push_back(k);
         }
         if (filters.empty()) return false;
@@ -803,6 +804,31 @@ struct Emitter {
     void unit(int k, bool render, int pass_level, bool fx) {
         const DevOp &op = P.ops[(size_t)k];
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
+        if (op.op == OP_FILTER && is_mod_stage(k)) {
+            // A connected cutoff: the coefficient code (a division, two polynomials, the math library's tan() for cutoffs outside 0 .. Nyquist)
+            // is bulky, so it stands ONCE per pass in a loop over the sub-blocks — with the redo of a sub-block that met a NaN as a second
+            // trip through the same code — instead of once per sub-block and case (a kernel of 280 KB otherwise: the instruction cache holds 64).
+            filter_feed(k);
+            const std::string f = "f" + num(k);
+            line("#pragma unroll 1");
+            line("        for (int sb = 0; sb < " + num(kChunk / opt.filter_sub) + "; ++sb) {");
+            line("            for (bool exact = false;; exact = true) {  // (once; twice when some row's recurrence met a NaN: then as written)");
+            const int per = std::max(1, std::min(R, 64 / opt.filter_sub));
+            for (int r0 = 0; r0 < R; r0 += per) {
+                const int r1 = std::min(R - 1, r0 + 1);
+                line("                " + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", sb, " + num(op.attr) + ", " + mod_x[{k, r0}] + ", " + mod_f[{k, r0}] + ", " +
+                     mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
+            }
+            line("                jit_lds_barrier();");
+            line("                if (exact) " + f + ".serial_exact(X[0], tile, 0); else " + f + ".serial<4>(X[0], tile, 0);");
+            line("                jit_lds_barrier();");
+            line("                if (exact || !" + f + ".failed(tile)) break;");
+            line("            }");
+            for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, v" + num(op.out_buf) + "_" + num(r) + ");");
+            for (int r = 0; r < R; r++) line("            " + f + ".carry(" + num(r) + ", sb, " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
+            line("        }");
+            return;
+        }
         if (op.op == OP_FILTER) {
             filter_feed(k);
             for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) filter_sub_block(k, sb, std::string());

@@ -39,7 +39,7 @@ def main():
             return d.Multiply(d.Osc(f), 0.5)
 
     variants = []
-    envsets = [("nt", {}), ("nt/segmajor", {"DUSP_FUSED_SEGMAJOR": "1"}), ("nt/it8", {"DUSP_FUSED_ITEMS": "8"}), ("nt/it2", {"DUSP_FUSED_ITEMS": "2"})]
+    envsets = [("nt", {}), ("nt/plainfx", {"DUSP_FUSED_FX32": "2"}), ("nt/r8", {"DUSP_FUSED_R": "8"}), ("nt/it2", {"DUSP_FUSED_ITEMS": "2"})]
     KNOBS = ["DUSP_FUSED_R", "DUSP_FUSED_FX32", "DUSP_FUSED_ITEMS", "DUSP_FUSED_TABLE", "DUSP_FUSED_SEGMAJOR"]
 
     def context_under(env):  # the library reads its A/B knobs once, when a context is created
