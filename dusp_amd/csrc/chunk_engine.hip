@@ -178,23 +178,9 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                         if (!has_lastF || ft != lastF) {
                             has_lastF = true;
                             lastF = ft;
-                            if (op.attr == 0) {  // LP
-                                const double lamda = filter_lamda(0, ft, sr);
-                                const double l2 = lamda * lamda;
-                                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                                a1 = 2.0 * a0;
-                                a2 = a0;
-                                b1 = 2.0 * a0 * (1.0 - l2);
-                                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-                            } else {  // HP
-                                const double lamda = filter_lamda(1, ft, sr);
-                                const double l2 = lamda * lamda;
-                                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                                a1 = 0.0;
-                                a2 = -a0;
-                                b1 = 2.0 * a0 * (l2 - 1.0);
-                                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-                            }
+                            double kf[5];
+                            butterworth_coefficients(op.attr == 0 ? 0 : 1, ft, sr, kf);  // Filter.js:66-84 (filter_lamda.hpp: shared by every engine)
+                            a0 = kf[0]; a1 = kf[1]; a2 = kf[2]; b1 = kf[3]; b2 = kf[4];
                         }
                         const double xin = (double)xv[k];
                         const float y = (float)(a0 * xin + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));
@@ -724,23 +710,9 @@ __global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, Loop
                     if (!has_lastF || ft != lastF) {
                         has_lastF = true;
                         lastF = ft;
-                        if (L.filter.attr == 0) {
-                            const double lamda = filter_lamda(0, ft, sr);
-                            const double l2 = lamda * lamda;
-                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                            a1 = 2.0 * a0;
-                            a2 = a0;
-                            b1 = 2.0 * a0 * (1.0 - l2);
-                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
-                        } else {
-                            const double lamda = filter_lamda(1, ft, sr);
-                            const double l2 = lamda * lamda;
-                            a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                            a1 = 0.0;
-                            a2 = -a0;
-                            b1 = 2.0 * a0 * (l2 - 1.0);
-                            b2 = a0 * (1.0 - 2.0 * lamda + l2);
-                        }
+                        double kf[5];
+                        butterworth_coefficients(L.filter.attr == 0 ? 0 : 1, ft, sr, kf);
+                        a0 = kf[0]; a1 = kf[1]; a2 = kf[2]; b1 = kf[3]; b2 = kf[4];
                     }
                     const double xf = (double)delayed;
                     const float y = (float)(a0 * xf + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));

@@ -1176,26 +1176,8 @@ __device__ __forceinline__ void jit_input(const JitArgs &A, const JitCtx &X, uin
     for (int c = 0; c < 4; ++c) out[c] = n0 + c < A.n_samples ? src[n0 + c] : 0.f;
 }
 
-// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
-__device__ __forceinline__ void jit_filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
-    if (kind == 0) {
-        const double lamda = filter_lamda(0, f, sr);
-        const double l2 = lamda * lamda;
-        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
-        k[1] = 2.0 * k[0];
-        k[2] = k[0];
-        k[3] = 2.0 * k[0] * (1.0 - l2);
-        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
-    } else {
-        const double lamda = filter_lamda(1, f, sr);
-        const double l2 = lamda * lamda;
-        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
-        k[1] = 0.0;
-        k[2] = -k[0];
-        k[3] = 2.0 * k[0] * (l2 - 1.0);
-        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
-    }
-}
+// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP): filter_lamda.hpp, shared by every engine
+__device__ __forceinline__ void jit_filter_coefficients(int kind, double f, double sr, double (&k)[5]) { butterworth_coefficients(kind, f, sr, k); }
 
 // ---- Filter (src/components/Filter.js:27-51) with an unconnected cutoff.  y = f32((P - b1 y1) - b2 y2) with
 // P = (a0 x + a1 x1) + a2 x2 is a recurrence in y only.  P is lane-parallel: every lane computes its four samples' from its own

@@ -97,23 +97,9 @@ __global__ void __launch_bounds__(256) dusp_loop2_kernel(ChunkArgs a, LoopShape 
         lastF = st[NP];
         if (!has_lastF || ft != lastF) {
             lastF = ft;
-            if (L.filter.attr == 0) {  // LP (Filter.js:67-75)
-                const double lamda = filter_lamda(0, ft, srd);
-                const double l2 = lamda * lamda;
-                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                a1 = 2.0 * a0;
-                a2 = a0;
-                b1 = 2.0 * a0 * (1.0 - l2);
-                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-            } else {  // HP (Filter.js:76-84)
-                const double lamda = filter_lamda(1, ft, srd);
-                const double l2 = lamda * lamda;
-                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                a1 = 0.0;
-                a2 = -a0;
-                b1 = 2.0 * a0 * (l2 - 1.0);
-                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-            }
+            double kf[5];
+            butterworth_coefficients(L.filter.attr == 0 ? 0 : 1, ft, srd, kf);  // Filter.js:66-84 (filter_lamda.hpp: shared by every engine)
+            a0 = kf[0]; a1 = kf[1]; a2 = kf[2]; b1 = kf[3]; b2 = kf[4];
         }
         c.a0 = a0; c.a1 = a1; c.a2 = a2;
         c.xd1 = st[7 * NP];
@@ -367,23 +353,9 @@ __global__ void __launch_bounds__(kWWaves * 64) dusp_loop3_kernel(ChunkArgs a, L
         lastF = st[NP];
         if (!has_lastF || ft != lastF) {
             lastF = ft;
-            if (L.filter.attr == 0) {  // LP (Filter.js:67-75)
-                const double lamda = filter_lamda(0, ft, srd);
-                const double l2 = lamda * lamda;
-                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                a1 = 2.0 * a0;
-                a2 = a0;
-                b1 = 2.0 * a0 * (1.0 - l2);
-                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-            } else {  // HP (Filter.js:76-84)
-                const double lamda = filter_lamda(1, ft, srd);
-                const double l2 = lamda * lamda;
-                a0 = 1.0 / (1.0 + 2.0 * lamda + l2);
-                a1 = 0.0;
-                a2 = -a0;
-                b1 = 2.0 * a0 * (l2 - 1.0);
-                b2 = a0 * (1.0 - 2.0 * lamda + l2);
-            }
+            double kf[5];
+            butterworth_coefficients(L.filter.attr == 0 ? 0 : 1, ft, srd, kf);  // Filter.js:66-84 (filter_lamda.hpp: shared by every engine)
+            a0 = kf[0]; a1 = kf[1]; a2 = kf[2]; b1 = kf[3]; b2 = kf[4];
         }
         c.a0 = a0; c.a1 = a1; c.a2 = a2;
         // x1 / x2 are f32-valued (they were read out of Float32Arrays, Filter.js:47-48)

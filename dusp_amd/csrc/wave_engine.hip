@@ -58,26 +58,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ double or0w(double v) { return (v != v || v == 0.0) ? 0.0 : v; }  // JS `v || 0`
 
-// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP)
-__device__ __forceinline__ void filter_coefficients(int kind, double f, double sr, double (&k)[5]) {
-    if (kind == 0) {
-        const double lamda = filter_lamda(0, f, sr);
-        const double l2 = lamda * lamda;
-        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
-        k[1] = 2.0 * k[0];
-        k[2] = k[0];
-        k[3] = 2.0 * k[0] * (1.0 - l2);
-        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
-    } else {
-        const double lamda = filter_lamda(1, f, sr);
-        const double l2 = lamda * lamda;
-        k[0] = 1.0 / (1.0 + 2.0 * lamda + l2);
-        k[1] = 0.0;
-        k[2] = -k[0];
-        k[3] = 2.0 * k[0] * (l2 - 1.0);
-        k[4] = k[0] * (1.0 - 2.0 * lamda + l2);
-    }
-}
+// Butterworth coefficients of Filter.js:66-84 (kind 0 = LP, 1 = HP): filter_lamda.hpp, shared by every engine
+__device__ __forceinline__ void filter_coefficients(int kind, double f, double sr, double (&k)[5]) { butterworth_coefficients(kind, f, sr, k); }
 
 struct V4 {
     float v[4];
