@@ -761,6 +761,12 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
         opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
+        // (a connected cutoff parks three values per sample in two sets of rows: fewer rows per workgroup before the table image goes)
+        while (opt.filter_mod && !opt.filter_sub && (per_wave > 1 || waves > 1)) {
+            if (per_wave > 1) per_wave /= 2;
+            else waves /= 2;
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
+        }
         if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
             opt.lds_table = -1, opt.table_bytes = 0;
             opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget, opt.filter_mod);

@@ -75,9 +75,11 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // Behind the rows: one word that says "given back", then y1 / y2 of every row of every Filter stage of the circuit (the stages share
 // the tile, one after the other, but each has its own recurrence memory).
 // (mod: a stage with a connected cutoff shares the tile — rows of three arrays, P / b1 / b2 per sample: JitFilterKM)
-inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod) {
-    return (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8 + 16 + (size_t)stages * (size_t)rows * 16;
+inline size_t jit_filter_rows_bytes(int rows, int sub, bool mod) {
+    // (with a connected cutoff: two sets of rows — sub-block s + 1 is parked while s is served)
+    return (size_t)(mod ? 2 : 1) * (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8;
 }
+inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod) { return jit_filter_rows_bytes(rows, sub, mod) + 16 + (size_t)stages * (size_t)rows * 16; }
 inline int jit_filter_stages(const Program &P) {
     int n = 0;
     for (const DevOp &op : P.ops) n += op.op == OP_FILTER;
@@ -146,7 +148,7 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
         if (op.op == OP_MULTI_OSC) n = 512;
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
-        if (jit_ring_ops(op)) n = op.op == OP_DELAY ? 1536 : 1024;      // the slot-ownership table; a Delay: inputs, fractions and group table of JitDelayGather
+        if (jit_ring_ops(op)) n = op.op == OP_DELAY ? 512 : 1024;       // the slot-ownership table; a Delay (JitDelayGather): the chunk's read values, or a table of 512
         if (jit_delay_short(op)) n = 512;                               // the chunk before and this one, side by side
         need = std::max(need, n);
     }
@@ -504,12 +506,13 @@ struct Emitter {
                 }
             }
             if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
-                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + "> f" + num(k) + ";");
+                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++) line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.state_slot) + ");");
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
-                line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + "> f" + num(k) + ";");
+                line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + ", " +
+                     num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++)
                     line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
@@ -809,23 +812,36 @@ struct Emitter {
             // is bulky, so it stands ONCE per pass in a loop over the sub-blocks — with the redo of a sub-block that met a NaN as a second
             // trip through the same code — instead of once per sub-block and case (a kernel of 280 KB otherwise: the instruction cache holds 64).
             filter_feed(k);
-            const std::string f = "f" + num(k);
-            line("#pragma unroll 1");
-            line("        for (int sb = 0; sb < " + num(kChunk / opt.filter_sub) + "; ++sb) {");
-            line("            for (bool exact = false;; exact = true) {  // (once; twice when some row's recurrence met a NaN: then as written)");
+            const std::string f = "f" + num(k), N = num(kChunk / opt.filter_sub), kind = num(op.attr);
             const int per = std::max(1, std::min(R, 64 / opt.filter_sub));
-            for (int r0 = 0; r0 < R; r0 += per) {
-                const int r1 = std::min(R - 1, r0 + 1);
-                line("                " + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", sb, " + num(op.attr) + ", " + mod_x[{k, r0}] + ", " + mod_f[{k, r0}] + ", " +
-                     mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
-            }
-            line("                jit_lds_barrier();");
-            line("                if (exact) " + f + ".serial_exact(X[0], tile, 0); else " + f + ".serial<4>(X[0], tile, 0);");
-            line("                jit_lds_barrier();");
-            line("                if (exact || !" + f + ".failed(tile)) break;");
-            line("            }");
-            for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, v" + num(op.out_buf) + "_" + num(r) + ");");
+            auto parks = [&](const std::string &indent, const std::string &sb, const std::string &buf, const char *again) {
+                for (int r0 = 0; r0 < R; r0 += per) {
+                    const int r1 = std::min(R - 1, r0 + 1);
+                    line(indent + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", " + sb + ", " + buf + ", " + again + ", " + kind + ", " + mod_x[{k, r0}] + ", " +
+                         mod_f[{k, r0}] + ", " + mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
+                }
+            };
+            // The tile holds two sets of rows: while one wave runs sub-block sb out of one, everybody parks sub-block sb + 1 in the other
+            // (the serving wave its own rows behind its recurrences); waves 0 and 1 take turns at serving.
+            parks("        ", "0", "0", "false");
+            line("        jit_lds_barrier();");
+            line("#pragma unroll 1");
+            line("        for (int sb = 0; sb < " + N + "; ++sb) {");
+            line("            const int buf = sb & 1;");
+            line(std::string("            const uint32_t who = ") + (opt.waves >= 2 ? "(uint32_t)(sb & 1);" : "0u;"));
             for (int r = 0; r < R; r++) line("            " + f + ".carry(" + num(r) + ", sb, " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
+            line("            " + f + ".serial<4>(X[0], tile, who, buf);");
+            line("            if (sb + 1 < " + N + ") {");
+            parks("                ", "sb + 1", "buf ^ 1", "false");
+            line("            }");
+            line("            jit_lds_barrier();");
+            line("            if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
+            parks("                ", "sb", "buf", "true");
+            line("                jit_lds_barrier();");
+            line("                " + f + ".serial_exact(X[0], tile, who, buf);");
+            line("                jit_lds_barrier();");
+            line("            }");
+            for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, buf, v" + num(op.out_buf) + "_" + num(r) + ");");
             line("        }");
             return;
         }

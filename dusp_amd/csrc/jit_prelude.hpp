@@ -888,7 +888,7 @@ struct JitRingOps {
         T = jit_u(A.resume ? A.state[(size_t)state_slot * A.n_pad + X.inst] : A.init_state[state_slot]);
     }
     enum : int { RO_NONE = 0, RO_READ, RO_READ_CLEAR, RO_ADD, RO_STORE };
-    template <int KIND, int ATTR>
+    template <int KIND, int ATTR, int OWN = 1024>  // OWN: entries of the slot-ownership table (a power of two; fewer only cost extra rounds)
     __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, float *scr, int64_t ring_base, uint32_t len, const float (&p0)[4],
                                          const float (&p1)[4], float (&out)[4]) {
         constexpr bool is_delay = KIND == OP_DELAY, is_mono = KIND == OP_MONO_DELAY, is_readback = KIND == OP_READBACK_DELAY;
@@ -898,10 +898,10 @@ struct JitRingOps {
         const uint32_t lane = X.lane;
         float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
         uint32_t *own = (uint32_t *)scr;
-        constexpr uint32_t kOwnMask = 1023u, kFree = 0xffffffffu;
+        constexpr uint32_t kOwnMask = (uint32_t)OWN - 1u, kFree = 0xffffffffu;
         jit_wave_sync();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
+        for (int k = 0; k < OWN / 256; ++k) ((uint4 *)own)[lane + 64 * k] = uint4{kFree, kFree, kFree, kFree};
         // what operation j of a sample does
         constexpr int kind0 = is_delay ? RO_READ_CLEAR : is_mono ? RO_ADD : is_readback ? RO_STORE
                               : is_reader ? ((ATTR & 1) ? RO_READ_CLEAR : RO_READ)
@@ -1010,29 +1010,49 @@ struct JitRingOps {
 };
 
 // ---- Delay with a signal-rate delay (an LFO on the delay time: SimpleDelay, chorus, flanger), Delay.js:26-40, WITHOUT slot rounds
-// where the taps allow it.  What the reference does to one ring slot during a chunk is a sequence in sample order: the read-and-clear
-// of the sample whose slot it is (slot s0 + t belongs to sample t), and the `+=` of every tap that lands there, each rounded to
-// f32.  When the tap positions t + delay[t] do not decrease along the chunk (a delay that falls by less than a sample per sample:
-// any audio-rate modulation short of a jump), the samples whose floor tap lands in one slot are CONSECUTIVE, so a slot's whole
-// sequence follows from two small groups of samples — those with floor(position) = slot (floor taps) and slot - 1 (ceil taps):
-// every lane takes slots of its own and replays their sequences out of the chunk's inputs in LDS, the ring is read and written once per
-// touched slot, nothing is bid for and nothing waits on another lane.  A chunk whose taps do decrease somewhere (or that holds a
-// negative / NaN delay, or spans more slots than the tables hold) takes the ordered slot operations (JitRingOps) instead —
-// whatever the modulation does, the result is the reference's.
-// scr: 1536 floats per wave — x (256 f32), the taps' fractions (256 f64), the groups' first / last samples (768 x 2 u16); the slot
-// operations' ownership table (1024 words) takes the same space when a chunk needs them.
+// where the taps allow it.  What the reference does to one ring slot during a chunk is a sequence in sample order: the `+=` of every
+// tap that lands there, each rounded to f32, and the read-and-clear by the sample whose slot it is (slot s0 + t belongs to sample t).
+// When the tap positions t + delay[t] do not decrease along the chunk (a delay that falls by less than a sample per sample: any
+// audio-rate modulation short of a jump), never put more than two floor taps into one slot, and every tap lands ahead of its own
+// sample (a delay of at least a sample), a slot's sequence is short and known from NEIGHBOURING samples alone:
+//     [ceil taps of the one or two samples whose floor tap fell one slot below]  [floor taps of the one or two samples that fall here]
+// (a tap with fraction 0 brings its `+= in * 0` along).  So the first sample of every such group OWNS its slot: it takes the slot's
+// value, replays that sequence out of its own and its neighbours' registers (the lane below and above by DPP) and stores the result —
+// into the ring, or, for a slot of this chunk's read window, into the wave's row of read values, because everything that lands on such
+// a slot lands BEFORE its sample reads it; the last sample in front of a gap owns the slot that only receives ceil taps.  Nothing is
+// bid for, nothing waits on another lane, every touched slot is read and written once.  A chunk that breaks a condition (a jump,
+// a delay below one sample, a negative / NaN delay, taps wrapping onto the read window) takes the ordered slot operations
+// (JitRingOps) instead — whatever the modulation does, the result is the reference's.
+// scr: 512 floats per wave — the chunk's 256 read values; the slot operations' ownership table (512 words) takes the same space when
+// a chunk needs them.
 struct JitDelayGather {
     JitRingOps rounds;  // (holds T: the previous chunk's last input, what the unit's state carries)
-    static constexpr int kTable = 768;
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot) { rounds.begin_delay(A, X, state_slot); }
+    static __device__ __forceinline__ float dpp_up(float mine, float edge) {  // the lane below's value; lane 0 gets `edge`
+        return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(edge), __float_as_uint(mine), 0x138, 0xf, 0xf, false));
+    }
+    static __device__ __forceinline__ float dpp_down(float mine, float edge) {  // the lane above's value; lane 63 gets `edge`
+        return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(edge), __float_as_uint(mine), 0x130, 0xf, 0xf, false));
+    }
+    static __device__ __forceinline__ double dpp_up(double mine) {  // (lane 0's value is never used: its neighbours below do not exist)
+        const uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)__double2loint(mine), 0x138, 0xf, 0xf, false);
+        const uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)__double2hiint(mine), 0x138, 0xf, 0xf, false);
+        return __hiloint2double((int)hi, (int)lo);
+    }
+    static __device__ __forceinline__ double dpp_down(double mine) {
+        const uint32_t lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)__double2loint(mine), 0x130, 0xf, 0xf, false);
+        const uint32_t hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)__double2hiint(mine), 0x130, 0xf, 0xf, false);
+        return __hiloint2double((int)hi, (int)lo);
+    }
     __device__ __forceinline__ void tick(const JitArgs &A, const JitCtx &X, uint32_t g, float *scr, int64_t ring_base, uint32_t len, const float (&x)[4],
                                          const float (&dl)[4], float (&out)[4]) {
         const double dlen = (double)len;
         const uint32_t lane = X.lane;
         const uint32_t tb0 = (uint32_t)((A.clock0 + (uint64_t)g * kChunk) % (uint64_t)len);
-        // where every sample's taps land, exactly as Delay.js:33-36 computes it
-        int32_t rl[4];   // floor tap's slot, relative to the chunk's first slot (0 .. len - 1), or -1
-        double fr[4];
+        // where every sample's taps land, exactly as Delay.js:33-36 computes it.  Local index i = c + 2: samples 4 lane - 2 .. 4 lane + 5
+        int32_t R[8];   // floor tap's slot, relative to the chunk's first slot (0 .. len - 1)
+        double F[7];    // the tap's fraction
+        float Xs[7];    // the input sample
         bool ok = len >= 2u * kChunk;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1042,117 +1062,111 @@ struct JitDelayGather {
             double tW = (double)tb + (double)dl[c];
             if (!(tW >= 0.0 && tW < dlen)) tW = (tW >= dlen && tW < 2.0 * dlen) ? tW - dlen : fmod(tW, dlen);
             const double lo = floor(tW);
-            fr[c] = tW - trunc(tW);
+            F[c + 2] = tW - trunc(tW);
             const bool valid = lo >= 0.0 && lo < dlen;
-            ok = ok && valid;
             int32_t r = valid ? (int32_t)lo - (int32_t)tb0 : -1;
             if (valid && r < 0) r += (int32_t)len;
-            rl[c] = r;
+            R[c + 2] = r;
+            Xs[c + 2] = x[c];
+            ok = ok && valid && r > (int32_t)t;  // (ahead of its own sample: whatever lands in the read window lands before the slot is read)
         }
-        // non-decreasing along the chunk, and the span the tables can hold?
-        const int32_t before = __builtin_amdgcn_update_dpp(0, rl[3], 0x138, 0xf, 0xf, false);   // lane - 1's last (lane 0: 0)
-        const int32_t after = __builtin_amdgcn_update_dpp(0x7fffffff, rl[0], 0x130, 0xf, 0xf, false);  // lane + 1's first (lane 63: "more")
-        ok = ok && rl[0] >= before && rl[1] >= rl[0] && rl[2] >= rl[1] && rl[3] >= rl[2];
-        const int32_t base = __builtin_amdgcn_readlane(rl[0], 0), top = __builtin_amdgcn_readlane(rl[3], 63);
-        ok = ok && top - base + 2 <= kTable && (uint32_t)(top + 2) <= len;  // (every relative slot up to top + 1 is a ring slot of its own)
+        // the neighbours: two samples of the lane below, two of the lane above (one for the inputs)
+        R[0] = __builtin_amdgcn_update_dpp(-9, R[4], 0x138, 0xf, 0xf, false);
+        R[1] = __builtin_amdgcn_update_dpp(-9, R[5], 0x138, 0xf, 0xf, false);
+        R[6] = __builtin_amdgcn_update_dpp(0x7ffffff0, R[2], 0x130, 0xf, 0xf, false);
+        R[7] = __builtin_amdgcn_update_dpp(0x7ffffff0, R[3], 0x130, 0xf, 0xf, false);
+        Xs[0] = dpp_up(Xs[4], 0.f);
+        Xs[1] = dpp_up(Xs[5], 0.f);
+        Xs[6] = dpp_down(Xs[2], 0.f);
+        F[0] = dpp_up(F[4]);
+        F[1] = dpp_up(F[5]);
+        F[6] = dpp_down(F[2]);
+        // non-decreasing along the chunk, at most two floor taps per slot, every relative slot a ring slot of its own?
+        ok = ok && R[2] >= R[1] && R[3] >= R[2] && R[4] >= R[3] && R[5] >= R[4] && R[4] > R[2] && R[5] > R[3] && R[6] > R[4] && R[7] > R[5];
+        const int32_t top = __builtin_amdgcn_readlane(R[5], 63);
+        ok = ok && (uint32_t)(top + 2) <= len;
         if (!__all(ok)) {
-            rounds.tick<OP_DELAY, 0>(A, X, g, scr, ring_base, len, x, dl, out);
+            rounds.tick<OP_DELAY, 0, 512>(A, X, g, scr, ring_base, len, x, dl, out);
             return;
         }
         float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
-        float *Xr = scr;                       // [256]
-        double *Fr = (double *)(scr + 256);    // [256]
-        uint32_t *Gr = (uint32_t *)(scr + 768);  // [kTable]: first sample | last sample << 16 of the group whose floor taps land at base + index
+        float *OUT = scr;  // [256]: what the chunk's samples read
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the last chunk's ring stores stay in front of these loads: a wave's accesses to one address keep their order)
-        // this lane's own slots (relative 4 lane + c: the chunk's read window) and the slots beyond it that taps reach, fetched while the
-        // tables are laid out
+        // the chunk's read window as the ring holds it; slots beyond it that this lane's samples own, fetched at once
         float old[4];
+        uint32_t a0 = tb0 + lane * 4;
+        if (a0 >= len) a0 -= len;
+        const bool quad = a0 + 4u <= len && (a0 & 3u) == 0u && (((uintptr_t)ring) & 15u) == 0u;
+        if (quad) {
+            const f32x4 v = *(const f32x4 *)(ring + a0);
+            old[0] = v[0]; old[1] = v[1]; old[2] = v[2]; old[3] = v[3];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t a = a0 + c;
+                if (a >= len) a -= len;
+                old[c] = ring[a];
+            }
+        }
+        float far_floor[4], far_ceil[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            uint32_t a = tb0 + lane * 4 + c;
+            const int i = c + 2;
+            uint32_t a = tb0 + (uint32_t)R[i];
             if (a >= len) a -= len;
-            old[c] = ring[a];
-        }
-        const int32_t beyond = base > kChunk ? base : kChunk;  // first slot behind the read window that may be touched
-        constexpr int kAhead = 5;                              // passes of 64 slots fetched ahead (a steady delay below 256 + 64 needs 5 at most)
-        float far_[kAhead];
-#pragma unroll
-        for (int i = 0; i < kAhead; ++i) {
-            const int32_t r = beyond + (int32_t)lane + 64 * i;
-            far_[i] = 0.f;
-            if (r <= top + 1) {
-                uint32_t a = tb0 + (uint32_t)r;
-                if (a >= len) a -= len;
-                far_[i] = ring[a];
-            }
+            far_floor[c] = (R[i] != R[i - 1] && R[i] >= kChunk) ? ring[a] : 0.f;       // this sample owns its floor tap's slot, beyond the window
+            uint32_t a1 = a + 1u;
+            if (a1 >= len) a1 -= len;
+            far_ceil[c] = (R[i + 1] > R[i] + 1 && R[i] + 1 >= kChunk) ? ring[a1] : 0.f;  // ... and the slot behind it, which only ceil taps reach
         }
         jit_wave_sync();  // (the scratch's previous user is done)
-        jit_row_put(Xr, lane, x);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Fr[lane * 4 + c] = fr[c];
-#pragma unroll
-        for (int k = 0; k < kTable / 256; ++k) ((uint4 *)Gr)[lane + 64 * k] = uint4{0xffffu, 0xffffu, 0xffffu, 0xffffu};  // first 65535, last 0: empty
+        jit_row_put(OUT, lane, old);
         jit_wave_sync();
+        auto add = [](float acc, double v) __attribute__((always_inline)) { return (float)((double)acc + v); };
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int32_t prev = c == 0 ? (lane == 0 ? -2 : before) : rl[c - 1], next = c == 3 ? after : rl[c + 1];
-            unsigned short *e = (unsigned short *)(Gr + (rl[c] - base));
-            if (rl[c] != prev) e[0] = (unsigned short)(lane * 4 + c);
-            if (rl[c] != next) e[1] = (unsigned short)(lane * 4 + c);
-        }
-        jit_wave_sync();
-        // One slot's sequence.  r: relative slot; acc: what the ring holds there; returns what the slot's own sample reads (r < 256).
-        auto replay = [&](int32_t r, float &acc) __attribute__((always_inline)) -> float {
+            const int i = c + 2;
+            const int32_t r = R[i];
             uint32_t a = tb0 + (uint32_t)r;
             if (a >= len) a -= len;
-            const int32_t idx = r - base;
-            float seen = 0.f;
-            bool pending = r < kChunk;
-            for (int which = 0; which < 2; ++which) {  // ceil taps of the group below, then floor taps of the slot's own group
-                const int32_t gi = idx - 1 + which;
-                if (gi < 0 || gi > top - base) continue;
-                const uint32_t e = Gr[gi];
-                const int32_t first = (int32_t)(e & 0xffffu), last = (int32_t)(e >> 16);
-                for (int32_t t = first; t <= last; ++t) {
-                    if (pending && t >= r) { seen = acc; acc = 0.f; pending = false; }  // `out[t] = buf[tB]; buf[tB] = 0` (Delay.js:28-29)
-                    const double xin = (double)Xr[t], f = Fr[t];
-                    if (which == 0) {
-                        if (f != 0.0 && a != 0u) acc = (float)((double)acc + xin * f);  // ceil tap (at index `length` — slot 0 — it is dropped)
-                    } else {
-                        acc = (float)((double)acc + xin * (1.0 - f));                   // floor tap
-                        if (f == 0.0) acc = (float)((double)acc + xin * f);             // ... and a ceil tap that lands on the same slot
-                    }
+            if (r != R[i - 1]) {  // first of its group: the slot's whole sequence
+                float acc = r < kChunk ? OUT[r] : far_floor[c];
+                const bool below2 = R[i - 2] == r - 1, below1 = R[i - 1] == r - 1;  // ceil taps of the samples one slot below (at index `length` — slot 0 — they are dropped)
+                if (below2 && F[i - 2] != 0.0 && a != 0u) acc = add(acc, (double)Xs[i - 2] * F[i - 2]);
+                if (below1 && F[i - 1] != 0.0 && a != 0u) acc = add(acc, (double)Xs[i - 1] * F[i - 1]);
+                acc = add(acc, (double)Xs[i] * (1.0 - F[i]));                          // floor tap
+                if (F[i] == 0.0) acc = add(acc, (double)Xs[i] * F[i]);                // ... and a ceil tap that lands on the same slot
+                if (R[i + 1] == r) {                                                   // the group's second sample
+                    acc = add(acc, (double)Xs[i + 1] * (1.0 - F[i + 1]));
+                    if (F[i + 1] == 0.0) acc = add(acc, (double)Xs[i + 1] * F[i + 1]);
+                }
+                if (r < kChunk) OUT[r] = acc;
+                else if (X.live) ring[a] = acc;
+            }
+            if (R[i + 1] > r + 1) {  // last of its group in front of a gap: the slot behind, reached by this group's ceil taps only
+                uint32_t a1 = a + 1u;
+                if (a1 >= len) a1 -= len;
+                if (a1 != 0u && (F[i] != 0.0 || (R[i - 1] == r && F[i - 1] != 0.0))) {
+                    float acc = r + 1 < kChunk ? OUT[r + 1] : far_ceil[c];
+                    if (R[i - 1] == r && F[i - 1] != 0.0) acc = add(acc, (double)Xs[i - 1] * F[i - 1]);
+                    if (F[i] != 0.0) acc = add(acc, (double)Xs[i] * F[i]);
+                    if (r + 1 < kChunk) OUT[r + 1] = acc;
+                    else if (X.live) ring[a1] = acc;
                 }
             }
-            if (pending) { seen = acc; acc = 0.f; }
-            return seen;
-        };
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float acc = old[c];
-            out[c] = replay((int32_t)(lane * 4 + c), acc);
-            uint32_t a = tb0 + lane * 4 + c;
-            if (a >= len) a -= len;
-            if (X.live) ring[a] = acc;
         }
-        // slots beyond the read window that taps reach: read-modify-write, one lane each
+        jit_wave_sync();
+        jit_row_get(OUT, lane, out);  // `out[t] = buf[tB]`
+        if (X.live) {                 // `buf[tB] = 0` (Delay.js:28-29): the whole read window
+            if (quad) *(f32x4 *)(ring + a0) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else {
 #pragma unroll
-        for (int i = 0; i < kAhead; ++i) {
-            const int32_t r = beyond + (int32_t)lane + 64 * i;
-            if (r <= top + 1) {
-                uint32_t a = tb0 + (uint32_t)r;
-                if (a >= len) a -= len;
-                float acc = far_[i];
-                (void)replay(r, acc);
-                if (X.live) ring[a] = acc;
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t a = a0 + c;
+                    if (a >= len) a -= len;
+                    ring[a] = 0.f;
+                }
             }
-        }
-        for (int32_t r = beyond + (int32_t)lane + 64 * kAhead; r <= top + 1; r += 64) {  // (a span wider than that: fetched as they come)
-            uint32_t a = tb0 + (uint32_t)r;
-            if (a >= len) a -= len;
-            float acc = ring[a];
-            (void)replay(r, acc);
-            if (X.live) ring[a] = acc;
         }
         rounds.T = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
     }
@@ -1191,7 +1205,9 @@ __device__ __forceinline__ void jit_filter_coefficients(int kind, double f, doub
 //   tile: rows of SUB + 2 doubles, row = wave R + r; then one word that says "given back"; then y1 / y2 of every row, stage by stage.
 //   SUB = 256, 128 or 64 by what LDS holds next to the table image
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-template <int WAVES, int R, int SUB, int NA>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
+// MEM: byte offset from the tile's start of the word that says "given back" and, behind it, the stages' y1 / y2 (behind the rows of whichever
+// kind of stage needs more of them: the stages of a circuit share the tile one after the other, their recurrence memories must not meet it)
+template <int WAVES, int R, int SUB, int NA, int MEM>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
     double a[NA][3];                        // this wave's instances: a0 a1 a2 (wave-uniform)
@@ -1206,8 +1222,9 @@ struct JitFilterK {
 
     // fr: the cutoff of the instance THIS LANE serves when its wave runs the recurrences (a constant, or that instance's parameter: jit_row_param)
     // y1 / y2 of row `row` of this stage
+    static __device__ __forceinline__ uint32_t flag_address(double *tile) { return row_address(tile, 0) + (uint32_t)MEM; }
     __device__ __forceinline__ uint32_t memory_address(double *tile, uint32_t row) const {
-        return row_address(tile, WAVES * R) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
+        return flag_address(tile) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
     }
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double *tile, int stage_, int kind, float fr, int state_slot) {
         stage = stage_;
@@ -1338,7 +1355,7 @@ struct JitFilterK {
             yr += PB / 2;
         }
         const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;  // (some row's: the sub-block is given back whole)
-        if (X.lane == 0) *(lds_u32 *)(uintptr_t)row_address(tile, WAVES * R) = met_nan ? 1u : 0u;
+        if (X.lane == 0) *(lds_u32 *)(uintptr_t)flag_address(tile) = met_nan ? 1u : 0u;
         if (!met_nan) {
             mem[0] = u1;
             mem[1] = u2;
@@ -1349,7 +1366,7 @@ struct JitFilterK {
     }
     // after the barrier that ends serial(), every wave: was the sub-block given back?
     static __device__ __forceinline__ bool failed(double *tile) {
-        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)row_address(tile, WAVES * R)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)flag_address(tile)) != 0;
     }
     // the sub-block as Filter.js:40-46 writes it, on freshly parked rows
     __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
@@ -1406,11 +1423,13 @@ __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X
 // y = f32((P - b1[t] y1) - b2[t] y2) runs like the constant-cutoff stage's: the WAVES x R instances of the workgroup side by side on
 // the lanes of ONE wave, out of a shared tile whose rows hold P, b1 and b2 of a sub-block (three arrays of SUB doubles; y goes
 // over the P values already consumed).  Same protocol as JitFilterK: park / serial / failed / serial_exact / pick, memory behind the tile.
-template <int WAVES, int R, int SUB>
+template <int WAVES, int R, int SUB, int MEM>
 struct JitFilterKM {
     static constexpr int kPitch = 3 * SUB + 2;  // doubles per row (even: rows stay 16-byte aligned)
+    static constexpr int kBuf = WAVES * R * kPitch;  // the tile is TWO such sets of rows: while one wave runs sub-block s out of one, the others park s + 1 in the other
     float x1[R], x2[R];                         // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     float flast[R];                             // the cutoff of the last sample ticked (what `lastF` and the coefficients in the unit's state belong to)
+    float px1[R], px2[R];                       // x1 / x2 as they stood in front of the sub-block parked last (a sub-block that met a NaN is parked again)
     bool ticked[R];
     int stage;
 #ifdef DUSP_JIT_PROFILE
@@ -1419,11 +1438,12 @@ struct JitFilterKM {
     typedef __attribute__((address_space(3))) double lds_double;
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {
+    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {  // (rows WAVES R .. 2 WAVES R - 1: the second buffer)
         return ((uint32_t)(uintptr_t)(lds_double *)(tile + (size_t)row * kPitch)) & 0x3ffffu;
     }
+    static __device__ __forceinline__ uint32_t flag_address(double *tile) { return row_address(tile, 0) + (uint32_t)MEM; }
     __device__ __forceinline__ uint32_t memory_address(double *tile, uint32_t row) const {
-        return row_address(tile, WAVES * R) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
+        return flag_address(tile) + 16u + ((uint32_t)stage * (WAVES * R) + row) * 16u;
     }
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, double *tile, int stage_, int state_slot) {
         stage = stage_;
@@ -1436,8 +1456,8 @@ struct JitFilterKM {
     }
     __device__ __forceinline__ void begin_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) {
         const double *is = A.init_state + state_slot;
-        x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
-        x2[r] = jit_u((float)is[8]);
+        px1[r] = x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
+        px2[r] = x2[r] = jit_u((float)is[8]);
         flast[r] = 0.f;
         ticked[r] = false;
     }
@@ -1448,9 +1468,11 @@ struct JitFilterKM {
     // 4 j' .. 4 j' + 3) through the row itself: the owners lay the sub-block's inputs and cutoffs out there as floats, everybody reads
     // theirs (and the two inputs before it; in front of the sub-block, the carried pair), then the doubles go over them.
     // xa / fa: input and cutoff registers of instance r0, xb / fb of instance r0 + 1 (PER == 2).
+    // buf: which half of the tile; again: the sub-block is parked a second time (it met a NaN): the carried pair as it stood in front of it
     template <int PER>
-    __device__ __forceinline__ void parkm(const JitCtx &X, double *tile, int r0, int s, int kind, const float (&xa)[4], const float (&fa)[4],
+    __device__ __forceinline__ void parkm(const JitCtx &X, double *tile, int r0, int s, int buf, bool again, int kind, const float (&xa)[4], const float (&fa)[4],
                                           const float (&xb)[4], const float (&fb)[4]) const {
+        tile += (size_t)buf * kBuf;
         static_assert(PER * SUB <= 64 && (PER == 1 || PER == 2), "one or two instances per pass");
         const int mine = PER == 2 ? (int)(X.lane / SUB) : 0;          // which of the pass's instances this lane works for
         const int j = (int)(X.lane % SUB);
@@ -1475,7 +1497,8 @@ struct JitFilterKM {
             const float *row = (const float *)drow;
             const float xin = row[j], fc = row[SUB + j];
             // the two inputs before this one: earlier samples of the sub-block, else what the instance carries
-            const float c1 = mine == 0 ? x1[r0] : x1[(r0 + 1) % R], c2 = mine == 0 ? x2[r0] : x2[(r0 + 1) % R];
+            const int rm = mine == 0 ? r0 : (r0 + 1) % R;
+            const float c1 = again ? px1[rm] : x1[rm], c2 = again ? px2[rm] : x2[rm];
             const float m1 = j >= 1 ? row[j - 1] : c1;
             const float m2 = j >= 2 ? row[j - 2] : (j == 1 ? c1 : c2);
             double k[5];
@@ -1494,12 +1517,15 @@ struct JitFilterKM {
     // behind sub-block s of slot r: the instance's carried inputs and cutoff are now the sub-block's last (its owners' last lane holds them)
     __device__ __forceinline__ void carry(int r, int s, const float (&x)[4], const float (&f)[4]) {
         const int last = (s + 1) * (SUB / 4) - 1;
+        px1[r] = x1[r];
+        px2[r] = x2[r];
         x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), last));
         x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), last)));
         flast[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f[3]), last));
         ticked[r] = true;
     }
-    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, int buf, float (&out)[4]) {
+        tile += (size_t)buf * kBuf;
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
@@ -1521,13 +1547,13 @@ struct JitFilterKM {
         for (int i = 0; i < PB / 4; ++i) dst[i] = y4[i];
     }
     template <int PB_>  // (the generated text passes the constant-cutoff stage's block size; three values per step: always blocks of 4 here)
-    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who, int buf) {
         constexpr int PB = 4;
         if (X.wave != who || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t row = row_address(tile, X.lane);
+        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
@@ -1550,7 +1576,7 @@ struct JitFilterKM {
             yr += PB / 2;
         }
         const bool met_nan = __builtin_amdgcn_ballot_w64(!(u1 == u1)) != 0;
-        if (X.lane == 0) *(lds_u32 *)(uintptr_t)row_address(tile, WAVES * R) = met_nan ? 1u : 0u;
+        if (X.lane == 0) *(lds_u32 *)(uintptr_t)flag_address(tile) = met_nan ? 1u : 0u;
         if (!met_nan) {
             mem[0] = u1;
             mem[1] = u2;
@@ -1560,11 +1586,11 @@ struct JitFilterKM {
 #endif
     }
     static __device__ __forceinline__ bool failed(double *tile) {
-        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)row_address(tile, WAVES * R)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)flag_address(tile)) != 0;
     }
-    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who, int buf) {
         if (X.wave != who || X.lane >= WAVES * R) return;
-        const uint32_t row = row_address(tile, X.lane);
+        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);

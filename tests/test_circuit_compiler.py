@@ -92,7 +92,7 @@ def test_feedback_edges_read_last_iterations_registers():
     assert len(late) == 1                                        # the loop's one back edge: the Filter's previous chunk
     w = late.pop()
     assert re.search(r"%s\[c\] = v%s\[c\]" % (w, w[1:]), text)   # carried over at the end of the iteration
-    assert "JitFilterK<8, 1, 256, 1>" in text and "JitDelayK" in text
+    assert "JitFilterK<8, 1, 256, 1, " in text and "JitDelayK" in text
 
 
 def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
@@ -156,7 +156,7 @@ def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     # and done as written if a recurrence met a NaN)
     assert fast.count("f3.feed(") == 3 and fast.count("f3.park(") == 12 and fast.count("f3.serial<8>(") == 2 and fast.count("f3.pick(") == 6
     assert fast.count("if (f3.failed(tile))") == 2 and fast.count("f3.serial_exact(") == 2
-    assert "JitFilterK<16, 3, 128, 1>" in text and "dusp_jit_pass" not in text
+    assert "JitFilterK<16, 3, 128, 1, " in text and "dusp_jit_pass" not in text
     with pytest.raises(runtime.DuspHipError, match="per_wave"):
         source(uni.words, waves=16, per_wave=5)
 
