@@ -18,6 +18,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DUSP_WAVE_JIT", "2")  # wait for every circuit's compiled kernel
 
 
+def box_fill_GBps(ctx, torch, stream):
+    """What a pure write stream sustains on THIS box: dusp_fill_device (16-byte coalesced stores) over 4 GiB, best of 4."""
+    buf = torch.empty(1 << 30, dtype=torch.float32, device="cuda")
+    best = 1e9
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ctx.fill(buf.data_ptr(), buf.numel(), 0.25, stream)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    del buf
+    return 4.0 * (1 << 30) / (best * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -42,6 +57,8 @@ def main():
     def uni_of(graphs):
         return descriptor.unify([descriptor.extract(g) for g in graphs])
 
+    FILL = box_fill_GBps(ctx, torch, stream)
+    print("fill kernel on this box: %.0f GB/s" % FILL, flush=True)
     cfgs = {}
     records = []
     T10 = int(10 * sr * args.scale)
@@ -92,7 +109,8 @@ def main():
               % (name, prog.engine, prog.shape, n_inst, n, ms, samples / ms / 1e3, 4 * samples / ms / 1e6, host_s), flush=True)
         records.append({"config": name, "engine": prog.engine, "shape": prog.shape, "kernel": "dusp_jit_render" if "compiled kernel" in prog.shape else "dusp_%s_kernel" % prog.engine,
                         "instances": n_inst, "channels": prog.n_out_channels, "n_samples": n, "avg_ms": round(ms, 4),
-                        "first_render_ms_compile_inclusive": round(ts[0], 3), "algorithmic_bytes": 4 * samples, "frac_of_8TBps": round(4 * samples / (ms * 1e-3) / 8e12, 4)})
+                        "first_render_ms_compile_inclusive": round(ts[0], 3), "algorithmic_bytes": 4 * samples, "frac_of_8TBps": round(4 * samples / (ms * 1e-3) / 8e12, 4),
+                        "frac_of_fill": round(4 * samples / (ms * 1e-3) / 1e9 / FILL, 4), "box_fill_GBps": round(FILL, 1)})
         prog.close()
         del out
     if args.json:

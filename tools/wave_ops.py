@@ -17,9 +17,26 @@ from dusp_amd import descriptor, runtime  # noqa: E402
 
 sr = 48000
 d.configure(sr)
+def box_fill_GBps(ctx, torch, stream):
+    """What a pure write stream sustains on THIS box: dusp_fill_device (16-byte coalesced stores) over 4 GiB, best of 4."""
+    buf = torch.empty(1 << 30, dtype=torch.float32, device="cuda")
+    best = 1e9
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ctx.fill(buf.data_ptr(), buf.numel(), 0.25, stream)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    del buf
+    return 4.0 * (1 << 30) / (best * 1e-3) / 1e9
+
+
 ctx = runtime.Context(0, sr)
 stream = torch.cuda.current_stream().cuda_stream
 V, n = 16384, 48000
+FILL = box_fill_GBps(ctx, torch, stream)
+print("fill kernel on this box: %.0f GB/s" % FILL, flush=True)
 graphs = {
     "osc(k)": lambda k: d.Osc(110 + k / 8),
     "osc(k) x 4": lambda k: d.Sum(d.Sum(d.Osc(110 + k / 8), d.Osc(50 + k / 16)), d.Sum(d.Osc(70 + k / 4), d.Osc(30 + k / 2))),
@@ -88,7 +105,8 @@ for name, g in graphs.items():
     print("%-28s %8.3f ms  %8.1f Gsamples/s  %5.1f %% of 8 TB/s   [%s %s]" % (name, ms, V_ * prog.n_out_channels * n / ms / 1e6, 100 * algo / (ms * 1e-3) / 8e12, prog.engine, prog.shape), flush=True)
     records.append({"graph": name, "kernel": "dusp_jit_render" if "compiled kernel" in prog.shape else prog.engine, "engine": prog.engine, "shape": prog.shape,
                     "instances": V_, "channels": prog.n_out_channels, "n_samples": n, "avg_ms": round(ms, 4), "first_render_ms_compile_inclusive": round(first_ms, 3),
-                    "algorithmic_bytes": algo, "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4)})
+                    "algorithmic_bytes": algo, "frac_of_8TBps": round(algo / (ms * 1e-3) / 8e12, 4),
+                    "frac_of_fill": round(algo / (ms * 1e-3) / 1e9 / FILL, 4), "box_fill_GBps": round(FILL, 1)})
     prog.close()
     del out
 if json_path:
