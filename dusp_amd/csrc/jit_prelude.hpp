@@ -1210,6 +1210,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int WAVES, int R, int SUB, int NA, int MEM>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
+    static constexpr int kBuf = WAVES * R * kPitch;  // a pipelined kernel's tile holds TWO such sets of rows (`buf`): sub-block s + 1 is parked while s is served
     double a[NA][3];                        // this wave's instances: a0 a1 a2 (wave-uniform)
     float x1[R], x2[R];                     // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     double k[5], lastF;                     // lane = row (the same in every wave): that instance's coefficients
@@ -1278,7 +1279,8 @@ struct JitFilterK {
         x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
     }
     // sub-block s of slot r: the lanes whose samples it holds put their four P values into the wave's row
-    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[4]) {
+    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[4], int buf = 0) {
+        tile += (size_t)buf * kBuf;
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             f64x2 *row = (f64x2 *)(tile + (size_t)(X.wave * R + r) * kPitch) + ((int)X.lane - first) * 2;
@@ -1286,7 +1288,8 @@ struct JitFilterK {
             row[1] = f64x2{p[2], p[3]};
         }
     }
-    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4], int buf = 0) {
+        tile += (size_t)buf * kBuf;
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
@@ -1327,12 +1330,12 @@ struct JitFilterK {
     // that to +0 (see loop2_engine.hip).  A sub-block that met a NaN in some row is given back: the word after row 0 says so,
     // y1 / y2 stay as they were, every wave parks its rows again (failed()) and serial_exact() does the sub-block as written.
     template <int PB>  // 8, or 4 where the kernel is short of registers (two sets of PB doubles)
-    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who, int buf = 0) {
         if (X.wave != who || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t row = row_address(tile, X.lane);
+        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
@@ -1369,9 +1372,9 @@ struct JitFilterK {
         return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)flag_address(tile)) != 0;
     }
     // the sub-block as Filter.js:40-46 writes it, on freshly parked rows
-    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who, int buf = 0) {
         if (X.wave != who || X.lane >= WAVES * R) return;
-        const uint32_t row = row_address(tile, X.lane);
+        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         const double b1 = k[3], b2 = k[4];
