@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
                     }
                     if (++tBuffer == len) tBuffer = 0;
                 }
+                st[0] = (double)x.at(kChunk - 1);  // (the last input: what a kernel that takes the render over — write-once ring — starts from)
                 break;
             }
             case OP_CB_READER: {  // CircleBufferReader.js:12-25

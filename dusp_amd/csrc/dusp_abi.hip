@@ -29,6 +29,8 @@ hipError_t launch_state_init(double *state, const double *init, uint32_t n_slots
 hipError_t launch_fill(float *out, size_t n_floats, float value, hipStream_t stream);
 hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uint64_t ring_samples, const float *saved_bufs, float *chunk_scratch,
                                 uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, hipStream_t stream);
+hipError_t launch_chunk_to_wave(const float *chunk_rings, float *wave_rings, uint64_t ring_samples, const float *chunk_scratch, float *saved_bufs, uint32_t n_bufs,
+                                uint32_t n_inst, uint32_t n_pad, const double *state, double *init_state, uint32_t n_slots, hipStream_t stream);
 hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
 hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, bool wide, hipStream_t stream);
@@ -151,6 +153,10 @@ struct dusp_program {
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
+    // channel counts that grow during the first chunks (Program::warm_ops): those chunks on the chunk engine, the rest on a compiled kernel
+    bool handoff_ok = false;
+    DevBuf<double> d_handoff_init;   // the unit state the chunk engine left (instance 0), as the compiled kernel's start state
+    DevBuf<float> d_handoff_out;     // the two parts' PCM before they are put side by side
     DevBuf<int64_t> d_jit_regime;  // per-instance delays: [slot, ring length, mono] per unit, then the verdicts (render_jit)
 
     dusp_program() = default;
@@ -162,6 +168,8 @@ struct dusp_program {
         for (DevBuf<double> *b : {&d_init, &d_state, &d_fused_state, &d_jit_dk}) b->release();
         d_jit_scan.release();
         d_jit_regime.release();
+        d_handoff_init.release();
+        d_handoff_out.release();
         d_ops.release();
         d_out_bufs.release();
         d_seg.release();
@@ -441,6 +449,26 @@ static int finish_build(dusp_program *prog) {
     prog->jit_consts_uploaded = false;
     prog->jit_ok = engine == DUSP_ENGINE_WAVE && ctx->knobs.wave_jit != 0 &&
                    dusp::jit_eligible(prog->P, prog->wave, prog->jit_why);
+    // Channel counts that grow during the first chunks keep a program on the chunk engine — for those chunks.  When the SETTLED op list is
+    // one the circuit compiler takes, a single circuit's render hands over behind them (render_device: rings, outlets' last chunk and
+    // unit state move into the compiled kernel's layout).
+    prog->handoff_ok = false;
+    if (engine == DUSP_ENGINE_CHUNK && !prog->P.warm_ops.empty() && !prog->resumable && prog->requested_engine == DUSP_ENGINE_AUTO && ctx->knobs.wave_jit != 0 &&
+        prog->P.g.n_inputs == 0) {
+        auto checked = std::move(prog->wave.ramp_checked);
+        prog->wave = dusp::WavePlan();
+        prog->wave.ramp_checked = std::move(checked);
+        std::string why;
+        if (dusp::plan_wave(prog->P, prog->wave, /*will_continue=*/true, /*settled_only=*/true) && dusp::jit_eligible(prog->P, prog->wave, why)) {
+            prog->handoff_ok = true;
+            for (size_t k = 0; k < prog->wave.osc_level.size() && k < prog->P.ops.size(); k++)
+                if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
+            for (size_t k = 0; k < prog->wave.ramp_fastdiv.size() && k < prog->P.ops.size(); k++)
+                if (prog->P.ops[k].op == dusp::OP_RAMP) prog->P.ops[k].attr = prog->wave.ramp_fastdiv[k];
+            for (dusp::DevOp &op : prog->P.ops)  // (the kernel continues rings the chunk engine kept in the reference's state)
+                if (op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) op.pad = dusp::kDelayExactRing;
+        }
+    }
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const dusp::Program &P = prog->P;
@@ -603,6 +631,9 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS (kernel compiling)", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     else if (prog->engine == DUSP_ENGINE_WAVE)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
+    if (prog->engine == DUSP_ENGINE_CHUNK && prog->handoff_ok && prog->jit_waves)
+        std::snprintf(info->shape, sizeof info->shape, "%d warm-up chunks here, then compiled kernel: %d units, %dx%d", (int)prog->P.warm_ops.size(), (int)prog->P.ops.size(),
+                      prog->jit_waves, prog->jit_per_wave);
     return DUSP_OK;
 }
 
@@ -641,14 +672,17 @@ constexpr int kJitLater = 1;  // render_jit: the kernel is being compiled in the
 
 // WAVE programs the circuit compiler takes: ONE kernel generated for this circuit's structure (jit_codegen.hpp), compiled for
 // gfx950 in process the first time the structure is seen (jit_engine.hip), cached from then on.
+// handoff_chunks > 0: this launch continues a render whose first handoff_chunks chunks the chunk engine has just rendered (Program::warm_ops):
+// start state in d_handoff_init, rings and outlets' last chunk already in this kernel's layout.
+// probe: only find out whether the kernel is at hand (DUSP_OK) or being compiled in the background (kJitLater); nothing is launched.
 static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uint32_t n_chunks, const float *d_params, const float *d_inputs, float *d_out,
-                      hipStream_t stream) {
+                      hipStream_t stream, uint32_t handoff_chunks = 0, bool probe = false) {
     dusp_ctx *ctx = prog->ctx;
     const dusp::Program &P = prog->P;
     const uint32_t n_pad = (n_inst + 63u) & ~63u;
     const size_t n_slots = P.init_state.size();
-    const bool persistent = prog->resumable && prog->persistent;
-    const bool resume = prog->keep_memory;
+    const bool persistent = (prog->resumable && prog->persistent) || handoff_chunks > 0;
+    const bool resume = prog->keep_memory || handoff_chunks > 0;
     if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
     // Per-instance (parameter) delays: the kernel a Delay gets depends on where its instances' values lie — all of at least a chunk
     // (write-once ring), all below a chunk (no ring), or neither (ordered slot operations) — so the column is looked at first
@@ -699,10 +733,10 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     a.inputs = d_inputs;
     a.out = d_out;
     a.state = prog->d_state.p;
-    a.init_state = prog->d_init.p;
+    a.init_state = handoff_chunks ? prog->d_handoff_init.p : prog->d_init.p;
     a.n_samples = n_samples;
     a.ring_samples = (uint64_t)P.ring_samples;
-    a.clock0 = (uint64_t)P.g.clock0;
+    a.clock0 = (uint64_t)P.g.clock0 + (uint64_t)handoff_chunks * dusp::kChunk;
     a.n_inst = n_inst;
     a.n_pad = n_pad;
     a.n_groups = n_chunks;
@@ -813,7 +847,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         // than that does not wait for it: the compile starts in a background thread, THIS render runs on the interpreter (same
         // PCM, same state), and the next render of the structure — in this process, or in any with DUSP_JIT_CACHE set — finds
         // its kernel.  DUSP_WAVE_JIT=2 always waits (tests, benchmarks).
-        if (ctx->knobs.wave_jit == 1 && !dusp::jit_code_ready(src->text)) {
+        if (ctx->knobs.wave_jit == 1 && (!handoff_chunks || probe) && !dusp::jit_code_ready(src->text)) {
             // interpreter: ~0.7 ns per unit and chunk with the chip full, ~1 us per unit and chunk along one wavefront's serial path
             const double units = (double)P.ops.size();
             const double est_ms = std::max(units * (double)n_inst * n_chunks * 0.7e-6, units * (double)a.seg_groups * 1.0e-3);
@@ -844,6 +878,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         else break;
         if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod, opt.pipeline);
     }
+    if (probe) return DUSP_OK;
     // (from here on the render happens on the compiled kernel: workspaces)
     HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
     a.state = prog->d_state.p;
@@ -879,7 +914,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     a.dk = prog->d_jit_dk.p;
     const unsigned per_block = (unsigned)(waves * per_wave);
     const unsigned grid = (unsigned)((n_virtual + per_block - 1) / per_block);
-    HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+    if (!handoff_chunks) HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));  // (a hand-off's clock started in front of the chunk engine's part)
     if (a.n_seg > 1 && !src->scans.empty()) {  // one accumulate pass + prefix per FM level that has scanned oscillators, then the render pass
         const size_t per = src->scans.size() * (size_t)n_inst * a.n_seg;
         HIP_TRY(ctx, prog->d_seg.ensure(2 * per));
@@ -927,7 +962,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     prog->last_n_pad = n_pad;
     prog->rendered = true;
     prog->h_state_valid = false;
-    prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
+    prog->next_clock = P.g.clock0 + (int64_t)(n_chunks + handoff_chunks) * dusp::kChunk;
     return DUSP_OK;
 }
 
@@ -953,6 +988,7 @@ static int check_guards(dusp_program *prog, hipStream_t stream) {
     else if (!prog->d_host_frames.intact()) hit = "staging frames";
     else if (!prog->d_host_par.intact()) hit = "staging parameters";
     else if (!prog->d_host_in.intact()) hit = "staging inputs";
+    else if (!prog->d_handoff_init.intact() || !prog->d_handoff_out.intact()) hit = "hand-off buffers";
     else if (!prog->d_ops.intact() || !prog->d_out_bufs.intact() || !prog->d_init.intact()) hit = "program constants";
     else if (!prog->d_jit_fk.intact() || !prog->d_jit_dk.intact() || !prog->d_jit_scan.intact()) hit = "compiled kernel's constants";
     else if (ctx->tables_guarded && ctx->d_tables && !guard_intact((const char *)ctx->d_tables + sizeof(float) * dusp::kNumTables * ctx->table_stride)) hit = "lookup tables";
@@ -1118,6 +1154,72 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         prog->h_state_valid = false;
         prog->next_clock = P.g.clock0 + (int64_t)n_chunks * dusp::kChunk;
         return DUSP_OK;
+    }
+    // Channel counts that grow during the first chunks (Program::warm_ops): a single circuit renders those chunks here, on the chunk engine
+    // (with the reference's own ring protocol), and the rest on the kernel compiled for its settled op list — rings, every outlet's last
+    // chunk and the unit state move into that kernel's layout in between (dusp_chunk_to_wave_kernel).
+    if (prog->engine == DUSP_ENGINE_CHUNK && prog->handoff_ok && n_inst == 1 && !prog->keep_memory && P.g.clock0 % dusp::kChunk == 0) {
+        const uint64_t first_chunk = (uint64_t)P.g.clock0 / dusp::kChunk;
+        const uint32_t n_warm = (uint32_t)P.warm_ops.size();
+        const uint32_t W = first_chunk < n_warm ? (uint32_t)std::min<uint64_t>(n_chunks, n_warm - first_chunk) : 0u;
+        // (under the default knob a structure seen for the first time renders on the chunk engine alone while its kernel compiles in the background)
+        if (W > 0 && W < n_chunks &&
+            render_jit(prog, n_inst, n_samples - (size_t)W * dusp::kChunk, n_chunks - W, d_params, d_inputs, d_out, stream, W, /*probe=*/true) == DUSP_OK) {
+            const size_t n_ch = P.out_bufs.size(), n_head = (size_t)W * dusp::kChunk, n_rest = n_samples - n_head;
+            const uint32_t n_bufs = (uint32_t)std::max(1, P.n_bufs);
+            HIP_TRY(ctx, prog->d_scratch.ensure((size_t)n_bufs * dusp::kChunk * n_pad));
+            HIP_TRY(ctx, prog->d_state.ensure(std::max<size_t>(1, n_slots) * n_pad));
+            HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
+            HIP_TRY(ctx, prog->d_rings_wave.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
+            HIP_TRY(ctx, prog->d_saved_bufs.ensure((size_t)n_bufs * dusp::kChunk * n_inst));
+            HIP_TRY(ctx, prog->d_handoff_init.ensure(std::max<size_t>(1, n_slots)));
+            HIP_TRY(ctx, prog->d_handoff_out.ensure(n_ch * std::max(n_head, n_rest)));
+            HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)n_bufs * dusp::kChunk * n_pad * sizeof(float), stream));
+            if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+            HIP_TRY(ctx, dusp::launch_state_init(prog->d_state.p, prog->d_init.p, (uint32_t)n_slots, n_pad, stream));
+            dusp::ChunkArgs a{};
+            a.ops = prog->d_ops.p;
+            a.out_bufs = prog->d_out_bufs.p;
+            a.scratch = prog->d_scratch.p;
+            a.state = prog->d_state.p;
+            a.rings = prog->d_rings.p;
+            a.params = d_params;
+            a.tables = ctx->d_tables;
+            a.inputs = d_inputs;
+            a.out = prog->d_handoff_out.p;
+            a.n_samples = n_head;
+            a.clock0 = P.g.clock0;
+            a.n_ops = (uint32_t)P.ops.size();
+            a.n_out = (uint32_t)n_ch;
+            a.n_inst = n_inst;
+            a.n_pad = n_pad;
+            a.n_chunks = W;
+            a.sample_rate = (uint32_t)P.g.sample_rate;
+            a.table_stride = ctx->table_stride;
+            a.flags = dusp::kChunkFlagResumable;  // (rings in the reference's own state: a compiled kernel continues them)
+            a.n_warm = n_warm;
+            for (uint32_t k = 0, at = a.n_ops; k < a.n_warm; k++) {
+                a.warm_first[k] = at;
+                a.warm_n[k] = (uint32_t)P.warm_ops[k].size();
+                at += a.warm_n[k];
+            }
+            HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
+            HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_out, n_samples * sizeof(float), prog->d_handoff_out.p, n_head * sizeof(float), n_head * sizeof(float), n_ch,
+                                          hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(ctx, dusp::launch_chunk_to_wave(prog->d_rings.p, prog->d_rings_wave.p, (uint64_t)P.ring_samples, prog->d_scratch.p, prog->d_saved_bufs.p, n_bufs,
+                                                    n_inst, n_pad, prog->d_state.p, prog->d_handoff_init.p, (uint32_t)n_slots, stream));
+            std::swap(prog->d_rings_wave.p, prog->d_rings.p);  // (same size; the compiled kernel's rings are the program's rings from here on)
+            std::swap(prog->d_rings_wave.cap, prog->d_rings.cap);
+            prog->last_n_inst = n_inst;
+            const int rc = render_jit(prog, n_inst, n_rest, n_chunks - W, d_params, d_inputs, prog->d_handoff_out.p, stream, W);
+            if (rc == kJitLater) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: internal error: a hand-off that does not wait for its kernel");
+            if (rc != DUSP_OK) return rc;
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_out + n_head, n_samples * sizeof(float), prog->d_handoff_out.p, n_rest * sizeof(float), n_rest * sizeof(float), n_ch,
+                                          hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
+            return DUSP_OK;
+        }
     }
     if (prog->keep_memory) {  // continuing: chunk buffers and rings hold what the previous segment left
         if (n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");

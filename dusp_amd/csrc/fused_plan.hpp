@@ -506,14 +506,16 @@ inline bool delay_write_once(const DevOp &op) {
 
 // Can the wave engine (one wavefront per instance, chunk buffers in LDS) run this program?
 // will_continue: the program is resumable, i.e. later launches pick up rings and parked chunk buffers in the reference's layout
-inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = false) {
+// settled_only: plan the settled op list of a program whose first chunks run op lists of their own (Program::warm_ops) — those chunks
+// are rendered by the chunk engine and the rest handed to a compiled kernel (dusp_abi.hip)
+inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = false, bool settled_only = false) {
     const Graph &g = P.g;
     auto no = [&](const std::string &why) {
         plan.why = why;
         plan.ok = false;
         return false;
     };
-    if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
+    if (!P.warm_ops.empty() && !settled_only) return no("channel counts grow during the first chunks");
     // CircleBuffer nodes: with a lane-constant offset a node touches 256 consecutive slots per chunk (lane-parallel); a
     // signal-rate offset can make two samples of one chunk meet in one slot, and a ring shorter than a chunk wraps onto
     // itself: those go through the ordered slot operations (below: ring_events)

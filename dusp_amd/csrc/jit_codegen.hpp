@@ -45,6 +45,7 @@ struct JitOptions {
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int filter_stages = 0;   // Filter stages of the circuit (jit_filter_stages): each keeps its rows' y1 / y2 behind the tile
     bool filter_mod = false; // one of them has a connected cutoff (jit_filter_mod): the tile's rows hold P, b1 and b2 of a sub-block
+    bool mod_double = false; // a stage with a connected cutoff parks sub-block s + 1 in a second set of rows while s is served (measured slower than one set: off)
     bool pipeline = false;   // the tile holds two sets of rows: a circuit with ONE constant-cutoff Filter stage parks sub-block s + 1 while s is served (Emitter::loop)
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
@@ -77,8 +78,8 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // the tile, one after the other, but each has its own recurrence memory).
 // (mod: a stage with a connected cutoff shares the tile — rows of three arrays, P / b1 / b2 per sample: JitFilterKM)
 inline size_t jit_filter_rows_bytes(int rows, int sub, bool mod, bool pipeline = false) {
-    // (with a connected cutoff, and in pipelined kernels: two sets of rows — sub-block s + 1 is parked while s is served)
-    return (size_t)(mod || pipeline ? 2 : 1) * (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8;
+    // (pipeline — in pipelined kernels, or with JitOptions::mod_double: two sets of rows — sub-block s + 1 is parked while s is served)
+    return (size_t)(pipeline ? 2 : 1) * (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8;
 }
 inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod, bool pipeline = false) {
     return jit_filter_rows_bytes(rows, sub, mod, pipeline) + 16 + (size_t)stages * (size_t)rows * 16;
@@ -160,7 +161,7 @@ inline size_t jit_scratch_floats(const Program &P) {
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline) : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline || opt.mod_double) : 0) +
                                     (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
@@ -414,7 +415,7 @@ struct Emitter {
         }
         if (opt.scratch_floats) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
-                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline) / 4) : 0);
+                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline || opt.mod_double) / 4) : 0);
             line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         }
         // constants and parameters the used ops name
@@ -511,13 +512,13 @@ struct Emitter {
                 }
             }
             if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
-                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline)) + "> f" + num(k) + ";");
+                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline || opt.mod_double)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++) line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.state_slot) + ");");
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
                 line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + ", " +
-                     num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline)) + "> f" + num(k) + ";");
+                     num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline || opt.mod_double)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++)
                     line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
@@ -704,10 +705,10 @@ struct Emitter {
         lagged[(size_t)fop.out_buf] = 1;
         for (size_t c = 0; c < P.ops.size(); c++)
             if (used[c] && grp_post[c] && P.ops[c].out_buf >= 0) lagged[(size_t)P.ops[c].out_buf] = 1;
-        // every outlet's registers live across iterations
+        // registers of the outlets ticked late live across iterations; the others' belong to one iteration
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int u = plan.order[at];
-            if (used[(size_t)u] && P.ops[(size_t)u].out_buf >= 0)
+            if (used[(size_t)u] && P.ops[(size_t)u].out_buf >= 0 && lagged[(size_t)P.ops[(size_t)u].out_buf])
                 for (int r = 0; r < copies(u); r++) line("    float v" + num(P.ops[(size_t)u].out_buf) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
         }
         for (int r = 0; r < R; r++) line("    double q" + num(k) + "_" + num(r) + "[4];");
@@ -729,7 +730,22 @@ struct Emitter {
                     for (int r = 0; r < copies(producer[(size_t)b]); r++)
                         line(std::string(indent) + "for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
         };
+        // which window a wave does its side work in: never one it serves (waves 0 / 1 serve the even / odd ones); SIMD-aware like the overlapped form
+        {
+            std::string pick = num(subs - 1);
+            for (int i = opt.waves - 1; i >= 0; i--) {
+                const int simd = i & 3, group = i >> 2, half = std::max(1, subs / 2);
+                const int w = simd == 0 ? (2 * (group % half) + 1) % subs : simd == 1 ? 2 * (group % half) : (group + simd) % subs;
+                pick = "X[0].wave == " + num(i) + "u ? " + num(w) + " : " + pick;
+            }
+            line("    const int my_window = (int)jit_u((uint32_t)(" + pick + "));");
+        }
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        for (size_t at = 0; at < plan.order.size(); at++) {
+            const int u = plan.order[at];
+            if (used[(size_t)u] && P.ops[(size_t)u].out_buf >= 0 && !lagged[(size_t)P.ops[(size_t)u].out_buf])
+                for (int r = 0; r < copies(u); r++) line("        float v" + num(P.ops[(size_t)u].out_buf) + "_" + num(r) + "[4];");
+        }
         line("        auto side0 = [&]() __attribute__((always_inline)) {  // (a wave runs it whole, in one window it does not serve)");
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int u = plan.order[at];
@@ -764,43 +780,35 @@ struct Emitter {
         for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", 0, q" + num(k) + "_" + num(r) + ", 0);");
         line("            jit_lds_barrier();");
         line("        }");
-        // which window a wave does its side work in: never one it serves (waves 0 / 1 serve the even / odd ones); SIMD-aware like the overlapped form
-        std::vector<unsigned> workers((size_t)subs, 0u);
-        for (int i = 0; i < opt.waves; i++) {
-            const int simd = i & 3, group = i >> 2, half = std::max(1, subs / 2);
-            const int w = simd == 0 ? (2 * (group % half) + 1) % subs : simd == 1 ? 2 * (group % half) : (group + simd) % subs;
-            workers[(size_t)w] |= 1u << i;
-        }
-        for (int sb = 0; sb < subs; sb++) {
-            const std::string buf = num(sb & 1), who = num(sb & 1), other = num((sb & 1) ^ 1);
-            line("        " + f + ".serial<" + PB + ">(X[0], tile, " + who + ", " + buf + ");  // (wave " + who + "; the others fall through)");
-            if (sb == 0) {
-                line("        if (g > X[0].g_begin) {  // the chunk before: its last sub-block, then what hangs on the Filter's output");
-                line("            const uint32_t gp = g - 1;");
-                for (int r = 0; r < R; r++)
-                    line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(subs - 1) + ", v" + num(fop.out_buf) + "_" + num(r) + ", " + num((subs - 1) & 1) + ");");
-                tail("            ");
-                line("        }");
-            } else
-                for (int r = 0; r < R; r++)
-                    line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb - 1) + ", v" + num(fop.out_buf) + "_" + num(r) + ", " + other + ");");
-            if (workers[(size_t)sb])
-                line("        if ((" + num((long long)workers[(size_t)sb]) + "u >> X[0].wave) & 1u) { side0(); if (g + 1 < X[0].g_end) early(g + 1); }  // (beside the recurrences)");
-            if (sb + 1 < subs)
-                for (int r = 0; r < R; r++) line("        " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb + 1) + ", q" + num(k) + "_" + num(r) + ", " + other + ");");
-            else {
-                line("        if (g + 1 < X[0].g_end) {  // the next chunk's first sub-block (its feed-forward halves were made a chunk ahead)");
-                for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", 0, qn" + num(k) + "_" + num(r) + ", " + other + ");");
-                line("        }");
-            }
-            line("        jit_lds_barrier();");
-            line("        if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
-            for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", " + num(sb) + ", q" + num(k) + "_" + num(r) + ", " + buf + ");");
-            line("            jit_lds_barrier();");
-            line("            " + f + ".serial_exact(X[0], tile, " + who + ", " + buf + ");");
-            line("            jit_lds_barrier();");
-            line("        }");
-        }
+        // the sub-blocks in a run-time loop: every piece of text stands once (the instruction cache holds 64 KB)
+        const std::string vf = "v" + num(fop.out_buf) + "_";
+        line("#pragma unroll 1");
+        line("        for (int sb = 0; sb < " + num(subs) + "; ++sb) {");
+        line("            const int buf = sb & 1;  // (= the serving wave: 0 and 1 take turns)");
+        line("            " + f + ".serial<" + PB + ">(X[0], tile, (uint32_t)buf, buf);");
+        line("            if (sb == 0) {");
+        line("                if (g > X[0].g_begin) {  // the chunk before: its last sub-block, then what hangs on the Filter's output");
+        line("                    const uint32_t gp = g - 1;");
+        for (int r = 0; r < R; r++) line("                    " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(subs - 1) + ", " + vf + num(r) + ", " + num((subs - 1) & 1) + ");");
+        tail("                    ");
+        line("                }");
+        line("            } else {");
+        for (int r = 0; r < R; r++) line("                " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb - 1, " + vf + num(r) + ", buf ^ 1);");
+        line("            }");
+        line("            if (sb == my_window) { side0(); if (g + 1 < X[0].g_end) early(g + 1); }  // (beside the recurrences)");
+        line("            if (sb + 1 < " + num(subs) + ") {");
+        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", sb + 1, q" + num(k) + "_" + num(r) + ", buf ^ 1);");
+        line("            } else if (g + 1 < X[0].g_end) {  // the next chunk's first sub-block (its feed-forward halves were made a chunk ahead)");
+        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", 0, qn" + num(k) + "_" + num(r) + ", buf ^ 1);");
+        line("            }");
+        line("            jit_lds_barrier();");
+        line("            if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
+        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", sb, q" + num(k) + "_" + num(r) + ", buf);");
+        line("                jit_lds_barrier();");
+        line("                " + f + ".serial_exact(X[0], tile, (uint32_t)buf, buf);");
+        line("                jit_lds_barrier();");
+        line("            }");
+        line("        }");
         // PCM and late registers of outlets that are not ticked late keep their place at the end of the iteration
         for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
             if (!lagged[(size_t)P.out_bufs[oc]])
@@ -966,6 +974,21 @@ struct Emitter {
                          mod_f[{k, r0}] + ", " + mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
                 }
             };
+            if (!opt.mod_double) {  // one set of rows: park, serve, pick up — sub-block by sub-block
+                line("#pragma unroll 1");
+                line("        for (int sb = 0; sb < " + N + "; ++sb) {");
+                line("            for (bool exact = false;; exact = true) {  // (once; twice when some row's recurrence met a NaN: then as written)");
+                parks("                ", "sb", "0", "false");
+                line("                jit_lds_barrier();");
+                line("                if (exact) " + f + ".serial_exact(X[0], tile, 0, 0); else " + f + ".serial<4>(X[0], tile, 0, 0);");
+                line("                jit_lds_barrier();");
+                line("                if (exact || !" + f + ".failed(tile)) break;");
+                line("            }");
+                for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, 0, v" + num(op.out_buf) + "_" + num(r) + ");");
+                for (int r = 0; r < R; r++) line("            " + f + ".carry(" + num(r) + ", sb, " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
+                line("        }");
+                return;
+            }
             // The tile holds two sets of rows: while one wave runs sub-block sb out of one, everybody parks sub-block sb + 1 in the other
             // (the serving wave its own rows behind its recurrences); waves 0 and 1 take turns at serving.
             parks("        ", "0", "0", "false");

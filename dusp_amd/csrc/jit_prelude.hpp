@@ -1429,7 +1429,7 @@ __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X
 template <int WAVES, int R, int SUB, int MEM>
 struct JitFilterKM {
     static constexpr int kPitch = 3 * SUB + 2;  // doubles per row (even: rows stay 16-byte aligned)
-    static constexpr int kBuf = WAVES * R * kPitch;  // the tile is TWO such sets of rows: while one wave runs sub-block s out of one, the others park s + 1 in the other
+    static constexpr int kBuf = WAVES * R * kPitch;  // (JitOptions::mod_double: the tile is TWO such sets of rows — sub-block s + 1 parked in one while s is served out of the other)
     float x1[R], x2[R];                         // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     float flast[R];                             // the cutoff of the last sample ticked (what `lastF` and the coefficients in the unit's state belong to)
     float px1[R], px2[R];                       // x1 / x2 as they stood in front of the sub-block parked last (a sub-block that met a NaN is parked again)

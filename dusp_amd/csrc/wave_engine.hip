@@ -1116,6 +1116,33 @@ __global__ void dusp_wave_to_chunk_kernel(const float *wave_rings, float *chunk_
     }
 }
 
+// The other way: a program whose first chunks ran on the chunk engine (channel counts that grow at first: Program::warm_ops) goes on
+// on a compiled kernel — rings [slot][instance] -> [instance][slot], every outlet's last chunk [buffer][t][instance] ->
+// [instance][buffer][t], and the unit state of instance 0 becomes the state the kernel starts from (the compiled kernels read ONE
+// start state for all instances: the hand-off is taken for single circuits).
+__global__ void dusp_chunk_to_wave_kernel(const float *chunk_rings, float *wave_rings, uint64_t ring_samples, const float *chunk_scratch, float *saved_bufs,
+                                          uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, const double *state, double *init_state, uint32_t n_slots) {
+    const uint64_t total_r = ring_samples * n_inst, total_b = (uint64_t)n_bufs * kChunk * n_inst;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total_r + total_b + n_slots; k += (uint64_t)gridDim.x * blockDim.x) {
+        if (k < total_r) {
+            const uint64_t inst = k / ring_samples, slot = k - inst * ring_samples;
+            wave_rings[k] = chunk_rings[slot * n_pad + inst];
+        } else if (k < total_r + total_b) {
+            const uint64_t j = k - total_r, inst = j / ((uint64_t)n_bufs * kChunk), bt = j - inst * (uint64_t)n_bufs * kChunk;
+            saved_bufs[j] = chunk_scratch[bt * n_pad + inst];
+        } else {
+            const uint64_t slot = k - total_r - total_b;
+            init_state[slot] = state[slot * n_pad];
+        }
+    }
+}
+hipError_t launch_chunk_to_wave(const float *chunk_rings, float *wave_rings, uint64_t ring_samples, const float *chunk_scratch, float *saved_bufs, uint32_t n_bufs,
+                                uint32_t n_inst, uint32_t n_pad, const double *state, double *init_state, uint32_t n_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(dusp_chunk_to_wave_kernel, dim3(1024), dim3(256), 0, stream, chunk_rings, wave_rings, ring_samples, chunk_scratch, saved_bufs, n_bufs,
+                       n_inst, n_pad, state, init_state, n_slots);
+    return hipGetLastError();
+}
+
 hipError_t launch_wave_to_chunk(const float *wave_rings, float *chunk_rings, uint64_t ring_samples, const float *saved_bufs, float *chunk_scratch,
                                 uint32_t n_bufs, uint32_t n_inst, uint32_t n_pad, hipStream_t stream) {
     hipLaunchKernelGGL(dusp_wave_to_chunk_kernel, dim3(1024), dim3(256), 0, stream, wave_rings, chunk_rings, ring_samples, saved_bufs,

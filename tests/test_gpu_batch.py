@@ -719,3 +719,47 @@ def test_first_render_does_not_wait_for_the_compiler(oracle):
     off = knob_context(48000, DUSP_WAVE_JIT=0).build(ex.words, runtime.ENGINE_WAVE)
     assert np.array_equal(off.render(n)[0], want) and "chunk buffers in LDS" in off.shape
     off.close()
+
+
+@pytest.mark.parametrize("name", ["grow_feedback_filter", "grow_feedback_multiosc", "grow_feedback_stereo", "grow_two_loops", "patch_scary"])
+def test_growing_channel_counts_hand_over_to_a_compiled_kernel(name, oracle):
+    """Circuits whose channel counts grow during the first chunks (a feedback edge sees one channel at first, more later: Program::warm_ops)
+    render those chunks on the chunk engine and the rest on the kernel compiled for the settled circuit: same PCM and state as the chunk
+    engine alone, the reference's windows, and 10 s in milliseconds instead of a quarter of a second."""
+    from conftest import Golden
+    g = Golden(name)
+    ctx = render.context(g.sample_rate)
+    n = 480000
+    prog = ctx.build(g.desc)  # AUTO
+    assert prog.engine == "chunk"
+    pcm = prog.render(n)[0]
+    assert "then compiled kernel" in prog.read_shape(), prog.read_shape()
+    ms = prog.last_kernel_ms()
+    ref = ctx.build(g.desc, runtime.ENGINE_CHUNK)
+    want = ref.render(n)[0]
+    assert "compiled" not in ref.read_shape()
+    assert np.array_equal(pcm, want), "first mismatch at sample %d" % int(np.argmax((pcm != want).any(axis=0)))  # (Filters too: the engines share their coefficients)
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u), ref.state(u), equal_nan=True), u
+    head = oracle.render(g.desc, 256 * 12)
+    assert np.max(np.abs(pcm[:, :256 * 12].astype(np.float64) - head)) <= 1e-5 * max(1.0, float(np.max(np.abs(head))))
+    assert ms <= 20.0, ms
+    prog.close()
+    ref.close()
+
+
+def test_a_second_process_finds_its_kernel_on_disk():
+    """The code-object cache (on by default): the first render of a circuit in a NEW process does not pay the compile again — nor a render on
+    the interpreter — when an earlier process left the kernel on disk (tools/first_call.py: FM voice under an envelope, 10 s)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    first, second = rep["empty_cache_waiting_for_the_compile"], rep["second_process_default_knob"]
+    assert "compiled kernel" in first["shape"] and "compiled kernel" in second["shape"], rep
+    assert first["first_ms"] > 100.0            # (a real hiprtc compile)
+    assert second["first_ms"] <= 30.0, rep      # (generate the text, read the file, load the module, render, download: milliseconds)

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 CSVs of tools/profile.sh into profiles/<tag>_*.{csv,md,json}."""
+"""Condense the rocprofv3 CSVs of tools/profile.sh into profiles/<tag>_*.{csv,md,json}:
+    python tools/profile_summary.py <gpurun_out/profile_<tag>> <profiles> <tag>
+Machine-readable per-config evidence (one record per BASELINE config and per tools/wave_ops.py graph: kernel, avg_ms, algorithmic bytes,
+fraction of 8 TB/s, fraction of the same box's fill kernel) out of the JSON records tools/configs_bench.py --json / tools/wave_ops.py --json wrote:
+    python tools/profile_summary.py configs <configs.json> <wave_ops.json> <profiles/rNN_configs.json>"""
 import collections
 import csv
 import glob
@@ -8,6 +12,14 @@ import os
 import shutil
 import sys
 
+if sys.argv[1] == "configs":
+    out = {"note": "kernel time by HIP events around the launch (median of 3 renders; `first_render_ms_compile_inclusive` is the first of them: for a new "
+                   "circuit structure it contains the hiprtc compile unless the code-object cache held it), 1 x MI355X; algorithmic_bytes = 4 B x instances x "
+                   "channels x samples written, 0 read; frac_of_fill = against dusp_fill_device on the same box in the same process",
+           "configs": json.load(open(sys.argv[2])), "wave_ops": json.load(open(sys.argv[3]))}
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print("%d configs, %d graphs -> %s" % (len(out["configs"]), len(out["wave_ops"]), sys.argv[4]))
+    sys.exit(0)
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 lines = ["# rocprofv3 summary (%s)" % tag, "",
@@ -67,6 +79,9 @@ lines += ["", "Dispatch: %s" % json.dumps(meta), ""]
 for f in newest(os.path.join(src, "configs", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "%s_configs_kernel_stats.csv" % tag))
     lines += ["## other BASELINE configs: `python3 tools/configs_bench.py --rounds 2` under --kernel-trace --stats", "",
+              "(kernel durations from the trace: launches only — the lines of `configs.log` below are HIP-event medians over the rounds, so a round-1 "
+              "render of a NEW circuit structure, which contains its hiprtc compile, does not show in them; `first_render_ms_compile_inclusive` in "
+              "`%s_configs.json` keeps that figure apart)" % tag, "",
               "| kernel | calls | avg ms | min ms | max ms |", "|---|---|---|---|---|"]
     for r in csv.DictReader(open(f)):
         if "dusp_" in r["Name"]:
