@@ -242,7 +242,6 @@ static dusp::Knobs read_knobs() {
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
-    k.jit_pipeline = num("DUSP_JIT_PIPELINE", k.jit_pipeline);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
         if (std::sscanf(f, "%dx%d", &w, &r) == 2 && w >= 1 && w <= 16 && r >= 1 && r <= 4) k.jit_force_waves = w, k.jit_force_per_wave = r;
@@ -795,19 +794,16 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
-        // ONE constant-cutoff stage: two sets of tile rows, sub-block s + 1 parked while s is served (jit_codegen.hpp pipeline_loop) — where LDS holds them
-        opt.pipeline = opt.filter_stages == 1 && !opt.filter_mod && !persistent && !opt.profile && waves >= 2 && ctx->knobs.jit_pipeline != 0 &&
-                       dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, false, true) != 0;
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod, opt.pipeline);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
         // (a connected cutoff parks three values per sample in two sets of rows: fewer rows per workgroup before the table image goes)
         while (opt.filter_mod && !opt.filter_sub && (per_wave > 1 || waves > 1)) {
             if (per_wave > 1) per_wave /= 2;
             else waves /= 2;
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod, opt.pipeline);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
         }
         if (!opt.filter_sub) {  // (cannot happen with a 99 KB image: 64 rows of 64 samples take 33 KB)
             opt.lds_table = -1, opt.table_bytes = 0;
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget, opt.filter_mod, opt.pipeline);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget, opt.filter_mod);
         }
     } else {
         while (waves < most && (unsigned)waves < want) waves *= 2;
@@ -825,7 +821,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         waves = std::min(most, ctx->knobs.jit_force_waves);
         per_wave = ctx->knobs.jit_force_per_wave;
         if (filter_stage) {
-            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod, opt.pipeline);
+            opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
             if (!opt.filter_sub) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: DUSP_JIT_FORCE: the Filter stage's rows do not fit LDS at this geometry");
         }
     }
@@ -876,7 +872,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         else if (per_wave > 1) per_wave /= 2;  // (4, 2, 1: an odd count leaves the last round of workgroups a third full at the usual batch sizes)
         else if (waves > 4) waves /= 2;
         else break;
-        if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod, opt.pipeline);
+        if (filter_stage) opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
     }
     if (probe) return DUSP_OK;
     // (from here on the render happens on the compiled kernel: workspaces)
@@ -1598,7 +1594,6 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         return DUSP_ERR_ARG;
     }
     const bool continued = (lds_table & 2) != 0 && (P.ring_samples != 0 || !P.feed_forward);
-    const bool want_pipeline = (lds_table & 4) != 0;
     lds_table &= 1;
     if (continued)
         for (dusp::DevOp &op : P.ops)
@@ -1634,9 +1629,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     opt.filter_mod = dusp::jit_filter_mod(P);
     if (plan.has_filter) {
         const size_t left = 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4;
-        opt.pipeline = want_pipeline && opt.filter_stages == 1 && !opt.filter_mod && !continued && waves >= 2 &&
-                       dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, false, true) != 0;
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, opt.filter_mod, opt.pipeline);
+        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, opt.filter_mod);
         if (!opt.filter_sub) {
             g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
             return DUSP_ERR_ARG;

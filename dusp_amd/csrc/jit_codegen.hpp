@@ -45,8 +45,6 @@ struct JitOptions {
     int filter_sub = 256;    // samples per sub-block of the Filter stage (jit_filter_sub)
     int filter_stages = 0;   // Filter stages of the circuit (jit_filter_stages): each keeps its rows' y1 / y2 behind the tile
     bool filter_mod = false; // one of them has a connected cutoff (jit_filter_mod): the tile's rows hold P, b1 and b2 of a sub-block
-    bool mod_double = false; // a stage with a connected cutoff parks sub-block s + 1 in a second set of rows while s is served (measured slower than one set: off)
-    bool pipeline = false;   // the tile holds two sets of rows: a circuit with ONE constant-cutoff Filter stage parks sub-block s + 1 while s is served (Emitter::loop)
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
@@ -77,13 +75,8 @@ inline int jit_table_source(const JitOptions &opt, int table_id) {
 // Behind the rows: one word that says "given back", then y1 / y2 of every row of every Filter stage of the circuit (the stages share
 // the tile, one after the other, but each has its own recurrence memory).
 // (mod: a stage with a connected cutoff shares the tile — rows of three arrays, P / b1 / b2 per sample: JitFilterKM)
-inline size_t jit_filter_rows_bytes(int rows, int sub, bool mod, bool pipeline = false) {
-    // (pipeline — in pipelined kernels, or with JitOptions::mod_double: two sets of rows — sub-block s + 1 is parked while s is served)
-    return (size_t)(pipeline ? 2 : 1) * (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8;
-}
-inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod, bool pipeline = false) {
-    return jit_filter_rows_bytes(rows, sub, mod, pipeline) + 16 + (size_t)stages * (size_t)rows * 16;
-}
+inline size_t jit_filter_rows_bytes(int rows, int sub, bool mod) { return (size_t)rows * (size_t)((mod ? 3 * sub : sub) + 2) * 8; }
+inline size_t jit_filter_tile_bytes(int rows, int sub, int stages, bool mod) { return jit_filter_rows_bytes(rows, sub, mod) + 16 + (size_t)stages * (size_t)rows * 16; }
 inline int jit_filter_stages(const Program &P) {
     int n = 0;
     for (const DevOp &op : P.ops) n += op.op == OP_FILTER;
@@ -94,10 +87,9 @@ inline bool jit_filter_mod(const Program &P) {
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) return true;
     return false;
 }
-inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left, bool mod, bool pipeline = false) {
+inline int jit_filter_sub(int waves, int per_wave, int stages, size_t lds_left, bool mod) {
     for (int sub : {256, 128, 64, 32})
-        if ((!mod || sub <= 64) && (!pipeline || sub <= 128) &&  // (a connected cutoff: one sample per lane and sub-block; a pipeline: two sub-blocks at least)
-            jit_filter_tile_bytes(waves * per_wave, sub, stages, mod, pipeline) <= lds_left) return sub;
+        if ((!mod || sub <= 64) && jit_filter_tile_bytes(waves * per_wave, sub, stages, mod) <= lds_left) return sub;  // (a connected cutoff: one sample per lane and sub-block)
     return 0;
 }
 // A circuit whose whole chunk body is a few dozen instructions (constant-f oscillators, Ramp, Timer, the elementwise maps; two units
@@ -161,7 +153,7 @@ inline size_t jit_scratch_floats(const Program &P) {
 }
 inline size_t jit_lds_bytes(const JitOptions &opt, bool has_filter) {
     return std::max<size_t>(16, (opt.lds_table >= 0 ? opt.table_bytes : 0) +
-                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline || opt.mod_double) : 0) +
+                                    (has_filter ? jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod) : 0) +
                                     (size_t)opt.waves * opt.scratch_floats * 4);
 }
 
@@ -232,7 +224,6 @@ struct Emitter {
                                    // ahead as `vn`, copied into `v` at the top of the chunk they belong to
     bool predeclared = false;      // unit(): the outlets' register arrays are declared at the top of the loop body already
     int delay_half = 0;            // unit(): 0 a write-once Delay's whole tick, 1 its reads only, 2 its writes only
-    std::string gname = "g";       // unit(): the chunk index a unit's text names (a pipelined kernel ticks what hangs on its Filter one iteration late: "gp")
 
     Emitter(const Program &P_, const WavePlan &plan_, JitOptions o, JitSource &out_) : P(P_), plan(plan_), opt(o), out(out_), R(std::max(1, o.per_wave)) {}
 
@@ -415,7 +406,7 @@ struct Emitter {
         }
         if (opt.scratch_floats) {
             const long long at = (long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4) +
-                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod, opt.pipeline || opt.mod_double) / 4) : 0);
+                                 (out.has_filter ? (long long)(jit_filter_tile_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_stages, opt.filter_mod) / 4) : 0);
             line("    float *scr = lds + " + num(at) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         }
         // constants and parameters the used ops name
@@ -512,13 +503,13 @@ struct Emitter {
                 }
             }
             if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
-                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline || opt.mod_double)) + "> f" + num(k) + ";");
+                line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++) line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.state_slot) + ");");
             } else if (op.op == OP_FILTER) {  // one object per Filter: the recurrence's state lives in the lanes of wave 0 (lane = instance of the workgroup)
                 const std::string f = op.in[1].kind == SRC_PARAM ? "jit_row_param<" + W + ", " + RR + ">(A, X[0], " + num(op.in[1].idx) + ")" : opnd(k, 1, "0", 0);
                 line("    JitFilterK<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + (op.in[1].kind == SRC_PARAM ? RR : std::string("1")) + ", " +
-                     num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod, opt.pipeline || opt.mod_double)) + "> f" + num(k) + ";");
+                     num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.attr) + ", " + f + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++)
                     line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
@@ -683,152 +674,6 @@ struct Emitter {
         // (rows are per wave: a wave parks into and picks from its own rows only; wave 0 touches the others' between the barriers)
     }
 
-    // The pipelined form of a circuit with ONE constant-cutoff Filter stage (BASELINE configs[3], a filtered voice): the tile holds two
-    // sets of rows, so that in phase k — the serving wave running the recurrences of sub-block k out of one set — everybody else picks
-    // up sub-block k - 1 and parks sub-block k + 1 in the other (the serving wave does both for its own rows behind its recurrences;
-    // waves 0 and 1 take turns).  One barrier per sub-block instead of two, and neither parking nor picking stands between two serves.
-    // What hangs on the Filter's output (post units, the PCM store, late readers' registers) is ticked one iteration late, right after
-    // the previous chunk's last sub-block has been picked up (`gp` = g - 1); everything else keeps its place from the overlapped form:
-    // side units and next chunk's early units in one window per wave.
-    bool pipeline_loop(bool render, int pass_level, const std::vector<char> &used, bool fx) {
-        if (!render || !opt.pipeline || opt.profile || opt.persistent || opt.waves < 2) return false;
-        const int subs = kChunk / opt.filter_sub;
-        if (subs < 2 || subs % 2 != 0) return false;
-        int k = -1, n_stages = 0;
-        for (size_t at = 0; at < plan.order.size(); at++)
-            if (used[(size_t)plan.order[at]] && is_filter_stage(plan.order[at])) { k = plan.order[at]; n_stages++; }
-        if (n_stages != 1 || chained[(size_t)k] || is_mod_stage(k)) return false;
-        const DevOp &fop = P.ops[(size_t)k];
-        const std::string f = "f" + num(k), PB = num(opt.filter_block);
-        // buffers ticked late: the Filter's outlet and the post units'
-        std::vector<char> lagged((size_t)std::max(1, P.n_bufs), 0);
-        lagged[(size_t)fop.out_buf] = 1;
-        for (size_t c = 0; c < P.ops.size(); c++)
-            if (used[c] && grp_post[c] && P.ops[c].out_buf >= 0) lagged[(size_t)P.ops[c].out_buf] = 1;
-        // registers of the outlets ticked late live across iterations; the others' belong to one iteration
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int u = plan.order[at];
-            if (used[(size_t)u] && P.ops[(size_t)u].out_buf >= 0 && lagged[(size_t)P.ops[(size_t)u].out_buf])
-                for (int r = 0; r < copies(u); r++) line("    float v" + num(P.ops[(size_t)u].out_buf) + "_" + num(r) + "[4] = {0.f, 0.f, 0.f, 0.f};");
-        }
-        for (int r = 0; r < R; r++) line("    double q" + num(k) + "_" + num(r) + "[4];");
-        predeclared = true;
-        // the tail of chunk `gp`: what hangs on the Filter, the PCM of lagged outlets, late readers' registers of lagged outlets
-        auto tail = [&](const char *indent) {
-            gname = "gp";
-            for (size_t at = 0; at < plan.order.size(); at++) {
-                const int u = plan.order[at];
-                if (used[(size_t)u] && grp_post[(size_t)u] && !is_filter_stage(u)) unit(u, render, pass_level, fx);
-            }
-            gname = "g";
-            for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
-                if (lagged[(size_t)P.out_bufs[oc]])
-                    for (int r = 0; r < R; r++)
-                        line(std::string(indent) + "jit_store(A, " + ctx(r) + ", gp, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
-            for (int b = 0; b < P.n_bufs; b++)
-                if (lagged[(size_t)b] && late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
-                    for (int r = 0; r < copies(producer[(size_t)b]); r++)
-                        line(std::string(indent) + "for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
-        };
-        // which window a wave does its side work in: never one it serves (waves 0 / 1 serve the even / odd ones); SIMD-aware like the overlapped form
-        {
-            std::string pick = num(subs - 1);
-            for (int i = opt.waves - 1; i >= 0; i--) {
-                const int simd = i & 3, group = i >> 2, half = std::max(1, subs / 2);
-                const int w = simd == 0 ? (2 * (group % half) + 1) % subs : simd == 1 ? 2 * (group % half) : (group + simd) % subs;
-                pick = "X[0].wave == " + num(i) + "u ? " + num(w) + " : " + pick;
-            }
-            line("    const int my_window = (int)jit_u((uint32_t)(" + pick + "));");
-        }
-        line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int u = plan.order[at];
-            if (used[(size_t)u] && P.ops[(size_t)u].out_buf >= 0 && !lagged[(size_t)P.ops[(size_t)u].out_buf])
-                for (int r = 0; r < copies(u); r++) line("        float v" + num(P.ops[(size_t)u].out_buf) + "_" + num(r) + "[4];");
-        }
-        line("        auto side0 = [&]() __attribute__((always_inline)) {  // (a wave runs it whole, in one window it does not serve)");
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int u = plan.order[at];
-            if (!used[(size_t)u] || !grp_side[(size_t)u]) continue;
-            delay_half = split_delay[(size_t)u] ? 2 : 0;
-            unit(u, render, pass_level, fx);
-        }
-        line("        };");
-        line("        auto early = [&](uint32_t g) __attribute__((always_inline)) {  // (its own g: it works for the chunk after this one)");
-        in_early = true;
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int u = plan.order[at];
-            if (!used[(size_t)u] || !grp_early[(size_t)u]) continue;
-            delay_half = split_delay[(size_t)u] ? 1 : 0;
-            unit(u, render, pass_level, fx);
-        }
-        delay_half = 0;
-        filter_feed(k, "qn", false);
-        in_early = false;
-        line("        };");
-        line("        if (g == X[0].g_begin) early(g);");
-        for (size_t at = 0; at < plan.order.size(); at++) {
-            const int u = plan.order[at];
-            if (used[(size_t)u] && grp_early[(size_t)u] && P.ops[(size_t)u].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)u].out_buf])
-                for (int r = 0; r < copies(u); r++) {
-                    const std::string id = num(P.ops[(size_t)u].out_buf) + "_" + num(r);
-                    line("        for (int c = 0; c < 4; ++c) v" + id + "[c] = vn" + id + "[c];");
-                }
-        }
-        for (int r = 0; r < R; r++) line("        for (int c = 0; c < 4; ++c) q" + num(k) + "_" + num(r) + "[c] = qn" + num(k) + "_" + num(r) + "[c];");
-        line("        if (g == X[0].g_begin) {  // the first chunk's first sub-block: nobody has parked it yet");
-        for (int r = 0; r < R; r++) line("            " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", 0, q" + num(k) + "_" + num(r) + ", 0);");
-        line("            jit_lds_barrier();");
-        line("        }");
-        // the sub-blocks in a run-time loop: every piece of text stands once (the instruction cache holds 64 KB)
-        const std::string vf = "v" + num(fop.out_buf) + "_";
-        line("#pragma unroll 1");
-        line("        for (int sb = 0; sb < " + num(subs) + "; ++sb) {");
-        line("            const int buf = sb & 1;  // (= the serving wave: 0 and 1 take turns)");
-        line("            " + f + ".serial<" + PB + ">(X[0], tile, (uint32_t)buf, buf);");
-        line("            if (sb == 0) {");
-        line("                if (g > X[0].g_begin) {  // the chunk before: its last sub-block, then what hangs on the Filter's output");
-        line("                    const uint32_t gp = g - 1;");
-        for (int r = 0; r < R; r++) line("                    " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(subs - 1) + ", " + vf + num(r) + ", " + num((subs - 1) & 1) + ");");
-        tail("                    ");
-        line("                }");
-        line("            } else {");
-        for (int r = 0; r < R; r++) line("                " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb - 1, " + vf + num(r) + ", buf ^ 1);");
-        line("            }");
-        line("            if (sb == my_window) { side0(); if (g + 1 < X[0].g_end) early(g + 1); }  // (beside the recurrences)");
-        line("            if (sb + 1 < " + num(subs) + ") {");
-        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", sb + 1, q" + num(k) + "_" + num(r) + ", buf ^ 1);");
-        line("            } else if (g + 1 < X[0].g_end) {  // the next chunk's first sub-block (its feed-forward halves were made a chunk ahead)");
-        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", 0, qn" + num(k) + "_" + num(r) + ", buf ^ 1);");
-        line("            }");
-        line("            jit_lds_barrier();");
-        line("            if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
-        for (int r = 0; r < R; r++) line("                " + f + ".park(" + ctx(r) + ", tile, " + num(r) + ", sb, q" + num(k) + "_" + num(r) + ", buf);");
-        line("                jit_lds_barrier();");
-        line("                " + f + ".serial_exact(X[0], tile, (uint32_t)buf, buf);");
-        line("                jit_lds_barrier();");
-        line("            }");
-        line("        }");
-        // PCM and late registers of outlets that are not ticked late keep their place at the end of the iteration
-        for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
-            if (!lagged[(size_t)P.out_bufs[oc]])
-                for (int r = 0; r < R; r++)
-                    line("        jit_store(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
-        for (int b = 0; b < P.n_bufs; b++)
-            if (!lagged[(size_t)b] && late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
-                for (int r = 0; r < copies(producer[(size_t)b]); r++)
-                    line("        for (int c = 0; c < 4; ++c) w" + num(b) + "_" + num(r) + "[c] = v" + num(b) + "_" + num(r) + "[c];");
-        line("    }");
-        line("    if (X[0].g_end > X[0].g_begin) {  // the last chunk's last sub-block and tail");
-        line("        const uint32_t gp = X[0].g_end - 1;");
-        for (int r = 0; r < R; r++)
-            line("        " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", " + num(subs - 1) + ", v" + num(fop.out_buf) + "_" + num(r) + ", " + num((subs - 1) & 1) + ");");
-        tail("        ");
-        line("    }");
-        predeclared = false;
-        return true;
-    }
-
     void loop(bool render, int pass_level, const std::vector<char> &used, bool fx) {
         const bool sorted = render && opt.overlap && plan_overlap(used);
         const bool rotate = sorted && opt.rotate && plan_rotate(used);
@@ -842,7 +687,6 @@ struct Emitter {
                 if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
-        if (overlapped && rotate && pipeline_loop(render, pass_level, used, fx)) return;
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
         phase = 0;
         if (opt.profile && render) line("        ph_t = __builtin_readcyclecounter();");
@@ -967,49 +811,26 @@ struct Emitter {
             filter_feed(k);
             const std::string f = "f" + num(k), N = num(kChunk / opt.filter_sub), kind = num(op.attr);
             const int per = std::max(1, std::min(R, 64 / opt.filter_sub));
-            auto parks = [&](const std::string &indent, const std::string &sb, const std::string &buf, const char *again) {
+            auto parks = [&](const std::string &indent, const std::string &sb) {
                 for (int r0 = 0; r0 < R; r0 += per) {
                     const int r1 = std::min(R - 1, r0 + 1);
-                    line(indent + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", " + sb + ", " + buf + ", " + again + ", " + kind + ", " + mod_x[{k, r0}] + ", " +
+                    line(indent + f + ".parkm<" + num(per) + ">(X[0], tile, " + num(r0) + ", " + sb + ", " + kind + ", " + mod_x[{k, r0}] + ", " +
                          mod_f[{k, r0}] + ", " + mod_x[{k, r1}] + ", " + mod_f[{k, r1}] + ");");
                 }
             };
-            if (!opt.mod_double) {  // one set of rows: park, serve, pick up — sub-block by sub-block
-                line("#pragma unroll 1");
-                line("        for (int sb = 0; sb < " + N + "; ++sb) {");
-                line("            for (bool exact = false;; exact = true) {  // (once; twice when some row's recurrence met a NaN: then as written)");
-                parks("                ", "sb", "0", "false");
-                line("                jit_lds_barrier();");
-                line("                if (exact) " + f + ".serial_exact(X[0], tile, 0, 0); else " + f + ".serial<4>(X[0], tile, 0, 0);");
-                line("                jit_lds_barrier();");
-                line("                if (exact || !" + f + ".failed(tile)) break;");
-                line("            }");
-                for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, 0, v" + num(op.out_buf) + "_" + num(r) + ");");
-                for (int r = 0; r < R; r++) line("            " + f + ".carry(" + num(r) + ", sb, " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
-                line("        }");
-                return;
-            }
-            // The tile holds two sets of rows: while one wave runs sub-block sb out of one, everybody parks sub-block sb + 1 in the other
-            // (the serving wave its own rows behind its recurrences); waves 0 and 1 take turns at serving.
-            parks("        ", "0", "0", "false");
-            line("        jit_lds_barrier();");
+            // one set of rows: park, serve, pick up — sub-block by sub-block (a second set of rows, sub-block s + 1 parked while s is served,
+            // measured slower: the parks then compete with the serving wave's own)
             line("#pragma unroll 1");
             line("        for (int sb = 0; sb < " + N + "; ++sb) {");
-            line("            const int buf = sb & 1;");
-            line(std::string("            const uint32_t who = ") + (opt.waves >= 2 ? "(uint32_t)(sb & 1);" : "0u;"));
+            line("            for (bool exact = false;; exact = true) {  // (once; twice when some row's recurrence met a NaN: then as written)");
+            parks("                ", "sb");
+            line("                jit_lds_barrier();");
+            line("                if (exact) " + f + ".serial_exact(X[0], tile, 0); else " + f + ".serial<4>(X[0], tile, 0);");
+            line("                jit_lds_barrier();");
+            line("                if (exact || !" + f + ".failed(tile)) break;");
+            line("            }");
+            for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, v" + num(op.out_buf) + "_" + num(r) + ");");
             for (int r = 0; r < R; r++) line("            " + f + ".carry(" + num(r) + ", sb, " + mod_x[{k, r}] + ", " + mod_f[{k, r}] + ");");
-            line("            " + f + ".serial<4>(X[0], tile, who, buf);");
-            line("            if (sb + 1 < " + N + ") {");
-            parks("                ", "sb + 1", "buf ^ 1", "false");
-            line("            }");
-            line("            jit_lds_barrier();");
-            line("            if (" + f + ".failed(tile)) {  // a NaN in some row's recurrence: the sub-block once more, as written");
-            parks("                ", "sb", "buf", "true");
-            line("                jit_lds_barrier();");
-            line("                " + f + ".serial_exact(X[0], tile, who, buf);");
-            line("                jit_lds_barrier();");
-            line("            }");
-            for (int r = 0; r < R; r++) line("            " + f + ".pick(" + ctx(r) + ", tile, " + num(r) + ", sb, buf, v" + num(op.out_buf) + "_" + num(r) + ");");
             line("        }");
             return;
         }
@@ -1055,7 +876,7 @@ struct Emitter {
                 const std::string p0 = opnd_array(k, 0, "t" + id, r);
                 std::string p1 = p0;
                 if (op.op != OP_CB_READER && !(op.op == OP_CB_WRITER && (op.attr & 2))) p1 = opnd_array(k, 1, "tz" + id, r);
-                line("        q" + id + ".tick" + (op.op == OP_DELAY ? std::string() : "<" + num(op.op) + ", " + num(op.attr) + ">") + "(A, " + X_ + ", " + gname + ", scr, (int64_t)" + dref +
+                line("        q" + id + ".tick" + (op.op == OP_DELAY ? std::string() : "<" + num(op.op) + ", " + num(op.attr) + ">") + "(A, " + X_ + ", g, scr, (int64_t)" + dref +
                      ", (uint32_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + p0 + ", " + p1 + ", " + (has_out ? v : "u" + id) + ");");
                 continue;
             }
@@ -1073,7 +894,7 @@ struct Emitter {
                 break;
             case OP_RAMP:
                 decl();
-                line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(" + X_ + ", " + gname + ", " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
+                line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(" + X_ + ", g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
                      num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
                 break;
             case OP_MULTIPLY: each(opnd(k, 0, "c", r) + " * " + opnd(k, 1, "c", r)); break;  // Multiply.js:23-34
@@ -1085,7 +906,7 @@ struct Emitter {
                 break;
             case OP_INPUT:
                 decl();
-                line("        jit_input(A, " + X_ + ", " + gname + ", " + num(op.attr) + ", " + v + ");");
+                line("        jit_input(A, " + X_ + ", g, " + num(op.attr) + ", " + v + ");");
                 break;
             case OP_FIXED_DELAY: case OP_COMB_FILTER: case OP_ALL_PASS: {
                 decl();
@@ -1150,8 +971,8 @@ struct Emitter {
                     break;
                 }
                 const std::string x = opnd_array(k, 0, "t" + id, r);
-                if (delay_half == 2) line("        y" + id + ".write(" + X_ + ", " + gname + ", " + x + ");");
-                else line("        y" + id + ".tick(" + X_ + ", " + gname + ", " + x + ", " + v + ");");
+                if (delay_half == 2) line("        y" + id + ".write(" + X_ + ", g, " + x + ");");
+                else line("        y" + id + ".tick(" + X_ + ", g, " + x + ", " + v + ");");
                 break;
             }
             default:

@@ -1210,7 +1210,6 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int WAVES, int R, int SUB, int NA, int MEM>  // NA = R, or 1 when the cutoff is a constant of the circuit: one set of coefficients serves all
 struct JitFilterK {
     static constexpr int kPitch = SUB + 2;  // doubles per row
-    static constexpr int kBuf = WAVES * R * kPitch;  // a pipelined kernel's tile holds TWO such sets of rows (`buf`): sub-block s + 1 is parked while s is served
     double a[NA][3];                        // this wave's instances: a0 a1 a2 (wave-uniform)
     float x1[R], x2[R];                     // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     double k[5], lastF;                     // lane = row (the same in every wave): that instance's coefficients
@@ -1279,8 +1278,7 @@ struct JitFilterK {
         x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
     }
     // sub-block s of slot r: the lanes whose samples it holds put their four P values into the wave's row
-    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[4], int buf = 0) {
-        tile += (size_t)buf * kBuf;
+    static __device__ __forceinline__ void park(const JitCtx &X, double *tile, int r, int s, const double (&p)[4]) {
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             f64x2 *row = (f64x2 *)(tile + (size_t)(X.wave * R + r) * kPitch) + ((int)X.lane - first) * 2;
@@ -1288,8 +1286,7 @@ struct JitFilterK {
             row[1] = f64x2{p[2], p[3]};
         }
     }
-    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4], int buf = 0) {
-        tile += (size_t)buf * kBuf;
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
@@ -1330,12 +1327,12 @@ struct JitFilterK {
     // that to +0 (see loop2_engine.hip).  A sub-block that met a NaN in some row is given back: the word after row 0 says so,
     // y1 / y2 stay as they were, every wave parks its rows again (failed()) and serial_exact() does the sub-block as written.
     template <int PB>  // 8, or 4 where the kernel is short of registers (two sets of PB doubles)
-    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who, int buf = 0) {
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
         if (X.wave != who || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
+        const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
@@ -1372,9 +1369,9 @@ struct JitFilterK {
         return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)flag_address(tile)) != 0;
     }
     // the sub-block as Filter.js:40-46 writes it, on freshly parked rows
-    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who, int buf = 0) {
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
         if (X.wave != who || X.lane >= WAVES * R) return;
-        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
+        const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         const double b1 = k[3], b2 = k[4];
@@ -1429,10 +1426,8 @@ __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X
 template <int WAVES, int R, int SUB, int MEM>
 struct JitFilterKM {
     static constexpr int kPitch = 3 * SUB + 2;  // doubles per row (even: rows stay 16-byte aligned)
-    static constexpr int kBuf = WAVES * R * kPitch;  // (JitOptions::mod_double: the tile is TWO such sets of rows — sub-block s + 1 parked in one while s is served out of the other)
     float x1[R], x2[R];                         // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
     float flast[R];                             // the cutoff of the last sample ticked (what `lastF` and the coefficients in the unit's state belong to)
-    float px1[R], px2[R];                       // x1 / x2 as they stood in front of the sub-block parked last (a sub-block that met a NaN is parked again)
     bool ticked[R];
     int stage;
 #ifdef DUSP_JIT_PROFILE
@@ -1441,7 +1436,7 @@ struct JitFilterKM {
     typedef __attribute__((address_space(3))) double lds_double;
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {  // (rows WAVES R .. 2 WAVES R - 1: the second buffer)
+    static __device__ __forceinline__ uint32_t row_address(double *tile, uint32_t row) {
         return ((uint32_t)(uintptr_t)(lds_double *)(tile + (size_t)row * kPitch)) & 0x3ffffu;
     }
     static __device__ __forceinline__ uint32_t flag_address(double *tile) { return row_address(tile, 0) + (uint32_t)MEM; }
@@ -1459,8 +1454,8 @@ struct JitFilterKM {
     }
     __device__ __forceinline__ void begin_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) {
         const double *is = A.init_state + state_slot;
-        px1[r] = x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
-        px2[r] = x2[r] = jit_u((float)is[8]);
+        x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
+        x2[r] = jit_u((float)is[8]);
         flast[r] = 0.f;
         ticked[r] = false;
     }
@@ -1471,11 +1466,9 @@ struct JitFilterKM {
     // 4 j' .. 4 j' + 3) through the row itself: the owners lay the sub-block's inputs and cutoffs out there as floats, everybody reads
     // theirs (and the two inputs before it; in front of the sub-block, the carried pair), then the doubles go over them.
     // xa / fa: input and cutoff registers of instance r0, xb / fb of instance r0 + 1 (PER == 2).
-    // buf: which half of the tile; again: the sub-block is parked a second time (it met a NaN): the carried pair as it stood in front of it
     template <int PER>
-    __device__ __forceinline__ void parkm(const JitCtx &X, double *tile, int r0, int s, int buf, bool again, int kind, const float (&xa)[4], const float (&fa)[4],
+    __device__ __forceinline__ void parkm(const JitCtx &X, double *tile, int r0, int s, int kind, const float (&xa)[4], const float (&fa)[4],
                                           const float (&xb)[4], const float (&fb)[4]) const {
-        tile += (size_t)buf * kBuf;
         static_assert(PER * SUB <= 64 && (PER == 1 || PER == 2), "one or two instances per pass");
         const int mine = PER == 2 ? (int)(X.lane / SUB) : 0;          // which of the pass's instances this lane works for
         const int j = (int)(X.lane % SUB);
@@ -1501,7 +1494,7 @@ struct JitFilterKM {
             const float xin = row[j], fc = row[SUB + j];
             // the two inputs before this one: earlier samples of the sub-block, else what the instance carries
             const int rm = mine == 0 ? r0 : (r0 + 1) % R;
-            const float c1 = again ? px1[rm] : x1[rm], c2 = again ? px2[rm] : x2[rm];
+            const float c1 = x1[rm], c2 = x2[rm];
             const float m1 = j >= 1 ? row[j - 1] : c1;
             const float m2 = j >= 2 ? row[j - 2] : (j == 1 ? c1 : c2);
             double k[5];
@@ -1520,15 +1513,12 @@ struct JitFilterKM {
     // behind sub-block s of slot r: the instance's carried inputs and cutoff are now the sub-block's last (its owners' last lane holds them)
     __device__ __forceinline__ void carry(int r, int s, const float (&x)[4], const float (&f)[4]) {
         const int last = (s + 1) * (SUB / 4) - 1;
-        px1[r] = x1[r];
-        px2[r] = x2[r];
         x1[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), last));
         x2[r] = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), last)));
         flast[r] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f[3]), last));
         ticked[r] = true;
     }
-    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, int buf, float (&out)[4]) {
-        tile += (size_t)buf * kBuf;
+    static __device__ __forceinline__ void pick(const JitCtx &X, const double *tile, int r, int s, float (&out)[4]) {
         const int first = s * (SUB / 4);
         if ((int)X.lane >= first && (int)X.lane < first + SUB / 4) {
             const f32x4 y = ((const f32x4 *)(tile + (size_t)(X.wave * R + r) * kPitch))[(int)X.lane - first];
@@ -1550,13 +1540,13 @@ struct JitFilterKM {
         for (int i = 0; i < PB / 4; ++i) dst[i] = y4[i];
     }
     template <int PB_>  // (the generated text passes the constant-cutoff stage's block size; three values per step: always blocks of 4 here)
-    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who, int buf) {
+    __device__ __forceinline__ void serial(const JitCtx &X, double *tile, uint32_t who) {
         constexpr int PB = 4;
         if (X.wave != who || X.lane >= WAVES * R) return;
 #ifdef DUSP_JIT_PROFILE
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
+        const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
@@ -1591,9 +1581,9 @@ struct JitFilterKM {
     static __device__ __forceinline__ bool failed(double *tile) {
         return __builtin_amdgcn_readfirstlane((int)*(const lds_u32 *)(uintptr_t)flag_address(tile)) != 0;
     }
-    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who, int buf) {
+    __device__ __forceinline__ void serial_exact(const JitCtx &X, double *tile, uint32_t who) {
         if (X.wave != who || X.lane >= WAVES * R) return;
-        const uint32_t row = row_address(tile, X.lane + (uint32_t)buf * (WAVES * R));
+        const uint32_t row = row_address(tile, X.lane);
         const lds_double *pr = (const lds_double *)(uintptr_t)row;
         lds_f32x4 *yr = (lds_f32x4 *)(uintptr_t)row;
         lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);

@@ -109,13 +109,13 @@ class _PinnedBlock:
             pass
 
 
-def circuit_kernel_source(words, waves=16, per_wave=1, lds_table=True, compile=False, continued=False, pipeline=False):
+def circuit_kernel_source(words, waves=16, per_wave=1, lds_table=True, compile=False, continued=False):
     """HIP text of the kernel the circuit compiler generates for a descriptor (dusp_circuit_kernel_source; needs no GPU).
     Raises DuspHipError(-2) for circuits that stay on the interpreter."""
     L = load()
     words = np.ascontiguousarray(words, dtype=np.float64)
     buf = ctypes.create_string_buffer(1 << 20)
-    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, per_wave, int(bool(lds_table)) | (2 if continued else 0) | (4 if pipeline else 0), int(compile), buf, len(buf))
+    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, per_wave, int(bool(lds_table)) | (2 if continued else 0), int(compile), buf, len(buf))
     if n < 0:
         raise DuspHipError(n, L.dusp_last_error(None).decode())
     return buf.value.decode()

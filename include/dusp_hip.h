@@ -211,8 +211,7 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
  *   per_wave   circuit instances per wavefront (1 .. 4; renders that are split in time use 1)
  *   lds_table  bit 0: assume the oscillators' first wave table is antisymmetric (half image in LDS), as a context would find;
  *              bit 1: the text of a program built with DUSP_ENGINE_RESUMABLE (a circuit with delay lines / feedback that will be
- *              continued: outlets parked between launches, rings kept in the reference's own state);
- *              bit 2: the pipelined form of a circuit with one constant-cutoff Filter stage (two sets of tile rows), as a render picks it
+ *              continued: outlets parked between launches, rings kept in the reference's own state)
  *   compile    non-zero: also compile the text for gfx950
  *   text, cap  receives at most cap - 1 characters, NUL-terminated (cap 0: nothing is copied)
  * Returns the length of the text, DUSP_ERR_UNSUPPORTED when the circuit stays on the interpreter (dusp_last_error(NULL) says
