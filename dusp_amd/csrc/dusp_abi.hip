@@ -155,6 +155,7 @@ struct dusp_program {
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
     // channel counts that grow during the first chunks (Program::warm_ops): those chunks on the chunk engine, the rest on a compiled kernel
     bool handoff_ok = false;
+    std::string handoff_why;  // when not: what keeps the settled circuit on the chunk engine
     DevBuf<double> d_handoff_init;   // the unit state the chunk engine left (instance 0), as the compiled kernel's start state
     DevBuf<float> d_handoff_out;     // the two parts' PCM before they are put side by side
     DevBuf<int64_t> d_jit_regime;  // per-instance delays: [slot, ring length, mono] per unit, then the verdicts (render_jit)
@@ -452,13 +453,17 @@ static int finish_build(dusp_program *prog) {
     // one the circuit compiler takes, a single circuit's render hands over behind them (render_device: rings, outlets' last chunk and
     // unit state move into the compiled kernel's layout).
     prog->handoff_ok = false;
+    prog->handoff_why.clear();
     if (engine == DUSP_ENGINE_CHUNK && !prog->P.warm_ops.empty() && !prog->resumable && prog->requested_engine == DUSP_ENGINE_AUTO && ctx->knobs.wave_jit != 0 &&
         prog->P.g.n_inputs == 0) {
         auto checked = std::move(prog->wave.ramp_checked);
         prog->wave = dusp::WavePlan();
         prog->wave.ramp_checked = std::move(checked);
         std::string why;
-        if (dusp::plan_wave(prog->P, prog->wave, /*will_continue=*/true, /*settled_only=*/true) && dusp::jit_eligible(prog->P, prog->wave, why)) {
+        const bool planned = dusp::plan_wave(prog->P, prog->wave, /*will_continue=*/true, /*settled_only=*/true);
+        if (!planned) prog->handoff_why = prog->wave.why;
+        else if (!dusp::jit_eligible(prog->P, prog->wave, why)) prog->handoff_why = why;
+        if (planned && prog->handoff_why.empty()) {
             prog->handoff_ok = true;
             for (size_t k = 0; k < prog->wave.osc_level.size() && k < prog->P.ops.size(); k++)
                 if (prog->wave.osc_level[k] >= 0) prog->P.ops[k].d[0] = (double)prog->wave.osc_level[k];
@@ -630,6 +635,8 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS (kernel compiling)", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     else if (prog->engine == DUSP_ENGINE_WAVE)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
+    if (prog->engine == DUSP_ENGINE_CHUNK && !prog->P.warm_ops.empty() && !prog->handoff_ok && !prog->handoff_why.empty())
+        std::snprintf(info->shape, sizeof info->shape, "warm-up, then not compiled: %.34s", prog->handoff_why.c_str());
     if (prog->engine == DUSP_ENGINE_CHUNK && prog->handoff_ok && prog->jit_waves)
         std::snprintf(info->shape, sizeof info->shape, "%d warm-up chunks here, then compiled kernel: %d units, %dx%d", (int)prog->P.warm_ops.size(), (int)prog->P.ops.size(),
                       prog->jit_waves, prog->jit_per_wave);
@@ -682,7 +689,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     const size_t n_slots = P.init_state.size();
     const bool persistent = (prog->resumable && prog->persistent) || handoff_chunks > 0;
     const bool resume = prog->keep_memory || handoff_chunks > 0;
-    if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
+    if (resume && !handoff_chunks && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
     // Per-instance (parameter) delays: the kernel a Delay gets depends on where its instances' values lie — all of at least a chunk
     // (write-once ring), all below a chunk (no ring), or neither (ordered slot operations) — so the column is looked at first
     // (one small launch + a few bytes back; only programs with such a unit pay it).  The verdict lives in the operand's spare word.
@@ -1159,8 +1166,12 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         const uint32_t n_warm = (uint32_t)P.warm_ops.size();
         const uint32_t W = first_chunk < n_warm ? (uint32_t)std::min<uint64_t>(n_chunks, n_warm - first_chunk) : 0u;
         // (under the default knob a structure seen for the first time renders on the chunk engine alone while its kernel compiles in the background)
-        if (W > 0 && W < n_chunks &&
-            render_jit(prog, n_inst, n_samples - (size_t)W * dusp::kChunk, n_chunks - W, d_params, d_inputs, d_out, stream, W, /*probe=*/true) == DUSP_OK) {
+        int ready = kJitLater;
+        if (W > 0 && W < n_chunks) {
+            ready = render_jit(prog, n_inst, n_samples - (size_t)W * dusp::kChunk, n_chunks - W, d_params, d_inputs, d_out, stream, W, /*probe=*/true);
+            if (ready != DUSP_OK && ready != kJitLater) return ready;  // (a kernel that does not compile is a failure, not a reason to render elsewhere)
+        }
+        if (ready == DUSP_OK) {
             const size_t n_ch = P.out_bufs.size(), n_head = (size_t)W * dusp::kChunk, n_rest = n_samples - n_head;
             const uint32_t n_bufs = (uint32_t)std::max(1, P.n_bufs);
             HIP_TRY(ctx, prog->d_scratch.ensure((size_t)n_bufs * dusp::kChunk * n_pad));

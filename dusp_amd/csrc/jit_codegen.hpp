@@ -145,7 +145,7 @@ inline size_t jit_scratch_floats(const Program &P) {
         if (op.op == OP_SAMPLE_RATE_REDUX) n = (op.in[0].kind == SRC_BUF || op.in[1].kind == SRC_BUF) ? 768 : 256;
         if (op.op == OP_MULTI_OSC) n = 512;
         if (op.op == OP_SHAPE && op.in[0].kind == SRC_BUF) n = 512;    // 256 doubles: the running sum's addends
-        if (jit_ring_ops(op)) n = op.op == OP_DELAY ? 512 : 1024;       // the slot-ownership table; a Delay (JitDelayGather): the chunk's read values, or a table of 512
+        if (jit_ring_ops(op)) n = (op.op == OP_DELAY || op.op == OP_MONO_DELAY) ? 512 : 1024;       // the slot-ownership table; a Delay (JitDelayGather): the chunk's read values, or a table of 512
         if (jit_delay_short(op)) n = 512;                               // the chunk before and this one, side by side
         need = std::max(need, n);
     }
@@ -451,12 +451,12 @@ struct Emitter {
                     break;
                 case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:
                     if (jit_ring_ops(op)) {
-                        if (op.op == OP_DELAY) {  // slots replayed lane-parallel where the taps do not decrease, slot rounds where they do
-                            line("    JitDelayGather q" + id + ";");
-                            line("    q" + id + ".begin(A, " + ctx(r) + ", " + num(op.state_slot) + ");");  // (a continued launch: the carried sample from the last one)
+                        if (op.op == OP_DELAY || op.op == OP_MONO_DELAY) {  // slots replayed lane-parallel where the taps do not decrease, slot rounds where they do
+                            line(std::string("    JitDelayGather<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> q" + id + ";");
+                            line("    q" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (a continued launch: a Delay's carried sample from the last one)
                         } else {
                             line("    JitRingOps q" + id + ";");
-                            line("    q" + id + ".begin(A, " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ");");  // (MonoDelay indexes with the circuit clock: no state)
+                            line("    q" + id + ".begin(A, " + num(op.state_slot) + ");");
                         }
                     } else if (jit_delay_short(op)) {
                         line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
@@ -564,7 +564,7 @@ struct Emitter {
                     if (op.op == OP_TIMER)
                         line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
                     if (jit_ring_ops(op)) {
-                        if (op.op != OP_MONO_DELAY) line("        " + slot + " = q" + id + (op.op == OP_DELAY ? ".rounds.T;" : ".T;"));
+                        if (op.op != OP_MONO_DELAY) line("        " + slot + " = q" + id + (op.op == OP_DELAY ? ".rounds.T;" : ".T;"));  // (MonoDelay: no state)
                         continue;
                     }
                     if (op.op == OP_DELAY) line("        " + slot + " = " + (jit_delay_short(op) ? "z" : "y") + id + ".carried;");
@@ -876,7 +876,7 @@ struct Emitter {
                 const std::string p0 = opnd_array(k, 0, "t" + id, r);
                 std::string p1 = p0;
                 if (op.op != OP_CB_READER && !(op.op == OP_CB_WRITER && (op.attr & 2))) p1 = opnd_array(k, 1, "tz" + id, r);
-                line("        q" + id + ".tick" + (op.op == OP_DELAY ? std::string() : "<" + num(op.op) + ", " + num(op.attr) + ">") + "(A, " + X_ + ", g, scr, (int64_t)" + dref +
+                line("        q" + id + ".tick" + (op.op == OP_DELAY || op.op == OP_MONO_DELAY ? std::string() : "<" + num(op.op) + ", " + num(op.attr) + ">") + "(A, " + X_ + ", g, scr, (int64_t)" + dref +
                      ", (uint32_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + p0 + ", " + p1 + ", " + (has_out ? v : "u" + id) + ");");
                 continue;
             }

@@ -1025,9 +1025,15 @@ struct JitRingOps {
 // (JitRingOps) instead — whatever the modulation does, the result is the reference's.
 // scr: 512 floats per wave — the chunk's 256 read values; the slot operations' ownership table (512 words) takes the same space when
 // a chunk needs them.
+// MONO: MonoDelay (MonoDelay.js:16-28) — the same taps, except that a ceil tap at index `length` wraps to slot 0 instead of being dropped,
+// and a sample's read comes behind its own taps (which, with a delay of a sample at least, land elsewhere); no carried state.
+template <bool MONO>
 struct JitDelayGather {
-    JitRingOps rounds;  // (holds T: the previous chunk's last input, what the unit's state carries)
-    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot) { rounds.begin_delay(A, X, state_slot); }
+    JitRingOps rounds;  // (holds T: the previous chunk's last input, what a Delay's state carries)
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int state_slot) {
+        if (MONO) rounds.T = 0.0;
+        else rounds.begin_delay(A, X, state_slot);
+    }
     static __device__ __forceinline__ float dpp_up(float mine, float edge) {  // the lane below's value; lane 0 gets `edge`
         return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(edge), __float_as_uint(mine), 0x138, 0xf, 0xf, false));
     }
@@ -1086,7 +1092,7 @@ struct JitDelayGather {
         const int32_t top = __builtin_amdgcn_readlane(R[5], 63);
         ok = ok && (uint32_t)(top + 2) <= len;
         if (!__all(ok)) {
-            rounds.tick<OP_DELAY, 0, 512>(A, X, g, scr, ring_base, len, x, dl, out);
+            rounds.tick<MONO ? OP_MONO_DELAY : OP_DELAY, 0, 512>(A, X, g, scr, ring_base, len, x, dl, out);
             return;
         }
         float *ring = A.rings + (size_t)X.inst * (size_t)A.ring_samples + (size_t)ring_base;
@@ -1132,8 +1138,8 @@ struct JitDelayGather {
             if (r != R[i - 1]) {  // first of its group: the slot's whole sequence
                 float acc = r < kChunk ? OUT[r] : far_floor[c];
                 const bool below2 = R[i - 2] == r - 1, below1 = R[i - 1] == r - 1;  // ceil taps of the samples one slot below (at index `length` — slot 0 — they are dropped)
-                if (below2 && F[i - 2] != 0.0 && a != 0u) acc = add(acc, (double)Xs[i - 2] * F[i - 2]);
-                if (below1 && F[i - 1] != 0.0 && a != 0u) acc = add(acc, (double)Xs[i - 1] * F[i - 1]);
+                if (below2 && F[i - 2] != 0.0 && (MONO || a != 0u)) acc = add(acc, (double)Xs[i - 2] * F[i - 2]);
+                if (below1 && F[i - 1] != 0.0 && (MONO || a != 0u)) acc = add(acc, (double)Xs[i - 1] * F[i - 1]);
                 acc = add(acc, (double)Xs[i] * (1.0 - F[i]));                          // floor tap
                 if (F[i] == 0.0) acc = add(acc, (double)Xs[i] * F[i]);                // ... and a ceil tap that lands on the same slot
                 if (R[i + 1] == r) {                                                   // the group's second sample
@@ -1146,7 +1152,7 @@ struct JitDelayGather {
             if (R[i + 1] > r + 1) {  // last of its group in front of a gap: the slot behind, reached by this group's ceil taps only
                 uint32_t a1 = a + 1u;
                 if (a1 >= len) a1 -= len;
-                if (a1 != 0u && (F[i] != 0.0 || (R[i - 1] == r && F[i - 1] != 0.0))) {
+                if ((MONO || a1 != 0u) && (F[i] != 0.0 || (R[i - 1] == r && F[i - 1] != 0.0))) {
                     float acc = r + 1 < kChunk ? OUT[r + 1] : far_ceil[c];
                     if (R[i - 1] == r && F[i - 1] != 0.0) acc = add(acc, (double)Xs[i - 1] * F[i - 1]);
                     if (F[i] != 0.0) acc = add(acc, (double)Xs[i] * F[i]);
@@ -1168,7 +1174,7 @@ struct JitDelayGather {
                 }
             }
         }
-        rounds.T = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        if (!MONO) rounds.T = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
     }
 };
 

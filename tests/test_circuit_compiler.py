@@ -140,7 +140,9 @@ def test_constant_delays_need_no_slot_operations():
     moving = source(descriptor.extract(d.Delay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200), 1024)).words)
     assert "JitDelayGather" in moving                                                               # a moving tap: slots replayed lane-parallel (slot rounds where taps decrease)
     mono = source(descriptor.extract(d.MonoDelay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200))).words)
-    assert "JitRingOps" in mono                                                                     # MonoDelay: ordered slot operations
+    assert "JitDelayGather<true>" in mono                                                           # MonoDelay likewise (its ceil tap wraps)
+    readback = source(descriptor.extract(d.ReadBackDelay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200))).words)
+    assert "JitRingOps" in readback and "JitDelayGather" not in readback                            # ReadBackDelay: ordered slot operations
 
 
 def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():

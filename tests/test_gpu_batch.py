@@ -721,7 +721,7 @@ def test_first_render_does_not_wait_for_the_compiler(oracle):
     off.close()
 
 
-@pytest.mark.parametrize("name", ["grow_feedback_filter", "grow_feedback_multiosc", "grow_feedback_stereo", "grow_two_loops", "patch_scary"])
+@pytest.mark.parametrize("name", ["patch_scary"])  # (the grow_* vectors settle within their first chunk and are wave-engine programs as they stand)
 def test_growing_channel_counts_hand_over_to_a_compiled_kernel(name, oracle):
     """Circuits whose channel counts grow during the first chunks (a feedback edge sees one channel at first, more later: Program::warm_ops)
     render those chunks on the chunk engine and the rest on the kernel compiled for the settled circuit: same PCM and state as the chunk
