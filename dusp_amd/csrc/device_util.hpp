@@ -140,8 +140,41 @@ struct Table {
         a = upper ? -y : x;
         b = upper ? -x : y;
     }
+    // T[i] and T[i+1] - T[i] (i < N - 1) for the lerp's delta form (lerp_delta below).  Above the middle the pair is the mirrored
+    // one with both signs turned, so the difference is that pair's own: one select, not two.  D32: every difference of
+    // neighbours in the table is an f32 (one v_sub_f32); else it is taken in f64, where it is exact for any table whose
+    // neighbours are within 2^29 of each other (dusp_table_upload checks both: table_delta).
+    template <bool D32>
+    __device__ __forceinline__ void pair_delta(uint32_t i, double &a, double &d) const {
+        float x, y, af;
+        if (TBL == 0) {
+            x = g[i];
+            y = g[i + 1];
+            af = x;
+        } else {
+            const uint32_t j = min(i, N - 1 - i);  // i <= M  <=>  i <= N - 1 - i  (N - 1 = 2 M)
+            const float *p = word(j);
+            x = p[0];
+            y = p[1];
+            af = i > M ? -y : x;
+        }
+        a = (double)af;
+        if (D32) {
+            float df;  // (one v_sub_f32 the vectorizer cannot see: it would pair two of them up behind four register moves)
+            asm("v_sub_f32 %0, %1, %2" : "=v"(df) : "v"(y), "v"(x));
+            d = (double)df;
+        } else
+            d = (double)y - (double)x;
+    }
 };
 
+// The oscillator's lerp (Osc.js:43-46) `T[i] (1 - fraction) + T[i+1] fraction` in its DELTA form, where it is the same arithmetic:
+// with the fraction on a grid of 2^-28 or coarser both products are exact in f64 (a 24-bit entry times a weight of at most 29
+// bits), so the reference's three roundings are ONE rounding of the exact sum a wa + b wb = a + (b - a) fraction — and with
+// b - a exact that is fma(b - a, fraction, a).  F = the fraction in units of 2^-32.
+__device__ __forceinline__ float lerp_delta(double a, double d, uint32_t F) {
+    return (float)fma(d, (double)F * (1.0 / 4294967296.0), a);
+}
 
 __device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t m, double inv_m) {
     const uint32_t q = (uint32_t)((double)x * inv_m);

@@ -22,6 +22,7 @@
 #include "jit_codegen.hpp"
 #include "jit_engine.hpp"
 #include "program.hpp"
+#include "table_checks.hpp"
 
 namespace dusp {
 hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream);
@@ -52,6 +53,8 @@ struct dusp_ctx {
     bool table_antisym[dusp::kNumTables] = {false, false, false, false, false};
     bool table_finite[dusp::kNumTables] = {false, false, false, false, false};
     bool table_fx32_ok[dusp::kNumTables] = {false, false, false, false, false};  // min nonzero |T| >= 2^-20
+    int table_bound[dusp::kNumTables] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // every |entry| <= 2^bound (1000: not finite / not set)
+    int table_delta[dusp::kNumTables] = {0, 0, 0, 0, 0};  // the lerp's delta form (device_util.hpp lerp_delta): 2 every T[t+1] - T[t] is an f32, 1 exact in f64, 0 neither (or not finite)
     // TABLE_FORM_*: the uploaded table equals a closed form of the index (saw, square, triangle) or of the sine table's entry
     // (8bit) on EVERY entry, bit for bit — checked at upload — so kernels may evaluate it instead of gathering (device_util.hpp)
     int table_form[dusp::kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -343,6 +346,12 @@ int dusp_table_upload(dusp_ctx *ctx, int table_id, const float *table, size_t n)
     bool big = finite;
     for (size_t t = 0; big && t < n; t++) big = table[t] == 0.f || std::fabs(table[t]) >= 9.5367431640625e-07f;
     ctx->table_fx32_ok[table_id] = big;
+    ctx->table_delta[table_id] = dusp::table_delta_class(table, n);
+    {
+        float top = 0.f;
+        for (size_t t = 0; t < n; t++) top = std::max(top, std::fabs(table[t]));
+        ctx->table_bound[table_id] = !finite ? 1000 : top == 0.f ? 0 : std::ilogb(top) + 1;
+    }
     ctx->table_set[table_id] = true;
     ctx->table_generation++;
     // closed forms (device_util.hpp): every entry has to match, sign of zero included
@@ -767,7 +776,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     dusp::JitOptions opt;
     opt.persistent = persistent;
     opt.profile = ctx->knobs.jit_profile != 0;
-    for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k];
+    for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->table_delta[k], opt.table_bound[k] = ctx->table_bound[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
         if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && ctx->knobs.jit_lds_table != 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
@@ -1039,6 +1048,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         L.table_antisym = ctx->table_antisym[prog->fused.table_id];
         L.table_finite = ctx->table_finite[prog->fused.table_id];
         L.table_fx32_ok = ctx->table_fx32_ok[prog->fused.table_id];
+        L.table_delta = ctx->table_delta[prog->fused.table_id];
         L.table_form = ctx->table_form[prog->fused.table_id];
         L.knobs = ctx->knobs;
         HIP_TRY(ctx, prog->d_recs.ensure(n_inst));
@@ -1630,6 +1640,8 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         opt.table_form[2] = dusp::TABLE_FORM_SQUARE;
         if (P.g.sample_rate % 4 == 0) opt.table_form[3] = dusp::TABLE_FORM_TRIANGLE;
         opt.table_form[4] = dusp::TABLE_FORM_8BIT;
+        for (int k = 0; k < 5; k++) opt.table_bound[k] = 1;  // (the oscillators' tables stay within [-1, 1])
+        opt.table_delta[0] = 1;  // (the sine table: differences of neighbours exact in f64 at any sample rate, in f32 at some — 44.1 kHz, not 48)
         for (const dusp::DevOp &op : P.ops)
             if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
                 opt.lds_table = 0;

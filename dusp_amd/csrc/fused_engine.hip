@@ -288,6 +288,63 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                 // with it (a Ramp between values that are zero or of ordinary magnitude — A.r_scale_ok, checked on the host — has no f32
                 // value that 2^-32 would push below the normal range), so a product is one rounding like the Multiply unit's; (3) products and
                 // the `|| 0` additions go two at a time (v_pk_mul_f32 / v_pk_add_f32).
+                // Delta form (device_util.hpp lerp_delta), where the phase grid is 2^-28 or coarser and the table's neighbours differ by exact
+                // values (A.table_delta: 2 in f32, 1 in f64; the LDS image or the gathered table): T[i] + (T[i+1] - T[i]) fraction in ONE fma is
+                // the reference's three roundings, whatever the shape; index.fraction is one 64-bit integer, the lane's four phases are four
+                // v_lshl_add_u64 off its first (q, 2q, 3q and the step's 256q as 32.32 integers, wave-uniform), a wrap is a subtract and a
+                // minimum on the high word, the fold into the half image another subtract and minimum.
+                if ((TBL == 0 || TBL == 1) && e_min >= -28 && A.table_delta) {
+                    unsigned long long PF[RS], Q1[RS], Q2[RS], Q3[RS], C[RS];
+                    auto uni = [](unsigned long long v) {
+                        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                    };
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) {
+                        const OscRec rc = recs[inst[sub + r]];
+                        const int up = 32 + rc.E;  // phases are integers in units of 2^E, -28 <= E <= 0: as 32.32 integers, shifted up
+                        PF[r] = (((unsigned long long)I[r][0]) << 32) | F[r][0];
+                        const uint64_t q2 = addmod(rc.Fm, rc.Fm, rc.S);
+                        Q1[r] = uni(rc.Fm << up);
+                        Q2[r] = uni(q2 << up);
+                        Q3[r] = uni(addmod(q2, rc.Fm, rc.S) << up);
+                        C[r] = uni(rc.step256 << up);
+                    }
+                    auto run_delta = [&](uint32_t ga, uint32_t gb, auto vec, auto d32) {
+                        for (uint32_t g = ga; g < gb; ++g) {
+                            float rv[4] = {1.f, 1.f, 1.f, 1.f};
+                            ramp4(rv);
+#pragma unroll
+                            for (int r = 0; r < RS; ++r) {
+                                float v[4];
+                                double ta[4], td[4];
+                                uint32_t fv[4];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const unsigned long long Pc = c == 0 ? PF[r] : PF[r] + (c == 1 ? Q1[r] : c == 2 ? Q2[r] : Q3[r]);
+                                    uint32_t i = (uint32_t)(Pc >> 32);
+                                    if (c) i = min(i, i - sr);  // (i < 2 sr; an underflow loses the min)
+                                    fv[c] = (uint32_t)Pc;
+                                    table.template pair_delta<decltype(d32)::value>(i, ta[c], td[c]);
+                                }
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[c] = finish(lerp_delta(ta[c], td[c], fv[c]), rv[c], gain[r]);
+                                const unsigned long long s = PF[r] + C[r];
+                                const uint32_t h = (uint32_t)(s >> 32);
+                                PF[r] = ((unsigned long long)min(h, h - sr) << 32) | (uint32_t)s;
+                                store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
+                            }
+                            row += kChunk;
+                        }
+                    };
+                    if (A.table_delta == 2) {
+                        run_delta(g0, gm, std::true_type{}, std::true_type{});
+                        run_delta(gm, g1, std::false_type{}, std::true_type{});
+                    } else {
+                        run_delta(g0, gm, std::true_type{}, std::false_type{});
+                        run_delta(gm, g1, std::false_type{}, std::false_type{});
+                    }
+                    continue;
+                }
                 const bool lean = KIND == FUSED_OSC_RAMP && FINITE && e_min >= -28 && A.r_scale_ok;
                 auto run_lean = [&](uint32_t ga, uint32_t gb, auto vec) {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -452,6 +509,7 @@ hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t
                            L.knobs.fused_fx32 != 2  // (DUSP_FUSED_FX32=2: A/B, the plain form)
                        ? 1 : 0;
     A.fx32_ok = L.table_fx32_ok && L.knobs.fused_fx32 ? 1 : 0;  // (knobs: device_types.hpp, read when the context was created)
+    A.table_delta = L.knobs.fused_fx32 == 1 ? L.table_delta : 0;  // (DUSP_FUSED_FX32=2 / =3: A/B, the plain / the lean form)
     A.seg_major = L.knobs.fused_segmajor;
 
     int tbl = (L.table_antisym && L.sample_rate % 2 == 0) ? 1 : 0;

@@ -161,6 +161,7 @@ struct FusedLaunch {
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
     bool table_antisym, table_finite, table_fx32_ok;
+    int table_delta;  // the lerp's delta form on this table (table_checks.hpp table_delta_class): 0 no, 1 differences in f64, 2 in f32
     int table_form;  // TABLE_FORM_* (device_util.hpp): saw / square / triangle are evaluated from the index instead of gathered
     Knobs knobs;
 };
@@ -183,6 +184,7 @@ struct FusedArgs {
     float s_min, s_max;
     int32_t s_playing, s_finished, shape_state_word, s_left_is_shape, s_right_is_shape;
     int32_t table_form;  // TABLE_FORM_* of the Osc's table (kernels instantiated with TBL == 2 evaluate it)
+    int32_t table_delta; // the lerp's delta form on the Osc's table: 0 no, 1 differences of neighbours in f64, 2 in f32
 };
 
 // q' of Markstein's division-by-reciprocal: q = t*r; rem = fma(-q, d, t); q' = fma(rem, r, q).

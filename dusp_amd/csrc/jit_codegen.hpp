@@ -50,6 +50,8 @@ struct JitOptions {
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
+    int table_delta[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // the lerp's delta form (device_util.hpp lerp_delta): 0 not for this table, 1 differences of neighbours in f64, 2 in f32
+    int table_bound[kNumTables] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // every |entry| <= 2^bound (finite tables; 1000: not known to be)
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
     bool persistent = false; // a continued program with delay lines / feedback: outlets parked between launches, rings in the reference's state
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
@@ -273,6 +275,12 @@ struct Emitter {
         return tmp;
     }
     std::string in_lds(int table_id) const { return num(jit_table_source(opt, table_id)) + ", " + num(opt.table_form[table_id]); }
+    // the constant-f oscillator's fast form on this table: LEAN (delta lerp out of the LDS image or a gather: 2 with the differences
+    // in f64, 3 in f32), else 1 FX
+    int osc_fast_mode(int table_id) const {
+        const int tf = jit_table_source(opt, table_id);
+        return (tf == 0 || tf == 1) && opt.table_delta[table_id] ? 1 + opt.table_delta[table_id] : 1;
+    }
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
@@ -384,6 +392,41 @@ struct Emitter {
         return in;
     }
 
+    // Outlets that cannot be NaN in the fast copy of the chunk loop — their copy-out is one addition (-0 -> +0) instead of a
+    // test, a select and the addition (`x || 0`, renderChannelData.js:44).  A bound 2^E on every sample's magnitude, by
+    // structure: a constant-f oscillator (finite f in the fast copy) is bounded by its table, a product by the product of
+    // its operands' bounds, a sum by twice the larger; constants and parameters on the way are checked once per wave
+    // (|k| <= 2^30, which a NaN fails too: `small`, part of the fast copy's condition).  Everything below 2^120 is finite, and
+    // finite operands make no NaN in a product or a sum.  Anything else: not known (1000).
+    std::vector<std::string> small;  // scalars the fast copy requires to be small
+    std::vector<char> out_finite;    // per outlet channel: cannot be NaN in the fast copy
+    std::vector<char> visiting;
+    int bound_of_operand(int k, int j, std::vector<std::string> &checks) {
+        const DevOp &op = P.ops[(size_t)k];
+        const DevOperand &o = op.in[j];
+        if (o.kind == SRC_BUF) return bound_of_buf(o.idx, checks);
+        for (int r = 0; r < (o.kind == SRC_PARAM ? R : 1); r++) {
+            const std::string name = opnd(k, j, "0", r);
+            if (std::find(checks.begin(), checks.end(), name) == checks.end()) checks.push_back(name);
+        }
+        return 30;
+    }
+    int bound_of_buf(int buf, std::vector<std::string> &checks) {
+        const int k = buf >= 0 && buf < (int)producer.size() ? producer[(size_t)buf] : -1;
+        if (k < 0 || visiting[(size_t)k]) return 1000;
+        const DevOp &op = P.ops[(size_t)k];
+        int e = 1000;
+        visiting[(size_t)k] = 1;
+        if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) e = opt.table_bound[op.attr];
+        else if (op.op == OP_REPEATER) e = bound_of_operand(k, 0, checks);
+        else if (op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_SUBTRACT) {
+            const int a = bound_of_operand(k, 0, checks), b = bound_of_operand(k, 1, checks);
+            e = a >= 1000 || b >= 1000 ? 1000 : op.op == OP_MULTIPLY ? a + b : std::max(a, b) + 1;
+        }
+        visiting[(size_t)k] = 0;
+        return e > 120 ? 1000 : e;
+    }
+
     // One kernel.  pass_level < 0: the render kernel; else the accumulate pass of that FM level (only the cone of its scanned
     // oscillators, no lookups for them, no stores; ends by writing their phase totals).
     void kernel(int pass_level) {
@@ -439,7 +482,7 @@ struct Emitter {
                     if (op.in[0].kind != SRC_BUF) {
                         line("    JitOscK o" + id + ";");
                         line("    o" + id + ".begin(A, " + ctx(r) + ", " + opnd(k, 0, "0", r) + ", " + num(op.state_slot) + ");");
-                        fast += " && o" + id + ".fx32";
+                        fast += " && o" + id + (osc_fast_mode(op.attr) >= 2 ? ".lean" : ".fx32");
                     } else {
                         int scan_id = -1;
                         for (size_t i = 0; i < out.scans.size(); i++)
@@ -525,6 +568,17 @@ struct Emitter {
         // the chunk loop, twice: with the constant-f oscillators in 32.32 fixed point, and in the general form
         if (opt.profile) line("    const unsigned long long stamp_loop = __builtin_readcyclecounter();");
         if (opt.profile) line("    unsigned long long ph[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, ph_t = 0ull;  // (cycles from barrier to barrier, as wave 0 sees them)");
+        out_finite.assign(P.out_bufs.size(), 0);
+        if (render) {
+            visiting.assign(P.ops.size(), 0);
+            for (size_t oc = 0; oc < P.out_bufs.size(); oc++) {
+                std::vector<std::string> checks;
+                if (bound_of_buf(P.out_bufs[oc], checks) >= 1000) continue;
+                out_finite[oc] = 1;
+                for (const std::string &c : checks)
+                    if (std::find(small.begin(), small.end(), c) == small.end()) small.push_back(c), fast += " && jit_small(" + c + ")";
+            }
+        }
         line("    if (" + fast + ") {");
         loop(render, pass_level, used, true);
         line("    } else {");
@@ -785,7 +839,7 @@ struct Emitter {
         if (render)
             for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
                 for (int r = 0; r < R; r++)
-                    line("        jit_store(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
+                    line("        jit_store<" + std::string(fx && out_finite[oc] ? "true" : "false") + ">(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
         for (int b = 0; b < P.n_bufs; b++)
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
                 for (int r = 0; r < copies(producer[(size_t)b]); r++)
@@ -884,7 +938,7 @@ struct Emitter {
             case OP_OSC:
                 decl();
                 if (op.in[0].kind != SRC_BUF)
-                    line("        o" + id + ".tick<" + in_lds(op.attr) + ", " + (fx ? "true" : "false") + ">(" + X_ + ", " + table_row(op.attr) + ", " + v + ");");
+                    line("        o" + id + ".tick<" + in_lds(op.attr) + ", " + num(fx ? osc_fast_mode(op.attr) : 0) + ">(" + X_ + ", " + table_row(op.attr) + ", " + v + ");");
                 else {
                     const bool lookup = render || plan.osc_level[(size_t)k] < pass_level;
                     const std::string f = opnd_array(k, 0, "t" + id, r);

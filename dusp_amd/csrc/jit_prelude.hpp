@@ -87,6 +87,7 @@ __device__ __forceinline__ unsigned long long jit_u(unsigned long long v) {
 }
 __device__ __forceinline__ double jit_u(double v) { return __longlong_as_double((long long)jit_u((unsigned long long)__double_as_longlong(v))); }
 __device__ __forceinline__ bool jit_u(bool v) { return jit_u(v ? 1u : 0u) != 0u; }
+__device__ __forceinline__ bool jit_small(float k) { return jit_u(fabsf(k) <= 1073741824.f); }  // (a wave-uniform scalar; NaN fails)
 
 // rows of 256 floats in a wave's LDS scratch: every lane its four samples
 __device__ __forceinline__ void jit_row_put(float *row, uint32_t lane, const float (&v)[4]) { ((f32x4 *)row)[lane] = f32x4{v[0], v[1], v[2], v[3]}; }
@@ -177,6 +178,17 @@ __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uin
     }
 }
 
+// T[idx] and T[idx + 1] - T[idx] for the lerp's delta form (device_util.hpp lerp_delta): the LDS half image or a gather from L2
+template <int TF, bool D32>
+__device__ __forceinline__ void jit_pair_delta(const JitCtx &X, const float *gtab, uint32_t idx, double &a, double &d) {
+    if (TF == 1) X.table.pair_delta<D32>(idx, a, d);
+    else {
+        Table<0> t;
+        t.g = gtab;
+        t.pair_delta<D32>(idx, a, d);
+    }
+}
+
 // ---- Osc (src/components/Osc/Osc.js:35-47) with an unconnected f — a constant or a per-instance parameter.  Equal increments:
 // phase(n) = (phase0 + (n + 1) q) mod S in exact 2^-36 fixed point, so the lane jumps to its own samples and thereafter
 // advances by (256 q) mod S per chunk; nothing crosses lanes, nothing is carried but this lane's own phase.
@@ -184,15 +196,21 @@ __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uin
 // fast copy when every such oscillator of the wave qualifies, so that no branch stands inside the loop):
 //   FX   every phase is a multiple of 2^-32 (any f32 f with |f| >= 2^-8, i.e. lsb(f) >= 2^-31, from a start phase on that
 //        grid): index and fraction are two u32, advanced by add-with-carry; the fraction converts to f64 in one step
+//   LEAN every phase is a multiple of 2^-28 (any f32 f with |f| >= 2^-4) and the table's neighbours differ by f32 values: the
+//        lerp in its delta form (one fma: device_util.hpp lerp_delta), index.fraction as ONE 64-bit integer — the lane's
+//        four phases are four v_lshl_add_u64 off its first (q, 2q, 3q and the chunk's step in scalar registers), a wrap is
+//        a subtract and a minimum on the high word — and the fold into the half image another subtract and minimum
 //   else the general u64 form
-// All the lookups of a chunk are issued before the first lerp.
+// All the lookups of a chunk are issued before the first lerp.  The FX and LEAN copies are only entered with a finite f, so
+// they carry no NaN select.
 struct JitOscK {
     uint32_t I, F;                 // FX: index and 2^-32 fraction of this lane's first sample of the next chunk
     uint32_t qI, qF, cI, cF;       // increment per sample / per chunk in the same form (wave-uniform)
     unsigned long long P;          // general form: phase of this lane's first sample of the next chunk
     unsigned long long q, q256;    // increment per sample / per chunk, mod S (wave-uniform)
     unsigned long long P_init;     // phase before the render's first sample (wave-uniform)
-    bool bad, fx32;                // bad: f is NaN / Inf (every sample NaN); fx32: qualifies for the FX form
+    unsigned long long Q1, Q2, Q3, C; // LEAN: q, 2q, 3q, 256q mod S as 32.32 integers (wave-uniform)
+    bool bad, fx32, lean;          // bad: f is NaN / Inf (every sample NaN); fx32 / lean: qualifies for the FX / LEAN form
 
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float f, int state_slot) {
         double fd = (double)f;
@@ -209,7 +227,13 @@ struct JitOscK {
         q256 = jit_u(q256);
         P_init = jit_u(P_init);
         bad = jit_u(bad);
-        fx32 = ((q | P_init) & 15ull) == 0ull;
+        fx32 = ((q | P_init) & 15ull) == 0ull && !bad;
+        lean = ((q | P_init) & 255ull) == 0ull && !bad;
+        const unsigned long long q2 = addmod(q, q, X.S);
+        Q1 = q >> 4;
+        Q2 = q2 >> 4;
+        Q3 = addmod(q2, q, X.S) >> 4;
+        C = q256 >> 4;
         I = (uint32_t)(P >> kJFrac);
         F = (uint32_t)((P & kJMask) >> 4);
         qI = (uint32_t)(q >> kJFrac);
@@ -224,10 +248,30 @@ struct JitOscK {
         f = f2;
         i = i2;
     }
-    template <int TF, int FORM, bool FX>
+    template <int TF, int FORM, int MODE>  // MODE: 0 general, 1 FX, 2 LEAN (differences of neighbours in f64), 3 LEAN (in f32)
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
         float ta[4], tb[4];
-        if (FX) {
+        if (MODE >= 2) {
+            const unsigned long long PF = ((unsigned long long)I << 32) | F;
+            uint32_t fv[4];
+            double da[4], dd[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned long long Pc = c == 0 ? PF : PF + (c == 1 ? Q1 : c == 2 ? Q2 : Q3);
+                uint32_t i = (uint32_t)(Pc >> 32);
+                if (c) i = min(i, i - X.sr);  // (i < 2 sr; an underflow loses the min)
+                fv[c] = (uint32_t)Pc;
+                jit_pair_delta<TF, MODE == 3>(X, gtab, i, da[c], dd[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = lerp_delta(da[c], dd[c], fv[c]);
+            const unsigned long long s = PF + C;
+            const uint32_t h = (uint32_t)(s >> 32);
+            I = min(h, h - X.sr);
+            F = (uint32_t)s;
+            return;
+        }
+        if (MODE == 1) {
             uint32_t iv[4], fv[4];
             iv[0] = I;
             fv[0] = F;
@@ -259,8 +303,10 @@ struct JitOscK {
             }
             P = addmod(P, q256, X.S);
         }
+        if (MODE == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out[c] = bad ? __builtin_nanf("") : out[c];
+            for (int c = 0; c < 4; ++c) out[c] = bad ? __builtin_nanf("") : out[c];
+        }
     }
     // the phase after ceil(n_samples / 256) ticks (state write-back)
     __device__ __forceinline__ double end_phase(const JitArgs &A, const JitCtx &X) const {
@@ -1179,10 +1225,12 @@ struct JitDelayGather {
 };
 
 // ---- copy-out (src/renderChannelData.js:35-44): `x || 0`, then this lane's four samples of the outlet's channel
+// FINITE: the generator has shown that this outlet cannot be NaN here (jit_codegen.hpp bound_of_buf): only -0 is left to fix
+template <bool FINITE>
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
     if (!X.live) return;
     const uint64_t n0 = X.n0(g);
-    const float w[4] = {fix_out<false>(v[0]), fix_out<false>(v[1]), fix_out<false>(v[2]), fix_out<false>(v[3])};
+    const float w[4] = {fix_out<FINITE>(v[0]), fix_out<FINITE>(v[1]), fix_out<FINITE>(v[2]), fix_out<FINITE>(v[3])};
     float *row = A.out + ((size_t)X.inst * A.n_out + oc) * A.n_samples + n0;
     if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, w, n0, A.n_samples);
     else store4<false>(row, w, n0, A.n_samples);

@@ -75,3 +75,17 @@ def test_filter_coefficients_are_as_close_to_exact_as_the_reference_arithmetic(t
     assert rep["cases"] > 4_000_000 and rep["bad"] == 0
     assert rep["worst_ulp"] <= 6.0 and max(rep["worst_lp"][:3] + rep["worst_hp"][:3]) <= 4.5, rep
     assert rep["outside_rel"] <= 1e-9, rep
+
+
+def test_the_lerp_in_its_delta_form_is_the_reference_expression(tmp_path):
+    """dusp_amd/csrc/device_util.hpp lerp_delta / Table::pair_delta (one fma on T[i] and T[i+1] - T[i], what the compiled kernels' and the fused
+    engine's oscillators evaluate when every phase is a multiple of 2^-28) against Osc.js:43-46 as written, at every index of the sine table
+    at four sample rates, and the table classification (table_checks.hpp) the choice of form rests on: 48 kHz takes its differences in f64
+    (class 1: two pairs next to the middle differ by 25 bits), 44.1 kHz in f32 (class 2)."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "lerp_delta_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "lerp_delta_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] > 2_000_000 and rep["bad"] == 0, rep
+    assert rep["classes"] == [1, 2, 1, 2], rep

@@ -108,7 +108,7 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
     uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
     fast = source(uni.words, waves=16, per_wave=2, compile=True).split("} else {")[0]
     side = fast.split("auto side0 = [&]()")[1].split("};")[0]
-    assert ".tick<1, 0, true>" in side and side.count(".write(") == 2 and ".read(" not in side      # oscillators and the ring writes of both instances
+    assert ".tick<1, 0, 2>" in side and side.count(".write(") == 2 and ".read(" not in side      # oscillators and the ring writes of both instances
     early = fast.split("auto early = [&](uint32_t g)")[1].split("};")[0]
     assert early.count(".read(") == 2 and early.count("f4.feed(") == 2 and ".write(" not in early     # ring reads and feed-forward halves, a chunk ahead
     assert "if (g == X[0].g_begin) early(g);" in fast and fast.count("if (g + 1 < X[0].g_end) early(g + 1);") == 2
@@ -152,7 +152,7 @@ def test_instances_of_a_wave_share_what_does_not_depend_on_the_instance():
     uni = descriptor.unify([descriptor.extract(d.Filter(d.Multiply(d.Osc(110 + k), d.Ramp(48000, 1, 0).trigger()), 800)) for k in (0, 8)])
     text = source(uni.words, waves=16, per_wave=3, compile=True)
     fast = text.split("} else {")[0]
-    assert fast.count("jit_ramp<") == 1 and fast.count(".tick<1, 0, true>") == 3   # one envelope, three oscillators
+    assert fast.count("jit_ramp<") == 1 and fast.count(".tick<1, 0, 2>") == 3   # one envelope, three oscillators
     # 48 recurrences side by side on wave 0, in two sub-blocks of 128 samples (what LDS holds next to the table image): the feed-forward
     # half once per instance and chunk, into registers; each sub-block parked from there, followed by its give-back branch (parked again
     # and done as written if a recurrence met a NaN)
@@ -178,11 +178,11 @@ def test_saw_square_triangle_are_evaluated_not_looked_up():
     mix = d.Sum(d.Sum(d.Osc(110, "saw"), d.Osc(220, "square")), d.Sum(d.Osc(330, "triangle"), d.Sum(d.Osc(440), d.Osc(550, "8bit"))))
     text = source(descriptor.extract(mix).words, waves=4, compile=True)
     fast = text.split("} else {")[0]
-    for args in ("tick<2, 1, true>", "tick<2, 2, true>", "tick<2, 3, true>", "tick<1, 0, true>", "tick<3, 4, true>"):
+    for args in ("tick<2, 1, 1>", "tick<2, 2, 1>", "tick<2, 3, 1>", "tick<1, 0, 2>", "tick<3, 4, 1>"):
         assert fast.count(args) == 1, args
     # without a context's verdict on the tables nothing is assumed: everything is gathered
     plain = source(descriptor.extract(mix).words, waves=4, lds_table=False)
-    assert "tick<0, 0, true>" in plain and "tick<2," not in plain
+    assert "tick<0, 0, 1>" in plain and "tick<2," not in plain
 
 
 def _compile_in_a_fresh_process(cache, name="fm_sum"):
