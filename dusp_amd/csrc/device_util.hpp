@@ -94,14 +94,24 @@ DUSP_HD float closed_table_entry(const TableForm &F, uint32_t i) {
 DUSP_HD float eightbit_of_sine(float sine) { return (float)(js_round_small((double)sine * 128.0) / 128.0); }
 
 // Table access.  TBL == 0: padded full table in global memory (served by L2).
-// TBL == 1: half table H[0..M+1] = T[0..M+1] in LDS (M = sr/2, N = sr+1); T[i] = -H[N-i] above M.
-//   LDS image: blocks of 33 words, block b = H[32b .. 32b+32] (the 33rd word repeats the next
+// TBL == 1: half table in LDS (M = sr/2, N = sr+1 = 2M+1: T[i] = -T[N-i]), stored BACKWARDS from the middle:
+//   E[t] = T[M+1-t], t = 0 .. M+1.  With a = |i - M| (one v_sad_u32 — no select between i and its mirror image):
+//       i <= M:  T[i] =  E[a+1],  T[i+1] =  E[a]
+//       i >  M:  T[i] = -E[a],    T[i+1] = -E[a+1]
+//   so the lerp's pair is the two adjacent words E[a], E[a+1] either way, and T[i+1] - T[i] = E[a] - E[a+1] on both sides.
+//   (i == M may be read either way: T[M+1] = -T[M].)
+//   LDS image: blocks of 33 words, block b = E[32b .. 32b+32] (the 33rd word repeats the next
 //   block's first), so word(k) = k + (k >> 5).  The odd pitch spreads the arithmetic progressions a
 //   wave reads (lane l looks up phase0 + 4 l f) over the 32 banks — a linear image measured 9-way
-//   conflicts on average over the 1024-voice sweep, this one 2.8 — and word(k)+1 always holds
-//   H[k+1], so the lerp's pair is two adjacent words.
+//   conflicts on average over the 1024-voice sweep, this one 2.8 — and word(k)+1 always holds E[k+1].
 // TBL == 2: no table at all — saw / square / triangle in closed form (`form`).
 // TBL == 3: "8bit", evaluated from the SINE half-table image in LDS.
+__device__ __forceinline__ uint32_t abs_diff(uint32_t a, uint32_t b) {  // |a - b| (the compiler spells max - min in three instructions)
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b));  // (b: wave-uniform wherever this is used)
+    return r;
+}
+
 template <int TBL>
 struct Table {
     const float *g;
@@ -114,11 +124,12 @@ struct Table {
     __device__ __forceinline__ float at(uint32_t i) const {
         if (TBL == 0) return g[i];
         if (TBL == 2) return closed_table_entry(form, i);
-        const float v = *word(min(i, N - i));
-        const float s = i > M ? -v : v;
+        const bool upper = i > M;
+        const float v = *word(abs_diff(i, M) + (upper ? 0u : 1u));
+        const float s = upper ? -v : v;
         return TBL == 3 ? eightbit_of_sine(s) : s;
     }
-    __device__ __forceinline__ void pair(uint32_t i, float &a, float &b) const {  // (T[i], T[i+1])
+    __device__ __forceinline__ void pair(uint32_t i, float &a, float &b) const {  // (T[i], T[i+1]), i < N - 1
         if (TBL == 0) {
             a = g[i];
             b = g[i + 1];
@@ -135,30 +146,33 @@ struct Table {
             return;
         }
         const bool upper = i > M;
-        const float *p = word(upper ? N - i - 1 : i);
-        const float x = p[0], y = p[1];
-        a = upper ? -y : x;
-        b = upper ? -x : y;
+        const float *p = word(abs_diff(i, M));
+        const float p0 = p[0], p1 = p[1];
+        a = upper ? -p0 : p1;
+        b = upper ? -p1 : p0;
     }
-    // T[i] and T[i+1] - T[i] (i < N - 1) for the lerp's delta form (lerp_delta below).  Above the middle the pair is the mirrored
-    // one with both signs turned, so the difference is that pair's own: one select, not two.  D32: every difference of
-    // neighbours in the table is an f32 (one v_sub_f32); else it is taken in f64, where it is exact for any table whose
-    // neighbours are within 2^29 of each other (dusp_table_upload checks both: table_delta).
+    // T[i] and T[i+1] - T[i] for the lerp's delta form (lerp_delta below), given where the image holds them: a = |i - M| and
+    // which side of the middle i is on.  D32: every difference of neighbours in the table is an f32 (one v_sub_f32); else it is
+    // taken in f64, where it is exact for any table whose neighbours are within 2^28 of each other (dusp_table_upload checks
+    // both: table_checks.hpp table_delta_class).
     template <bool D32>
-    __device__ __forceinline__ void pair_delta(uint32_t i, double &a, double &d) const {
-        float x, y, af;
+    __device__ __forceinline__ void pair_delta_at(uint32_t a_img, bool upper, double &a, double &d) const {
+        const float *p = word(a_img);
+        const float p0 = p[0], p1 = p[1];
+        a = (double)(upper ? -p0 : p1);
+        delta<D32>(p0, p1, d);
+    }
+    template <bool D32>
+    __device__ __forceinline__ void pair_delta(uint32_t i, double &a, double &d) const {  // i < N - 1
         if (TBL == 0) {
-            x = g[i];
-            y = g[i + 1];
-            af = x;
-        } else {
-            const uint32_t j = min(i, N - 1 - i);  // i <= M  <=>  i <= N - 1 - i  (N - 1 = 2 M)
-            const float *p = word(j);
-            x = p[0];
-            y = p[1];
-            af = i > M ? -y : x;
-        }
-        a = (double)af;
+            const float x = g[i], y = g[i + 1];
+            a = (double)x;
+            delta<D32>(y, x, d);
+        } else
+            pair_delta_at<D32>(abs_diff(i, M), i > M, a, d);
+    }
+    template <bool D32>
+    static __device__ __forceinline__ void delta(float y, float x, double &d) {  // y - x
         if (D32) {
             float df;  // (one v_sub_f32 the vectorizer cannot see: it would pair two of them up behind four register moves)
             asm("v_sub_f32 %0, %1, %2" : "=v"(df) : "v"(y), "v"(x));
@@ -175,6 +189,38 @@ struct Table {
 __device__ __forceinline__ float lerp_delta(double a, double d, uint32_t F) {
     return (float)fma(d, (double)F * (1.0 / 4294967296.0), a);
 }
+
+// A phase on that grid as ONE 64-bit integer that is also a double: index.fraction in 32.32 fixed point plus 0x41300000 in the
+// high word are the bits of 2^20 + phase (the double's last place is 2^-32 there).  Integer adds step it exactly, v_fract_f64
+// of it IS the fraction (no conversion, no scaling), and the biased high word goes straight into the half image's address:
+// with s = |h - (bias + sr)| (phases below 2 sr: one subtraction of sr pending or not) the image index is a = |s - M|, and the
+// sample lies above the table's middle iff (s > M) != (h < bias + sr).
+constexpr uint32_t kPhaseBias = 0x41300000u;
+struct LeanPhase {
+    // Pc: biased phase of one sample, below bias + 2 sr.  WRAPPED: known to be below bias + sr already.
+    template <bool WRAPPED>
+    static __device__ __forceinline__ void locate(unsigned long long Pc, uint32_t sr, uint32_t M, uint32_t &a_img, bool &upper, double &fraction) {
+        const uint32_t h = (uint32_t)(Pc >> 32);
+        if (WRAPPED) {
+            a_img = abs_diff(h, kPhaseBias + M);
+            upper = h > kPhaseBias + M;
+        } else {
+            const uint32_t s = abs_diff(h, kPhaseBias + sr);
+            a_img = abs_diff(s, M);
+            upper = (s > M) != (h < kPhaseBias + sr);
+        }
+        fraction = __builtin_amdgcn_fract(__longlong_as_double((long long)Pc));
+    }
+    static __device__ __forceinline__ uint32_t index(unsigned long long Pc, uint32_t sr) {  // the table index itself (gathers from L2)
+        const uint32_t h = (uint32_t)(Pc >> 32);
+        return min(h - kPhaseBias, h - (kPhaseBias + sr));  // (an underflow loses the min)
+    }
+    static __device__ __forceinline__ unsigned long long step(unsigned long long P, unsigned long long c, uint32_t sr) {  // (P + c) mod sr, both below sr
+        const unsigned long long s = P + c;
+        const uint32_t h = (uint32_t)(s >> 32);
+        return ((unsigned long long)(h >= kPhaseBias + sr ? h - sr : h) << 32) | (uint32_t)s;
+    }
+};
 
 __device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t m, double inv_m) {
     const uint32_t q = (uint32_t)((double)x * inv_m);
@@ -216,14 +262,14 @@ __device__ __forceinline__ void store4(float *row, const float (&v)[4], uint64_t
             if (t + c < n_samples) row[c] = v[c];
 }
 
-// Cooperative fill of the LDS half-table image (33-word pitch, see Table<1>).
+// Cooperative fill of the LDS half-table image (33-word pitch, backwards from the middle: see Table<1>).
 template <int BLOCK>
 __device__ __forceinline__ void load_half_table(float *lds, const float *table, uint32_t sample_rate) {
     const uint32_t last = sample_rate / 2 + 1;
     const uint32_t n_words = last + (last >> 5) + 2;
     for (uint32_t q = threadIdx.x; q < n_words; q += BLOCK) {
-        const uint32_t src = (q / 33) * 32 + (q % 33);
-        lds[q] = table[min(src, last)];
+        const uint32_t t = (q / 33) * 32 + (q % 33);  // E[t] = T[M + 1 - t]
+        lds[q] = table[last - min(t, last)];
     }
     __syncthreads();
 }

@@ -246,6 +246,7 @@ static dusp::Knobs read_knobs() {
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
+    k.jit_lean = num("DUSP_JIT_LEAN", k.jit_lean);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
         if (std::sscanf(f, "%dx%d", &w, &r) == 2 && w >= 1 && w <= 16 && r >= 1 && r <= 4) k.jit_force_waves = w, k.jit_force_per_wave = r;
@@ -776,7 +777,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     dusp::JitOptions opt;
     opt.persistent = persistent;
     opt.profile = ctx->knobs.jit_profile != 0;
-    for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->table_delta[k], opt.table_bound[k] = ctx->table_bound[k];
+    for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->knobs.jit_lean ? ctx->table_delta[k] : 0, opt.table_bound[k] = ctx->table_bound[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
         if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && ctx->knobs.jit_lds_table != 0 && ctx->table_antisym[op.attr] && P.g.sample_rate % 2 == 0 &&
@@ -873,6 +874,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
         jit_scratch = scratch;
+        if (getenv("DUSP_JIT_LOG")) fprintf(stderr, "[dusp jit] %d waves x %d instances, filter block %d: %d bytes of scratch per lane\n", waves, per_wave, opt.filter_block, scratch);
         if (scratch <= ctx->knobs.jit_spill_bytes || ctx->knobs.jit_force_waves) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
@@ -1615,6 +1617,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         return DUSP_ERR_ARG;
     }
     const bool continued = (lds_table & 2) != 0 && (P.ring_samples != 0 || !P.feed_forward);
+    const bool lean_recurrence = (lds_table & 4) != 0;  // (the Filter stage's recurrence loop with 4 P values per register set: what a render falls back to when the kernel spills)
     lds_table &= 1;
     if (continued)
         for (dusp::DevOp &op : P.ops)
@@ -1634,6 +1637,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     opt.waves = waves;
     opt.per_wave = per_wave;
     opt.persistent = continued;
+    if (lean_recurrence) opt.filter_block = 4;
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
         opt.table_form[1] = dusp::TABLE_FORM_SAW;
@@ -1641,7 +1645,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         if (P.g.sample_rate % 4 == 0) opt.table_form[3] = dusp::TABLE_FORM_TRIANGLE;
         opt.table_form[4] = dusp::TABLE_FORM_8BIT;
         for (int k = 0; k < 5; k++) opt.table_bound[k] = 1;  // (the oscillators' tables stay within [-1, 1])
-        opt.table_delta[0] = 1;  // (the sine table: differences of neighbours exact in f64 at any sample rate, in f32 at some — 44.1 kHz, not 48)
+        opt.table_delta[0] = getenv("DUSP_JIT_LEAN") && atoi(getenv("DUSP_JIT_LEAN")) == 0 ? 0 : 1;  // (the sine table: differences of neighbours exact in f64 at any sample rate, in f32 at some — 44.1 kHz, not 48)
         for (const dusp::DevOp &op : P.ops)
             if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
                 opt.lds_table = 0;

@@ -290,11 +290,11 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                 // the `|| 0` additions go two at a time (v_pk_mul_f32 / v_pk_add_f32).
                 // Delta form (device_util.hpp lerp_delta), where the phase grid is 2^-28 or coarser and the table's neighbours differ by exact
                 // values (A.table_delta: 2 in f32, 1 in f64; the LDS image or the gathered table): T[i] + (T[i+1] - T[i]) fraction in ONE fma is
-                // the reference's three roundings, whatever the shape; index.fraction is one 64-bit integer, the lane's four phases are four
-                // v_lshl_add_u64 off its first (q, 2q, 3q and the step's 256q as 32.32 integers, wave-uniform), a wrap is a subtract and a
-                // minimum on the high word, the fold into the half image another subtract and minimum.
+                // the reference's three roundings, whatever the shape; index.fraction is one 64-bit integer that is also a double (device_util.hpp
+                // LeanPhase): the lane's four phases are four v_lshl_add_u64 off its first (q, 2q, 3q and the step's 256q as 32.32 integers,
+                // wave-uniform), the fraction is v_fract_f64 of it, the wrap and the fold into the half image are two v_sad_u32.
                 if ((TBL == 0 || TBL == 1) && e_min >= -28 && A.table_delta) {
-                    unsigned long long PF[RS], Q1[RS], Q2[RS], Q3[RS], C[RS];
+                    unsigned long long PD[RS], Q1[RS], Q2[RS], Q3[RS], C[RS];
                     auto uni = [](unsigned long long v) {
                         return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
                     };
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
                     for (int r = 0; r < RS; ++r) {
                         const OscRec rc = recs[inst[sub + r]];
                         const int up = 32 + rc.E;  // phases are integers in units of 2^E, -28 <= E <= 0: as 32.32 integers, shifted up
-                        PF[r] = (((unsigned long long)I[r][0]) << 32) | F[r][0];
+                        PD[r] = (((unsigned long long)(I[r][0] + kPhaseBias)) << 32) | F[r][0];
                         const uint64_t q2 = addmod(rc.Fm, rc.Fm, rc.S);
                         Q1[r] = uni(rc.Fm << up);
                         Q2[r] = uni(q2 << up);
@@ -316,21 +316,24 @@ __global__ void __launch_bounds__(BLOCK) dusp_fused_kernel(FusedArgs A, const Os
 #pragma unroll
                             for (int r = 0; r < RS; ++r) {
                                 float v[4];
-                                double ta[4], td[4];
-                                uint32_t fv[4];
+                                double ta[4], td[4], fr[4];
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
-                                    const unsigned long long Pc = c == 0 ? PF[r] : PF[r] + (c == 1 ? Q1[r] : c == 2 ? Q2[r] : Q3[r]);
-                                    uint32_t i = (uint32_t)(Pc >> 32);
-                                    if (c) i = min(i, i - sr);  // (i < 2 sr; an underflow loses the min)
-                                    fv[c] = (uint32_t)Pc;
-                                    table.template pair_delta<decltype(d32)::value>(i, ta[c], td[c]);
+                                    const unsigned long long Pc = c == 0 ? PD[r] : PD[r] + (c == 1 ? Q1[r] : c == 2 ? Q2[r] : Q3[r]);
+                                    if (TBL == 1) {
+                                        uint32_t a_img;
+                                        bool upper;
+                                        if (c == 0) LeanPhase::locate<true>(Pc, sr, table.M, a_img, upper, fr[c]);
+                                        else LeanPhase::locate<false>(Pc, sr, table.M, a_img, upper, fr[c]);
+                                        table.template pair_delta_at<decltype(d32)::value>(a_img, upper, ta[c], td[c]);
+                                    } else {
+                                        fr[c] = __builtin_amdgcn_fract(__longlong_as_double((long long)Pc));
+                                        table.template pair_delta<decltype(d32)::value>(LeanPhase::index(Pc, sr), ta[c], td[c]);
+                                    }
                                 }
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) v[c] = finish(lerp_delta(ta[c], td[c], fv[c]), rv[c], gain[r]);
-                                const unsigned long long s = PF[r] + C[r];
-                                const uint32_t h = (uint32_t)(s >> 32);
-                                PF[r] = ((unsigned long long)min(h, h - sr) << 32) | (uint32_t)s;
+                                for (int c = 0; c < 4; ++c) v[c] = finish((float)fma(td[c], fr[c], ta[c]), rv[c], gain[r]);
+                                PD[r] = LeanPhase::step(PD[r], C[r], sr);
                                 store4<decltype(vec)::value>(row + roff[r], v, (uint64_t)g * kChunk + lane * 4, A.n_samples);
                             }
                             row += kChunk;

@@ -178,17 +178,6 @@ __device__ __forceinline__ void jit_pair(const JitCtx &X, const float *gtab, uin
     }
 }
 
-// T[idx] and T[idx + 1] - T[idx] for the lerp's delta form (device_util.hpp lerp_delta): the LDS half image or a gather from L2
-template <int TF, bool D32>
-__device__ __forceinline__ void jit_pair_delta(const JitCtx &X, const float *gtab, uint32_t idx, double &a, double &d) {
-    if (TF == 1) X.table.pair_delta<D32>(idx, a, d);
-    else {
-        Table<0> t;
-        t.g = gtab;
-        t.pair_delta<D32>(idx, a, d);
-    }
-}
-
 // ---- Osc (src/components/Osc/Osc.js:35-47) with an unconnected f — a constant or a per-instance parameter.  Equal increments:
 // phase(n) = (phase0 + (n + 1) q) mod S in exact 2^-36 fixed point, so the lane jumps to its own samples and thereafter
 // advances by (256 q) mod S per chunk; nothing crosses lanes, nothing is carried but this lane's own phase.
@@ -196,10 +185,10 @@ __device__ __forceinline__ void jit_pair_delta(const JitCtx &X, const float *gta
 // fast copy when every such oscillator of the wave qualifies, so that no branch stands inside the loop):
 //   FX   every phase is a multiple of 2^-32 (any f32 f with |f| >= 2^-8, i.e. lsb(f) >= 2^-31, from a start phase on that
 //        grid): index and fraction are two u32, advanced by add-with-carry; the fraction converts to f64 in one step
-//   LEAN every phase is a multiple of 2^-28 (any f32 f with |f| >= 2^-4) and the table's neighbours differ by f32 values: the
-//        lerp in its delta form (one fma: device_util.hpp lerp_delta), index.fraction as ONE 64-bit integer — the lane's
-//        four phases are four v_lshl_add_u64 off its first (q, 2q, 3q and the chunk's step in scalar registers), a wrap is
-//        a subtract and a minimum on the high word — and the fold into the half image another subtract and minimum
+//   LEAN every phase is a multiple of 2^-28 (any f32 f with |f| >= 2^-4) and the table's neighbours differ by exact values: the
+//        lerp in its delta form (one fma: device_util.hpp lerp_delta), index.fraction as ONE 64-bit integer that is also a
+//        double (LeanPhase) — the lane's four phases are four v_lshl_add_u64 off its first (q, 2q, 3q and the chunk's step
+//        in scalar registers), the fraction is v_fract_f64 of it, the wrap and the fold into the half image are two v_sad_u32
 //   else the general u64 form
 // All the lookups of a chunk are issued before the first lerp.  The FX and LEAN copies are only entered with a finite f, so
 // they carry no NaN select.
@@ -209,6 +198,7 @@ struct JitOscK {
     unsigned long long P;          // general form: phase of this lane's first sample of the next chunk
     unsigned long long q, q256;    // increment per sample / per chunk, mod S (wave-uniform)
     unsigned long long P_init;     // phase before the render's first sample (wave-uniform)
+    unsigned long long PD;         // LEAN: this lane's first sample of the next chunk, index.fraction as a biased 64-bit integer (LeanPhase)
     unsigned long long Q1, Q2, Q3, C; // LEAN: q, 2q, 3q, 256q mod S as 32.32 integers (wave-uniform)
     bool bad, fx32, lean;          // bad: f is NaN / Inf (every sample NaN); fx32 / lean: qualifies for the FX / LEAN form
 
@@ -220,6 +210,7 @@ struct JitOscK {
         const long long qs = (long long)(fd * kJ36);  // exact for |f| >= 2^-13 (or f == 0)
         q = qs >= 0 ? (unsigned long long)qs : X.S - (unsigned long long)(-qs);
         if (q >= X.S) q -= X.S;
+        if (bad) q = 1ull;  // (every sample is NaN whatever the phase; an increment off the 2^-32 grid keeps such an oscillator out of the FX / LEAN copies, which carry no select for it)
         P_init = (unsigned long long)(A.init_state[state_slot] * kJ36);
         q256 = jit_mulmod(q, kChunk, X.S, X.inv_S);
         P = addmod(P_init, jit_mulmod(q, X.n0(X.g_begin) + 1, X.S, X.inv_S), X.S);
@@ -227,8 +218,8 @@ struct JitOscK {
         q256 = jit_u(q256);
         P_init = jit_u(P_init);
         bad = jit_u(bad);
-        fx32 = ((q | P_init) & 15ull) == 0ull && !bad;
-        lean = ((q | P_init) & 255ull) == 0ull && !bad;
+        fx32 = ((q | P_init) & 15ull) == 0ull;  // (never with a NaN / Inf f: q is odd then)
+        lean = ((q | P_init) & 255ull) == 0ull;
         const unsigned long long q2 = addmod(q, q, X.S);
         Q1 = q >> 4;
         Q2 = q2 >> 4;
@@ -236,6 +227,7 @@ struct JitOscK {
         C = q256 >> 4;
         I = (uint32_t)(P >> kJFrac);
         F = (uint32_t)((P & kJMask) >> 4);
+        PD = ((unsigned long long)(I + kPhaseBias) << 32) | F;
         qI = (uint32_t)(q >> kJFrac);
         qF = (uint32_t)((q & kJMask) >> 4);
         cI = (uint32_t)(q256 >> kJFrac);
@@ -251,24 +243,25 @@ struct JitOscK {
     template <int TF, int FORM, int MODE>  // MODE: 0 general, 1 FX, 2 LEAN (differences of neighbours in f64), 3 LEAN (in f32)
     __device__ __forceinline__ void tick(const JitCtx &X, const float *gtab, float (&out)[4]) {
         float ta[4], tb[4];
-        if (MODE >= 2) {
-            const unsigned long long PF = ((unsigned long long)I << 32) | F;
-            uint32_t fv[4];
-            double da[4], dd[4];
+        if (MODE >= 2) {  // LEAN (device_util.hpp LeanPhase, lerp_delta)
+            double da[4], dd[4], fr[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const unsigned long long Pc = c == 0 ? PF : PF + (c == 1 ? Q1 : c == 2 ? Q2 : Q3);
-                uint32_t i = (uint32_t)(Pc >> 32);
-                if (c) i = min(i, i - X.sr);  // (i < 2 sr; an underflow loses the min)
-                fv[c] = (uint32_t)Pc;
-                jit_pair_delta<TF, MODE == 3>(X, gtab, i, da[c], dd[c]);
+                const unsigned long long Pc = c == 0 ? PD : PD + (c == 1 ? Q1 : c == 2 ? Q2 : Q3);
+                uint32_t a_img;
+                bool upper;
+                if (c == 0) LeanPhase::locate<true>(Pc, X.sr, X.table.M, a_img, upper, fr[c]);
+                else LeanPhase::locate<false>(Pc, X.sr, X.table.M, a_img, upper, fr[c]);
+                if (TF == 1) X.table.pair_delta_at<MODE == 3>(a_img, upper, da[c], dd[c]);
+                else {
+                    Table<0> t;
+                    t.g = gtab;
+                    t.pair_delta<MODE == 3>(LeanPhase::index(Pc, X.sr), da[c], dd[c]);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[c] = lerp_delta(da[c], dd[c], fv[c]);
-            const unsigned long long s = PF + C;
-            const uint32_t h = (uint32_t)(s >> 32);
-            I = min(h, h - X.sr);
-            F = (uint32_t)s;
+            for (int c = 0; c < 4; ++c) out[c] = (float)fma(dd[c], fr[c], da[c]);
+            PD = LeanPhase::step(PD, C, X.sr);
             return;
         }
         if (MODE == 1) {

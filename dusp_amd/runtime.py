@@ -12,7 +12,7 @@ import numpy as np
 from .wavetables import N_TABLES, make_table
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdusp_hip.so")
+LIB_PATH = os.environ.get("DUSP_HIP_LIB") or os.path.join(_HERE, "libdusp_hip.so")  # (DUSP_HIP_LIB: another build of the library, for A/B runs)
 
 ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED, ENGINE_WAVE, ENGINE_LOOP = 0, 1, 2, 3, 4
 ENGINE_RESUMABLE = 0x100  # OR into the engine: the program will be continued (Program.continue_with)
@@ -109,13 +109,13 @@ class _PinnedBlock:
             pass
 
 
-def circuit_kernel_source(words, waves=16, per_wave=1, lds_table=True, compile=False, continued=False):
+def circuit_kernel_source(words, waves=16, per_wave=1, lds_table=True, compile=False, continued=False, lean_recurrence=False):
     """HIP text of the kernel the circuit compiler generates for a descriptor (dusp_circuit_kernel_source; needs no GPU).
     Raises DuspHipError(-2) for circuits that stay on the interpreter."""
     L = load()
     words = np.ascontiguousarray(words, dtype=np.float64)
     buf = ctypes.create_string_buffer(1 << 20)
-    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, per_wave, int(bool(lds_table)) | (2 if continued else 0), int(compile), buf, len(buf))
+    n = L.dusp_circuit_kernel_source(words.ctypes.data, words.size, waves, per_wave, int(bool(lds_table)) | (2 if continued else 0) | (4 if lean_recurrence else 0), int(compile), buf, len(buf))
     if n < 0:
         raise DuspHipError(n, L.dusp_last_error(None).decode())
     return buf.value.decode()
