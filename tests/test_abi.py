@@ -89,3 +89,14 @@ def test_the_lerp_in_its_delta_form_is_the_reference_expression(tmp_path):
     rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
     assert rep["cases"] > 2_000_000 and rep["bad"] == 0, rep
     assert rep["classes"] == [1, 2, 1, 2], rep
+
+
+def test_increments_reach_fixed_point_through_the_f64_mantissa_exactly(tmp_path):
+    """dusp_amd/csrc/jit_prelude.hpp jit_fix36 (a scanned oscillator's f32 increments as 2^-36 fixed point: trunc(f 2^36) read out of the
+    mantissa field of |.| + 2^52) against the C cast it stands for, over every exponent below 2^16, both signs, edge and random mantissas."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "fix36_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "fix36_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] > 10_000 and rep["bad"] == 0, rep
