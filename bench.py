@@ -45,6 +45,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="voices60", choices=["voices60", "cfg5"])
     ap.add_argument("--mode", default="pcm", choices=["pcm", "mixdown"])
+    ap.add_argument("--mix", default="chain", choices=["chain", "reduce"],
+                    help="mixdown on N > 1 GPUs: 'chain' = ONE left-deep chain continued rank to rank, window by window (bit for bit the single chain: "
+                         "shard.chain_mixdown); 'reduce' = every rank's partial mix added onto rank 0 by an f32 reduction (tolerance-level)")
     ap.add_argument("--seconds", type=float, default=None, help="rendered duration per voice (default: 60 / cfg5: 1)")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (voices60, default 1024) / in total (cfg5, default 65536)")
     ap.add_argument("--sample-rate", type=int, default=48000)
@@ -174,7 +177,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dusp_amd import runtime
-    from dusp_amd.shard import instance_range, reduce_mixdown, render_and_gather
+    from dusp_amd.shard import chain_mixdown, instance_range, reduce_mixdown, render_and_gather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(world_env or "1")
@@ -226,7 +229,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     p_ptr = d_params.data_ptr() if d_params is not None else None
 
+    chained = mixdown and world > 1 and args.mix == "chain"
+    # (chain: windows of the timeline travel down the ranks as a pipeline; ~4 windows per rank keep every GPU busy most of the time)
+    chain_window = max(65536, (n_samples // (4 * world) + 2047) // 2048 * 2048)
+
+    def chain_step():
+        def render_window(first, n, init, raw, out):
+            prog.render_chain_window(first, n, init.data_ptr() if init is not None else None, raw, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return chain_mixdown(render_window, n_samples, chain_window, d_out)
+
     def step():
+        if chained:
+            return chain_step()
         prog.render_device(n_samples, n_inst, p_ptr, d_out.data_ptr(), stream)
         if mixdown and world > 1:
             reduce_mixdown(d_out[0])
@@ -242,8 +256,13 @@ def main():
     # kernel time: HIP events on the launch stream, one pair per step
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    mix_root = None
     for a, b in ev:
         a.record()
+        if chained:
+            mix_root = chain_step()  # (the events bracket the rank's whole step: renders of its windows and the waits between them)
+            b.record()
+            continue
         prog.render_device(n_samples, n_inst, p_ptr, d_out.data_ptr(), stream)
         b.record()
         if mixdown and world > 1:
@@ -257,7 +276,7 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
 
     # sanity: the timed output is real PCM (parity is the tests' job; here just refuse an all-zero / NaN buffer)
-    head = d_out[0, 0, :4096].float().cpu().numpy()
+    head = (mix_root[0, :4096] if (chained and rank == 0) else d_out[0, 0, :4096] if not chained else torch.ones(8)).float().cpu().numpy()
     if not np.isfinite(head).all() or float(np.abs(head).max()) == 0.0:
         raise SystemExit("bench: rendered buffer is empty or non-finite")
 
@@ -345,7 +364,7 @@ def main():
                                       "voices folded through Sum.many into one channel per rank, partials reduced onto rank 0" if mixdown
                                       else "every voice's PCM written"),
                        "voices_per_gpu": n_voices, "voices_total": n_total, "n_samples": n_samples, "engine": prog.engine, "shape": prog.shape,
-                       "parallelism": "voices sharded over %d GPU(s), %s" % (world, "reduce of the partial mixes" if mixdown and world > 1 else "no collective")},
+                       "parallelism": "voices sharded over %d GPU(s), %s" % (world, ("one chain continued rank to rank, window by window (bit for bit)" if chained else "reduce of the partial mixes") if mixdown and world > 1 else "no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},

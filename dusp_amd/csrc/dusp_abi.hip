@@ -151,6 +151,10 @@ struct dusp_program {
     std::string jit_why;
     std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, 8 x instances per wavefront + Filter block) -> kernel text (+ constants, scan list)
     bool jit_consts_uploaded = false;
+    // dusp_render_chain_window: the window the next render of this (sum chain) program is (set for the duration of that call)
+    bool chain_on = false, chain_raw = false;
+    const float *chain_init = nullptr;
+    uint64_t chain_first = 0;
     uint64_t jit_table_generation = 0;  // ctx->table_generation the texts in jit_src were generated against
     int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
     DevBuf<float> d_jit_fk;
@@ -677,6 +681,24 @@ int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
     return render_device(prog, n_instances, n_samples, d_params, nullptr, d_out, stream_);
 }
 
+int dusp_render_chain_window(dusp_program *prog, uint64_t first_sample, size_t n_samples, const float *d_init, int raw, float *d_out, void *stream_) {
+    if (!prog) return DUSP_ERR_ARG;
+    if (prog->engine != DUSP_ENGINE_FUSED || prog->fused.kind != dusp::FUSED_SUMCHAIN)
+        CTX_FAIL(prog->ctx, DUSP_ERR_UNSUPPORTED, "dusp_render_chain_window: the program is not on the fused sum chain (a Sum.many of constant-f oscillators)");
+    if (prog->P.g.n_params > 0) CTX_FAIL(prog->ctx, DUSP_ERR_UNSUPPORTED, "dusp_render_chain_window: programs with per-instance parameters are not chained");
+    if (first_sample % 2048 != 0) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "dusp_render_chain_window: first_sample must be a multiple of 2048");
+    if (first_sample > (1ull << 40)) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "dusp_render_chain_window: first_sample out of range");
+    if ((((uintptr_t)d_init | (uintptr_t)d_out) & 15) != 0) CTX_FAIL(prog->ctx, DUSP_ERR_ARG, "dusp_render_chain_window: d_init and d_out must be 16-byte aligned");
+    prog->chain_on = true;
+    prog->chain_first = first_sample;
+    prog->chain_init = d_init;
+    prog->chain_raw = raw != 0;
+    const int rc = render_device(prog, 1, n_samples, nullptr, nullptr, d_out, stream_);
+    prog->chain_on = false;
+    prog->chain_init = nullptr;
+    return rc;
+}
+
 int dusp_render_device_inputs(dusp_program *prog, size_t n_instances, size_t n_samples, const float *d_params, const float *d_inputs,
                               float *d_out, void *stream_) {
     if (!prog) return DUSP_ERR_ARG;
@@ -1065,7 +1087,12 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
             int gb = (uint64_t)n_inst * ((groups + 7) / 8) >= slots ? 8 : 4;
             if ((groups + gb - 1) / gb > 65535) gb = 8;
             if ((groups + gb - 1) / gb > 65535) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: too many samples for the fused sum chain; use DUSP_ENGINE_CHUNK");
-            dusp::build_sum_voices(prog->fused, (uint32_t)P.g.sample_rate, gb, (uint64_t)n_chunks * dusp::kChunk, prog->h_sum_voices, prog->h_sum_end);
+            if (prog->chain_on) {  // (dusp_render_chain_window: this launch is a window of the timeline and continues another rank's sums)
+                L.chain_first = prog->chain_first;
+                L.chain_init = prog->chain_init;
+                L.chain_raw = prog->chain_raw;
+            }
+            dusp::build_sum_voices(prog->fused, (uint32_t)P.g.sample_rate, gb, L.chain_first + (uint64_t)n_chunks * dusp::kChunk, prog->h_sum_voices, prog->h_sum_end);
             HIP_TRY(ctx, prog->d_sum_voices.ensure(prog->h_sum_voices.size()));
             HIP_TRY(ctx, hipMemcpyAsync(prog->d_sum_voices.p, prog->h_sum_voices.data(), prog->h_sum_voices.size() * sizeof(dusp::SumVoice), hipMemcpyHostToDevice, stream));
             std::vector<double> end((size_t)prog->fused.n_state_words * n_inst);

@@ -76,6 +76,11 @@ struct SumArgs {
     uint32_t n_voices, n_inst, n_groups, n_blocks, sample_rate, vec4_ok;
     double r_d, r_y0, r_y1, r_t0;  // the voices' common Ramp (kernels instantiated with ENV == 2)
     int32_t r_playing, r_fastdiv;
+    // A window of the render that continues a chain (dusp_render_chain_window: the voices of one `Sum.many` dealt over several
+    // GPUs): blocks first_block .. of the timeline go to `out`, whose first sample is the window's; the running sums start as
+    // `init` (same layout as `out`) instead of zeros; raw: no `x || 0` at the copy-out (a partial sum that another rank continues).
+    const float *init;
+    uint32_t first_block, raw;
 };
 
 // The feedback voice of BASELINE configs[3] as the loop engine sees it (chunk_engine.hip).
@@ -161,6 +166,9 @@ struct FusedLaunch {
     uint32_t n_inst, n_chunks, sample_rate, table_stride;
     int n_cus;
     bool table_antisym, table_finite, table_fx32_ok;
+    const float *chain_init = nullptr;  // sum chain only (dusp_render_chain_window): the sums another GPU's voices left, laid out like `out`
+    uint64_t chain_first = 0;           // ... the window's first sample (a whole number of the launch's blocks)
+    bool chain_raw = false;             // ... no `x || 0` at the copy-out (a partial sum)
     int table_delta;  // the lerp's delta form on this table (table_checks.hpp table_delta_class): 0 no, 1 differences in f64, 2 in f32
     int table_form;  // TABLE_FORM_* (device_util.hpp): saw / square / triangle are evaluated from the index instead of gathered
     Knobs knobs;

@@ -41,16 +41,29 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
     const uint64_t n_items = (uint64_t)A.n_inst * A.n_blocks;
     const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
     const uint32_t sr = A.sample_rate;
-    const uint32_t n_full = A.vec4_ok ? (uint32_t)(A.n_samples / kChunk) : 0u;
+    const uint32_t n_full = A.first_block * GB + (A.vec4_ok ? (uint32_t)(A.n_samples / kChunk) : 0u);  // (groups counted like g0: from the render's first sample)
 
     for (uint64_t item = (uint64_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6); item < n_items; item += total_waves) {
-        const uint32_t blk = (uint32_t)(item % A.n_blocks);
+        const uint32_t blk = (uint32_t)(item % A.n_blocks) + A.first_block;  // (a window: blocks counted from the render's first sample)
         const uint32_t inst = (uint32_t)(item / A.n_blocks);
         const uint32_t g0 = blk * GB;
+        const size_t row_at = (size_t)inst * A.n_samples + (size_t)(g0 - A.first_block * GB) * kChunk + lane * 4;
         float acc[GB][4];
 #pragma unroll
         for (int g = 0; g < GB; ++g)
             for (int c = 0; c < 4; ++c) acc[g][c] = 0.f;  // 0 + v0 == v0: the chain starts at the first voice
+        if (A.init) {  // ... or continues the sums another GPU's voices left (whole groups, 16-byte rows: the host checks)
+#pragma unroll
+            for (int g = 0; g < GB; ++g)
+                if (g0 + g < n_full) {
+                    const f32x4 v = *(const f32x4 *)(A.init + row_at + (size_t)g * kChunk);
+                    acc[g][0] = v[0]; acc[g][1] = v[1]; acc[g][2] = v[2]; acc[g][3] = v[3];
+                } else if (g0 + g < A.n_groups) {  // (the window's last, partial group)
+                    const uint64_t t = (uint64_t)(g0 + g - A.first_block * GB) * kChunk + lane * 4;
+                    for (int c = 0; c < 4; ++c)
+                        if (t + c < A.n_samples) acc[g][c] = A.init[row_at + (size_t)g * kChunk + c];
+                }
+        }
         float env[ENV == 2 ? GB : 1][4];
         if (ENV == 2) {  // Ramp.js:25-40 in closed form: t(n) = min(t0 + n + 1, duration) while playing
             const double dy = A.r_y1 - A.r_y0, rcp = 1.0 / A.r_d;
@@ -127,17 +140,17 @@ __global__ void __launch_bounds__(BLOCK) dusp_sumchain_kernel(SumArgs A) {
                     }
             }
         }
-        float *row = A.out + (size_t)inst * A.n_samples + (size_t)g0 * kChunk + lane * 4;
+        float *row = A.out + row_at;
 #pragma unroll
         for (int g = 0; g < GB; ++g) {
             const uint32_t gg = g0 + g;
             if (gg >= A.n_groups) break;
             float v[4];
-            for (int c = 0; c < 4; ++c) v[c] = fix_out<FINITE>(acc[g][c]);
+            for (int c = 0; c < 4; ++c) v[c] = A.raw ? acc[g][c] : fix_out<FINITE>(acc[g][c]);
             if (gg < n_full)
                 store4<true>(row, v, 0, A.n_samples);
             else
-                store4<false>(row, v, (uint64_t)gg * kChunk + lane * 4, A.n_samples);
+                store4<false>(row, v, (uint64_t)(gg - A.first_block * GB) * kChunk + lane * 4, A.n_samples);
             row += kChunk;
         }
     }
@@ -165,8 +178,13 @@ hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const Su
     A.inv_sr = 1.0 / (double)L.sample_rate;
     A.n_voices = (uint32_t)plan.sum_f.size();
     A.n_inst = L.n_inst;
-    A.n_groups = (uint32_t)((L.n_samples + kChunk - 1) / kChunk);
-    A.n_blocks = (A.n_groups + gb - 1) / gb;
+    // (a window of a chain: L.chain_first is a whole number of blocks — the caller checks; groups and blocks count from the render's first sample)
+    A.first_block = (uint32_t)(L.chain_first / ((uint64_t)gb * kChunk));
+    A.init = L.chain_init;
+    A.raw = L.chain_raw ? 1u : 0u;
+    const uint32_t window_groups = (uint32_t)((L.n_samples + kChunk - 1) / kChunk);
+    A.n_groups = A.first_block * (uint32_t)gb + window_groups;
+    A.n_blocks = (window_groups + gb - 1) / gb;
     A.sample_rate = L.sample_rate;
     A.vec4_ok = (L.n_samples % 4 == 0) && (((uintptr_t)L.out & 15) == 0);
     A.r_d = plan.r_d;
@@ -181,7 +199,7 @@ hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const Su
     const int grid = tbl ? L.n_cus : L.n_cus * 8;
     const bool finite = L.table_finite && plan.sum_env == 0;  // (enveloped voices: products may overflow, so the copy-out keeps the full `x || 0`)
     // INT needs blk * (bs >> 32) < 2^32
-    const bool use_int = plan.sum_all_int && (uint64_t)A.n_blocks * L.sample_rate < (1ull << 32);
+    const bool use_int = plan.sum_all_int && ((uint64_t)A.first_block + A.n_blocks) * L.sample_rate < (1ull << 32);
 
 #define DUSP_S5(TB, IN, G, FIN, EN) \
     return TB ? launch_sum<1, IN, G, FIN, 1024, EN>(A, grid, lds_bytes, stream) : launch_sum<0, IN, G, FIN, 256, EN>(A, grid, 0, stream)

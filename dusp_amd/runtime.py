@@ -23,7 +23,7 @@ EXPORTS = [
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
     "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
-    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source", "dusp_jit_cache_dir",
+    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source", "dusp_jit_cache_dir", "dusp_render_chain_window",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.dusp_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.dusp_fill_device.argtypes = [vp, vp, sz, ctypes.c_float, vp]
     L.dusp_render_device_inputs.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.dusp_render_chain_window.argtypes = [vp, ctypes.c_uint64, sz, vp, ci, vp, vp]
     L.dusp_render_host_inputs.argtypes = [vp, sz, sz, vp, vp, vp, ci]
     L.dusp_host_alloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.dusp_host_free.argtypes = [vp, vp]
@@ -272,6 +273,11 @@ class Program:
             self.ctx._check(self._L.dusp_render_device_inputs(self._h, n_instances, n_samples, d_params, d_inputs, d_out, stream))
         else:
             self.ctx._check(self._L.dusp_render_device(self._h, n_instances, n_samples, d_params, d_out, stream))
+
+    def render_chain_window(self, first_sample, n_samples, d_init, raw, d_out, stream=None):
+        """dusp_render_chain_window: the window [first_sample, first_sample + n_samples) of a fused sum-chain program's timeline, its sums
+        continued from d_init (None: the chain's first voices are this program's); raw: a partial sum for the next rank (shard.chain_mixdown)."""
+        self.ctx._check(self._L.dusp_render_chain_window(self._h, first_sample, n_samples, d_init, int(bool(raw)), d_out, stream))
 
     def state(self, unit, instance=0):
         buf = np.zeros(128, dtype=np.float64)

@@ -12,10 +12,16 @@ a time.  Receives land directly in their final place of the root's [n_instances,
 buffer, no second copy.  A round only waits for the tile it carries, so a caller can render tile k+1 on
 its render stream while round k is on the wire (render_and_gather).
 
-Mix-down (the `Sum.many` reading of BASELINE configs[2]) across ranks: every rank folds its own voices in
-the reference's left-deep order (Sum.js:18-29) into one partial; reduce_mixdown() adds the partials onto
-rank 0 (an f32 sum reduction; RCCL picks the order).  The summation order then differs from the single
-left-deep chain at the rank boundaries — tolerance-level, not bit-exact.
+Mix-down (the `Sum.many` reading of BASELINE configs[2]) across ranks, two ways:
+  * reduce_mixdown(): every rank folds its own voices in the reference's left-deep order (Sum.js:18-29) into one
+    partial and the partials are added onto rank 0 (an f32 sum reduction; RCCL picks the order).  The summation
+    order then differs from the single left-deep chain at the rank boundaries — tolerance-level, not bit-exact.
+  * chain_mixdown(): the chain itself, BIT FOR BIT.  The f32 order of the adds is part of the result, so the ranks'
+    voice ranges are links of ONE chain: rank r continues, for a window of the timeline, the running sums rank r-1
+    left for that window (dusp_render_chain_window) and hands its own on to rank r+1; the last rank's output is the
+    mix.  Windows travel down the ranks as a pipeline — rank r works on window k while rank r+1 works on window k-1 —
+    so all GPUs are busy after world-1 steps; what moves per window and link is one f32 partial per sample (point
+    to point: exactly the neighbour links xGMI has), and the finished windows go from the last rank to rank 0.
 """
 import torch
 import torch.distributed as dist
@@ -147,3 +153,86 @@ def reduce_mixdown(partial, group=None):
     rank 0, None elsewhere.  The partial is overwritten on the root."""
     dist.reduce(partial, dst=(dist.get_global_rank(group, 0) if group is not None else 0), op=dist.ReduceOp.SUM, group=group)
     return partial if dist.get_rank(group) == 0 else None
+
+
+def chain_mixdown(render_window, n_samples, window, like, group=None):
+    """One `Sum.many` chain whose voices are dealt over the ranks in contiguous runs (rank 0 the first voices), bit for bit.
+
+    render_window(first, n, init, raw, out) must enqueue, on the CURRENT stream, this rank's links of the chain for the
+    samples [first, first + n): the sums continue from `init` (a [1, n] tensor; None on rank 0) and land in `out` ([1, n]);
+    raw says the sums travel on (no `x || 0`): true on every rank but the last.  With dusp_amd.runtime that is
+    Program.render_chain_window(first, n, init.data_ptr(), raw, out.data_ptr(), stream).
+    `window`: samples per pipeline step (a multiple of 2048).  `like`: a tensor that fixes device and dtype (float32).
+    Returns the mix [1, n_samples] on rank 0, None elsewhere.  CPU tensors (gloo, tests) run the same steps synchronously."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if window <= 0 or window % 2048 != 0:
+        raise ValueError("window must be a positive multiple of 2048 samples")
+    gr = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    n_windows = (n_samples + window - 1) // window
+    spans = [(k * window, min((k + 1) * window, n_samples)) for k in range(n_windows)]
+    on_gpu = like.is_cuda
+    new = lambda n: torch.empty((1, n), dtype=torch.float32, device=like.device)
+    last = world - 1
+    mix = new(n_samples) if (rank == 0 or rank == last) else None  # (the last rank assembles it; rank 0 receives it, or IS the last rank)
+    comm = torch.cuda.Stream(device=like.device) if on_gpu else None
+    sends = []
+    # what arrives from the rank before, two windows ahead of the render (posted early so the transfer overlaps the render before it)
+    inbox = {}
+
+    def post_recv(k):
+        if rank == 0 or k >= n_windows or k in inbox:
+            return
+        a, b = spans[k]
+        buf = new(b - a)
+        if on_gpu:
+            with torch.cuda.stream(comm):
+                inbox[k] = (buf, dist.irecv(buf, gr(rank - 1), group=group))
+        else:
+            inbox[k] = (buf, dist.irecv(buf, gr(rank - 1), group=group))
+
+    post_recv(0)
+    for k, (a, b) in enumerate(spans):
+        post_recv(k + 1)
+        init = None
+        if rank > 0:
+            init, req = inbox.pop(k)
+            if on_gpu:
+                with torch.cuda.stream(comm):
+                    req.wait()
+                torch.cuda.current_stream(like.device).wait_stream(comm)
+            else:
+                req.wait()
+        out = mix[:, a:b] if rank == last else new(b - a)
+        render_window(a, b - a, init, rank != last, out)
+        if rank != last:  # the partial sums travel on
+            if on_gpu:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ready)
+                    sends.append((out, dist.isend(out, gr(rank + 1), group=group)))
+            else:
+                sends.append((out, dist.isend(out, gr(rank + 1), group=group)))
+        elif last != 0:  # a finished window: to rank 0
+            piece = out.contiguous()
+            if on_gpu:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ready)
+                    sends.append((piece, dist.isend(piece, gr(0), group=group)))
+            else:
+                sends.append((piece, dist.isend(piece, gr(0), group=group)))
+    if rank == 0 and last != 0:  # the finished windows, in order (posted after this rank's own steps: it is the pipeline's first stage)
+        pieces = []
+        for a, b in spans:
+            buf = new(b - a)
+            pieces.append((a, b, buf, dist.irecv(buf, gr(last), group=group)))
+        for a, b, buf, req in pieces:
+            req.wait()
+            mix[:, a:b].copy_(buf)
+    for _, req in sends:
+        req.wait()
+    if on_gpu:
+        torch.cuda.current_stream(like.device).wait_stream(comm)
+    return mix if rank == 0 else None

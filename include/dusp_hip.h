@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 5
+#define DUSP_ABI_VERSION 6
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -152,6 +152,20 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info);
  * resident in HBM; nothing crosses PCIe. */
 int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
                        const float *d_params, float *d_out, void *stream);
+
+/* One `Sum.many` dealt over several GPUs, bit for bit (replaces the single process's left-deep chain of
+ * src/components/Sum.js:18-29 — ((v0 + v1) + v2) + ... with an f32 rounding per add — when the voices of the mix are sharded):
+ * the program holds a CONTIGUOUS run of the chain's voices (built on the fused sum chain: every voice a constant-f oscillator,
+ * bare or under the supported envelopes), and this call renders the window [first_sample, first_sample + n_samples) of the
+ * render's timeline, one instance, CONTINUING the chain from d_init — the running sums the ranks before this one left for the
+ * same window — instead of from zero (d_init NULL: this rank holds the chain's first voices).  raw != 0 writes the sums as
+ * they stand (a partial sum another rank continues: no `x || 0`, so a NaN travels on as the reference's would); the rank with
+ * the chain's last voices passes raw = 0 and gets the mix as dusp_render_device would have written it.
+ *   first_sample  a multiple of 2048 (whole blocks of the kernel)
+ *   d_init, d_out device pointers, f32 [n_out_channels = 1][n_samples], 16-byte aligned; they may be the same buffer
+ * Asynchronous like dusp_render_device.  DUSP_ERR_UNSUPPORTED for a program that is not on the fused sum chain. */
+int dusp_render_chain_window(dusp_program *prog, uint64_t first_sample, size_t n_samples,
+                             const float *d_init, int raw, float *d_out, void *stream);
 
 /* Host callers (the N-API addon): uploads h_params, renders, downloads into h_out
  * (same layouts as above) and synchronises.  The download is what the caller

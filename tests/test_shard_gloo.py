@@ -165,3 +165,101 @@ def test_bench_gather_runs_at_one_rank():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.visible_gpus() == torch.cuda.device_count()
+
+
+# ---- one Sum.many chain over several ranks, bit for bit (shard.chain_mixdown / dusp_render_chain_window)
+
+def _chain_voice_freqs(n_voices):
+    return [55.0 + 13.25 * k for k in range(n_voices)]
+
+
+def _chain_worker(rank, world, port, n_voices, n_samples, window, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dusp_amd as d
+    from dusp_amd import descriptor
+    from dusp_amd.shard import chain_mixdown, instance_range
+    from oracle import oracle
+    d.configure(48000)
+    lo, hi = instance_range(n_voices, rank, world)
+    freqs = _chain_voice_freqs(n_voices)
+    # this rank's voices, each rendered by itself (what the sum chain kernel looks up), WITHOUT the copy-out's `x || 0` mattering: sines
+    mine = [oracle.render(descriptor.extract(d.Osc(f)).words, n_samples)[0] for f in freqs[lo:hi]]
+    calls = []
+
+    def render_window(first, n, init, raw, out):  # the CPU stand-in of Program.render_chain_window: left-deep f32 adds (Sum.js:18-29)
+        calls.append((first, n, init is not None, raw))
+        acc = init[0].numpy().copy() if init is not None else np.zeros(n, dtype=np.float32)
+        for v in mine:
+            acc = (acc + v[first:first + n]).astype(np.float32)
+        if not raw:
+            acc = np.where(np.isnan(acc), np.float32(0), acc) + np.float32(0)
+        out[0] = torch.from_numpy(acc)
+
+    mix = chain_mixdown(render_window, n_samples, window, torch.zeros(1), group=None)
+    spans = [(a, min(a + window, n_samples) - a) for a in range(0, n_samples, window)]
+    assert calls == [(a, n, rank > 0, rank != world - 1) for a, n in spans]
+    if rank == 0:
+        np.save(result_path, mix.numpy())
+    else:
+        assert mix is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_voices,n_samples,window", [(2, 7, 5000, 2048), (3, 8, 4096, 2048), (1, 3, 3000, 2048)])
+def test_one_sum_chain_over_several_ranks_is_the_single_chain_bit_for_bit(tmp_path, oracle, world, n_voices, n_samples, window):
+    """shard.chain_mixdown on gloo ranks: every rank continues, window by window, the running sums the rank before left; the root's
+    mix equals the single-process render of the whole `Sum.many` (the oracle: the reference's left-deep f32 chain) bit for bit."""
+    import dusp_amd as d
+    from dusp_amd import descriptor
+    result = str(tmp_path / "mix.npy")
+    mp.spawn(_chain_worker, args=(world, _free_port(), n_voices, n_samples, window, result), nprocs=world, join=True)
+    got = np.load(result)
+    d.configure(48000)
+    whole = descriptor.extract(d.Sum.many([d.Osc(f) for f in _chain_voice_freqs(n_voices)]))
+    want = oracle.render(whole.words, n_samples)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["osc", "gain", "ramp"])
+def test_a_chain_split_between_two_programs_equals_the_whole_chain_on_the_gpu(oracle, kind):
+    """dusp_render_chain_window: the first voices of a `Sum.many` in one program, the rest in another that continues the first one's raw
+    sums window by window — the HIP kernels' side of shard.chain_mixdown — against the whole chain in one program and the oracle."""
+    import dusp_amd as d
+    from dusp_amd import descriptor, runtime
+    d.configure(48000)
+    n_voices, cut, n_samples, window = 11, 4, 2048 * 5 + 700, 4096
+    def voice(k):
+        o = d.Osc(55.0 + 13.25 * k)
+        if kind == "gain": return d.Multiply(o, 0.25 + k / 16)
+        if kind == "ramp": return d.Multiply(o, d.Ramp(n_samples - 900, 1, 0).trigger())
+        return o
+    words = lambda ks: descriptor.extract(d.Sum.many([voice(k) for k in ks])).words
+    ctx = runtime.Context(0, 48000)
+    whole, first, rest = ctx.build(words(range(n_voices))), ctx.build(words(range(cut))), ctx.build(words(range(cut, n_voices)))
+    assert "sumchain" in whole.shape and "sumchain" in first.shape and "sumchain" in rest.shape
+    want = torch.empty((1, n_samples), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    whole.render_device(n_samples, 1, None, want.data_ptr(), stream)
+    got = torch.full((1, n_samples), float("nan"), dtype=torch.float32, device="cuda")
+    for a in range(0, n_samples, window):
+        n = min(window, n_samples - a)
+        part = torch.full((1, n), float("nan"), dtype=torch.float32, device="cuda")
+        first.render_chain_window(a, n, None, True, part.data_ptr(), stream)
+        piece = torch.empty((1, n), dtype=torch.float32, device="cuda")
+        rest.render_chain_window(a, n, part.data_ptr(), False, piece.data_ptr(), stream)
+        got[:, a:a + n] = piece
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert np.array_equal(got.cpu().numpy(), oracle.render(words(range(n_voices)), n_samples))
+    with pytest.raises(runtime.DuspHipError):  # windows start on whole blocks
+        first.render_chain_window(100, 2048, None, True, got.data_ptr(), stream)
+    other = ctx.build(descriptor.extract(d.Filter(d.Osc(100), 500)).words)
+    with pytest.raises(runtime.DuspHipError):  # only programs on the fused sum chain
+        other.render_chain_window(0, 2048, None, True, got.data_ptr(), stream)
+    for p in (whole, first, rest, other):
+        p.close()
