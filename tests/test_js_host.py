@@ -113,7 +113,7 @@ console.log(JSON.stringify({flen: f.length, plen: p.length, riff: f.toString('as
 @needs_node
 def test_addon_loads_and_fails_loudly_without_gpu():
     rep = run_js("check_addon.js", "--sampleRate=48000")
-    assert rep["abi"] == 5 and "gfx950" in rep["version"]
+    assert rep["abi"] == 6 and "gfx950" in rep["version"]
     assert set(rep["exports"]) >= {"ctxCreate", "tableUpload", "programBuild", "programContinue", "render", "stateDownload"}
     assert rep["nullRejects"] == "renderAudioBuffer expects an outlet"  # the reference's own string
     if not rep["gpu"]:
