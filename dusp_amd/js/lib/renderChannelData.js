@@ -72,6 +72,46 @@ function writeBack(n, prog, circuit, chunkSize, nSamples) {
 
 const RESUMABLE = 0x100 // DUSP_ENGINE_RESUMABLE (include/dusp_hip.h)
 
+/* A circuit's wiring by unit identity, in process order: which units, and what feeds every inlet.  A host callback that
+ * rewires the graph (`a then b`, constructOperation.js:45-61: the finish hook of `a` points a Repeater at `b`, whose units join
+ * the running circuit) shows up as another text; the device program is then built again for the new circuit, every unit's
+ * state coming from the objects (the state write-back of the segment before). */
+const unitIds = new WeakMap()
+let nextUnitId = 1
+const idOf = (u) => { if (!unitIds.has(u)) unitIds.set(u, nextUnitId++); return unitIds.get(u) }
+const RING_OPS = new Set([OP.DELAY, OP.MONO_DELAY, OP.READBACK_DELAY, OP.FIXED_DELAY, OP.COMB_FILTER, OP.ALL_PASS, OP.CB_READER, OP.CB_WRITER])
+function wiringOf(circuit) {
+  const units = circuit.units
+  const at = new Map(units.map((u, i) => [u, i]))
+  const ids = new Set(), late = [] // late: edges read a chunk late (the source ticks after its reader), as [source id, reader id]
+  let text = '', rings = false
+  units.forEach((u, i) => {
+    ids.add(idOf(u))
+    const spec = UNITS[u.constructor.name]
+    if (spec && RING_OPS.has(spec.op)) rings = true
+    text += idOf(u) + '('
+    for (const name of Object.keys(u.inlets || {})) {
+      const inlet = u.inlets[name]
+      if (inlet.connected) {
+        const src = inlet.outlet.unit
+        text += name + ':' + idOf(src) + ','
+        if (!(at.get(src) < i)) late.push([idOf(src), idOf(u)])
+      }
+    }
+    text += ')'
+  })
+  return { text, ids, late, rings }
+}
+/* Why a rewired circuit cannot simply start on a new device program (null: it can).  What a program keeps on the device only
+ * — delay lines, CircleBuffers, the previous chunk of an outlet that something reads a chunk late — would have to move into the
+ * new program's layout; not built, so such circuits are refused rather than rendered from zeros. */
+function cannotRebuild(before, after) {
+  if (before.rings) return 'the circuit holds delay lines or CircleBuffers on the device'
+  if (before.late.length) return 'an edge of the circuit is read a chunk late, its last chunk lives on the device'
+  for (const [src] of after.late) if (before.ids.has(src)) return 'the new process order reads a unit of the old circuit a chunk late'
+  return null
+}
+
 /* Renders a circuit piecewise, in time order.  Every call continues where the previous one stopped:
  *
  * Event-segmented rendering (SURVEY.md 8f-3).  The reference runs every event with t < clock + chunk at the start
@@ -86,16 +126,21 @@ class SegmentRenderer {
     this.circuit = this.first.circuit
     this.chunk = this.first.chunkSize
     this.sampleRate = this.first.sampleRate
-    // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer; host-computed signals: Noise): ticked here, firing = segment boundary
-    this.tickers = this.circuit.units.filter((u) => ((UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick) || u.isHostSignal) &&
-      !deviceRetrigger(u, this.circuit.units)) // (a Retriggerer of a Shape / AHD runs on the device)
-    for (const u of this.tickers)
-      if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
+    this.retick()
     this.hasEvents = !!(this.circuit.events && this.circuit.events.length) || this.tickers.length > 0
     this.engine = resumable || this.hasEvents ? engine | RESUMABLE : engine
     this.native = native()
     this.prog = null
+    this.wiring = null
     this.clock = 0
+  }
+
+  // units that act through host callbacks between chunks (Retriggerer, SporadicRetriggerer; host-computed signals: Noise): ticked here, firing = segment boundary
+  retick() {
+    this.tickers = this.circuit.units.filter((u) => ((UNITS[u.constructor.name] && UNITS[u.constructor.name].hostTick) || u.isHostSignal) &&
+      !deviceRetrigger(u, this.circuit.units)) // (a Retriggerer of a Shape / AHD runs on the device)
+    for (const u of this.tickers)
+      if (!u.hostTick) throw 'dusp-hip: ' + u.label + ' needs host-side ticking, which only this package\'s own unit classes provide'
   }
 
   /* the next nSamples samples (a whole number of chunks, except in the last call of a render) ->
@@ -131,6 +176,19 @@ class SegmentRenderer {
         next = this.clock + (1 + quiet) * chunk
       }
       const ex = !this.prog && !this.hasEvents ? this.first : extract(this.outlet, { allowEvents: true, allowClock: true })
+      const wiring = wiringOf(ex.circuit)
+      if (this.prog && wiring.text !== this.wiring.text) { // a callback rewired the circuit (`then`: unDusp.js): another device program from here on
+        const why = cannotRebuild(this.wiring, wiring)
+        if (why) throw 'dusp-hip: the circuit was rewired during the render (' + why + '): not supported on the GPU path'
+        n.programDestroy(this.prog)
+        this.prog = null
+        this.circuit = ex.circuit
+        const before = this.tickers
+        this.retick()
+        if (this.tickers.length !== before.length || this.tickers.some((u, i) => u !== before[i]))
+          throw 'dusp-hip: the circuit was rewired during the render (units that tick on the host joined or left): not supported on the GPU path'
+      }
+      this.wiring = wiring
       if (!this.prog) this.prog = n.programBuild(contextFor(ex.sampleRate), ex.words, this.engine)
       else n.programContinue(this.prog, ex.words)
       const len = Math.min(next, start + nSamples) - this.clock // the last segment may end inside a chunk

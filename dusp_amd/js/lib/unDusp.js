@@ -7,7 +7,7 @@
  * belong to — positional arguments and the two sides of an operator each start from scratch, so "#id" references
  * resolve inside "[Multiply a:[Osc #x 3] b:#x]" but not in "[Osc #x 3] * #x" (the reference throws there, and so
  * does this).  `!` / `~!` build a Retriggerer / SporadicRetriggerer, which this package ticks on the host
- * between segments.  `then` (rewires the graph from a finish callback) is refused with a "dusp-hip:" string.
+ * between segments.  `then` rewires the graph from a finish callback: renderChannelData rebuilds the device program there.
  */
 const graph = require('./graph')
 const quick = require('./quick')
@@ -140,10 +140,16 @@ function constructOperation(node, index) {
       if (!a.stop || !a.trigger) throw "invalide use of '!~' operator"
       new graph.SporadicRetriggerer(a, b)
       return a
-    case 'then': // (constructOperation.js:45-61) a finish hook that REWIRES the circuit: the units it brings in join the
-      // running circuit behind one-chunk-late edges (the reference's process order), i.e. the new device program would have
-      // to inherit the old one's chunk buffers — not carried over today, so the operator is refused
-      throw 'dusp-hip: operator ' + node.operator + ' is not supported on the GPU path'
+    case 'then': { // (constructOperation.js:45-61; `destinations` is never passed there, so always this form) a Repeater that
+      // plays `a` until it finishes, then `b`: the finish hook REWIRES the circuit.  The hook runs on the host where the
+      // finish is a scheduled event (`a for 2 then b`); renderChannelData's SegmentRenderer then builds a new device program
+      // for the rewired circuit (a circuit that holds device-only memory — delay lines, late edges — is refused there).
+      const out = new graph.Repeater()
+      out.IN = a
+      if (a !== null && typeof a === 'object') a.onFinish = () => { out.IN = b }
+      else throw 'dusp-hip: `then` needs a unit or patch to finish on its left'
+      return out
+    }
     default: throw 'Unknown operator: ' + node.operator
   }
 }

@@ -71,6 +71,8 @@ async function main() {
   // unsupported graphs reject with a string
   class Crackle extends lib.Unit { constructor() { super(); this.addOutlet('out') } } // a unit kind this package does not know
   report.unsupported = await lib.renderChannelData(new lib.Multiply(new Crackle(), 0.5), 0.01).then(() => 'resolved', (e) => e)
+  // `then` rewires the circuit from a finish hook: a new device program — unless the old circuit holds device-only memory (refused, not rendered from zeros)
+  report.thenWithDeviceMemory = await lib.renderChannelData(lib.unDusp('(O330 -> [Delay delay:100]) for 0.02 then O220'), 0.03).then(() => 'resolved', (e) => String(e))
   console.log(JSON.stringify(report))
   process.exit(report.failed.length ? 1 : 0)
 }

@@ -39,6 +39,8 @@ const graphs = [
   { name: 'component_shorthand', text: 'Osc220 * Ramp4800', duration: 0.02 }, // any component name works as a shorthand
   { name: 'at_trigger', text: 'O330 * (D0.02 at 0.03)', duration: 0.08, events: true },
   { name: 'for_finish', text: 'O330 for 0.02', duration: 0.03, events: true },
+  { name: 'then_two_tones', text: 'O330 for 0.02 then Z220.5 * 0.5', duration: 0.05, events: true }, // the finish hook rewires the circuit: `then`
+  { name: 'then_thrice', text: '(O330 * D0.01) for 0.011 then (Sq110 -> LP900) for 0.03 then O55.5', duration: 0.06, events: true },
   { name: 'delay_attribute', text: '[Delay in:O500 delay:300.5]', duration: 0.03 },
   { name: 'semitone', text: '[Osc f:[SemitoneToRatio in:O4 * 12] * 220]', duration: 0.05 },
   { name: 'retrigger', text: '(D0.02 ! 20) * O440', duration: 0.2, events: true }, // `!`: Retriggerer, ticked on the host

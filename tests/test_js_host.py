@@ -137,3 +137,4 @@ def test_js_render_channel_data_matches_reference_golden(sr):
     assert rep["manyRetriggered"] is True
     assert rep["manyRefusesHostTicked"].startswith("dusp-hip: renderMany does not take circuits with host-ticked units")
     assert rep["unsupported"].startswith("dusp-hip: unit type not supported")
+    assert rep["thenWithDeviceMemory"].startswith("dusp-hip: the circuit was rewired during the render (the circuit holds delay lines")
