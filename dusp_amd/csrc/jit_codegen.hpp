@@ -163,13 +163,28 @@ inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op);
 
 
 // Programs the compiler takes.  Everything else stays on the wave engine's interpreter (wave_engine.hip).
+// Largest circuit (channel-expanded units) the generator takes as straight-line code (DUSP_JIT_MAX_UNITS, read once).  Such code
+// outgrows the 64 KB instruction cache from about a hundred units on, but every instruction still serves 64 lanes and the
+// waves of a workgroup follow each other through it: measured (tools/big_circuits.py, 256 instances x 1 s, Sum.many of FM pairs)
+// 119 units 21.8 -> 3.8 ms, 239 units 44.4 -> 9.4 ms, 479 units 90 -> 21.9 ms against the interpreter.  What bounds it is the
+// compile: 6 s / 22 s / 80 s for those three (once per machine with the code-object cache, and in the background while the
+// interpreter renders under the default knob) — hence 256.
+inline size_t jit_max_units() {
+    static const size_t n = [] {
+        const char *e = getenv("DUSP_JIT_MAX_UNITS");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v >= 1 && v <= 4096 ? v : 256);
+    }();
+    return n;
+}
+
 inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &why) {
     auto no = [&](const char *w) {
         why = w;
         return false;
     };
     if (!plan.ok) return no("not a wave-engine program");
-    if (P.ops.size() > 96) return no("more than 96 channel-expanded units: straight-line code would outgrow the instruction cache");
+    if (P.ops.size() > jit_max_units()) return no("more channel-expanded units than the generator takes as straight-line code (DUSP_JIT_MAX_UNITS, 256: compile time)");
     if (P.out_bufs.size() > 16) return no("more than 16 output channels");
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];

@@ -765,3 +765,31 @@ def test_a_second_process_finds_its_kernel_on_disk():
     assert "compiled kernel" in first["shape"] and "compiled kernel" in second["shape"], rep
     assert first["first_ms"] > 100.0            # (a real hiprtc compile)
     assert second["first_ms"] <= 30.0, rep      # (generate the text, read the file, load the module, render, download: milliseconds)
+
+
+def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
+    """A Sum.many of FM pairs — voices the fused sum chain does not take — is 149 channel-expanded units: straight-line code beyond the
+    instruction cache, still several times the interpreter's speed (tools/big_circuits.py), so the generator takes circuits up to
+    DUSP_JIT_MAX_UNITS (256).  Same PCM as the chunk engine bit for bit and the oracle's; larger circuits stay on the interpreter."""
+    import dusp_amd as d
+    from dusp_amd import descriptor
+    d.configure(48000)
+    voice = lambda k, j: d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + j / 7 + k / 100), 40), 220 + 11.5 * j + k / 4))
+    mix = lambda k, nv: d.Sum.many([voice(k, j) for j in range(nv)])
+    uni = descriptor.unify([descriptor.extract(mix(k, 30)) for k in (0, 8, 16)])
+    n = 256 * 9 + 100
+    ctx = render.context(48000)
+    prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
+    assert prog.n_units == 149
+    pcm = prog.render(n, 3, uni.params)
+    assert "compiled kernel: 149 units" in prog.read_shape(), prog.read_shape()
+    ref = ctx.build(uni.words, runtime.ENGINE_CHUNK)
+    want = ref.render(n, 3, uni.params)
+    assert np.array_equal(pcm, want)
+    for i in range(3):
+        assert np.array_equal(pcm[i], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=i)), i
+    big = ctx.build(descriptor.extract(mix(0, 60)).words, runtime.ENGINE_WAVE)  # 299 units
+    big.render(512)
+    assert "compiled" not in big.read_shape()
+    for p in (prog, ref, big):
+        p.close()
