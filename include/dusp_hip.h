@@ -69,7 +69,7 @@ typedef enum {
  *           feedback edges, envelopes, the comb family, delay lines and CircleBuffer nodes lane-parallel or, where their
  *           accesses can meet inside a chunk, through ordered slot operations.  What stays on the interpreter kernel
  *           (chunk buffers in LDS) is decided by regime: continued programs with delay lines / feedback, circuits of more
- *           than 96 units, and a structure's FIRST render while its kernel compiles in the background.  Few instances and
+ *           than 256 units (DUSP_JIT_MAX_UNITS), and a structure's FIRST render while its kernel compiles in the background.  Few instances and
  *           a long render are split in time when the graph allows it.  Refuses by regime, not by unit: channel counts that
  *           grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
