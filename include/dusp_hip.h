@@ -68,7 +68,7 @@ typedef enum {
  *           one wave with the other units beside them; dusp_circuit_kernel_source) — every unit of the path: FM, Filters,
  *           feedback edges, envelopes, the comb family, delay lines and CircleBuffer nodes lane-parallel or, where their
  *           accesses can meet inside a chunk, through ordered slot operations.  What stays on the interpreter kernel
- *           (chunk buffers in LDS) is decided by regime: continued programs with delay lines / feedback, circuits of more
+ *           (chunk buffers in LDS) is decided by regime: circuits of more
  *           than 256 units (DUSP_JIT_MAX_UNITS), and a structure's FIRST render while its kernel compiles in the background.  Few instances and
  *           a long render are split in time when the graph allows it.  Refuses by regime, not by unit: channel counts that
  *           grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
