@@ -848,7 +848,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         while (waves < most && (unsigned)waves < want) waves *= 2;
         // instances per wavefront (unsplit renders of light circuits, jit_light): 4 or 2 while that leaves every CU a workgroup —
         // their independent unit blocks fill each other's latencies
-        if (a.n_seg == 1 && (dusp::jit_light(P) || ctx->knobs.wave_per_wave > 1))
+        // (not next to the table image: since the oscillators' delta form — 17 instructions a sample instead of 26 — one instance per wave is
+        // the faster: osc(k) 0.66 / 0.70 / 0.69 ms at 1 / 2 / 4, mul(osc, k) 0.68 / 0.66 / 0.70; ramp and timer graphs 0.79 / 0.66 / 0.63)
+        if (a.n_seg == 1 && ((dusp::jit_light(P) && opt.lds_table < 0) || ctx->knobs.wave_per_wave > 1))
             for (int r : {4, 2})
                 if (r <= per_wave_cap && (uint64_t)ctx->n_cus * waves * r <= n_inst) {
                     per_wave = r;
