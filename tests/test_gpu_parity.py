@@ -200,3 +200,29 @@ def test_malformed_descriptors_are_rejected_not_crashed():
                 assert e.status in (-1, -2, -4) and e.message
                 rejected += 1
     assert rejected > 300 and built > 50
+
+
+OSC_GOLDEN = [n for n in ALL_GOLDEN if n.startswith(("osc", "voice", "cfg2", "fm_", "summany_8", "mult_", "map_invert", "rest_timer_fm", "fam_multiosc"))]
+
+
+@pytest.mark.parametrize("knobs", [{"DUSP_JIT_LDS_TABLE": 0}, {"DUSP_JIT_LEAN": 0}, {"DUSP_FUSED_FX32": 3}, {"DUSP_FUSED_FX32": 2}, {"DUSP_FUSED_TABLE": "global"}],
+                         ids=["jit-gather", "jit-fx", "fused-lean", "fused-plain", "fused-gather"])
+def test_the_oscillators_other_forms_render_the_same_pcm(knobs, oracle):
+    """The oscillator's lerp has several forms of the same arithmetic, chosen by table, phase grid and knob: the delta form
+    over the LDS image (the default) or over gathers from L2 (no image: DUSP_JIT_LDS_TABLE=0, DUSP_FUSED_TABLE=global), the 32.32 form
+    (DUSP_JIT_LEAN=0), the fused engine's earlier lean and plain forms (DUSP_FUSED_FX32=3 / 2).  Every oscillator golden, bit for bit."""
+    seen = 0
+    for name in OSC_GOLDEN:
+        g = Golden(name)
+        ctx = knob_context(g.sample_rate, **knobs)
+        for engine in (runtime.ENGINE_AUTO, runtime.ENGINE_WAVE):
+            try:
+                prog = ctx.build(g.desc, engine)
+            except runtime.DuspHipError as e:
+                assert e.status == -2, e
+                continue
+            pcm = prog.render(g.n_samples)[0]
+            check(name, g.windowed(pcm), g.pcm, "wave" if engine == runtime.ENGINE_WAVE else None)
+            prog.close()
+            seen += 1
+    assert seen >= 2 * len(OSC_GOLDEN) - 8
