@@ -151,6 +151,7 @@ struct dusp_program {
     std::string jit_why;
     std::map<std::pair<int, int>, dusp::JitSource> jit_src;  // (wavefronts per workgroup, 8 x instances per wavefront + Filter block) -> kernel text (+ constants, scan list)
     bool jit_consts_uploaded = false;
+    int voice_loop = -1;  // the circuit's voices run in a loop on its compiled kernel (jit_codegen.hpp VoicePlan): -1 not looked at yet
     // dusp_render_chain_window: the window the next render of this (sum chain) program is (set for the duration of that call)
     bool chain_on = false, chain_raw = false;
     const float *chain_init = nullptr;
@@ -785,7 +786,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // Few instances, long render: cut time into segments so that the whole chip works on it
     a.n_seg = 1;
     a.seg_groups = n_chunks;
-    if (prog->wave.splittable && !ctx->knobs.jit_force_waves) {
+    if (prog->voice_loop < 0) {
+        dusp::VoicePlan voices;
+        prog->voice_loop = !persistent && P.ops.size() > dusp::jit_loop_voices_from() && dusp::jit_find_voices(P, prog->wave, voices) ? 1 : 0;
+    }
+    if (prog->wave.splittable && !ctx->knobs.jit_force_waves && !prog->voice_loop) {  // (voices in a loop: their scanned oscillators' start phases have no accumulate pass)
         const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
         uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
         if (ctx->knobs.wave_segments >= 0) n_seg = (uint64_t)ctx->knobs.wave_segments;

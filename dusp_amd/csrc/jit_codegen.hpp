@@ -35,6 +35,7 @@ struct JitSource {
     std::vector<Scan> scans;
     bool has_filter = false;
     int n_filters = 0;
+    bool voice_loop = false;    // the circuit's voices in a loop (VoicePlan): unsplit renders, one instance per wavefront
 };
 
 struct JitOptions {
@@ -163,6 +164,121 @@ inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op);
 
 
 // Programs the compiler takes.  Everything else stays on the wave engine's interpreter (wave_engine.hip).
+// ---- Voices in a loop.  `Sum.many(voices)` (Sum.js:18-29) of N isomorphic voices is N copies of one small circuit feeding a
+// left-deep chain of Sums: as straight-line code its text, its compile time and its footprint in the instruction cache grow
+// with N (jit_max_units below).  Where the voices are built from oscillators (constant f, a parameter, or a signal: FM), Multiply,
+// Sum and Subtract, the generator emits the voice's units ONCE, inside a loop over the voices: what differs from voice to
+// voice — constants, parameter slots, state slots — comes from a table behind the kernel's constants (fk), the oscillators'
+// state lives in per-voice arrays, and the chain is the loop's running sum (f32, in voice order: the chain's own roundings).
+struct VoicePlan {
+    bool ok = false;
+    int n_voices = 0;
+    std::vector<std::vector<int>> ops;  // [voice][t]: the op at template position t (an evaluation order of the voice: producers first)
+    std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
+};
+constexpr int kMaxLoopVoices = 128;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
+
+inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V) {
+    V = VoicePlan();
+    if (!plan.ok || P.out_bufs.size() != 1 || P.ring_samples != 0 || !P.feed_forward || plan.order.size() != P.ops.size()) return false;
+    const int n_ops = (int)P.ops.size();
+    std::vector<int> producer((size_t)std::max(1, P.n_bufs), -1), pos((size_t)n_ops, 0), owner((size_t)n_ops, -1);
+    for (int k = 0; k < n_ops; k++)
+        if (P.ops[(size_t)k].out_buf >= 0 && P.ops[(size_t)k].out_buf < P.n_bufs) producer[(size_t)P.ops[(size_t)k].out_buf] = k;
+    for (size_t at = 0; at < plan.order.size(); at++) pos[(size_t)plan.order[at]] = (int)at;
+    auto src = [&](const DevOperand &o) { return o.kind == SRC_BUF && o.idx >= 0 && o.idx < P.n_bufs ? producer[(size_t)o.idx] : -1; };
+    auto n_operands = [](const DevOp &op) { return op.op == OP_OSC ? 1 : 2; };
+    // a voice: everything its root reaches, producers first (operand 0's side, then operand 1's, then the unit)
+    auto collect = [&](int root, std::vector<int> &list) -> bool {
+        list.clear();
+        std::vector<std::pair<int, int>> stack{{root, 0}};
+        std::vector<char> seen((size_t)n_ops, 0);
+        while (!stack.empty()) {
+            auto &[k, j] = stack.back();
+            if (k < 0) return false;
+            const DevOp &op = P.ops[(size_t)k];
+            if (!(op.op == OP_OSC || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_SUBTRACT)) return false;
+            if ((int)list.size() > 64) return false;
+            if (j < n_operands(op)) {
+                const DevOperand &o = op.in[j++];
+                if (o.kind == SRC_BUF) {
+                    const int p = src(o);
+                    if (p < 0 || pos[(size_t)p] >= pos[(size_t)stack.back().first]) return false;  // (an edge read a chunk late: not here)
+                    if (!seen[(size_t)p]) { seen[(size_t)p] = 1; stack.push_back({p, 0}); }
+                } else if (o.kind != SRC_CONST && o.kind != SRC_PARAM) return false;
+                continue;
+            }
+            list.push_back(k);
+            stack.pop_back();
+        }
+        return true;
+    };
+    const int root = producer[(size_t)P.out_bufs[0]];
+    if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
+    std::vector<int> tmpl;
+    if (!collect(src(P.ops[(size_t)root].in[1]), tmpl)) return false;
+    auto same_shape = [&](const std::vector<int> &a) {
+        if (a.size() != tmpl.size()) return false;
+        for (size_t t = 0; t < a.size(); t++) {
+            const DevOp &x = P.ops[(size_t)a[t]], &y = P.ops[(size_t)tmpl[t]];
+            if (x.op != y.op || x.attr != y.attr) return false;
+            for (int j = 0; j < n_operands(x); j++) {
+                if (x.in[j].kind != y.in[j].kind) return false;
+                if (x.in[j].kind == SRC_BUF) {
+                    const size_t px = (size_t)(std::find(a.begin(), a.end(), src(x.in[j])) - a.begin()), py = (size_t)(std::find(tmpl.begin(), tmpl.end(), src(y.in[j])) - tmpl.begin());
+                    if (px != py || px >= a.size()) return false;
+                }
+            }
+        }
+        return true;
+    };
+    std::vector<std::vector<int>> rev;
+    std::vector<int> chain_rev;
+    for (int cur = root;;) {
+        const DevOp &sum = P.ops[(size_t)cur];
+        if (sum.op != OP_SUM || sum.in[0].kind != SRC_BUF || sum.in[1].kind != SRC_BUF) return false;
+        std::vector<int> v;
+        if (!collect(src(sum.in[1]), v) || !same_shape(v) || pos[(size_t)v.back()] >= pos[(size_t)cur]) return false;
+        rev.push_back(v);
+        chain_rev.push_back(cur);
+        if ((int)rev.size() > kMaxLoopVoices) return false;
+        const int a = src(sum.in[0]);
+        if (a < 0 || pos[(size_t)a] >= pos[(size_t)cur]) return false;
+        std::vector<int> first;
+        if (P.ops[(size_t)a].op != OP_SUM || (collect(a, first) && same_shape(first))) {  // the chain's first voice
+            if (!collect(a, first) || !same_shape(first)) return false;
+            rev.push_back(first);
+            break;
+        }
+        cur = a;
+    }
+    V.n_voices = (int)rev.size();
+    if (V.n_voices < 4 || V.n_voices > kMaxLoopVoices) return false;
+    V.ops.assign(rev.rbegin(), rev.rend());
+    V.chain.assign(chain_rev.rbegin(), chain_rev.rend());
+    // every unit of the circuit belongs to exactly one voice or to the chain, and a voice's outlets are read inside it (or by its Sum) only
+    int counted = 0;
+    for (int v = 0; v < V.n_voices; v++)
+        for (int k : V.ops[(size_t)v]) {
+            if (owner[(size_t)k] >= 0) return false;
+            owner[(size_t)k] = v;
+            counted++;
+        }
+    for (int k : V.chain) {
+        if (owner[(size_t)k] >= 0) return false;
+        owner[(size_t)k] = V.n_voices;
+        counted++;
+    }
+    if (counted != n_ops) return false;
+    for (int k = 0; k < n_ops; k++)
+        for (int j = 0; j < n_operands(P.ops[(size_t)k]); j++) {
+            const int p = src(P.ops[(size_t)k].in[j]);
+            if (p >= 0 && owner[(size_t)p] != owner[(size_t)k] && !(owner[(size_t)k] == V.n_voices && p == V.ops[(size_t)owner[(size_t)p]].back())) return false;
+        }
+    V.ok = true;
+    return true;
+}
+
 // Largest circuit (channel-expanded units) the generator takes as straight-line code (DUSP_JIT_MAX_UNITS, read once).  Such code
 // outgrows the 64 KB instruction cache from about a hundred units on, but every instruction still serves 64 lanes and the
 // waves of a workgroup follow each other through it: measured (tools/big_circuits.py, 256 instances x 1 s, Sum.many of FM pairs)
@@ -178,13 +294,26 @@ inline size_t jit_max_units() {
     return n;
 }
 
+// From how many units on a circuit of isomorphic voices (VoicePlan) gets the loop instead of straight-line code (DUSP_JIT_LOOP_VOICES)
+inline size_t jit_loop_voices_from() {
+    static const size_t n = [] {
+        const char *e = getenv("DUSP_JIT_LOOP_VOICES");
+        const long v = e ? atol(e) : -1;
+        return (size_t)(v >= 0 && v <= 4096 ? v : 96);
+    }();
+    return n;
+}
+
 inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &why) {
     auto no = [&](const char *w) {
         why = w;
         return false;
     };
     if (!plan.ok) return no("not a wave-engine program");
-    if (P.ops.size() > jit_max_units()) return no("more channel-expanded units than the generator takes as straight-line code (DUSP_JIT_MAX_UNITS, 256: compile time)");
+    if (P.ops.size() > jit_max_units()) {
+        VoicePlan voices;
+        if (!jit_find_voices(P, plan, voices)) return no("more channel-expanded units than the generator takes as straight-line code (DUSP_JIT_MAX_UNITS, 256: compile time)");
+    }
     if (P.out_bufs.size() > 16) return no("more than 16 output channels");
     for (size_t k = 0; k < P.ops.size(); k++) {
         const DevOp &op = P.ops[k];
@@ -1064,6 +1193,136 @@ struct Emitter {
         }
     }
 
+    // The kernel of a circuit whose voices run in a loop (VoicePlan above).  fk gets a table behind the ordinary constants:
+    // per voice NS floats — for every template operand that is a constant its value, for every one that is a parameter its
+    // slot, for every oscillator its state slot (small integers travel as floats).
+    bool run_voices(const VoicePlan &V) {
+        const std::vector<int> &T = V.ops[0];
+        const int NV = V.n_voices, n_t = (int)T.size();
+        auto n_operands = [](const DevOp &op) { return op.op == OP_OSC ? 1 : 2; };
+        // slots of the per-voice table
+        std::vector<int> slot_of((size_t)n_t * 2, -1), state_slot_of((size_t)n_t, -1);
+        int NS = 0;
+        for (int t = 0; t < n_t; t++) {
+            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            for (int j = 0; j < n_operands(op); j++)
+                if (op.in[j].kind != SRC_BUF) slot_of[(size_t)t * 2 + j] = NS++;
+            if (op.op == OP_OSC) state_slot_of[(size_t)t] = NS++;
+        }
+        const int VB = (int)out.fk.size();
+        for (int v = 0; v < NV; v++)
+            for (int t = 0; t < n_t; t++) {
+                const DevOp &op = P.ops[(size_t)V.ops[(size_t)v][(size_t)t]];
+                for (int j = 0; j < n_operands(op); j++)
+                    if (op.in[j].kind == SRC_CONST) out.fk.push_back(op.in[j].cval);
+                    else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
+                if (op.op == OP_OSC) out.fk.push_back((float)op.state_slot);
+            }
+        auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
+        auto tname = [&](int t) { return "t" + num(t); };
+        // operand j of template op t: an array of this chunk's samples, or a wave-uniform scalar out of the voice's table row
+        auto scalar = [&](int t, int j) {
+            const DevOperand &o = P.ops[(size_t)T[(size_t)t]].in[j];
+            const std::string at = "vt[" + num(slot_of[(size_t)t * 2 + j]) + "]";
+            return o.kind == SRC_PARAM ? "jit_param(A, X[0], (uint32_t)jit_u(" + at + "))" : "jit_u(" + at + ")";
+        };
+        auto operand = [&](int t, int j, const std::string &c) {
+            const DevOperand &o = P.ops[(size_t)T[(size_t)t]].in[j];
+            if (o.kind == SRC_BUF) return tname(pos_in(producer[(size_t)o.idx])) + "[" + c + "]";
+            return "s" + num(t) + "_" + num(j);
+        };
+        const std::string W = num(opt.waves), NVs = num(NV), row = "A.fk + (" + num(VB) + " + j * " + num(NS) + ")";
+        line("// generated by dusp_amd/csrc/jit_codegen.hpp — a circuit of " + NVs + " isomorphic voices summed by a left-deep chain: the voice's units once, in a loop");
+        line("#include \"jit_prelude.hpp\"");
+        line("using namespace dusp;");
+        line("");
+        line("extern \"C\" __global__ void __launch_bounds__(" + W + " * 64) dusp_jit_render(JitArgs A) {");
+        line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, false) / 4)) + "];");
+        line("    JitCtx X[1];");
+        line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", 1>(A, lds, X);");
+        std::string fast = "true";
+        for (int t = 0; t < n_t; t++) {
+            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op != OP_OSC) continue;
+            line(std::string("    ") + (op.in[0].kind != SRC_BUF ? "JitOscKV" : "JitOscS") + " o" + num(t) + "[" + NVs + "];");
+        }
+        line("    bool fast = true;");
+        line("    for (int j = 0; j < " + NVs + "; ++j) {");
+        line("        const float *vt = " + row + ";");
+        for (int t = 0; t < n_t; t++) {
+            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op != OP_OSC) continue;
+            const std::string slot = "(int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "])";
+            if (op.in[0].kind != SRC_BUF) {
+                line("        {");
+                line("            JitOscK o;");
+                line("            o.begin(A, X[0], " + scalar(t, 0) + ", " + slot + ");");
+                line("            o" + num(t) + "[j].keep(A, X[0], o);");
+                if (osc_fast_mode(op.attr) >= 2) line("            fast = fast && o.lean;");
+                line("        }");
+            } else
+                line("        o" + num(t) + "[j].begin(A, X[0], " + slot + ", -1, false);");
+        }
+        line("    }");
+        for (int fx = 1; fx >= 0; fx--) {
+            line(fx ? "    if (fast) {" : "    } else {");
+            line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+            line("        float acc[4] = {0.f, 0.f, 0.f, 0.f};  // (0 + v0: the chain's first voice as it stands, but for the sign of a zero the copy-out drops anyway)");
+            line("#pragma unroll 1");
+            line("        for (int j = 0; j < " + NVs + "; ++j) {");
+            line("            const float *vt = " + row + ";");
+            for (int t = 0; t < n_t; t++) {
+                const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+                for (int j = 0; j < n_operands(op); j++)
+                    if (op.in[j].kind != SRC_BUF && !(op.op == OP_OSC)) line("            const float s" + num(t) + "_" + num(j) + " = " + scalar(t, j) + ";");
+            }
+            for (int t = 0; t < n_t; t++) {
+                const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+                line("            float " + tname(t) + "[4];");
+                switch (op.op) {
+                case OP_OSC:
+                    if (op.in[0].kind != SRC_BUF) {
+                        const int mode = fx && osc_fast_mode(op.attr) >= 2 ? osc_fast_mode(op.attr) : 0;
+                        line("            {");
+                        line("                JitOscK o;");
+                        line("                o" + num(t) + "[j].lend<" + num(mode) + ">(o);");
+                        line("                o.tick<" + in_lds(op.attr) + ", " + num(mode) + ">(X[0], " + table_row(op.attr) + ", " + tname(t) + ");");
+                        line("                o" + num(t) + "[j].take<" + num(mode) + ">(o);");
+                        line("            }");
+                    } else {
+                        const std::string f = tname(pos_in(producer[(size_t)op.in[0].idx]));
+                        line("            if (!o" + num(t) + "[j].rare(X[0], " + f + ")) o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", true, false>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
+                        line("            else o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", true, true>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
+                    }
+                    break;
+                case OP_MULTIPLY: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " * " + operand(t, 1, "c") + ";"); break;
+                case OP_SUM: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " + " + operand(t, 1, "c") + ";"); break;
+                default: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " - " + operand(t, 1, "c") + ";"); break;  // OP_SUBTRACT
+                }
+            }
+            line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
+            line("        }");
+            line("        jit_store<false>(A, X[0], g, 0, acc);");
+            line("    }");
+        }
+        line("    }");
+        // state write-back: every oscillator's phase after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
+        line("    if (X[0].live && X[0].seg == X[0].n_seg - 1 && X[0].lane == 0)");
+        line("        for (int j = 0; j < " + NVs + "; ++j) {");
+        line("            const float *vt = " + row + ";");
+        for (int t = 0; t < n_t; t++) {
+            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op != OP_OSC) continue;
+            line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
+        }
+        line("        }");
+        line("}");
+        out.voice_loop = true;
+        out.text = s;
+        out.ok = true;
+        return true;
+    }
+
     bool run() {
         // execution order and who produces what
         pos_of_op.assign(P.ops.size(), 0);
@@ -1105,6 +1364,14 @@ struct Emitter {
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }
+        if (R == 1 && !opt.persistent && P.ops.size() > jit_loop_voices_from()) {  // voices in a loop (VoicePlan)
+            VoicePlan voices;
+            if (jit_find_voices(P, plan, voices)) {
+                out.fk.clear();  // (only the voices' table)
+                out.dk.clear();
+                return run_voices(voices);
+            }
+        }
         // Units that compute the same chunk for every instance — constants, closed forms of time, and whatever is built from
         // those alone — are emitted once per wave and shared by its R instances (the fused kernels' "one Ramp evaluation per
         // step for the block's voices", in general).  In execution order; an operand read late is not known yet: not shared.

@@ -307,6 +307,36 @@ struct JitOscK {
     }
 };
 
+// What a constant-f oscillator carries from chunk to chunk, for circuits whose voices run in a loop (jit_codegen.hpp run_voices): the
+// oscillators of voice j live in element j of a per-lane array, so only what tick() reads is kept — the LEAN form's phase and steps,
+// the general form's, and the phase the unit ends the render with (a function of f and the render's length alone).
+struct JitOscKV {
+    unsigned long long PD, Q1, Q2, Q3, C;  // LEAN
+    unsigned long long P, q, q256;         // general form
+    double end;                            // end_phase()
+    uint32_t bad;
+    __device__ __forceinline__ void keep(const JitArgs &A, const JitCtx &X, const JitOscK &o) {
+        PD = o.PD; Q1 = o.Q1; Q2 = o.Q2; Q3 = o.Q3; C = o.C;
+        P = o.P; q = o.q; q256 = o.q256;
+        end = o.end_phase(A, X);
+        bad = o.bad ? 1u : 0u;
+    }
+    template <int MODE>
+    __device__ __forceinline__ void lend(JitOscK &o) const {  // the fields tick<.., MODE> reads (wave-uniform ones made known as such)
+        if (MODE >= 2) {
+            o.PD = PD; o.Q1 = jit_u(Q1); o.Q2 = jit_u(Q2); o.Q3 = jit_u(Q3); o.C = jit_u(C);
+        } else {
+            o.P = P; o.q = jit_u(q); o.q256 = jit_u(q256);
+        }
+        o.bad = jit_u(bad) != 0u;
+    }
+    template <int MODE>
+    __device__ __forceinline__ void take(const JitOscK &o) {
+        if (MODE >= 2) PD = o.PD;
+        else P = o.P;
+    }
+};
+
 // ---- Osc with a connected f (FM): wavefront-wide phase accumulation.  Increments -> exact 2^-36 fixed point -> prefix of 4
 // inside the lane -> 6-step integer scan over the wave (sums < 2^61, no modulo inside) -> one exact modulo for the lane's
 // first sample, add-and-wrap for the next three.  Carried from chunk to chunk: the phase of the chunk's last sample and a

@@ -768,28 +768,39 @@ def test_a_second_process_finds_its_kernel_on_disk():
 
 
 def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
-    """A Sum.many of FM pairs — voices the fused sum chain does not take — is 149 channel-expanded units: straight-line code beyond the
-    instruction cache, still several times the interpreter's speed (tools/big_circuits.py), so the generator takes circuits up to
-    DUSP_JIT_MAX_UNITS (256).  Same PCM as the chunk engine bit for bit and the oracle's; larger circuits stay on the interpreter."""
+    """A Sum.many of FM pairs — voices the fused sum chain does not take — is 5 N - 1 channel-expanded units.  From 96 units on the
+    generator emits the voice's units ONCE, in a loop over the voices (jit_codegen.hpp VoicePlan: constants, parameter and state slots out
+    of a per-voice table, oscillator state in per-voice arrays, the chain as the loop's running f32 sum), whatever N up to 128; circuits
+    that are no such sum run as straight-line code up to DUSP_JIT_MAX_UNITS (256) and on the interpreter beyond.  Same PCM and unit state
+    as the chunk engine bit for bit, and the oracle's PCM."""
     import dusp_amd as d
     from dusp_amd import descriptor
     d.configure(48000)
     voice = lambda k, j: d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + j / 7 + k / 100), 40), 220 + 11.5 * j + k / 4))
     mix = lambda k, nv: d.Sum.many([voice(k, j) for j in range(nv)])
-    uni = descriptor.unify([descriptor.extract(mix(k, 30)) for k in (0, 8, 16)])
     n = 256 * 9 + 100
-    ctx = render.context(48000)
-    prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
-    assert prog.n_units == 149
-    pcm = prog.render(n, 3, uni.params)
-    assert "compiled kernel: 149 units" in prog.read_shape(), prog.read_shape()
-    ref = ctx.build(uni.words, runtime.ENGINE_CHUNK)
-    want = ref.render(n, 3, uni.params)
-    assert np.array_equal(pcm, want)
-    for i in range(3):
-        assert np.array_equal(pcm[i], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=i)), i
-    big = ctx.build(descriptor.extract(mix(0, 60)).words, runtime.ENGINE_WAVE)  # 299 units
+    for nv, knobs in ((30, {}), (30, {"DUSP_JIT_LOOP_VOICES": 4096}), (100, {})):
+        uni = descriptor.unify([descriptor.extract(mix(k, nv)) for k in (0, 8, 16)])
+        ctx = knob_context(48000, **knobs) if knobs else render.context(48000)
+        prog = ctx.build(uni.words, runtime.ENGINE_WAVE)
+        assert prog.n_units == 5 * nv - 1
+        pcm = prog.render(n, 3, uni.params)
+        assert "compiled kernel: %d units" % (5 * nv - 1) in prog.read_shape(), prog.read_shape()
+        ref = ctx.build(uni.words, runtime.ENGINE_CHUNK)
+        want = ref.render(n, 3, uni.params)
+        assert np.array_equal(pcm, want), (nv, knobs)
+        for u in range(prog.n_units):
+            for i in (0, 2):
+                assert np.array_equal(prog.state(u, i), ref.state(u, i), equal_nan=True), (nv, u, i)
+        if nv == 30:
+            for i in range(3):
+                assert np.array_equal(pcm[i], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=i)), i
+        prog.close()
+        ref.close()
+    # voices of two kinds by turns: no loop, and 4 x 40 + 2 x 40 + 79 = 319 units are more than straight-line code takes
+    other = lambda j: d.Multiply(d.Osc(50.5 + j), 0.25)
+    mixed = d.Sum.many([voice(0, j) if j % 2 else other(j) for j in range(80)])
+    big = render.context(48000).build(descriptor.extract(mixed).words, runtime.ENGINE_WAVE)
     big.render(512)
     assert "compiled" not in big.read_shape()
-    for p in (prog, ref, big):
-        p.close()
+    big.close()

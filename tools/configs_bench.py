@@ -69,6 +69,8 @@ def main():
     cfgs["cfg3a"] = (lambda: uni_of([d.Multiply(d.Osc(10 * k), d.Ramp(T60, 1, 0).trigger()) for k in (1, 2)]), T60,
                      (10.0 * np.arange(1, 1025)).astype(np.float32).reshape(1, -1))
     cfgs["cfg3b_sum1024"] = (lambda: uni_of([d.Sum.many([d.Osc(10 * k) for k in range(1, 1025)])]), T60, None)
+    # ... the same 1024 voices under their envelopes (configs[2]'s voice as BASELINE spells it), folded by Sum.many: the fused sum chain's enveloped form
+    cfgs["cfg3c_sum1024_enveloped"] = (lambda: uni_of([d.Sum.many([d.Multiply(d.Osc(10 * k), d.Ramp(T60, 1, 0).trigger()) for k in range(1, 1025)])]), T60, None)
     cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
                              (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
     cfgs["cfg4_loop8192_loop_engine"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_LOOP)
