@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -177,6 +178,17 @@ struct VoicePlan {
     std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
 };
 constexpr int kMaxLoopVoices = 128;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
+// units a voice may be made of: oscillators, Ramps (closed form), Multiply / Sum and the stateless maps of at most two operands
+inline bool jit_voice_unit(const DevOp &op) {
+    return op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST);
+}
+inline int jit_voice_operands(const DevOp &op) {
+    switch (op.op) {
+    case OP_RAMP: return 0;
+    case OP_OSC: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO: case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return 1;
+    default: return 2;
+    }
+}
 
 inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V) {
     V = VoicePlan();
@@ -187,7 +199,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         if (P.ops[(size_t)k].out_buf >= 0 && P.ops[(size_t)k].out_buf < P.n_bufs) producer[(size_t)P.ops[(size_t)k].out_buf] = k;
     for (size_t at = 0; at < plan.order.size(); at++) pos[(size_t)plan.order[at]] = (int)at;
     auto src = [&](const DevOperand &o) { return o.kind == SRC_BUF && o.idx >= 0 && o.idx < P.n_bufs ? producer[(size_t)o.idx] : -1; };
-    auto n_operands = [](const DevOp &op) { return op.op == OP_OSC ? 1 : 2; };
+    auto n_operands = [](const DevOp &op) { return jit_voice_operands(op); };
     // a voice: everything its root reaches, producers first (operand 0's side, then operand 1's, then the unit)
     auto collect = [&](int root, std::vector<int> &list) -> bool {
         list.clear();
@@ -197,7 +209,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
             auto &[k, j] = stack.back();
             if (k < 0) return false;
             const DevOp &op = P.ops[(size_t)k];
-            if (!(op.op == OP_OSC || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_SUBTRACT)) return false;
+            if (!jit_voice_unit(op) || (op.op == OP_RAMP && k < (int)plan.op_state.size() && plan.op_state[(size_t)k] >= 0)) return false;  // (a Ramp a Retriggerer restarts: not here)
             if ((int)list.size() > 64) return false;
             if (j < n_operands(op)) {
                 const DevOperand &o = op.in[j++];
@@ -222,6 +234,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         for (size_t t = 0; t < a.size(); t++) {
             const DevOp &x = P.ops[(size_t)a[t]], &y = P.ops[(size_t)tmpl[t]];
             if (x.op != y.op || x.attr != y.attr) return false;
+            if (x.op >= OP_MAP_FIRST && x.op <= OP_MAP_LAST && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;  // (FixedMultiply's factor, SecondsToSamples' rate: in the text's constants)
             for (int j = 0; j < n_operands(x); j++) {
                 if (x.in[j].kind != y.in[j].kind) return false;
                 if (x.in[j].kind == SRC_BUF) {
@@ -1199,7 +1212,7 @@ struct Emitter {
     bool run_voices(const VoicePlan &V) {
         const std::vector<int> &T = V.ops[0];
         const int NV = V.n_voices, n_t = (int)T.size();
-        auto n_operands = [](const DevOp &op) { return op.op == OP_OSC ? 1 : 2; };
+        auto n_operands = [](const DevOp &op) { return jit_voice_operands(op); };
         // slots of the per-voice table
         std::vector<int> slot_of((size_t)n_t * 2, -1), state_slot_of((size_t)n_t, -1);
         int NS = 0;
@@ -1207,8 +1220,27 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             for (int j = 0; j < n_operands(op); j++)
                 if (op.in[j].kind != SRC_BUF) slot_of[(size_t)t * 2 + j] = NS++;
-            if (op.op == OP_OSC) state_slot_of[(size_t)t] = NS++;
+            if (op.op == OP_OSC || op.op == OP_RAMP) state_slot_of[(size_t)t] = NS++;
         }
+        // f64 constants: the maps' (one per template unit, the same in every voice); then per voice the Ramps' duration, y0, y1
+        std::vector<int> dmap((size_t)n_t, -1), dramp((size_t)n_t, -1);
+        int ND = 0;
+        bool fastdiv = true;
+        for (int t = 0; t < n_t; t++) {
+            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) dmap[(size_t)t] = add_dk(op.d[0]);
+        }
+        for (int t = 0; t < n_t; t++)
+            if (P.ops[(size_t)T[(size_t)t]].op == OP_RAMP) dramp[(size_t)t] = ND, ND += 3;
+        const int DB = (int)out.dk.size();
+        for (int v = 0; v < NV; v++)
+            for (int t = 0; t < n_t; t++) {
+                const int k = V.ops[(size_t)v][(size_t)t];
+                const DevOp &op = P.ops[(size_t)k];
+                if (op.op != OP_RAMP) continue;
+                add_dk(op.d[0]); add_dk(op.d[1]); add_dk(op.d[2]);
+                fastdiv = fastdiv && k < (int)plan.ramp_fastdiv.size() && plan.ramp_fastdiv[(size_t)k];  // (the refined reciprocal only where the host has checked it on every voice's Ramp)
+            }
         const int VB = (int)out.fk.size();
         for (int v = 0; v < NV; v++)
             for (int t = 0; t < n_t; t++) {
@@ -1216,7 +1248,7 @@ struct Emitter {
                 for (int j = 0; j < n_operands(op); j++)
                     if (op.in[j].kind == SRC_CONST) out.fk.push_back(op.in[j].cval);
                     else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
-                if (op.op == OP_OSC) out.fk.push_back((float)op.state_slot);
+                if (op.op == OP_OSC || op.op == OP_RAMP) out.fk.push_back((float)op.state_slot);
             }
         auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
         auto tname = [&](int t) { return "t" + num(t); };
@@ -1295,9 +1327,18 @@ struct Emitter {
                         line("            else o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", true, true>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
                     }
                     break;
+                case OP_RAMP: {
+                    const std::string dd = "A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]), ss = "(int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "])";
+                    line("            jit_ramp<" + std::string(fastdiv ? "true" : "false") + ">(X[0], g, jit_u(" + dd + "]), jit_u(" + dd + " + 1]), jit_u(" + dd + " + 2]), A.init_state[" + ss + "], A.init_state[" + ss +
+                         " + 1] != 0.0, " + tname(t) + ");");
+                    break;
+                }
                 case OP_MULTIPLY: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " * " + operand(t, 1, "c") + ";"); break;
                 case OP_SUM: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " + " + operand(t, 1, "c") + ";"); break;
-                default: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " - " + operand(t, 1, "c") + ";"); break;  // OP_SUBTRACT
+                default:  // the stateless maps (map_ops.hpp)
+                    line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = map_apply(" + num(op.op) + ", " + operand(t, 0, "c") + ", " + (n_operands(op) > 1 ? operand(t, 1, "c") : std::string("0.f")) + ", jit_u(A.dk[" +
+                         num(dmap[(size_t)t]) + "]));");
+                    break;
                 }
             }
             line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
@@ -1312,6 +1353,7 @@ struct Emitter {
         line("            const float *vt = " + row + ";");
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op == OP_RAMP) line("            jit_ramp_end(A, X[0], jit_u(A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]) + "]), (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
             if (op.op != OP_OSC) continue;
             line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
         }

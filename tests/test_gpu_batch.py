@@ -797,6 +797,19 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
                 assert np.array_equal(pcm[i], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=i)), i
         prog.close()
         ref.close()
+    # voices with their own envelopes and a few maps: FM pair x Ramp (a duration per voice), rectified and scaled — 9 units a voice
+    env = lambda k, j: d.Multiply(d.Abs(voice(k, j)), d.FixedMultiply(0.5, d.Multiply(d.Ramp(1500 + 37 * j, 1, 0.125).trigger(), 1.0 + k / 64)))
+    uni = descriptor.unify([descriptor.extract(d.Sum.many([env(k, j) for j in range(33)])) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    assert "compiled kernel: %d units" % prog.n_units in prog.read_shape() and prog.n_units > 256, prog.read_shape()
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    assert np.array_equal(pcm, ref.render(n, 3, uni.params))
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u, 1), ref.state(u, 1), equal_nan=True), u
+    assert np.array_equal(pcm[2], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=2))
+    prog.close()
+    ref.close()
     # voices of two kinds by turns: no loop, and 4 x 40 + 2 x 40 + 79 = 319 units are more than straight-line code takes
     other = lambda j: d.Multiply(d.Osc(50.5 + j), 0.25)
     mixed = d.Sum.many([voice(0, j) if j % 2 else other(j) for j in range(80)])

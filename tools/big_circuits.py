@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Circuits above the circuit compiler's unit cap (DUSP_JIT_MAX_UNITS, 96): N voices summed by Sum.many where a voice is more than the
-fused sum chain takes (FM pairs, filtered or shaped oscillators), 256 instances x 1 s — the interpreter against straight-line compiled code.
+"""Big circuits: N voices summed by Sum.many where a voice is more than the fused sum chain takes (FM pairs, enveloped FM pairs, shaped
+oscillators), 256 instances x 1 s.  Isomorphic voices of oscillators / Ramps / Multiply / Sum / maps run in a LOOP from 96 units on
+(DUSP_JIT_LOOP_VOICES; =4096: never), other circuits as straight-line code up to DUSP_JIT_MAX_UNITS (256) and on the interpreter beyond.
   python tools/big_circuits.py [--voices=24,48,96]"""
 import os
 import sys
@@ -22,6 +23,7 @@ stream = torch.cuda.current_stream().cuda_stream
 voices = [int(v) for v in ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--voices=")] or ["24,48,96"])[0].split(",")]
 kinds = {
     "fm": lambda k, j: d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + j / 7 + k / 100), 40), 220 + 11.5 * j + k / 4)),
+    "fm*ramp": lambda k, j: d.Multiply(d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + j / 7 + k / 100), 40), 220 + 11.5 * j + k / 4)), d.Ramp(24000 + 100 * j, 1, 0).trigger()),
     "osc*shape": lambda k, j: d.Multiply(d.Osc(110 + 7.25 * j + k / 8), d.Shape("decay", 0.3 + j / 50).trigger()),
 }
 V, n = 256, 48000
