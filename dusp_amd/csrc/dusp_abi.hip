@@ -158,6 +158,8 @@ struct dusp_program {
     uint64_t chain_first = 0;
     uint64_t jit_table_generation = 0;  // ctx->table_generation the texts in jit_src were generated against
     int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
+    unsigned jit_segments = 1;            // ... the time segments it was cut into
+    bool jit_voices = false;              // ... its voices ran in a loop (jit_codegen.hpp VoicePlan)
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
@@ -644,8 +646,15 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     if (prog->engine == DUSP_ENGINE_LOOP)
         std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok && (prog->jit_waves || !prog->rendered))
-        std::snprintf(info->shape, sizeof info->shape, "%s, compiled kernel: %d units, %dx%d", prog->P.feed_forward ? "feed-forward" : "feedback",
-                      (int)prog->P.ops.size(), prog->jit_waves, prog->jit_per_wave);
+    {
+        const int at = std::snprintf(info->shape, sizeof info->shape, "%s, compiled kernel: %d units, %dx%d", prog->P.feed_forward ? "feed-forward" : "feedback",
+                                     (int)prog->P.ops.size(), prog->jit_waves, prog->jit_per_wave);
+        if (at > 0 && (size_t)at < sizeof info->shape && (prog->jit_voices || prog->jit_segments > 1)) {
+            if (prog->jit_voices && prog->jit_segments > 1) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", loop, %u seg", prog->jit_segments);
+            else if (prog->jit_voices) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", voice loop");
+            else std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", %u seg", prog->jit_segments);
+        }
+    }
     else if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS (kernel compiling)", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
     else if (prog->engine == DUSP_ENGINE_WAVE)
@@ -790,7 +799,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         dusp::VoicePlan voices;
         prog->voice_loop = !persistent && P.ops.size() > dusp::jit_loop_voices_from() && dusp::jit_find_voices(P, prog->wave, voices) ? 1 : 0;
     }
-    if (prog->wave.splittable && !ctx->knobs.jit_force_waves && !prog->voice_loop) {  // (voices in a loop: their scanned oscillators' start phases have no accumulate pass)
+    if (prog->wave.splittable && !ctx->knobs.jit_force_waves) {
         const uint64_t target = (uint64_t)ctx->n_cus * 8;  // wavefronts that fill the chip
         uint64_t n_seg = n_inst >= target ? 1 : std::min<uint64_t>(target / n_inst, n_chunks / 8);
         if (ctx->knobs.wave_segments >= 0) n_seg = (uint64_t)ctx->knobs.wave_segments;
@@ -800,9 +809,12 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             a.n_seg = (uint32_t)((n_chunks + a.seg_groups - 1) / a.seg_groups);  // no empty segments
         }
     }
+    // Voices in a loop (jit_codegen.hpp VoicePlan): where the circuit is a sum of isomorphic voices above jit_loop_voices_from() units
+    const bool voice_loop = prog->voice_loop != 0;
     // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
     dusp::JitOptions opt;
     opt.persistent = persistent;
+    opt.voice_loop = voice_loop;
     opt.profile = ctx->knobs.jit_profile != 0;
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->knobs.jit_lean ? ctx->table_delta[k] : 0, opt.table_bound[k] = ctx->table_bound[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
@@ -878,11 +890,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
         opt.per_wave = per_wave;
-        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8});
+        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0)});
         if (it == prog->jit_src.end()) {
             dusp::JitSource gen;
             if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
-            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8), std::move(gen)).first;
+            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0)), std::move(gen)).first;
         }
         src = &it->second;
         // A structure seen for the first time costs a compile of 0.3-0.8 s.  A render the interpreter kernel finishes sooner
@@ -1001,6 +1013,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     prog->jit_waves = waves;
     prog->jit_per_wave = per_wave;
+    prog->jit_segments = a.n_seg;
+    prog->jit_voices = src->voice_loop;
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;
@@ -1671,6 +1685,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     opt.waves = waves;
     opt.per_wave = per_wave;
     opt.persistent = continued;
+    opt.voice_loop = !continued;  // (where the circuit is a sum of isomorphic voices: the form an unsplit render gets)
     if (lean_recurrence) opt.filter_block = 4;
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms

@@ -55,6 +55,7 @@ struct JitOptions {
     int table_delta[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // the lerp's delta form (device_util.hpp lerp_delta): 0 not for this table, 1 differences of neighbours in f64, 2 in f32
     int table_bound[kNumTables] = {1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000, 1000};  // every |entry| <= 2^bound (finite tables; 1000: not known to be)
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
+    bool voice_loop = false; // a sum of isomorphic voices above jit_loop_voices_from() units gets its voices in a loop (VoicePlan): unsplit renders only
     bool persistent = false; // a continued program with delay lines / feedback: outlets parked between launches, rings in the reference's state
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
                              // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
@@ -1268,11 +1269,35 @@ struct Emitter {
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
         line("");
-        line("extern \"C\" __global__ void __launch_bounds__(" + W + " * 64) dusp_jit_render(JitArgs A) {");
+        // scanned oscillators (time-split renders: one accumulate pass + prefix per FM level gives every segment its start phases): scan
+        // i = (the template oscillator's ordinal) * NV + voice, as the host's prefix kernel and JitOscS::begin index them
+        std::vector<int> scan_base((size_t)n_t, -1), level_of((size_t)n_t, -1);
+        {
+            int n_scanned = 0;
+            for (int t = 0; t < n_t; t++) {
+                const int k = T[(size_t)t];
+                const DevOp &op = P.ops[(size_t)k];
+                if (op.op != OP_OSC || op.in[0].kind != SRC_BUF) continue;
+                scan_base[(size_t)t] = n_scanned * NV;
+                level_of[(size_t)t] = plan.osc_level[(size_t)k];
+                for (int v = 0; v < NV; v++) {
+                    const int kv = V.ops[(size_t)v][(size_t)t];
+                    out.scans.push_back({pos_of_op[(size_t)kv], P.ops[(size_t)kv].state_slot, plan.osc_level[(size_t)kv]});
+                    if (plan.osc_level[(size_t)kv] != level_of[(size_t)t]) { out.why = "voices whose oscillators stack differently"; return false; }
+                }
+                if (std::find(out.pass_levels.begin(), out.pass_levels.end(), level_of[(size_t)t]) == out.pass_levels.end()) out.pass_levels.push_back(level_of[(size_t)t]);
+                n_scanned++;
+            }
+            std::sort(out.pass_levels.begin(), out.pass_levels.end());
+        }
+        // pass_level < 0: the render kernel; else the accumulate pass of that FM level (oscillators of that level and above only total their
+        // increments over the segment, the ones below render; nothing is stored but the totals)
+        auto kernel_text = [&](int pass_level) {
+        const bool render = pass_level < 0;
+        line("extern \"C\" __global__ void __launch_bounds__(" + W + " * 64) " + (render ? std::string("dusp_jit_render") : "dusp_jit_pass" + num(pass_level)) + "(JitArgs A) {");
         line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, false) / 4)) + "];");
         line("    JitCtx X[1];");
         line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", 1>(A, lds, X);");
-        std::string fast = "true";
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op != OP_OSC) continue;
@@ -1293,13 +1318,13 @@ struct Emitter {
                 if (osc_fast_mode(op.attr) >= 2) line("            fast = fast && o.lean;");
                 line("        }");
             } else
-                line("        o" + num(t) + "[j].begin(A, X[0], " + slot + ", -1, false);");
+                line("        o" + num(t) + "[j].begin(A, X[0], " + slot + ", " + num(scan_base[(size_t)t]) + " + j, " + (!render && level_of[(size_t)t] >= pass_level ? "true" : "false") + ");");
         }
         line("    }");
         for (int fx = 1; fx >= 0; fx--) {
             line(fx ? "    if (fast) {" : "    } else {");
             line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
-            line("        float acc[4] = {0.f, 0.f, 0.f, 0.f};  // (0 + v0: the chain's first voice as it stands, but for the sign of a zero the copy-out drops anyway)");
+            if (render) line("        float acc[4] = {0.f, 0.f, 0.f, 0.f};  // (0 + v0: the chain's first voice as it stands, but for the sign of a zero the copy-out drops anyway)");
             line("#pragma unroll 1");
             line("        for (int j = 0; j < " + NVs + "; ++j) {");
             line("            const float *vt = " + row + ";");
@@ -1322,9 +1347,10 @@ struct Emitter {
                         line("                o" + num(t) + "[j].take<" + num(mode) + ">(o);");
                         line("            }");
                     } else {
-                        const std::string f = tname(pos_in(producer[(size_t)op.in[0].idx]));
-                        line("            if (!o" + num(t) + "[j].rare(X[0], " + f + ")) o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", true, false>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
-                        line("            else o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", true, true>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
+                        const std::string f = tname(pos_in(producer[(size_t)op.in[0].idx])), lookup = render || level_of[(size_t)t] < pass_level ? "true" : "false";
+                        line("            if (!o" + num(t) + "[j].rare(X[0], " + f + ")) o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", " + lookup + ", false>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
+                        line("            else o" + num(t) + "[j].tick<" + in_lds(op.attr) + ", " + lookup + ", true>(X[0], " + table_row(op.attr) + ", " + f + ", " + tname(t) + ");");
+                        if (lookup == "false") line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = 0.f;");
                     }
                     break;
                 case OP_RAMP: {
@@ -1341,24 +1367,38 @@ struct Emitter {
                     break;
                 }
             }
-            line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
+            if (render) line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
             line("        }");
-            line("        jit_store<false>(A, X[0], g, 0, acc);");
+            if (render) line("        jit_store<false>(A, X[0], g, 0, acc);");
             line("    }");
         }
         line("    }");
-        // state write-back: every oscillator's phase after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
-        line("    if (X[0].live && X[0].seg == X[0].n_seg - 1 && X[0].lane == 0)");
-        line("        for (int j = 0; j < " + NVs + "; ++j) {");
-        line("            const float *vt = " + row + ";");
-        for (int t = 0; t < n_t; t++) {
-            const DevOp &op = P.ops[(size_t)T[(size_t)t]];
-            if (op.op == OP_RAMP) line("            jit_ramp_end(A, X[0], jit_u(A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]) + "]), (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
-            if (op.op != OP_OSC) continue;
-            line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
+        if (render) {
+            // state write-back: every oscillator's phase after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
+            line("    if (X[0].live && X[0].seg == X[0].n_seg - 1 && X[0].lane == 0)");
+            line("        for (int j = 0; j < " + NVs + "; ++j) {");
+            line("            const float *vt = " + row + ";");
+            for (int t = 0; t < n_t; t++) {
+                const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+                if (op.op == OP_RAMP) line("            jit_ramp_end(A, X[0], jit_u(A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]) + "]), (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
+                if (op.op != OP_OSC) continue;
+                line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
+            }
+            line("        }");
+        } else {
+            line("    if (X[0].live && X[0].lane == 0)");
+            line("        for (int j = 0; j < " + NVs + "; ++j) {");
+            for (int t = 0; t < n_t; t++)
+                if (scan_base[(size_t)t] >= 0 && level_of[(size_t)t] == pass_level)
+                    line("            A.seg_sum[((size_t)(" + num(scan_base[(size_t)t]) + " + j) * A.n_inst + X[0].inst) * X[0].n_seg + X[0].seg] = o" + num(t) + "[j].packed();");
+            line("        }");
         }
-        line("        }");
         line("}");
+        line("");
+        };
+        kernel_text(-1);
+        if (plan.splittable)
+            for (int L : out.pass_levels) kernel_text(L);
         out.voice_loop = true;
         out.text = s;
         out.ok = true;
@@ -1406,7 +1446,7 @@ struct Emitter {
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }
-        if (R == 1 && !opt.persistent && P.ops.size() > jit_loop_voices_from()) {  // voices in a loop (VoicePlan)
+        if (R == 1 && opt.voice_loop && !opt.persistent && P.ops.size() > jit_loop_voices_from()) {  // voices in a loop (VoicePlan)
             VoicePlan voices;
             if (jit_find_voices(P, plan, voices)) {
                 out.fk.clear();  // (only the voices' table)

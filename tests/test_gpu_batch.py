@@ -810,6 +810,17 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
     assert np.array_equal(pcm[2], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=2))
     prog.close()
     ref.close()
+    # one circuit, a long render: time is cut into segments (every FM carrier's start phases from the loop's own accumulate pass + prefix)
+    one = descriptor.extract(d.Sum.many([env(3, j) for j in range(40)]))
+    prog = render.context(48000).build(one.words, runtime.ENGINE_WAVE)
+    long_n = 48000 + 77
+    pcm = prog.render(long_n)[0]
+    assert "compiled kernel: %d units" % prog.n_units in prog.read_shape() and "loop" in prog.read_shape() and "seg" in prog.read_shape(), prog.read_shape()
+    want, states = oracle.render(one.words, long_n, return_state=True)
+    assert np.array_equal(pcm, want)
+    for u, st in enumerate(states):
+        assert np.array_equal(prog.state(u), np.asarray(st, dtype=np.float64), equal_nan=True), u
+    prog.close()
     # voices of two kinds by turns: no loop, and 4 x 40 + 2 x 40 + 79 = 319 units are more than straight-line code takes
     other = lambda j: d.Multiply(d.Osc(50.5 + j), 0.25)
     mixed = d.Sum.many([voice(0, j) if j % 2 else other(j) for j in range(80)])
