@@ -179,13 +179,16 @@ struct VoicePlan {
     std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
 };
 constexpr int kMaxLoopVoices = 128;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
+constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (Shape: duration, min, max)
 // units a voice may be made of: oscillators, Ramps (closed form), Multiply / Sum and the stateless maps of at most two operands
 inline bool jit_voice_unit(const DevOp &op) {
-    return op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST);
+    return op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) ||
+           (op.op == OP_SHAPE && op.in[0].kind != SRC_BUF);  // (a Shape whose duration is not a signal: closed form)
 }
 inline int jit_voice_operands(const DevOp &op) {
     switch (op.op) {
     case OP_RAMP: return 0;
+    case OP_SHAPE: return 3;
     case OP_OSC: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO: case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return 1;
     default: return 2;
     }
@@ -236,6 +239,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
             const DevOp &x = P.ops[(size_t)a[t]], &y = P.ops[(size_t)tmpl[t]];
             if (x.op != y.op || x.attr != y.attr) return false;
             if (x.op >= OP_MAP_FIRST && x.op <= OP_MAP_LAST && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;  // (FixedMultiply's factor, SecondsToSamples' rate: in the text's constants)
+            if (x.op == OP_SHAPE && std::memcmp(&x.d[0], &y.d[0], 2 * sizeof(double)) != 0) return false;                            // (a Shape's edge values)
             for (int j = 0; j < n_operands(x); j++) {
                 if (x.in[j].kind != y.in[j].kind) return false;
                 if (x.in[j].kind == SRC_BUF) {
@@ -1215,13 +1219,13 @@ struct Emitter {
         const int NV = V.n_voices, n_t = (int)T.size();
         auto n_operands = [](const DevOp &op) { return jit_voice_operands(op); };
         // slots of the per-voice table
-        std::vector<int> slot_of((size_t)n_t * 2, -1), state_slot_of((size_t)n_t, -1);
+        std::vector<int> slot_of((size_t)n_t * kVoiceOperands, -1), state_slot_of((size_t)n_t, -1);
         int NS = 0;
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             for (int j = 0; j < n_operands(op); j++)
-                if (op.in[j].kind != SRC_BUF) slot_of[(size_t)t * 2 + j] = NS++;
-            if (op.op == OP_OSC || op.op == OP_RAMP) state_slot_of[(size_t)t] = NS++;
+                if (op.in[j].kind != SRC_BUF) slot_of[(size_t)t * kVoiceOperands + j] = NS++;
+            if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE) state_slot_of[(size_t)t] = NS++;
         }
         // f64 constants: the maps' (one per template unit, the same in every voice); then per voice the Ramps' duration, y0, y1
         std::vector<int> dmap((size_t)n_t, -1), dramp((size_t)n_t, -1);
@@ -1230,6 +1234,7 @@ struct Emitter {
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) dmap[(size_t)t] = add_dk(op.d[0]);
+            if (op.op == OP_SHAPE) dmap[(size_t)t] = add_dk(op.d[0]), add_dk(op.d[1]);
         }
         for (int t = 0; t < n_t; t++)
             if (P.ops[(size_t)T[(size_t)t]].op == OP_RAMP) dramp[(size_t)t] = ND, ND += 3;
@@ -1249,14 +1254,14 @@ struct Emitter {
                 for (int j = 0; j < n_operands(op); j++)
                     if (op.in[j].kind == SRC_CONST) out.fk.push_back(op.in[j].cval);
                     else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
-                if (op.op == OP_OSC || op.op == OP_RAMP) out.fk.push_back((float)op.state_slot);
+                if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE) out.fk.push_back((float)op.state_slot);
             }
         auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
         auto tname = [&](int t) { return "t" + num(t); };
         // operand j of template op t: an array of this chunk's samples, or a wave-uniform scalar out of the voice's table row
         auto scalar = [&](int t, int j) {
             const DevOperand &o = P.ops[(size_t)T[(size_t)t]].in[j];
-            const std::string at = "vt[" + num(slot_of[(size_t)t * 2 + j]) + "]";
+            const std::string at = "vt[" + num(slot_of[(size_t)t * kVoiceOperands + j]) + "]";
             return o.kind == SRC_PARAM ? "jit_param(A, X[0], (uint32_t)jit_u(" + at + "))" : "jit_u(" + at + ")";
         };
         auto operand = [&](int t, int j, const std::string &c) {
@@ -1300,6 +1305,7 @@ struct Emitter {
         line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", 1>(A, lds, X);");
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op == OP_SHAPE) line("    JitShape e" + num(t) + "[" + NVs + "];");
             if (op.op != OP_OSC) continue;
             line(std::string("    ") + (op.in[0].kind != SRC_BUF ? "JitOscKV" : "JitOscS") + " o" + num(t) + "[" + NVs + "];");
         }
@@ -1308,6 +1314,7 @@ struct Emitter {
         line("        const float *vt = " + row + ";");
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
+            if (op.op == OP_SHAPE) line("        e" + num(t) + "[j].begin(A, X[0], " + scalar(t, 0) + ", (int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "]));");
             if (op.op != OP_OSC) continue;
             const std::string slot = "(int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "])";
             if (op.in[0].kind != SRC_BUF) {
@@ -1331,7 +1338,7 @@ struct Emitter {
             for (int t = 0; t < n_t; t++) {
                 const DevOp &op = P.ops[(size_t)T[(size_t)t]];
                 for (int j = 0; j < n_operands(op); j++)
-                    if (op.in[j].kind != SRC_BUF && !(op.op == OP_OSC)) line("            const float s" + num(t) + "_" + num(j) + " = " + scalar(t, j) + ";");
+                    if (op.in[j].kind != SRC_BUF && !(op.op == OP_OSC) && !(op.op == OP_SHAPE && j == 0)) line("            const float s" + num(t) + "_" + num(j) + " = " + scalar(t, j) + ";");
             }
             for (int t = 0; t < n_t; t++) {
                 const DevOp &op = P.ops[(size_t)T[(size_t)t]];
@@ -1359,6 +1366,19 @@ struct Emitter {
                          " + 1] != 0.0, " + tname(t) + ");");
                     break;
                 }
+                case OP_SHAPE: {  // (min / max as arrays of this lane's four samples)
+                    std::string lim[2];
+                    for (int j = 1; j <= 2; j++) {
+                        if (op.in[j].kind == SRC_BUF) lim[j - 1] = tname(pos_in(producer[(size_t)op.in[j].idx]));
+                        else {
+                            lim[j - 1] = "m" + num(t) + "_" + num(j);
+                            line("            const float " + lim[j - 1] + "[4] = {" + operand(t, j, "0") + ", " + operand(t, j, "0") + ", " + operand(t, j, "0") + ", " + operand(t, j, "0") + "};");
+                        }
+                    }
+                    line("            e" + num(t) + "[j].tick(X[0], " + table_row(op.attr & 255) + ", " + num(op.attr) + ", jit_u(A.dk[" + num(dmap[(size_t)t]) + "]), jit_u(A.dk[" + num(dmap[(size_t)t] + 1) + "]), " + lim[0] + ", " + lim[1] +
+                         ", " + tname(t) + ");");
+                    break;
+                }
                 case OP_MULTIPLY: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " * " + operand(t, 1, "c") + ";"); break;
                 case OP_SUM: line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = " + operand(t, 0, "c") + " + " + operand(t, 1, "c") + ";"); break;
                 default:  // the stateless maps (map_ops.hpp)
@@ -1381,6 +1401,7 @@ struct Emitter {
             for (int t = 0; t < n_t; t++) {
                 const DevOp &op = P.ops[(size_t)T[(size_t)t]];
                 if (op.op == OP_RAMP) line("            jit_ramp_end(A, X[0], jit_u(A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]) + "]), (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
+                if (op.op == OP_SHAPE) line("            e" + num(t) + "[j].end(A, X[0], (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
                 if (op.op != OP_OSC) continue;
                 line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
             }

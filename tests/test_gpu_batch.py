@@ -810,6 +810,28 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
     assert np.array_equal(pcm[2], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=2))
     prog.close()
     ref.close()
+    # enveloped oscillators, the dusp strings' `O440 * D0.5` voices: Shape envelopes with a duration per voice (and per instance)
+    shaped = lambda k, j: d.Multiply(d.Osc(110 + 7.25 * j + k / 8), d.Shape("decay" if j % 2 else "attack", 0.02 + j / 500 + k / 6400).trigger())
+    uni = descriptor.unify([descriptor.extract(d.Sum.many([shaped(k, j) for j in range(30)])) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    if "loop" in prog.read_shape():  # (two tables by turns: not isomorphic — straight-line code; see below for the loop)
+        raise AssertionError(prog.read_shape())
+    assert np.array_equal(pcm, ref.render(n, 3, uni.params))
+    prog.close()
+    ref.close()
+    shaped = lambda k, j: d.Multiply(d.Osc(110 + 7.25 * j + k / 8), d.Shape("decay", 0.02 + j / 500 + k / 6400).trigger())
+    uni = descriptor.unify([descriptor.extract(d.Sum.many([shaped(k, j) for j in range(70)])) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    assert "compiled kernel: 279 units" in prog.read_shape() and "loop" in prog.read_shape(), prog.read_shape()
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    assert np.array_equal(pcm, ref.render(n, 3, uni.params))
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u, 2), ref.state(u, 2), equal_nan=True), u
+    prog.close()
+    ref.close()
     # one circuit, a long render: time is cut into segments (every FM carrier's start phases from the loop's own accumulate pass + prefix)
     one = descriptor.extract(d.Sum.many([env(3, j) for j in range(40)]))
     prog = render.context(48000).build(one.words, runtime.ENGINE_WAVE)
