@@ -250,6 +250,7 @@ static dusp::Knobs read_knobs() {
     k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
     k.wave_per_wave = num("DUSP_WAVE_PER_WAVE", k.wave_per_wave);
     k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
+    k.filter_fma = num("DUSP_FILTER_FMA", k.filter_fma);
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
@@ -816,6 +817,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     opt.persistent = persistent;
     opt.voice_loop = voice_loop;
     opt.profile = ctx->knobs.jit_profile != 0;
+    opt.filter_fma = ctx->knobs.filter_fma != 0;
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->knobs.jit_lean ? ctx->table_delta[k] : 0, opt.table_bound[k] = ctx->table_bound[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)

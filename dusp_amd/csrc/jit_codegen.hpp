@@ -57,6 +57,7 @@ struct JitOptions {
     size_t scratch_floats = 0;  // per-wave LDS scratch of the units with a sequential stage (jit_scratch_floats)
     bool voice_loop = false; // a sum of isomorphic voices above jit_loop_voices_from() units gets its voices in a loop (VoicePlan): unsplit renders only
     bool persistent = false; // a continued program with delay lines / feedback: outlets parked between launches, rings in the reference's state
+    bool filter_fma = false; // EXPERIMENT (DUSP_FILTER_FMA=1): the Filter stage's recurrence with one fused multiply-add on its dependent chain
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
                              // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
 };
@@ -1504,6 +1505,7 @@ struct Emitter {
         std::sort(out.pass_levels.begin(), out.pass_levels.end());
         line("// generated by dusp_amd/csrc/jit_codegen.hpp — one kernel per topologically sorted Circuit");
         if (opt.profile) line("#define DUSP_JIT_PROFILE 1");
+        if (opt.filter_fma) line("#define DUSP_FILTER_FMA 1  // (experiment: not the reference's roundings)");
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
         // f64 constants are read where they are used (loop-invariant scalar loads)

@@ -1376,7 +1376,13 @@ struct JitFilterK {
         f32x4 y4[PB / 4];
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
+#ifdef DUSP_FILTER_FMA
+            // EXPERIMENT (DUSP_FILTER_FMA=1, off by default): b2 y2 leaves P a step early, b1 y1 goes in by one fused multiply-add — the
+            // dependent chain is fma, cvt, cvt instead of mul, sub, sub, cvt, cvt; the sum is rounded once where Filter.js:40-46 rounds twice
+            const float y = (float)fma(-b1, u1, pv[i] - b2 * u2);
+#else
             const float y = (float)((pv[i] - b1 * u1) - b2 * u2);
+#endif
             y4[i >> 2][i & 3] = y;
             u2 = u1;
             u1 = (double)y;
