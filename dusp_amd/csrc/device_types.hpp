@@ -55,6 +55,7 @@ struct Knobs {
     int wave_per_wave = 0;       // DUSP_WAVE_PER_WAVE=n: circuit instances per wavefront in compiled kernels (0: automatic, up to 4)
     int loop_compiled = 1;       // DUSP_LOOP_COMPILED=0: AUTO keeps the feedback-voice shape on the two-stage loop kernel instead of a compiled one
     int jit_lean = 1;            // DUSP_JIT_LEAN=0: compiled kernels' constant-f oscillators keep the 32.32 form (no delta lerp: A/B)
+    int jit_log = 0;             // DUSP_JIT_LOG=1: the geometry search's steps on stderr (wavefronts x instances, Filter block, scratch bytes per lane)
     int jit_lds_table = 1;       // DUSP_JIT_LDS_TABLE=0: compiled kernels look wave tables up in HBM / L2 (no LDS image)
     int jit_spill_bytes = 64;    // DUSP_JIT_SPILL: scratch bytes per lane a compiled kernel may use before it is rebuilt for a smaller geometry
     int jit_force_waves = 0;     // DUSP_JIT_FORCE="WxR" (tests): compiled kernels with exactly W wavefronts per workgroup and R instances per wavefront,

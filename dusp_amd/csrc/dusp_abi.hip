@@ -255,6 +255,7 @@ static dusp::Knobs read_knobs() {
     k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
     k.jit_lean = num("DUSP_JIT_LEAN", k.jit_lean);
+    k.jit_log = num("DUSP_JIT_LOG", k.jit_log);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
         if (std::sscanf(f, "%dx%d", &w, &r) == 2 && w >= 1 && w <= 16 && r >= 1 && r <= 4) k.jit_force_waves = w, k.jit_force_per_wave = r;
@@ -917,7 +918,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_render", &render, &scratch, err))
             CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
         jit_scratch = scratch;
-        if (getenv("DUSP_JIT_LOG")) fprintf(stderr, "[dusp jit] %d waves x %d instances, filter block %d: %d bytes of scratch per lane\n", waves, per_wave, opt.filter_block, scratch);
+        if (ctx->knobs.jit_log) fprintf(stderr, "[dusp jit] %d waves x %d instances, filter block %d: %d bytes of scratch per lane\n", waves, per_wave, opt.filter_block, scratch);
         if (scratch <= ctx->knobs.jit_spill_bytes || ctx->knobs.jit_force_waves) break;  // (a few registers spilled outside the hot path is cheaper than halving the instances in flight)
         // The kernel spills at this geometry (16 wavefronts: 128 registers per lane).  A Filter circuit keeps its rows if it can —
         // half the wavefronts with twice the instances each have twice the registers — else instances per wave, then waves, go down.
