@@ -263,3 +263,35 @@ def test_a_chain_split_between_two_programs_equals_the_whole_chain_on_the_gpu(or
         other.render_chain_window(0, 2048, None, True, got.data_ptr(), stream)
     for p in (whole, first, rest, other):
         p.close()
+
+
+@pytest.mark.gpu
+def test_chain_mixdown_drives_the_hip_renderer_at_one_rank():
+    """shard.chain_mixdown over RCCL at world_size 1 (rank 0 is first and last link): the windows of the timeline rendered by
+    dusp_render_chain_window on the current stream land in the mix exactly as one dusp_render_device call writes it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    import dusp_amd as d
+    from dusp_amd import descriptor, runtime
+    from dusp_amd.shard import chain_mixdown
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        d.configure(48000)
+        words = descriptor.extract(d.Sum.many([d.Multiply(d.Osc(f), 0.125) for f in _chain_voice_freqs(9)])).words
+        prog = runtime.Context(0, 48000).build(words)
+        n = 2048 * 7 + 300
+        want = torch.empty((1, n), dtype=torch.float32, device="cuda")
+        prog.render_device(n, 1, None, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        calls = []
+
+        def render_window(first, count, init, raw, out):
+            calls.append((first, count, init is None, raw))
+            prog.render_chain_window(first, count, None if init is None else init.data_ptr(), raw, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+        mix = chain_mixdown(render_window, n, 4096, want)
+        torch.cuda.synchronize()
+        assert calls == [(a, min(4096, n - a), True, False) for a in range(0, n, 4096)]
+        assert torch.equal(mix, want)
+        prog.close()
+    finally:
+        dist.destroy_process_group()
