@@ -219,13 +219,16 @@ int dusp_state_download(dusp_program *prog, size_t instance, size_t unit, double
 /* The circuit compiler, on its own (needs no device).  Programs on the WAVE engine whose units it knows are rendered by ONE
  * kernel generated for that circuit — the chunk loop of src/Circuit.js:19-41 with every unit's `_tick` inlined in process
  * order, operands in registers — compiled for gfx950 in process (hiprtc) the first time a circuit structure is rendered and
- * cached afterwards.  This call returns that kernel's HIP text for a descriptor (for inspection, and so that the generator
+ * cached afterwards (in the process and on disk).  A circuit that is a `Sum.many` of isomorphic voices gets the voice's units
+ * ONCE, in a loop over the voices, from 96 units on; other circuits are straight-line code up to 256 units.  This call returns that kernel's HIP text for a descriptor (for inspection, and so that the generator
  * and the run-time compiler can be tested without a GPU):
  *   waves      wavefronts per workgroup the text is generated for (1 .. 16)
  *   per_wave   circuit instances per wavefront (1 .. 4; renders that are split in time use 1)
  *   lds_table  bit 0: assume the oscillators' first wave table is antisymmetric (half image in LDS), as a context would find;
  *              bit 1: the text of a program built with DUSP_ENGINE_RESUMABLE (a circuit with delay lines / feedback that will be
- *              continued: outlets parked between launches, rings kept in the reference's own state)
+ *              continued: outlets parked between launches, rings kept in the reference's own state);
+ *              bit 2: the Filter stage's recurrence loop with 4 P values per register set (what a render falls back to when the
+ *              kernel spills at 8)
  *   compile    non-zero: also compile the text for gfx950
  *   text, cap  receives at most cap - 1 characters, NUL-terminated (cap 0: nothing is copied)
  * Returns the length of the text, DUSP_ERR_UNSUPPORTED when the circuit stays on the interpreter (dusp_last_error(NULL) says
