@@ -231,9 +231,8 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         return true;
     };
     const int root = producer[(size_t)P.out_bufs[0]];
-    if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
+    if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[0].kind != SRC_BUF || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
     std::vector<int> tmpl;
-    if (!collect(src(P.ops[(size_t)root].in[1]), tmpl)) return false;
     auto same_shape = [&](const std::vector<int> &a) {
         if (a.size() != tmpl.size()) return false;
         for (size_t t = 0; t < a.size(); t++) {
@@ -251,26 +250,35 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         }
         return true;
     };
+    // The chain: `Sum.many` is left-deep (Sum.js:18-29: the chain in operand A, a voice in B); a string's `a + b + c + ..` builds the
+    // mirror image (the chain in B).  f32 addition commutes, so either way the mix is the running sum over the voices from the
+    // chain's bottom up.
     std::vector<std::vector<int>> rev;
     std::vector<int> chain_rev;
-    for (int cur = root;;) {
-        const DevOp &sum = P.ops[(size_t)cur];
-        if (sum.op != OP_SUM || sum.in[0].kind != SRC_BUF || sum.in[1].kind != SRC_BUF) return false;
-        std::vector<int> v;
-        if (!collect(src(sum.in[1]), v) || !same_shape(v) || pos[(size_t)v.back()] >= pos[(size_t)cur]) return false;
-        rev.push_back(v);
-        chain_rev.push_back(cur);
-        if ((int)rev.size() > kMaxLoopVoices) return false;
-        const int a = src(sum.in[0]);
-        if (a < 0 || pos[(size_t)a] >= pos[(size_t)cur]) return false;
-        std::vector<int> first;
-        if (P.ops[(size_t)a].op != OP_SUM || (collect(a, first) && same_shape(first))) {  // the chain's first voice
-            if (!collect(a, first) || !same_shape(first)) return false;
-            rev.push_back(first);
-            break;
+    auto walk = [&](int vi, int ci) -> bool {
+        rev.clear();
+        chain_rev.clear();
+        if (!collect(src(P.ops[(size_t)root].in[vi]), tmpl)) return false;
+        for (int cur = root;;) {
+            const DevOp &sum = P.ops[(size_t)cur];
+            if (sum.op != OP_SUM || sum.in[0].kind != SRC_BUF || sum.in[1].kind != SRC_BUF) return false;
+            std::vector<int> v;
+            if (!collect(src(sum.in[vi]), v) || !same_shape(v) || pos[(size_t)v.back()] >= pos[(size_t)cur]) return false;
+            rev.push_back(v);
+            chain_rev.push_back(cur);
+            if ((int)rev.size() > kMaxLoopVoices) return false;
+            const int a = src(sum.in[ci]);
+            if (a < 0 || pos[(size_t)a] >= pos[(size_t)cur]) return false;
+            std::vector<int> first;
+            if (collect(a, first) && same_shape(first)) {  // the chain's bottom: a voice
+                rev.push_back(first);
+                return true;
+            }
+            if (P.ops[(size_t)a].op != OP_SUM) return false;
+            cur = a;
         }
-        cur = a;
-    }
+    };
+    if (!walk(1, 0) && !walk(0, 1)) return false;
     V.n_voices = (int)rev.size();
     if (V.n_voices < 4 || V.n_voices > kMaxLoopVoices) return false;
     V.ops.assign(rev.rbegin(), rev.rend());
@@ -1271,7 +1279,7 @@ struct Emitter {
             return "s" + num(t) + "_" + num(j);
         };
         const std::string W = num(opt.waves), NVs = num(NV), row = "A.fk + (" + num(VB) + " + j * " + num(NS) + ")";
-        line("// generated by dusp_amd/csrc/jit_codegen.hpp — a circuit of " + NVs + " isomorphic voices summed by a left-deep chain: the voice's units once, in a loop");
+        line("// generated by dusp_amd/csrc/jit_codegen.hpp — a circuit of " + NVs + " isomorphic voices summed by a chain of Sums: the voice's units once, in a loop");
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
         line("");

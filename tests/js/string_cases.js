@@ -44,6 +44,8 @@ const graphs = [
   { name: 'delay_attribute', text: '[Delay in:O500 delay:300.5]', duration: 0.03 },
   { name: 'semitone', text: '[Osc f:[SemitoneToRatio in:O4 * 12] * 220]', duration: 0.05 },
   { name: 'retrigger', text: '(D0.02 ! 20) * O440', duration: 0.2, events: true }, // `!`: Retriggerer, ticked on the host
+  // 25 FM voices added up by `+` (a right-deep chain of Sums, 124 units): on the GPU the voices run in a loop (jit_codegen.hpp VoicePlan)
+  { name: 'additive_fm', text: Array.from({ length: 25 }, (_, j) => '[Osc f:[Osc ' + (3 + j) + '] * 40 + ' + (220 + 11.5 * j) + ']').join(' + '), duration: 0.05 },
   { name: 'number_only', text: '2 * 3 + 4', duration: 0.01 }, // not a graph: unDusp returns 10 and renderChannelData rejects it
   { name: 'unknown', text: '[Foo 1]', duration: 0.01 },
   { name: 'garbage', text: ']] nothing [[', duration: 0.01 },
