@@ -184,12 +184,13 @@ constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (
 // units a voice may be made of: oscillators, Ramps (closed form), Multiply / Sum and the stateless maps of at most two operands
 inline bool jit_voice_unit(const DevOp &op) {
     return op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) ||
-           (op.op == OP_SHAPE && op.in[0].kind != SRC_BUF);  // (a Shape whose duration is not a signal: closed form)
+           (op.op == OP_SHAPE && op.in[0].kind != SRC_BUF) ||  // (a Shape whose duration is not a signal: closed form)
+           (op.op == OP_AHD && op.in[0].kind != SRC_BUF && op.in[1].kind != SRC_BUF && op.in[2].kind != SRC_BUF);  // (an AHD with constant times)
 }
 inline int jit_voice_operands(const DevOp &op) {
     switch (op.op) {
     case OP_RAMP: return 0;
-    case OP_SHAPE: return 3;
+    case OP_SHAPE: case OP_AHD: return 3;
     case OP_OSC: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO: case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return 1;
     default: return 2;
     }
@@ -240,6 +241,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
             if (x.op != y.op || x.attr != y.attr) return false;
             if (x.op >= OP_MAP_FIRST && x.op <= OP_MAP_LAST && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;  // (FixedMultiply's factor, SecondsToSamples' rate: in the text's constants)
             if (x.op == OP_SHAPE && std::memcmp(&x.d[0], &y.d[0], 2 * sizeof(double)) != 0) return false;                            // (a Shape's edge values)
+            if (x.op == OP_AHD && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;                                  // (the AHD's sample period)
             for (int j = 0; j < n_operands(x); j++) {
                 if (x.in[j].kind != y.in[j].kind) return false;
                 if (x.in[j].kind == SRC_BUF) {
@@ -1234,7 +1236,7 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             for (int j = 0; j < n_operands(op); j++)
                 if (op.in[j].kind != SRC_BUF) slot_of[(size_t)t * kVoiceOperands + j] = NS++;
-            if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE) state_slot_of[(size_t)t] = NS++;
+            if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE || op.op == OP_AHD) state_slot_of[(size_t)t] = NS++;
         }
         // f64 constants: the maps' (one per template unit, the same in every voice); then per voice the Ramps' duration, y0, y1
         std::vector<int> dmap((size_t)n_t, -1), dramp((size_t)n_t, -1);
@@ -1244,6 +1246,7 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) dmap[(size_t)t] = add_dk(op.d[0]);
             if (op.op == OP_SHAPE) dmap[(size_t)t] = add_dk(op.d[0]), add_dk(op.d[1]);
+            if (op.op == OP_AHD) dmap[(size_t)t] = add_dk(op.d[0]);
         }
         for (int t = 0; t < n_t; t++)
             if (P.ops[(size_t)T[(size_t)t]].op == OP_RAMP) dramp[(size_t)t] = ND, ND += 3;
@@ -1263,7 +1266,7 @@ struct Emitter {
                 for (int j = 0; j < n_operands(op); j++)
                     if (op.in[j].kind == SRC_CONST) out.fk.push_back(op.in[j].cval);
                     else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
-                if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE) out.fk.push_back((float)op.state_slot);
+                if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE || op.op == OP_AHD) out.fk.push_back((float)op.state_slot);
             }
         auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
         auto tname = [&](int t) { return "t" + num(t); };
@@ -1312,9 +1315,12 @@ struct Emitter {
         line("    __shared__ __attribute__((aligned(16))) float lds[" + num((long long)(jit_lds_bytes(opt, false) / 4)) + "];");
         line("    JitCtx X[1];");
         line("    jit_begin<" + W + ", " + num(opt.lds_table) + ", 1>(A, lds, X);");
+        if (opt.scratch_floats)
+            line("    float *scr = lds + " + num((long long)((opt.lds_table >= 0 ? opt.table_bytes : 0) / 4)) + " + X[0].wave * " + num((long long)opt.scratch_floats) + ";");
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op == OP_SHAPE) line("    JitShape e" + num(t) + "[" + NVs + "];");
+            if (op.op == OP_AHD) line("    JitAHD a" + num(t) + "[" + NVs + "];");
             if (op.op != OP_OSC) continue;
             line(std::string("    ") + (op.in[0].kind != SRC_BUF ? "JitOscKV" : "JitOscS") + " o" + num(t) + "[" + NVs + "];");
         }
@@ -1324,6 +1330,7 @@ struct Emitter {
         for (int t = 0; t < n_t; t++) {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op == OP_SHAPE) line("        e" + num(t) + "[j].begin(A, X[0], " + scalar(t, 0) + ", (int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "]));");
+            if (op.op == OP_AHD) line("        a" + num(t) + "[j].begin(A, (int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "]));");
             if (op.op != OP_OSC) continue;
             const std::string slot = "(int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "])";
             if (op.in[0].kind != SRC_BUF) {
@@ -1375,6 +1382,15 @@ struct Emitter {
                          " + 1] != 0.0, " + tname(t) + ");");
                     break;
                 }
+                case OP_AHD: {  // (constant times: closed form unless a stage ends inside the chunk — then lane 0 walks it out of the wave's scratch)
+                    std::string tm[3];
+                    for (int j = 0; j < 3; j++) {
+                        tm[j] = "m" + num(t) + "_" + num(j);
+                        line("            const float " + tm[j] + "[4] = {" + operand(t, j, "0") + ", " + operand(t, j, "0") + ", " + operand(t, j, "0") + ", " + operand(t, j, "0") + "};");
+                    }
+                    line("            a" + num(t) + "[j].tick<false, false, false>(X[0], scr, jit_u(A.dk[" + num(dmap[(size_t)t]) + "]), " + tm[0] + ", " + tm[1] + ", " + tm[2] + ", " + tname(t) + ");");
+                    break;
+                }
                 case OP_SHAPE: {  // (min / max as arrays of this lane's four samples)
                     std::string lim[2];
                     for (int j = 1; j <= 2; j++) {
@@ -1411,6 +1427,7 @@ struct Emitter {
                 const DevOp &op = P.ops[(size_t)T[(size_t)t]];
                 if (op.op == OP_RAMP) line("            jit_ramp_end(A, X[0], jit_u(A.dk[" + num(DB) + " + j * " + num(ND) + " + " + num(dramp[(size_t)t]) + "]), (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
                 if (op.op == OP_SHAPE) line("            e" + num(t) + "[j].end(A, X[0], (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
+                if (op.op == OP_AHD) line("            a" + num(t) + "[j].end(A, X[0], (int)vt[" + num(state_slot_of[(size_t)t]) + "]);");
                 if (op.op != OP_OSC) continue;
                 line("            A.state[(size_t)(int)vt[" + num(state_slot_of[(size_t)t]) + "] * A.n_pad + X[0].inst] = o" + num(t) + "[j]." + (op.in[0].kind != SRC_BUF ? "end" : "end_phase()") + ";");
             }

@@ -832,6 +832,18 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
         assert np.array_equal(prog.state(u, 2), ref.state(u, 2), equal_nan=True), u
     prog.close()
     ref.close()
+    # notes under AHD envelopes (constant times, some stages ending inside a chunk: closed form and lane walk by turns)
+    note = lambda k, j: d.Multiply(d.Osc(110 + 7.25 * j + k / 8), d.AHD(0.002 + j / 4000, 0.004 + k / 8000, 0.02 + j / 900).trigger())
+    uni = descriptor.unify([descriptor.extract(d.Sum.many([note(k, j) for j in range(40)])) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    assert "compiled kernel: 159 units" in prog.read_shape() and "loop" in prog.read_shape(), prog.read_shape()
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    assert np.array_equal(pcm, ref.render(n, 3, uni.params))
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u, 1), ref.state(u, 1), equal_nan=True), u
+    prog.close()
+    ref.close()
     # one circuit, a long render: time is cut into segments (every FM carrier's start phases from the loop's own accumulate pass + prefix)
     one = descriptor.extract(d.Sum.many([env(3, j) for j in range(40)]))
     prog = render.context(48000).build(one.words, runtime.ENGINE_WAVE)
