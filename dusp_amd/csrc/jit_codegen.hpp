@@ -178,6 +178,7 @@ struct VoicePlan {
     int n_voices = 0;
     std::vector<std::vector<int>> ops;  // [voice][t]: the op at template position t (an evaluation order of the voice: producers first)
     std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
+    std::vector<int> tail;              // what hangs on the mix, in order: a master gain, an offset, a clip, .. (stateless units with one signal operand)
 };
 constexpr int kMaxLoopVoices = 128;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
 constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (Shape: duration, min, max)
@@ -231,7 +232,24 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         }
         return true;
     };
-    const int root = producer[(size_t)P.out_bufs[0]];
+    // from the outlet down: stateless units on the mix (one signal operand each), then the chain's top
+    int root = producer[(size_t)P.out_bufs[0]];
+    std::vector<int> tail_rev;
+    while (root >= 0 && (int)tail_rev.size() < 16) {
+        const DevOp &op = P.ops[(size_t)root];
+        const bool unary = op.op == OP_REPEATER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 1);
+        const bool binary = op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 2);
+        int signal = -1;
+        if (unary && op.in[0].kind == SRC_BUF) signal = 0;
+        else if (binary && (op.in[0].kind == SRC_BUF) != (op.in[1].kind == SRC_BUF) && (op.in[0].kind == SRC_BUF || op.in[0].kind == SRC_CONST || op.in[0].kind == SRC_PARAM) &&
+                 (op.in[1].kind == SRC_BUF || op.in[1].kind == SRC_CONST || op.in[1].kind == SRC_PARAM))
+            signal = op.in[0].kind == SRC_BUF ? 0 : 1;
+        if (signal < 0) break;
+        const int below = src(op.in[signal]);
+        if (below < 0 || pos[(size_t)below] >= pos[(size_t)root]) return false;
+        tail_rev.push_back(root);
+        root = below;
+    }
     if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[0].kind != SRC_BUF || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
     std::vector<int> tmpl;
     auto same_shape = [&](const std::vector<int> &a) {
@@ -285,6 +303,7 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
     if (V.n_voices < 4 || V.n_voices > kMaxLoopVoices) return false;
     V.ops.assign(rev.rbegin(), rev.rend());
     V.chain.assign(chain_rev.rbegin(), chain_rev.rend());
+    V.tail.assign(tail_rev.rbegin(), tail_rev.rend());
     // every unit of the circuit belongs to exactly one voice or to the chain, and a voice's outlets are read inside it (or by its Sum) only
     int counted = 0;
     for (int v = 0; v < V.n_voices; v++)
@@ -298,11 +317,26 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         owner[(size_t)k] = V.n_voices;
         counted++;
     }
+    for (int k : V.tail) {
+        if (owner[(size_t)k] >= 0) return false;
+        owner[(size_t)k] = V.n_voices + 1;
+        counted++;
+    }
     if (counted != n_ops) return false;
-    for (int k = 0; k < n_ops; k++)
+    for (int k = 0; k < n_ops; k++) {
+        if (owner[(size_t)k] > V.n_voices) continue;  // (the tail: its one signal operand is the unit below it, checked on the way down)
         for (int j = 0; j < n_operands(P.ops[(size_t)k]); j++) {
             const int p = src(P.ops[(size_t)k].in[j]);
-            if (p >= 0 && owner[(size_t)p] != owner[(size_t)k] && !(owner[(size_t)k] == V.n_voices && p == V.ops[(size_t)owner[(size_t)p]].back())) return false;
+            if (p >= 0 && owner[(size_t)p] != owner[(size_t)k] && !(owner[(size_t)k] == V.n_voices && owner[(size_t)p] < V.n_voices && p == V.ops[(size_t)owner[(size_t)p]].back())) return false;
+        }
+    }
+    for (int k = 0; k < n_ops; k++)  // nothing but the tail's first unit reads the mix, nothing but the next one a tail unit
+        for (int j = 0; j < kVoiceOperands && j < kMaxIn; j++) {
+            const int p = src(P.ops[(size_t)k].in[j]);
+            if (p < 0 || owner[(size_t)k] <= V.n_voices) continue;
+            if (j >= (P.ops[(size_t)k].op == OP_REPEATER ? 1 : n_operands(P.ops[(size_t)k]))) continue;
+            const size_t at = (size_t)(std::find(V.tail.begin(), V.tail.end(), k) - V.tail.begin());
+            if (p != (at == 0 ? V.chain.back() : V.tail[at - 1])) return false;
         }
     V.ok = true;
     return true;
@@ -1268,6 +1302,14 @@ struct Emitter {
                     else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
                 if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE || op.op == OP_AHD) out.fk.push_back((float)op.state_slot);
             }
+        // the tail's constants: ordinary entries of fk / dk (one unit each, not per voice)
+        std::vector<int> tail_fk(V.tail.size(), -1), tail_dk(V.tail.size(), -1);
+        for (size_t i = 0; i < V.tail.size(); i++) {
+            const DevOp &op = P.ops[(size_t)V.tail[i]];
+            for (int j = 0; j < 2 && j < (op.op == OP_REPEATER ? 1 : jit_voice_operands(op)); j++)
+                if (op.in[j].kind == SRC_CONST) tail_fk[i] = add_fk(op.in[j].cval);
+            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) tail_dk[i] = add_dk(op.d[0]);
+        }
         auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
         auto tname = [&](int t) { return "t" + num(t); };
         // operand j of template op t: an array of this chunk's samples, or a wave-uniform scalar out of the voice's table row
@@ -1414,7 +1456,27 @@ struct Emitter {
             }
             if (render) line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
             line("        }");
-            if (render) line("        jit_store<false>(A, X[0], g, 0, acc);");
+            if (render) {
+                std::string mix = "acc";
+                for (size_t i = 0; i < V.tail.size(); i++) {  // what hangs on the mix
+                    const DevOp &op = P.ops[(size_t)V.tail[i]];
+                    const std::string u = "u" + num((long long)i);
+                    auto side = [&](int j) -> std::string {
+                        const DevOperand &o = op.in[j];
+                        if (o.kind == SRC_BUF) return mix + "[c]";
+                        return o.kind == SRC_PARAM ? "jit_param(A, X[0], " + num(o.idx) + ")" : "jit_u(A.fk[" + num(tail_fk[i]) + "])";
+                    };
+                    line("        float " + u + "[4];");
+                    if (op.op == OP_REPEATER) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + ";");
+                    else if (op.op == OP_MULTIPLY) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " * " + side(1) + ";");
+                    else if (op.op == OP_SUM) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " + " + side(1) + ";");
+                    else
+                        line("        for (int c = 0; c < 4; ++c) " + u + "[c] = map_apply(" + num(op.op) + ", " + side(0) + ", " + (jit_voice_operands(op) > 1 ? side(1) : std::string("0.f")) + ", jit_u(A.dk[" + num(tail_dk[i]) +
+                             "]));");
+                    mix = u;
+                }
+                line("        jit_store<false>(A, X[0], g, 0, " + mix + ");");
+            }
             line("    }");
         }
         line("    }");

@@ -844,6 +844,16 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
         assert np.array_equal(prog.state(u, 1), ref.state(u, 1), equal_nan=True), u
     prog.close()
     ref.close()
+    # ... and what hangs on the mix: a master gain per instance, an offset, a clip
+    uni = descriptor.unify([descriptor.extract(d.HardClipAbove(d.Sum(d.Multiply(d.Sum.many([note(k, j) for j in range(40)]), 0.2 + k / 100), -0.05), 0.6)) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    assert "compiled kernel: 162 units" in prog.read_shape() and "loop" in prog.read_shape(), prog.read_shape()
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    assert np.array_equal(pcm, ref.render(n, 3, uni.params))
+    assert np.array_equal(pcm[1], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=1))
+    prog.close()
+    ref.close()
     # one circuit, a long render: time is cut into segments (every FM carrier's start phases from the loop's own accumulate pass + prefix)
     one = descriptor.extract(d.Sum.many([env(3, j) for j in range(40)]))
     prog = render.context(48000).build(one.words, runtime.ENGINE_WAVE)
