@@ -865,6 +865,14 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
     for u, st in enumerate(states):
         assert np.array_equal(prog.state(u), np.asarray(st, dtype=np.float64), equal_nan=True), u
     prog.close()
+    # a few instances, each cut in time (parameters per instance AND start phases per segment)
+    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Sum.many([env(k, j) for j in range(20)]), 0.5)) for k in (0, 8, 16, 24, 32)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(long_n, 5, uni.params)
+    assert "loop" in prog.read_shape() and "seg" in prog.read_shape(), prog.read_shape()
+    for i in (0, 3, 4):
+        assert np.array_equal(pcm[i], oracle.render(uni.words, long_n, params=uni.params, n_instances=5, instance=i)), i
+    prog.close()
     # voices of two kinds by turns: no loop, and 4 x 40 + 2 x 40 + 79 = 319 units are more than straight-line code takes
     other = lambda j: d.Multiply(d.Osc(50.5 + j), 0.25)
     mixed = d.Sum.many([voice(0, j) if j % 2 else other(j) for j in range(80)])
