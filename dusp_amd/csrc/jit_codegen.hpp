@@ -180,7 +180,7 @@ struct VoicePlan {
     std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
     std::vector<int> tail;              // what hangs on the mix, in order: a master gain, an offset, a clip, .. (stateless units with one signal operand)
 };
-constexpr int kMaxLoopVoices = 128;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
+constexpr int kMaxLoopVoices = 256;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
 constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (Shape: duration, min, max)
 // units a voice may be made of: oscillators, Ramps (closed form), Multiply / Sum and the stateless maps of at most two operands
 inline bool jit_voice_unit(const DevOp &op) {

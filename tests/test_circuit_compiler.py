@@ -238,7 +238,7 @@ def test_code_objects_are_cached_on_disk_and_a_damaged_file_is_compiled_again(tm
 def test_voices_of_a_sum_run_in_a_loop():
     """A Sum.many of N isomorphic voices above 96 units: the voice's units ONCE, inside a loop over the voices (jit_codegen.hpp VoicePlan /
     run_voices) — the text does not grow with N, names no per-voice constant, and carries one accumulate pass per FM level for time-split
-    renders; a sum of voices of two kinds, or a small one, is straight-line code; above 128 voices or 256 units of anything else: refused."""
+    renders; a sum of voices of two kinds, or a small one, is straight-line code; above 256 voices or 256 units of anything else: refused."""
     d.configure(48000)
     fm = lambda j: d.Osc(d.Sum(d.Multiply(d.Osc(3.0 + j / 7), 40), 220 + 11.5 * j))
     env = lambda j: d.Multiply(fm(j), d.Multiply(d.Shape("decay", 0.3 + j / 50).trigger(), d.Ramp(24000 + 100 * j, 1, 0).trigger()))
@@ -254,7 +254,7 @@ def test_voices_of_a_sum_run_in_a_loop():
     assert "in a loop" not in small.splitlines()[0] and "o3_0.tick<" in small
     mixed = d.Sum.many([fm(j) if j % 2 else d.Multiply(d.Osc(50.5 + j), 0.25) for j in range(40)])  # 20 x 4 + 20 x 2 + 39 = 159 units, two kinds of voice
     assert "in a loop" not in source(descriptor.extract(mixed).words).splitlines()[0]
-    for too_big in (d.Sum.many([fm(j) for j in range(129)]),
+    for too_big in (d.Sum.many([fm(j) for j in range(257)]),
                     d.Sum.many([fm(j) if j % 2 else d.Multiply(d.Osc(50.5 + j), 0.25) for j in range(80)])):
         with pytest.raises(runtime.DuspHipError, match="DUSP_JIT_MAX_UNITS"):
             source(descriptor.extract(too_big).words)

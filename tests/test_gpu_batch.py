@@ -770,7 +770,7 @@ def test_a_second_process_finds_its_kernel_on_disk():
 def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
     """A Sum.many of FM pairs — voices the fused sum chain does not take — is 5 N - 1 channel-expanded units.  From 96 units on the
     generator emits the voice's units ONCE, in a loop over the voices (jit_codegen.hpp VoicePlan: constants, parameter and state slots out
-    of a per-voice table, oscillator state in per-voice arrays, the chain as the loop's running f32 sum), whatever N up to 128; circuits
+    of a per-voice table, oscillator state in per-voice arrays, the chain as the loop's running f32 sum), whatever N up to 256; circuits
     that are no such sum run as straight-line code up to DUSP_JIT_MAX_UNITS (256) and on the interpreter beyond.  Same PCM and unit state
     as the chunk engine bit for bit, and the oracle's PCM."""
     import dusp_amd as d
