@@ -398,6 +398,9 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &wh
             break;
         case OP_AHD: case OP_SAMPLE_RATE_REDUX: case OP_MULTI_OSC: break;  // serial stage on one lane out of the wave's LDS scratch
         case OP_CB_READER: case OP_CB_WRITER: break;  // (an unconnected offset and a ring of at least a chunk: else plan.ring_events, above)
+        case OP_RETRIGGER:  // a Retriggerer of a Shape / an AHD of this circuit: a wave-uniform accumulator; a firing rewrites the target's registers before it ticks
+            if (((int)op.d[0] != OP_SHAPE && (int)op.d[0] != OP_AHD) || op.in[0].kind == SRC_BUF) return no("a Retriggerer of a Ramp, or with a signal-rate `rate`");
+            break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
             return no("a unit the circuit compiler does not emit yet");
@@ -447,6 +450,7 @@ struct Emitter {
         case OP_OSC: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_ABS: case OP_DECIBEL_TO_SCALER: case OP_SEMITONE_TO_RATIO:
         case OP_SECONDS_TO_SAMPLES: case OP_FIXED_MULTIPLY: return j < 1;
         case OP_RAMP: case OP_TIMER: case OP_INPUT: return false;
+        case OP_RETRIGGER: return j < 1;
         case OP_SHAPE: case OP_AHD: return j < 3;
         case OP_FIXED_DELAY: case OP_MULTI_OSC: case OP_CB_READER: return j < 1;
         case OP_CB_WRITER: return j < ((op.attr & 2) ? 1 : 2);  // (attr bit 1: nothing to mix on this channel)
@@ -737,6 +741,10 @@ struct Emitter {
                     line("    e" + id + ".begin(A, " + num(op.state_slot) + ");");
                     if (opt.persistent) line("    if (A.resume) jit_unpark(A, " + ctx(r) + ", " + num(op.out_buf) + ", e" + id + ".prev);");
                     break;
+                case OP_RETRIGGER:
+                    line("    JitRetrig r" + id + ";");
+                    line("    r" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    break;
                 case OP_SAMPLE_RATE_REDUX:
                     line("    JitSRR h" + id + ";");
                     line("    h" + id + ".begin(A, " + num(op.state_slot) + ");");
@@ -832,6 +840,7 @@ struct Emitter {
                     if (op.op == OP_SHAPE) line("        s" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_FIXED_DELAY || op.op == OP_COMB_FILTER || op.op == OP_ALL_PASS) line("        " + slot + " = (double)b" + id + ".tb;");
                     if (op.op == OP_AHD) line("        e" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_RETRIGGER) line("        " + slot + " = r" + id + ".T;");
                     if (op.op == OP_SAMPLE_RATE_REDUX) line("        h" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_MULTI_OSC) line("        " + slot + " = m" + id + ".phase;");
                     if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) line("        " + slot + " = n" + id + ".T;");
@@ -1158,6 +1167,15 @@ struct Emitter {
                 line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(" + X_ + ", g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
                      num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
                 break;
+            case OP_RETRIGGER: {  // Retriggerer.js:13-24; the target (chained behind it) ticks later in this chunk, from the rewritten state
+                int target = -1;
+                for (size_t kk = 0; kk < P.ops.size(); kk++)
+                    if ((P.ops[kk].op == OP_SHAPE || P.ops[kk].op == OP_AHD) && P.ops[kk].state_slot == op.attr) target = (int)kk;
+                const std::string tid = num(target) + sfx(target, r);
+                line("        if (r" + id + ".tick(" + X_ + ", " + opnd(k, 0, "0", r) + ")) { " +
+                     ((int)op.d[0] == OP_SHAPE ? "s" + tid + ".t = 0.0; s" + tid + ".playing = true;" : "e" + tid + ".stage = 1; e" + tid + ".playing = true;") + " }  // trigger()");
+                break;
+            }
             case OP_MULTIPLY: each(opnd(k, 0, "c", r) + " * " + opnd(k, 1, "c", r)); break;  // Multiply.js:23-34
             case OP_SUM: each(opnd(k, 0, "c", r) + " + " + opnd(k, 1, "c", r)); break;       // Sum.js:33-44
             case OP_REPEATER: each(opnd(k, 0, "c", r)); break;                                // Repeater.js:23-30

@@ -469,6 +469,30 @@ __device__ __forceinline__ void jit_ramp_end(const JitArgs &A, const JitCtx &X, 
     st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
 }
 
+// ---- Retriggerer (src/components/Retriggerer.js:13-24) of a Shape / an AHD of the same circuit: t += rate per sample; a crossing of the
+// sample rate triggers the target and subtracts the rate's unit.  Wave-uniform.  Most chunks see no crossing: then the accumulator is a
+// plain running f64 sum, which repeat_add() evaluates at once; a chunk with a crossing is walked (the subtraction breaks the closed form).
+struct JitRetrig {
+    double T;
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) { T = jit_u(A.init_state[state_slot]); }
+    __device__ __forceinline__ bool tick(const JitCtx &X, float rate_f) {  // -> fired in this chunk
+        const double rate = (double)rate_f, srd = X.srd;
+        bool fired = false;
+        double t = T;
+        const double quiet_end = (t >= 0.0 && rate > 0.0 && rate < 1.0e300) ? repeat_add(t, rate, kChunk) : srd;
+        if (quiet_end < srd) t = quiet_end;
+        else {
+#pragma unroll 8
+            for (int k = 0; k < kChunk; ++k) {
+                t += rate;
+                if (t >= srd) { fired = true; t -= srd; }
+            }
+        }
+        T = jit_u(t);
+        return jit_u(fired);
+    }
+};
+
 // ---- Timer (src/components/Timer.js:36-41): t += samplePeriod, each sum rounded to f64 — in closed form (repeat_add.hpp).  The
 // running value before the chunk is carried as a scalar; while a whole chunk stays inside one binade the 256 sums are
 // t_j = (T + j ce) 2^(K-52) (linear_run), else every lane jumps to its own four.
