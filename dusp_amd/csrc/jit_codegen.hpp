@@ -382,9 +382,7 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &wh
         const DevOp &op = P.ops[k];
         switch (op.op) {
         case OP_OSC: case OP_MULTIPLY: case OP_SUM: case OP_REPEATER: case OP_INPUT: break;
-        case OP_RAMP:
-            if (plan.op_state[k] >= 0) return no("a Ramp that a Retriggerer restarts");
-            break;
+        case OP_RAMP: break;  // (one a Retriggerer restarts: the closed form counted from its last restart, JitRampR)
         case OP_FILTER: break;  // (a connected cutoff: per-sample coefficients next to P in the stage's tile)
         case OP_DELAY: case OP_MONO_DELAY: case OP_READBACK_DELAY:  // write-once ring protocol, or ordered slot operations
             if (op.ring_len < 1 || op.ring_len >= (1ll << 31)) return no("delay ring out of range");
@@ -398,8 +396,8 @@ inline bool jit_eligible(const Program &P, const WavePlan &plan, std::string &wh
             break;
         case OP_AHD: case OP_SAMPLE_RATE_REDUX: case OP_MULTI_OSC: break;  // serial stage on one lane out of the wave's LDS scratch
         case OP_CB_READER: case OP_CB_WRITER: break;  // (an unconnected offset and a ring of at least a chunk: else plan.ring_events, above)
-        case OP_RETRIGGER:  // a Retriggerer of a Shape / an AHD of this circuit: a wave-uniform accumulator; a firing rewrites the target's registers before it ticks
-            if (((int)op.d[0] != OP_SHAPE && (int)op.d[0] != OP_AHD) || op.in[0].kind == SRC_BUF) return no("a Retriggerer of a Ramp, or with a signal-rate `rate`");
+        case OP_RETRIGGER:  // a Retriggerer of a Shape / an AHD / a Ramp of this circuit: a wave-uniform accumulator; a firing rewrites the target's registers before it ticks
+            if (((int)op.d[0] != OP_SHAPE && (int)op.d[0] != OP_AHD && (int)op.d[0] != OP_RAMP) || op.in[0].kind == SRC_BUF) return no("a Retriggerer with a signal-rate `rate`");
             break;
         default:
             if ((op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST)) break;
@@ -492,6 +490,7 @@ struct Emitter {
         const int tf = jit_table_source(opt, table_id);
         return (tf == 0 || tf == 1) && opt.table_delta[table_id] ? 1 + opt.table_delta[table_id] : 1;
     }
+    bool restarted(int k) const { return P.ops[(size_t)k].op == OP_RAMP && (size_t)k < plan.op_state.size() && plan.op_state[(size_t)k] >= 0; }  // a Ramp some Retriggerer restarts
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
@@ -741,6 +740,12 @@ struct Emitter {
                     line("    e" + id + ".begin(A, " + num(op.state_slot) + ");");
                     if (opt.persistent) line("    if (A.resume) jit_unpark(A, " + ctx(r) + ", " + num(op.out_buf) + ", e" + id + ".prev);");
                     break;
+                case OP_RAMP:
+                    if (restarted(k)) {
+                        line("    JitRampR a" + id + ";");
+                        line("    a" + id + ".begin(A, " + num(op.state_slot) + ");");
+                    }
+                    break;
                 case OP_RETRIGGER:
                     line("    JitRetrig r" + id + ";");
                     line("    r" + id + ".begin(A, " + num(op.state_slot) + ");");
@@ -829,7 +834,8 @@ struct Emitter {
                     const std::string slot = "A.state[(size_t)" + num(op.state_slot) + " * A.n_pad + " + ctx(r) + ".inst]", id = num((long long)k) + sfx((int)k, r);
                     if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) line("        " + slot + " = o" + id + ".end_phase(A, " + ctx(r) + ");");
                     if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) line("        " + slot + " = o" + id + ".end_phase();");
-                    if (op.op == OP_RAMP) line("        jit_ramp_end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_RAMP && restarted((int)k)) line("        a" + id + ".end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
+                    else if (op.op == OP_RAMP) line("        jit_ramp_end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_TIMER)
                         line("        " + slot + " = repeat_add(A.init_state[" + num(op.state_slot) + "], d" + num(dconst_of[k]) + ", (uint64_t)A.n_groups * kChunk);");
                     if (jit_ring_ops(op)) {
@@ -1164,16 +1170,21 @@ struct Emitter {
                 break;
             case OP_RAMP:
                 decl();
+                if (restarted(k)) {
+                    line("        a" + id + ".tick(" + X_ + ", g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" + num(dconst_of[(size_t)k] + 2) + ", " + v + ");");
+                    break;
+                }
                 line("        jit_ramp<" + std::string(plan.ramp_fastdiv[(size_t)k] ? "true" : "false") + ">(" + X_ + ", g, " + dref + ", d" + num(dconst_of[(size_t)k] + 1) + ", d" +
                      num(dconst_of[(size_t)k] + 2) + ", A.init_state[" + num(op.state_slot) + "], A.init_state[" + num(op.state_slot + 1) + "] != 0.0, " + v + ");");
                 break;
             case OP_RETRIGGER: {  // Retriggerer.js:13-24; the target (chained behind it) ticks later in this chunk, from the rewritten state
                 int target = -1;
                 for (size_t kk = 0; kk < P.ops.size(); kk++)
-                    if ((P.ops[kk].op == OP_SHAPE || P.ops[kk].op == OP_AHD) && P.ops[kk].state_slot == op.attr) target = (int)kk;
+                    if ((P.ops[kk].op == OP_SHAPE || P.ops[kk].op == OP_AHD || P.ops[kk].op == OP_RAMP) && P.ops[kk].state_slot == op.attr) target = (int)kk;
                 const std::string tid = num(target) + sfx(target, r);
                 line("        if (r" + id + ".tick(" + X_ + ", " + opnd(k, 0, "0", r) + ")) { " +
-                     ((int)op.d[0] == OP_SHAPE ? "s" + tid + ".t = 0.0; s" + tid + ".playing = true;" : "e" + tid + ".stage = 1; e" + tid + ".playing = true;") + " }  // trigger()");
+                     ((int)op.d[0] == OP_SHAPE ? "s" + tid + ".t = 0.0; s" + tid + ".playing = true;" : (int)op.d[0] == OP_RAMP ? "a" + tid + ".fire(g);" : "e" + tid + ".stage = 1; e" + tid + ".playing = true;") +
+                     " }  // trigger()");
                 break;
             }
             case OP_MULTIPLY: each(opnd(k, 0, "c", r) + " * " + opnd(k, 1, "c", r)); break;  // Multiply.js:23-34
@@ -1588,8 +1599,10 @@ struct Emitter {
         for (size_t at = 0; at < plan.order.size() && R > 1; at++) {
             const int k = plan.order[at];
             const DevOp &op = P.ops[(size_t)k];
-            bool ok = op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_TIMER || op.op == OP_SHAPE || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
-                      (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST);
+            bool retriggered = false;  // (a Retriggerer's target follows ITS instance's rate: never shared)
+            for (const DevOp &rt : P.ops) retriggered = retriggered || (rt.op == OP_RETRIGGER && rt.attr == op.state_slot && (op.op == OP_SHAPE || op.op == OP_AHD || op.op == OP_RAMP));
+            bool ok = !retriggered && (op.op == OP_OSC || (op.op == OP_RAMP && !restarted(k)) || op.op == OP_TIMER || op.op == OP_SHAPE || op.op == OP_MULTIPLY || op.op == OP_SUM || op.op == OP_REPEATER ||
+                      (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST));
             for (int j = 0; ok && j < kMaxIn; j++) {
                 if (!operand_live(op, j)) continue;
                 const DevOperand &o = op.in[j];

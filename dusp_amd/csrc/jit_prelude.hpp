@@ -469,7 +469,40 @@ __device__ __forceinline__ void jit_ramp_end(const JitArgs &A, const JitCtx &X, 
     st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
 }
 
-// ---- Retriggerer (src/components/Retriggerer.js:13-24) of a Shape / an AHD of the same circuit: t += rate per sample; a crossing of the
+// ---- A Ramp that a Retriggerer of the same circuit restarts (Ramp.js:19-23 trigger(): t = 0, playing): the closed form counted from
+// the chunk of its last restart.  (No refined reciprocal here: nobody has checked it on the t sequences a restart runs through.)
+struct JitRampR {
+    double t0;                  // t before the sample `origin`
+    unsigned long long origin;  // ... a sample index of this launch
+    bool playing;
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
+        t0 = jit_u(A.init_state[state_slot]);
+        playing = jit_u(A.init_state[state_slot + 1] != 0.0);
+        origin = 0ull;
+    }
+    __device__ __forceinline__ void fire(uint32_t g) {  // trigger() in front of chunk g's tick
+        t0 = 0.0;
+        origin = (unsigned long long)g * kChunk;
+        playing = true;
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, uint32_t g, double duration, double y0, double y1, float (&out)[4]) const {
+        const double dy = y1 - y0;
+        const uint64_t n0 = X.n0(g) - origin;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double tt = playing ? fmin(t0 + (double)(n0 + c + 1), duration) : t0;
+            out[c] = (float)(y0 + (tt / duration) * dy);
+        }
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, double duration, int state_slot) const {
+        const double since = (double)((uint64_t)A.n_groups * kChunk - origin);
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = playing ? fmin(t0 + since, duration) : t0;
+        st[A.n_pad] = (playing && t0 + since <= duration) ? 1.0 : 0.0;
+    }
+};
+
+// ---- Retriggerer (src/components/Retriggerer.js:13-24) of a Shape / an AHD / a Ramp of the same circuit: t += rate per sample; a crossing of the
 // sample rate triggers the target and subtracts the rate's unit.  Wave-uniform.  Most chunks see no crossing: then the accumulator is a
 // plain running f64 sum, which repeat_add() evaluates at once; a chunk with a crossing is walked (the subtraction breaks the closed form).
 struct JitRetrig {
