@@ -65,7 +65,8 @@ json_path = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json="
 records = []
 # patch topologies: the reference's own patches as extracted descriptors (constants only: every instance renders the same circuit)
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-PATCHES = ["patch_fm_osc", "patch_simple_delay", "patch_multitap", "patch_many_osc", "patch_stereo_detune", "patch_space"]
+PATCHES = ["patch_fm_osc", "patch_simple_delay", "patch_multitap", "patch_many_osc", "patch_stereo_detune", "patch_space",
+           "rt_shape_fast", "rt_dev_rhythm"]  # (+ two circuits with device Retriggerers: an enveloped oscillator retriggered at 50 Hz; two envelopes into a feedback delay line)
 for name in PATCHES:
     graphs["%s x 256" % name] = name
 for name, g in graphs.items():
