@@ -175,10 +175,11 @@ inline bool jit_delay_write_once(const DevOp &op) { return delay_write_once(op);
 // state lives in per-voice arrays, and the chain is the loop's running sum (f32, in voice order: the chain's own roundings).
 struct VoicePlan {
     bool ok = false;
-    int n_voices = 0;
-    std::vector<std::vector<int>> ops;  // [voice][t]: the op at template position t (an evaluation order of the voice: producers first)
-    std::vector<int> chain;             // the chain's Sum ops, bottom up (chain[i] adds voice i + 1)
-    std::vector<int> tail;              // what hangs on the mix, in order: a master gain, an offset, a clip, .. (stateless units with one signal operand)
+    int n_voices = 0, n_channels = 0;
+    std::vector<std::vector<int>> ops;    // [voice][t]: the op at template position t (an evaluation order of the voice: producers first)
+    std::vector<int> root_pos;            // [channel]: the template position of the voice's outlet that goes into that channel's chain
+    std::vector<std::vector<int>> chain;  // [channel]: the chain's Sum ops, bottom up (chain[c][i] adds voice i + 1)
+    std::vector<std::vector<int>> tail;   // [channel]: what hangs on the mix, in order: a master gain, an offset, a clip, .. (stateless units with one signal operand)
 };
 constexpr int kMaxLoopVoices = 256;     // (the oscillators' state arrays are per lane: 76 bytes a voice and constant-f oscillator)
 constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (Shape: duration, min, max)
@@ -186,7 +187,8 @@ constexpr int kVoiceOperands = 3;       // operands a voice's unit has at most (
 inline bool jit_voice_unit(const DevOp &op) {
     return op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) ||
            (op.op == OP_SHAPE && op.in[0].kind != SRC_BUF) ||  // (a Shape whose duration is not a signal: closed form)
-           (op.op == OP_AHD && op.in[0].kind != SRC_BUF && op.in[1].kind != SRC_BUF && op.in[2].kind != SRC_BUF);  // (an AHD with constant times)
+           (op.op == OP_AHD && op.in[0].kind != SRC_BUF && op.in[1].kind != SRC_BUF && op.in[2].kind != SRC_BUF) ||  // (an AHD with constant times)
+           (op.op == OP_PAN && op.in[1].kind != SRC_BUF);  // (a Pan whose position is not a signal: its compensation gain once per voice)
 }
 inline int jit_voice_operands(const DevOp &op) {
     switch (op.op) {
@@ -199,7 +201,7 @@ inline int jit_voice_operands(const DevOp &op) {
 
 inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V) {
     V = VoicePlan();
-    if (!plan.ok || P.out_bufs.size() != 1 || P.ring_samples != 0 || !P.feed_forward || plan.order.size() != P.ops.size()) return false;
+    if (!plan.ok || P.out_bufs.empty() || P.out_bufs.size() > 16 || P.ring_samples != 0 || !P.feed_forward || plan.order.size() != P.ops.size()) return false;
     const int n_ops = (int)P.ops.size();
     std::vector<int> producer((size_t)std::max(1, P.n_bufs), -1), pos((size_t)n_ops, 0), owner((size_t)n_ops, -1);
     for (int k = 0; k < n_ops; k++)
@@ -232,34 +234,51 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         }
         return true;
     };
-    // from the outlet down: stateless units on the mix (one signal operand each), then the chain's top
-    int root = producer[(size_t)P.out_bufs[0]];
-    std::vector<int> tail_rev;
-    while (root >= 0 && (int)tail_rev.size() < 16) {
-        const DevOp &op = P.ops[(size_t)root];
-        const bool unary = op.op == OP_REPEATER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 1);
-        const bool binary = op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 2);
-        int signal = -1;
-        if (unary && op.in[0].kind == SRC_BUF) signal = 0;
-        else if (binary && (op.in[0].kind == SRC_BUF) != (op.in[1].kind == SRC_BUF) && (op.in[0].kind == SRC_BUF || op.in[0].kind == SRC_CONST || op.in[0].kind == SRC_PARAM) &&
-                 (op.in[1].kind == SRC_BUF || op.in[1].kind == SRC_CONST || op.in[1].kind == SRC_PARAM))
-            signal = op.in[0].kind == SRC_BUF ? 0 : 1;
-        if (signal < 0) break;
-        const int below = src(op.in[signal]);
-        if (below < 0 || pos[(size_t)below] >= pos[(size_t)root]) return false;
-        tail_rev.push_back(root);
-        root = below;
+    // a voice with several outlets (a Pan: one per output channel): the union of what they reach, each unit once
+    auto collect_all = [&](const std::vector<int> &roots, std::vector<int> &list, std::vector<int> &root_pos) -> bool {
+        list.clear();
+        root_pos.clear();
+        for (int r : roots) {
+            std::vector<int> part;
+            if (!collect(r, part)) return false;
+            for (int k : part)
+                if (std::find(list.begin(), list.end(), k) == list.end()) list.push_back(k);
+            root_pos.push_back((int)(std::find(list.begin(), list.end(), r) - list.begin()));
+        }
+        return (int)list.size() <= 64;
+    };
+    const int C = (int)P.out_bufs.size();
+    // per output channel, from the outlet down: stateless units on the mix (one signal operand each), then the chain's top
+    std::vector<int> top((size_t)C, -1);
+    std::vector<std::vector<int>> tail_rev((size_t)C);
+    for (int c = 0; c < C; c++) {
+        int root = producer[(size_t)P.out_bufs[(size_t)c]];
+        while (root >= 0 && (int)tail_rev[(size_t)c].size() < 16) {
+            const DevOp &op = P.ops[(size_t)root];
+            const bool unary = op.op == OP_REPEATER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 1);
+            const bool binary = op.op == OP_MULTIPLY || op.op == OP_SUM || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST && jit_voice_operands(op) == 2);
+            int signal = -1;
+            if (unary && op.in[0].kind == SRC_BUF) signal = 0;
+            else if (binary && (op.in[0].kind == SRC_BUF) != (op.in[1].kind == SRC_BUF) && (op.in[0].kind == SRC_BUF || op.in[0].kind == SRC_CONST || op.in[0].kind == SRC_PARAM) &&
+                     (op.in[1].kind == SRC_BUF || op.in[1].kind == SRC_CONST || op.in[1].kind == SRC_PARAM))
+                signal = op.in[0].kind == SRC_BUF ? 0 : 1;
+            if (signal < 0) break;
+            const int below = src(op.in[signal]);
+            if (below < 0 || pos[(size_t)below] >= pos[(size_t)root]) return false;
+            tail_rev[(size_t)c].push_back(root);
+            root = below;
+        }
+        if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[0].kind != SRC_BUF || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
+        top[(size_t)c] = root;
     }
-    if (root < 0 || P.ops[(size_t)root].op != OP_SUM || P.ops[(size_t)root].in[0].kind != SRC_BUF || P.ops[(size_t)root].in[1].kind != SRC_BUF) return false;
-    std::vector<int> tmpl;
-    auto same_shape = [&](const std::vector<int> &a) {
-        if (a.size() != tmpl.size()) return false;
+    std::vector<int> tmpl, tmpl_roots;
+    auto same_shape = [&](const std::vector<int> &a, const std::vector<int> &a_roots) {
+        if (a.size() != tmpl.size() || a_roots != tmpl_roots) return false;
         for (size_t t = 0; t < a.size(); t++) {
             const DevOp &x = P.ops[(size_t)a[t]], &y = P.ops[(size_t)tmpl[t]];
             if (x.op != y.op || x.attr != y.attr) return false;
-            if (x.op >= OP_MAP_FIRST && x.op <= OP_MAP_LAST && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;  // (FixedMultiply's factor, SecondsToSamples' rate: in the text's constants)
-            if (x.op == OP_SHAPE && std::memcmp(&x.d[0], &y.d[0], 2 * sizeof(double)) != 0) return false;                            // (a Shape's edge values)
-            if (x.op == OP_AHD && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;                                  // (the AHD's sample period)
+            if (((x.op >= OP_MAP_FIRST && x.op <= OP_MAP_LAST) || x.op == OP_PAN || x.op == OP_AHD) && std::memcmp(&x.d[0], &y.d[0], sizeof(double)) != 0) return false;  // (FixedMultiply's factor, Pan's compensation dB, the AHD's sample period: in the text's constants)
+            if (x.op == OP_SHAPE && std::memcmp(&x.d[0], &y.d[0], 2 * sizeof(double)) != 0) return false;  // (a Shape's edge values)
             for (int j = 0; j < n_operands(x); j++) {
                 if (x.in[j].kind != y.in[j].kind) return false;
                 if (x.in[j].kind == SRC_BUF) {
@@ -270,41 +289,53 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
         }
         return true;
     };
-    // The chain: `Sum.many` is left-deep (Sum.js:18-29: the chain in operand A, a voice in B); a string's `a + b + c + ..` builds the
-    // mirror image (the chain in B).  f32 addition commutes, so either way the mix is the running sum over the voices from the
-    // chain's bottom up.
+    // The chains (one per output channel, link for link side by side): `Sum.many` is left-deep (Sum.js:18-29: the chain in operand A,
+    // a voice in B); a string's `a + b + c + ..` builds the mirror image (the chain in B).  f32 addition commutes, so either way a
+    // channel's mix is the running sum over the voices from the chain's bottom up.
     std::vector<std::vector<int>> rev;
-    std::vector<int> chain_rev;
+    std::vector<std::vector<int>> chain_rev((size_t)C);
     auto walk = [&](int vi, int ci) -> bool {
         rev.clear();
-        chain_rev.clear();
-        if (!collect(src(P.ops[(size_t)root].in[vi]), tmpl)) return false;
-        for (int cur = root;;) {
-            const DevOp &sum = P.ops[(size_t)cur];
-            if (sum.op != OP_SUM || sum.in[0].kind != SRC_BUF || sum.in[1].kind != SRC_BUF) return false;
-            std::vector<int> v;
-            if (!collect(src(sum.in[vi]), v) || !same_shape(v) || pos[(size_t)v.back()] >= pos[(size_t)cur]) return false;
+        for (auto &ch : chain_rev) ch.clear();
+        std::vector<int> cur = top, roots((size_t)C), below((size_t)C);
+        for (int c = 0; c < C; c++) roots[(size_t)c] = src(P.ops[(size_t)cur[(size_t)c]].in[vi]);
+        if (!collect_all(roots, tmpl, tmpl_roots)) return false;
+        for (;;) {
+            for (int c = 0; c < C; c++) {
+                const DevOp &sum = P.ops[(size_t)cur[(size_t)c]];
+                if (sum.op != OP_SUM || sum.in[0].kind != SRC_BUF || sum.in[1].kind != SRC_BUF) return false;
+                roots[(size_t)c] = src(sum.in[vi]);
+                below[(size_t)c] = src(sum.in[ci]);
+                if (roots[(size_t)c] < 0 || below[(size_t)c] < 0 || pos[(size_t)roots[(size_t)c]] >= pos[(size_t)cur[(size_t)c]] || pos[(size_t)below[(size_t)c]] >= pos[(size_t)cur[(size_t)c]]) return false;
+            }
+            std::vector<int> v, v_roots;
+            if (!collect_all(roots, v, v_roots) || !same_shape(v, v_roots)) return false;
             rev.push_back(v);
-            chain_rev.push_back(cur);
+            for (int c = 0; c < C; c++) chain_rev[(size_t)c].push_back(cur[(size_t)c]);
             if ((int)rev.size() > kMaxLoopVoices) return false;
-            const int a = src(sum.in[ci]);
-            if (a < 0 || pos[(size_t)a] >= pos[(size_t)cur]) return false;
-            std::vector<int> first;
-            if (collect(a, first) && same_shape(first)) {  // the chain's bottom: a voice
+            std::vector<int> first, first_roots;
+            if (collect_all(below, first, first_roots) && same_shape(first, first_roots)) {  // the chains' bottom: a voice
                 rev.push_back(first);
                 return true;
             }
-            if (P.ops[(size_t)a].op != OP_SUM) return false;
-            cur = a;
+            for (int c = 0; c < C; c++)
+                if (P.ops[(size_t)below[(size_t)c]].op != OP_SUM) return false;
+            cur = below;
         }
     };
     if (!walk(1, 0) && !walk(0, 1)) return false;
     V.n_voices = (int)rev.size();
+    V.n_channels = C;
     if (V.n_voices < 4 || V.n_voices > kMaxLoopVoices) return false;
     V.ops.assign(rev.rbegin(), rev.rend());
-    V.chain.assign(chain_rev.rbegin(), chain_rev.rend());
-    V.tail.assign(tail_rev.rbegin(), tail_rev.rend());
-    // every unit of the circuit belongs to exactly one voice or to the chain, and a voice's outlets are read inside it (or by its Sum) only
+    V.root_pos = tmpl_roots;
+    V.chain.resize((size_t)C);
+    V.tail.resize((size_t)C);
+    for (int c = 0; c < C; c++) {
+        V.chain[(size_t)c].assign(chain_rev[(size_t)c].rbegin(), chain_rev[(size_t)c].rend());
+        V.tail[(size_t)c].assign(tail_rev[(size_t)c].rbegin(), tail_rev[(size_t)c].rend());
+    }
+    // every unit of the circuit belongs to exactly one voice, one chain or one tail; a voice's outlets are read inside it (or by its Sums) only
     int counted = 0;
     for (int v = 0; v < V.n_voices; v++)
         for (int k : V.ops[(size_t)v]) {
@@ -312,32 +343,31 @@ inline bool jit_find_voices(const Program &P, const WavePlan &plan, VoicePlan &V
             owner[(size_t)k] = v;
             counted++;
         }
-    for (int k : V.chain) {
-        if (owner[(size_t)k] >= 0) return false;
-        owner[(size_t)k] = V.n_voices;
-        counted++;
-    }
-    for (int k : V.tail) {
-        if (owner[(size_t)k] >= 0) return false;
-        owner[(size_t)k] = V.n_voices + 1;
-        counted++;
+    for (int c = 0; c < C; c++) {
+        for (int k : V.chain[(size_t)c]) {
+            if (owner[(size_t)k] >= 0) return false;
+            owner[(size_t)k] = V.n_voices;
+            counted++;
+        }
+        for (int k : V.tail[(size_t)c]) {
+            if (owner[(size_t)k] >= 0) return false;
+            owner[(size_t)k] = V.n_voices + 1;
+            counted++;
+        }
     }
     if (counted != n_ops) return false;
     for (int k = 0; k < n_ops; k++) {
-        if (owner[(size_t)k] > V.n_voices) continue;  // (the tail: its one signal operand is the unit below it, checked on the way down)
+        if (owner[(size_t)k] > V.n_voices) continue;  // (a tail: its one signal operand is the unit below it, by the way it was found)
         for (int j = 0; j < n_operands(P.ops[(size_t)k]); j++) {
             const int p = src(P.ops[(size_t)k].in[j]);
-            if (p >= 0 && owner[(size_t)p] != owner[(size_t)k] && !(owner[(size_t)k] == V.n_voices && owner[(size_t)p] < V.n_voices && p == V.ops[(size_t)owner[(size_t)p]].back())) return false;
+            if (p < 0 || owner[(size_t)p] == owner[(size_t)k]) continue;
+            if (!(owner[(size_t)k] == V.n_voices && owner[(size_t)p] < V.n_voices)) return false;  // (only a chain reads a voice)
+            const std::vector<int> &vo = V.ops[(size_t)owner[(size_t)p]];
+            bool is_root = false;
+            for (int rp : V.root_pos) is_root = is_root || vo[(size_t)rp] == p;
+            if (!is_root) return false;
         }
     }
-    for (int k = 0; k < n_ops; k++)  // nothing but the tail's first unit reads the mix, nothing but the next one a tail unit
-        for (int j = 0; j < kVoiceOperands && j < kMaxIn; j++) {
-            const int p = src(P.ops[(size_t)k].in[j]);
-            if (p < 0 || owner[(size_t)k] <= V.n_voices) continue;
-            if (j >= (P.ops[(size_t)k].op == OP_REPEATER ? 1 : n_operands(P.ops[(size_t)k]))) continue;
-            const size_t at = (size_t)(std::find(V.tail.begin(), V.tail.end(), k) - V.tail.begin());
-            if (p != (at == 0 ? V.chain.back() : V.tail[at - 1])) return false;
-        }
     V.ok = true;
     return true;
 }
@@ -1309,7 +1339,7 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) dmap[(size_t)t] = add_dk(op.d[0]);
             if (op.op == OP_SHAPE) dmap[(size_t)t] = add_dk(op.d[0]), add_dk(op.d[1]);
-            if (op.op == OP_AHD) dmap[(size_t)t] = add_dk(op.d[0]);
+            if (op.op == OP_AHD || op.op == OP_PAN) dmap[(size_t)t] = add_dk(op.d[0]);
         }
         for (int t = 0; t < n_t; t++)
             if (P.ops[(size_t)T[(size_t)t]].op == OP_RAMP) dramp[(size_t)t] = ND, ND += 3;
@@ -1331,14 +1361,18 @@ struct Emitter {
                     else if (op.in[j].kind == SRC_PARAM) out.fk.push_back((float)op.in[j].idx);
                 if (op.op == OP_OSC || op.op == OP_RAMP || op.op == OP_SHAPE || op.op == OP_AHD) out.fk.push_back((float)op.state_slot);
             }
-        // the tail's constants: ordinary entries of fk / dk (one unit each, not per voice)
-        std::vector<int> tail_fk(V.tail.size(), -1), tail_dk(V.tail.size(), -1);
-        for (size_t i = 0; i < V.tail.size(); i++) {
-            const DevOp &op = P.ops[(size_t)V.tail[i]];
-            for (int j = 0; j < 2 && j < (op.op == OP_REPEATER ? 1 : jit_voice_operands(op)); j++)
-                if (op.in[j].kind == SRC_CONST) tail_fk[i] = add_fk(op.in[j].cval);
-            if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) tail_dk[i] = add_dk(op.d[0]);
-        }
+        // the tails' constants: ordinary entries of fk / dk (one unit each, not per voice)
+        const int C = V.n_channels;
+        std::vector<std::vector<int>> tail_fk((size_t)C), tail_dk((size_t)C);
+        for (int c = 0; c < C; c++)
+            for (size_t i = 0; i < V.tail[(size_t)c].size(); i++) {
+                const DevOp &op = P.ops[(size_t)V.tail[(size_t)c][i]];
+                tail_fk[(size_t)c].push_back(-1);
+                tail_dk[(size_t)c].push_back(-1);
+                for (int j = 0; j < 2 && j < (op.op == OP_REPEATER ? 1 : jit_voice_operands(op)); j++)
+                    if (op.in[j].kind == SRC_CONST) tail_fk[(size_t)c][i] = add_fk(op.in[j].cval);
+                if (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) tail_dk[(size_t)c][i] = add_dk(op.d[0]);
+            }
         auto pos_in = [&](int k) { return (int)(std::find(T.begin(), T.end(), k) - T.begin()); };
         auto tname = [&](int t) { return "t" + num(t); };
         // operand j of template op t: an array of this chunk's samples, or a wave-uniform scalar out of the voice's table row
@@ -1392,6 +1426,7 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op == OP_SHAPE) line("    JitShape e" + num(t) + "[" + NVs + "];");
             if (op.op == OP_AHD) line("    JitAHD a" + num(t) + "[" + NVs + "];");
+            if (op.op == OP_PAN) line("    double g" + num(t) + "[" + NVs + "];  // Pan.js:19-29: the centre compensation, a pow() of the pan position alone");
             if (op.op != OP_OSC) continue;
             line(std::string("    ") + (op.in[0].kind != SRC_BUF ? "JitOscKV" : "JitOscS") + " o" + num(t) + "[" + NVs + "];");
         }
@@ -1402,6 +1437,7 @@ struct Emitter {
             const DevOp &op = P.ops[(size_t)T[(size_t)t]];
             if (op.op == OP_SHAPE) line("        e" + num(t) + "[j].begin(A, X[0], " + scalar(t, 0) + ", (int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "]));");
             if (op.op == OP_AHD) line("        a" + num(t) + "[j].begin(A, (int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "]));");
+            if (op.op == OP_PAN) line("        g" + num(t) + "[j] = map_pan_compensation(" + scalar(t, 1) + ", jit_u(A.dk[" + num(dmap[(size_t)t]) + "]));");
             if (op.op != OP_OSC) continue;
             const std::string slot = "(int)jit_u(vt[" + num(state_slot_of[(size_t)t]) + "])";
             if (op.in[0].kind != SRC_BUF) {
@@ -1418,7 +1454,9 @@ struct Emitter {
         for (int fx = 1; fx >= 0; fx--) {
             line(fx ? "    if (fast) {" : "    } else {");
             line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
-            if (render) line("        float acc[4] = {0.f, 0.f, 0.f, 0.f};  // (0 + v0: the chain's first voice as it stands, but for the sign of a zero the copy-out drops anyway)");
+            if (render)
+                for (int c = 0; c < C; c++)
+                    line("        float acc" + num(c) + "[4] = {0.f, 0.f, 0.f, 0.f};" + (c ? "" : "  // (0 + v0: the chain's first voice as it stands, but for the sign of a zero the copy-out drops anyway)"));
             line("#pragma unroll 1");
             line("        for (int j = 0; j < " + NVs + "; ++j) {");
             line("            const float *vt = " + row + ";");
@@ -1453,6 +1491,9 @@ struct Emitter {
                          " + 1] != 0.0, " + tname(t) + ");");
                     break;
                 }
+                case OP_PAN:
+                    line("            for (int c = 0; c < 4; ++c) " + tname(t) + "[c] = map_pan(" + operand(t, 0, "c") + ", " + operand(t, 1, "c") + ", " + num(op.attr) + ", jit_u(g" + num(t) + "[j]));");
+                    break;
                 case OP_AHD: {  // (constant times: closed form unless a stage ends inside the chunk — then lane 0 walks it out of the wave's scratch)
                     std::string tm[3];
                     for (int j = 0; j < 3; j++) {
@@ -1483,29 +1524,32 @@ struct Emitter {
                     break;
                 }
             }
-            if (render) line("            for (int c = 0; c < 4; ++c) acc[c] = acc[c] + " + tname(n_t - 1) + "[c];  // (Sum.js:33-44: one f32 rounding per link of the chain)");
+            if (render)
+                for (int ch = 0; ch < C; ch++)
+                    line("            for (int c = 0; c < 4; ++c) acc" + num(ch) + "[c] = acc" + num(ch) + "[c] + " + tname(V.root_pos[(size_t)ch]) + "[c];" + (ch ? "" : "  // (Sum.js:33-44: one f32 rounding per link of the chain)"));
             line("        }");
-            if (render) {
-                std::string mix = "acc";
-                for (size_t i = 0; i < V.tail.size(); i++) {  // what hangs on the mix
-                    const DevOp &op = P.ops[(size_t)V.tail[i]];
-                    const std::string u = "u" + num((long long)i);
-                    auto side = [&](int j) -> std::string {
-                        const DevOperand &o = op.in[j];
-                        if (o.kind == SRC_BUF) return mix + "[c]";
-                        return o.kind == SRC_PARAM ? "jit_param(A, X[0], " + num(o.idx) + ")" : "jit_u(A.fk[" + num(tail_fk[i]) + "])";
-                    };
-                    line("        float " + u + "[4];");
-                    if (op.op == OP_REPEATER) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + ";");
-                    else if (op.op == OP_MULTIPLY) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " * " + side(1) + ";");
-                    else if (op.op == OP_SUM) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " + " + side(1) + ";");
-                    else
-                        line("        for (int c = 0; c < 4; ++c) " + u + "[c] = map_apply(" + num(op.op) + ", " + side(0) + ", " + (jit_voice_operands(op) > 1 ? side(1) : std::string("0.f")) + ", jit_u(A.dk[" + num(tail_dk[i]) +
-                             "]));");
-                    mix = u;
+            if (render)
+                for (int ch = 0; ch < C; ch++) {
+                    std::string mix = "acc" + num(ch);
+                    for (size_t i = 0; i < V.tail[(size_t)ch].size(); i++) {  // what hangs on the mix
+                        const DevOp &op = P.ops[(size_t)V.tail[(size_t)ch][i]];
+                        const std::string u = "u" + num(ch) + "_" + num((long long)i);
+                        auto side = [&](int j) -> std::string {
+                            const DevOperand &o = op.in[j];
+                            if (o.kind == SRC_BUF) return mix + "[c]";
+                            return o.kind == SRC_PARAM ? "jit_param(A, X[0], " + num(o.idx) + ")" : "jit_u(A.fk[" + num(tail_fk[(size_t)ch][i]) + "])";
+                        };
+                        line("        float " + u + "[4];");
+                        if (op.op == OP_REPEATER) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + ";");
+                        else if (op.op == OP_MULTIPLY) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " * " + side(1) + ";");
+                        else if (op.op == OP_SUM) line("        for (int c = 0; c < 4; ++c) " + u + "[c] = " + side(0) + " + " + side(1) + ";");
+                        else
+                            line("        for (int c = 0; c < 4; ++c) " + u + "[c] = map_apply(" + num(op.op) + ", " + side(0) + ", " + (jit_voice_operands(op) > 1 ? side(1) : std::string("0.f")) + ", jit_u(A.dk[" +
+                                 num(tail_dk[(size_t)ch][i]) + "]));");
+                        mix = u;
+                    }
+                    line("        jit_store<false>(A, X[0], g, " + num(ch) + ", " + mix + ");");
                 }
-                line("        jit_store<false>(A, X[0], g, 0, " + mix + ");");
-            }
             line("    }");
         }
         line("    }");

@@ -249,7 +249,9 @@ def test_voices_of_a_sum_run_in_a_loop():
     assert not re.search(r"\bk\d+\b = jit_u\(A\.fk", text[120])                              # constants come out of the voice's table row
     source(descriptor.extract(d.Sum.many([env(j) for j in range(40)])).words, compile=True)  # (and it compiles)
     mastered = source(descriptor.extract(d.HardClipAbove(d.Multiply(d.Sum.many([env(j) for j in range(30)]), 0.25), 0.9)).words)  # a master gain and a clip on the mix
-    assert "in a loop" in mastered.splitlines()[0] and "u0[c] = acc[c] * jit_u(A.fk[" in mastered and "u1[c] = map_apply(" in mastered and "jit_store<false>(A, X[0], g, 0, u1);" in mastered
+    assert "in a loop" in mastered.splitlines()[0] and "u0_0[c] = acc0[c] * jit_u(A.fk[" in mastered and "u0_1[c] = map_apply(" in mastered and "jit_store<false>(A, X[0], g, 0, u0_1);" in mastered
+    stereo = source(descriptor.extract(d.Sum.many([d.Pan(env(j), -1 + j / 15) for j in range(30)])).words)  # panned voices: a chain per output channel, the voice's units once
+    assert "in a loop" in stereo.splitlines()[0] and stereo.count("map_pan(") >= 4 and "map_pan_compensation(" in stereo and "jit_store<false>(A, X[0], g, 1, acc1);" in stereo
     small = source(descriptor.extract(d.Sum.many([fm(j) for j in range(12)])).words)         # 59 units: as before
     assert "in a loop" not in small.splitlines()[0] and "o3_0.tick<" in small
     mixed = d.Sum.many([fm(j) if j % 2 else d.Multiply(d.Osc(50.5 + j), 0.25) for j in range(40)])  # 20 x 4 + 20 x 2 + 39 = 159 units, two kinds of voice

@@ -854,6 +854,18 @@ def test_circuits_above_a_hundred_units_run_on_compiled_kernels(oracle):
     assert np.array_equal(pcm[1], oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=1))
     prog.close()
     ref.close()
+    # panned voices: two output channels, a chain each, the voice's units (and one compensation pow() per voice) once
+    uni = descriptor.unify([descriptor.extract(d.Multiply(d.Sum.many([d.Pan(note(k, j), -1 + j / 18 + k / 1000) for j in range(36)]), 0.5)) for k in (0, 8, 16)])
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, 3, uni.params)
+    assert prog.n_out_channels == 2 and "loop" in prog.read_shape(), prog.read_shape()
+    ref = render.context(48000).build(uni.words, runtime.ENGINE_CHUNK)
+    want = ref.render(n, 3, uni.params)
+    scale = float(np.max(np.abs(want)))
+    assert np.max(np.abs(pcm.astype(np.float64) - want)) <= 1e-6 * scale   # (Pan's compensation is a pow(): device math, the north star's tolerance)
+    assert np.max(np.abs(pcm[1].astype(np.float64) - oracle.render(uni.words, n, params=uni.params, n_instances=3, instance=1))) <= 1e-5 * scale
+    prog.close()
+    ref.close()
     # one circuit, a long render: time is cut into segments (every FM carrier's start phases from the loop's own accumulate pass + prefix)
     one = descriptor.extract(d.Sum.many([env(3, j) for j in range(40)]))
     prog = render.context(48000).build(one.words, runtime.ENGINE_WAVE)
