@@ -256,6 +256,8 @@ static dusp::Knobs read_knobs() {
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
     k.jit_lean = num("DUSP_JIT_LEAN", k.jit_lean);
     k.jit_log = num("DUSP_JIT_LOG", k.jit_log);
+    k.ring_window = num("DUSP_RING_WINDOW", k.ring_window);
+    k.ring_poison = num("DUSP_RING_POISON", k.ring_poison);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
         if (std::sscanf(f, "%dx%d", &w, &r) == 2 && w >= 1 && w <= 16 && r >= 1 && r <= 4) k.jit_force_waves = w, k.jit_force_per_wave = r;
@@ -722,6 +724,83 @@ constexpr int kJitLater = 1;  // render_jit: the kernel is being compiled in the
 
 // WAVE programs the circuit compiler takes: ONE kernel generated for this circuit's structure (jit_codegen.hpp), compiled for
 // gfx950 in process the first time the structure is seen (jit_engine.hip), cached from then on.
+// Rings start as zeros (Delay.js:14, CircleBuffer.js:12).  A render that nothing continues only ever touches part of a long ring — a
+// Delay of constant length d reads [clock, clock + n) and writes up to d + 1 further on; a CircleBuffer node with an unconnected
+// offset walks n slots from where its clock starts — and a default Delay line is five seconds per instance: zeroing all of it
+// was most of such a render's time (reference patch "multitap" x 256: 236 GB of fill for 0.6 ms of kernel).  So only what can be
+// touched is filled, with a chunk or two to spare for the kernels' look-ahead; anything else (a modulated or per-instance delay,
+// a ring shorter than its window, a program that will be continued) fills the whole ring as before.
+// instance_major: rings laid out [instance][slot] (wave engine, compiled kernels), else [slot][n_pad] (chunk engine).
+static hipError_t zero_rings(dusp_program *prog, uint32_t n_pad, uint32_t n_chunks, bool instance_major, hipStream_t stream) {
+    const dusp::Program &P = prog->P;
+    float *rings = prog->d_rings.p;
+    const size_t total = (size_t)P.ring_samples;
+    if (prog->ctx->knobs.ring_poison) {  // (tests: what the fill leaves out holds NaN patterns, so a window cut too short shows)
+        if (hipError_t e = hipMemsetAsync(rings, 0xff, total * n_pad * sizeof(float), stream)) return e;
+    }
+    struct Win { int64_t at, count; };
+    std::vector<Win> wins;
+    bool windowed = !prog->resumable && prog->ctx->knobs.ring_window != 0 && P.warm_ops.empty();
+    size_t covered = 0;
+    const double N = (double)n_chunks * dusp::kChunk, spare = 2.0 * dusp::kChunk + 4.0;
+    auto add = [&](const dusp::DevOp &op, double from, double upto) {  // [from, upto) in the op's ring, wrapped
+        const double len = (double)op.ring_len;
+        from -= spare;
+        upto += spare;
+        if (!(upto - from < len)) {
+            wins.push_back({op.ring_base, op.ring_len});
+            covered += (size_t)op.ring_len;
+            return;
+        }
+        double a = fmod(floor(from), len);
+        if (a < 0) a += len;
+        const int64_t at = (int64_t)a, count = (int64_t)(ceil(upto) - floor(from));
+        const int64_t head = std::min(count, op.ring_len - at);
+        wins.push_back({op.ring_base + at, head});
+        if (count > head) wins.push_back({op.ring_base, count - head});
+        covered += (size_t)count;
+    };
+    for (const dusp::DevOp &op : P.ops) {
+        if (!windowed) break;
+        if (op.ring_len <= 0) continue;
+        const double len = (double)op.ring_len, sr = (double)P.g.sample_rate;
+        const double c0 = (double)(P.g.clock0 % op.ring_len);
+        const bool k0 = op.in[0].kind == dusp::SRC_CONST, k1 = op.in[1].kind == dusp::SRC_CONST;
+        const double T0 = (size_t)op.state_slot < P.init_state.size() ? P.init_state[(size_t)op.state_slot] : NAN;  // (the nodes' own clock)
+        switch (op.op) {
+        case dusp::OP_DELAY:
+        case dusp::OP_MONO_DELAY: {
+            const double d = (double)op.in[1].cval;
+            if (k1 && d >= 0.0 && d < len) add(op, c0, c0 + N + d + 2.0);
+            else add(op, 0.0, len);
+            break;
+        }
+        case dusp::OP_CB_READER:
+        case dusp::OP_CB_WRITER: {
+            const double o = sr * (double)op.in[0].cval * (op.op == dusp::OP_CB_READER ? -1.0 : 1.0);
+            if (k0 && std::isfinite(T0) && std::isfinite(o) && fabs(T0 + o) < 1e15) add(op, T0 + o, T0 + o + N + 1.0);
+            else add(op, 0.0, len);
+            break;
+        }
+        case dusp::OP_READBACK_DELAY: {
+            const double d = (double)op.in[1].cval;
+            if (k1 && std::isfinite(T0) && d >= 0.0 && d < len && fabs(T0) < 1e15) add(op, T0 - d, T0 + N + 1.0);
+            else add(op, 0.0, len);
+            break;
+        }
+        default: add(op, 0.0, len);
+        }
+    }
+    if (!windowed || wins.empty() || covered * 2 > total || wins.size() > 64)
+        return hipMemsetAsync(rings, 0, total * n_pad * sizeof(float), stream);
+    for (const Win &w : wins) {
+        hipError_t e = instance_major ? hipMemset2DAsync(rings + w.at, total * sizeof(float), 0, (size_t)w.count * sizeof(float), n_pad, stream)
+                                      : hipMemsetAsync(rings + (size_t)w.at * n_pad, 0, (size_t)w.count * n_pad * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // handoff_chunks > 0: this launch continues a render whose first handoff_chunks chunks the chunk engine has just rendered (Program::warm_ops):
 // start state in d_handoff_init, rings and outlets' last chunk already in this kernel's layout.
 // probe: only find out whether the kernel is at hand (DUSP_OK) or being compiled in the background (kJitLater); nothing is launched.
@@ -942,7 +1021,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     a.state = prog->d_state.p;
     if (P.ring_samples && !resume) {  // Delay rings start as zeros (Delay.js:14); layout [instance][slot]
         HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
-        HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+        HIP_TRY(ctx, zero_rings(prog, n_pad, n_chunks, true, stream));
     }
     a.rings = prog->d_rings.p;
     a.resume = resume ? 1u : 0u;
@@ -1180,7 +1259,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         if (resume && n_inst != prog->last_n_inst) CTX_FAIL(ctx, DUSP_ERR_STATE, "render: the instance count cannot change while a program is being continued");
         if (P.ring_samples && !resume) {  // Delay rings start as zeros (Delay.js:14); wave-engine layout [instance][slot]
             HIP_TRY(ctx, prog->d_rings.ensure((size_t)P.ring_samples * n_pad));
-            HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+            HIP_TRY(ctx, zero_rings(prog, n_pad, n_chunks, true, stream));
         }
         w.rings = prog->d_rings.p;
         w.resume = resume ? 1u : 0u;
@@ -1310,7 +1389,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         HIP_TRY(ctx, prog->d_rings.ensure(std::max<size_t>(1, (size_t)P.ring_samples) * n_pad));
         // outlets' chunks and all rings start as zeros (SignalChunk.js:7, Delay.js:14, CircleBuffer.js:12)
         HIP_TRY(ctx, hipMemsetAsync(prog->d_scratch.p, 0, (size_t)std::max(1, P.n_bufs) * dusp::kChunk * n_pad * sizeof(float), stream));
-        if (P.ring_samples) HIP_TRY(ctx, hipMemsetAsync(prog->d_rings.p, 0, (size_t)P.ring_samples * n_pad * sizeof(float), stream));
+        if (P.ring_samples) HIP_TRY(ctx, zero_rings(prog, n_pad, n_chunks, false, stream));
     }
     prog->keep_memory = false;
     HIP_TRY(ctx, dusp::launch_state_init(prog->d_state.p, prog->d_init.p, (uint32_t)n_slots, n_pad, stream));

@@ -226,3 +226,36 @@ def test_the_oscillators_other_forms_render_the_same_pcm(knobs, oracle):
             prog.close()
             seen += 1
     assert seen >= 2 * len(OSC_GOLDEN) - 8
+
+
+RING_GOLDEN = [n for n in ALL_GOLDEN if n.startswith(("delay_", "loop_", "circlebuffer_", "fam_", "patch_"))]
+
+
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "interp"])
+def test_rings_are_zeroed_wherever_a_render_can_touch_them(engine):
+    """A render nothing continues zero-fills only the part of each delay ring it can touch (dusp_abi.hip zero_rings: a five-second
+    default Delay line is mostly out of a short render's reach).  DUSP_RING_POISON=1 fills the rings with NaN patterns first, so a window
+    cut too short shows in the PCM: every golden with a ring, alone and as a batch of 70 (two rows of instances), bit for bit against
+    the reference's own output, and the same with the windows switched off."""
+    seen = 0
+    for name in RING_GOLDEN:
+        g = Golden(name)
+        knobs = {"DUSP_RING_POISON": 1}
+        if engine == "interp":
+            knobs["DUSP_WAVE_JIT"] = 0
+        for window in (1, 0):
+            ctx = knob_context(g.sample_rate, DUSP_RING_WINDOW=window, **knobs)
+            try:
+                prog = ctx.build(g.desc, ENGINES[engine])
+            except runtime.DuspHipError as e:
+                assert engine in ("wave", "interp") and e.status == -2, e
+                continue
+            if prog.n_params or prog.n_inputs:
+                prog.close()
+                continue
+            pcm = prog.render(g.n_samples, 70)
+            for i in (0, 63, 64, 69):
+                check(name, g.windowed(pcm[i]), g.pcm, engine)
+            prog.close()
+            seen += 1
+    assert seen >= 2 * 10

@@ -74,8 +74,8 @@ for name, g in graphs.items():
         continue
     if isinstance(g, str):
         words = np.fromfile(os.path.join(GOLDEN, g + ".desc.f64"), dtype=np.float64)
-        V_, dp, params = 256, None, None  # (some of these patches own seconds of delay line per instance: patch_multitap's CircleBuffer is 230 M samples, so its
-        # launch starts by zero-filling 236 GB of rings for 256 instances — the 38 ms it shows are that fill, not its kernel)
+        V_, dp, params = 256, None, None  # (some of these patches own seconds of delay line per instance: patch_multitap's CircleBuffer is 230 M samples —
+        # 236 GB of rings for 256 instances; a render zero-fills the part of them it can reach (dusp_abi.hip zero_rings): 38 ms with the whole fill, 1.1 ms now)
         prog = ctx.build(words, runtime.ENGINE_AUTO)
     else:
         full = descriptor.unify([descriptor.extract(g(k)) for k in (0, 8, 16)])
