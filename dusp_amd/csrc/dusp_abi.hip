@@ -257,6 +257,8 @@ static dusp::Knobs read_knobs() {
     k.jit_lean = num("DUSP_JIT_LEAN", k.jit_lean);
     k.jit_log = num("DUSP_JIT_LOG", k.jit_log);
     k.ring_window = num("DUSP_RING_WINDOW", k.ring_window);
+    k.filter_scan = num("DUSP_FILTER_SCAN", k.filter_scan);
+    k.jit_nt = num("DUSP_JIT_NT", k.jit_nt);
     k.ring_poison = num("DUSP_RING_POISON", k.ring_poison);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
@@ -898,6 +900,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     opt.voice_loop = voice_loop;
     opt.profile = ctx->knobs.jit_profile != 0;
     opt.filter_fma = ctx->knobs.filter_fma != 0;
+    opt.nt_stores = ctx->knobs.jit_nt == 1 || (ctx->knobs.jit_nt == 2 && P.ring_samples != 0);
     for (int k = 0; k < dusp::kNumTables; k++) opt.table_form[k] = ctx->table_form[k], opt.table_delta[k] = ctx->knobs.jit_lean ? ctx->table_delta[k] : 0, opt.table_bound[k] = ctx->table_bound[k];
     // the LDS image goes to the first oscillator table that needs one (saw / square / triangle are evaluated, not looked up)
     for (const dusp::DevOp &op : P.ops)
@@ -907,8 +910,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
         }
     opt.scratch_floats = dusp::jit_scratch_floats(P);
-    opt.filter_stages = dusp::jit_filter_stages(P);
-    opt.filter_mod = dusp::jit_filter_mod(P);
+    // Filters whose cutoff is a constant of the circuit, high enough for the bound of jit_filter_scan_ok: a scan over the chunk, the circuit
+    // an ordinary one (no Filter stage).  Not for programs that are continued (the stage's y1 / y2 are what the other engines hand over).
+    opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && dusp::jit_filter_scan_ok(P);
+    opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
+    opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
@@ -1783,9 +1789,10 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
                 opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
             }
     }
-    opt.filter_stages = dusp::jit_filter_stages(P);
-    opt.filter_mod = dusp::jit_filter_mod(P);
-    if (plan.has_filter) {
+    opt.filter_scan = !continued && !(getenv("DUSP_FILTER_SCAN") && atoi(getenv("DUSP_FILTER_SCAN")) == 0) && dusp::jit_filter_scan_ok(P);
+    opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
+    opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
+    if (plan.has_filter && !opt.filter_scan) {
         const size_t left = 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4;
         opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, opt.filter_mod);
         if (!opt.filter_sub) {

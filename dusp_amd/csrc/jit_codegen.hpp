@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "device_types.hpp"
+#include "filter_lamda.hpp"
 #include "fused_plan.hpp"
 #include "program.hpp"
 
@@ -50,6 +51,7 @@ struct JitOptions {
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
+    bool filter_scan = false;  // every Filter of the circuit as a scan over the chunk (jit_filter_scan_ok, JitFilterScan): no Filter stage, no tile
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
     int table_delta[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // the lerp's delta form (device_util.hpp lerp_delta): 0 not for this table, 1 differences of neighbours in f64, 2 in f32
@@ -58,6 +60,7 @@ struct JitOptions {
     bool voice_loop = false; // a sum of isomorphic voices above jit_loop_voices_from() units gets its voices in a loop (VoicePlan): unsplit renders only
     bool persistent = false; // a continued program with delay lines / feedback: outlets parked between launches, rings in the reference's state
     bool filter_fma = false; // EXPERIMENT (DUSP_FILTER_FMA=1): the Filter stage's recurrence with one fused multiply-add on its dependent chain
+    bool nt_stores = false;  // the copy-out with non-temporal stores (circuits with delay rings in memory: DUSP_JIT_NT)
     bool profile = false;    // diagnostic build (DUSP_JIT_PROFILE=1): wave 0 of every workgroup stamps the cycle counter around the chunk loop and
                              // inside the Filter stage's serial part and leaves the sums in JitArgs::debug
 };
@@ -87,6 +90,64 @@ inline int jit_filter_stages(const Program &P) {
     int n = 0;
     for (const DevOp &op : P.ops) n += op.op == OP_FILTER;
     return n;
+}
+// Can every Filter of the circuit run as a scan (jit_prelude.hpp JitFilterScan)?  Each needs a cutoff that is a constant of the
+// circuit and coefficients whose all-pole part 1 / (1 + b1 z^-1 + b2 z^-2) has an impulse response of sum|h| <= 32: the scan carries
+// unrounded pairs where the reference rounds y to f32 every step (an error of at most 2^-24 |y| a step, which reaches later samples
+// through that all-pole part), so its results stay within 2^-24 sum|h| of the signal's scale of the reference's — 2^-19, 1.9e-6, a fifth
+// of this path's 1e-5.  (48 kHz: cutoffs between about 1.5 and 22.5 kHz, either kind.)
+inline bool jit_filter_scan_ok(const Program &P) {
+    bool any = false;
+    for (const DevOp &op : P.ops) {
+        if (op.op != OP_FILTER) continue;
+        any = true;
+        if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return false;
+        const double *is = P.init_state.data() + op.state_slot, f = (double)op.in[1].cval;
+        double k[5];
+        if (is[0] == 0.0 || f != is[1]) butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
+        else
+            for (int i = 0; i < 5; i++) k[i] = is[2 + i];
+        for (double v : k)
+            if (!std::isfinite(v)) return false;
+        double h1 = 1.0, h2 = 0.0, sum = 1.0;
+        int quiet = 0;
+        for (int t = 0; t < 100000 && quiet < 8; t++) {
+            const double h = -k[3] * h1 - k[4] * h2;
+            h2 = h1;
+            h1 = h;
+            sum += std::fabs(h);
+            if (!(sum <= 32.0)) return false;
+            quiet = std::fabs(h) < 1e-13 ? quiet + 1 : 0;
+        }
+        if (quiet < 8) return false;
+    }
+    if (!any) return false;
+    // ... and what hangs on a Filter's output must pass that deviation on as it is: sums, products, sign flips, copies, the SIGNAL
+    // inlet of a delay line or of another Filter (feedback loops included), the outlets.  Where a Filter reaches an oscillator's
+    // frequency, a delay TIME, a division, a power, a clip or an envelope — units that integrate or bend their input — the circuit
+    // keeps the Filter stage and its bits.
+    std::vector<char> tainted((size_t)std::max(1, P.n_bufs), 0);
+    for (int sweep = 0; sweep < 2 + (int)P.ops.size(); sweep++) {  // (to a fixed point: feedback edges run against the order)
+        bool grew = false;
+        for (const DevOp &op : P.ops) {
+            bool dep[kMaxIn] = {};
+            bool any_dep = false;
+            for (int j = 0; j < kMaxIn && j < std::max(op.n_in, 2); j++)
+                if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && tainted[(size_t)op.in[j].idx]) dep[j] = any_dep = true;
+            if (op.op != OP_FILTER && !any_dep) continue;
+            switch (op.op) {
+            case OP_FILTER: case OP_MULTIPLY: case OP_SUM: case OP_SUBTRACT: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_FIXED_MULTIPLY: break;
+            case OP_DELAY: case OP_MONO_DELAY:
+                if (dep[1]) return false;  // (the delay time)
+                break;
+            case OP_FIXED_DELAY: break;
+            default: return false;
+            }
+            if (op.out_buf >= 0 && op.out_buf < P.n_bufs && !tainted[(size_t)op.out_buf]) tainted[(size_t)op.out_buf] = 1, grew = true;
+        }
+        if (!grew) break;
+    }
+    return true;
 }
 inline bool jit_filter_mod(const Program &P) {
     for (const DevOp &op : P.ops)
@@ -524,7 +585,7 @@ struct Emitter {
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
-    bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER; }
+    bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && !opt.filter_scan; }  // (a scan Filter is a unit like any other)
     bool is_mod_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind == SRC_BUF; }  // a connected cutoff
 
     // The Filter stage keeps ONE wave busy with the recurrences while the others wait; whatever the chunk holds that neither feeds a
@@ -795,7 +856,14 @@ struct Emitter {
                 default: break;
                 }
             }
-            if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
+            if (op.op == OP_FILTER && opt.filter_scan) {  // a scan over the chunk: coefficients and matrix powers once, the memory per instance
+                line("    JitFilterScanK fk" + num(k) + ";");
+                line("    fk" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + opnd(k, 1, "0", 0) + ", " + num(op.state_slot) + ");");
+                for (int r = 0; r < copies(k); r++) {
+                    line("    JitFilterScan f" + num(k) + "_" + num(r) + ";");
+                    line("    f" + num(k) + "_" + num(r) + ".begin(A, " + num(op.state_slot) + ");");
+                }
+            } else if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) {  // a connected cutoff: coefficients per sample, in the tile next to P
                 line("    JitFilterKM<" + W + ", " + RR + ", " + num(opt.filter_sub) + ", " + num((long long)jit_filter_rows_bytes(opt.waves * opt.per_wave, opt.filter_sub, opt.filter_mod)) + "> f" + num(k) + ";");
                 line("    f" + num(k) + ".begin(A, X[0], tile, " + num(filter_ordinal++) + ", " + num(op.state_slot) + ");");
                 for (int r = 0; r < R; r++) line("    f" + num(k) + ".begin_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(op.state_slot) + ");");
@@ -849,7 +917,8 @@ struct Emitter {
         if (render) {
             // state write-back: what every unit holds after ceil(n_samples / 256) ticks, in the chunk engine's slot layout
             for (size_t k = 0; k < P.ops.size(); k++)
-                if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind == SRC_BUF) {
+                if (P.ops[k].op == OP_FILTER && opt.filter_scan) continue;  // (with the other units' state, below)
+                else if (P.ops[k].op == OP_FILTER && P.ops[k].in[1].kind == SRC_BUF) {
                     line("    f" + num((long long)k) + ".end(A, X[0], tile, " + num(P.ops[k].state_slot) + ");");
                     for (int r = 0; r < R; r++)
                         line("    f" + num((long long)k) + ".end_slot(A, " + ctx(r) + ", " + num(r) + ", " + num(P.ops[k].attr) + ", " + num(P.ops[k].state_slot) + ");");
@@ -879,6 +948,7 @@ struct Emitter {
                     if (op.op == OP_RETRIGGER) line("        " + slot + " = r" + id + ".T;");
                     if (op.op == OP_SAMPLE_RATE_REDUX) line("        h" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_MULTI_OSC) line("        " + slot + " = m" + id + ".phase;");
+                    if (op.op == OP_FILTER && opt.filter_scan) line("        f" + id + ".end(A, " + ctx(r) + ", fk" + num((long long)k) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) line("        " + slot + " = n" + id + ".T;");
                 }
                 line("    }");
@@ -1110,7 +1180,7 @@ struct Emitter {
     void unit(int k, bool render, int pass_level, bool fx) {
         const DevOp &op = P.ops[(size_t)k];
         const std::string dref = dconst_of[(size_t)k] >= 0 ? "d" + num(dconst_of[(size_t)k]) : std::string("0.0");
-        if (op.op == OP_FILTER && is_mod_stage(k)) {
+        if (op.op == OP_FILTER && !opt.filter_scan && is_mod_stage(k)) {
             // A connected cutoff: the coefficient code (a division, two polynomials, the math library's tan() for cutoffs outside 0 .. Nyquist)
             // is bulky, so it stands ONCE per pass in a loop over the sub-blocks — with the redo of a sub-block that met a NaN as a second
             // trip through the same code — instead of once per sub-block and case (a kernel of 280 KB otherwise: the instruction cache holds 64).
@@ -1140,7 +1210,7 @@ struct Emitter {
             line("        }");
             return;
         }
-        if (op.op == OP_FILTER) {
+        if (op.op == OP_FILTER && !opt.filter_scan) {
             filter_feed(k);
             for (int sb = 0; sb < kChunk / opt.filter_sub; sb++) filter_sub_block(k, sb, std::string());
             return;
@@ -1260,6 +1330,12 @@ struct Emitter {
                 if (!mix) line("        const float t" + id + "[4] = {0.f, 0.f, 0.f, 0.f};");
                 line("        n" + id + ".write<" + ((op.attr & 1) ? "true" : "false") + ", " + (mix ? "true" : "false") + ">(A, " + X_ + ", (int64_t)" + dref + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " +
                      opnd(k, 0, "0", r) + ", " + (mix ? x : "t" + id) + ");");
+                break;
+            }
+            case OP_FILTER: {  // (opt.filter_scan: the others left through the Filter stage above)
+                decl();
+                const std::string x = opnd_array(k, 0, "t" + id, r);
+                line("        f" + id + ".tick(" + X_ + ", fk" + num(k) + ", " + x + ", " + v + ");");
                 break;
             }
             case OP_MULTI_OSC: {
@@ -1624,7 +1700,7 @@ struct Emitter {
             } else if (op.op == OP_AHD)
                 dconst_of[k] = add_dk(op.d[0]); else if (op.op == OP_TIMER || (op.op >= OP_MAP_FIRST && op.op <= OP_MAP_LAST) || (op.op >= OP_WIDE_FIRST && op.op <= OP_WIDE_LAST))
                 dconst_of[k] = add_dk(op.d[0]);
-            if (op.op == OP_FILTER) { out.has_filter = true; out.n_filters++; }  // (the workgroup-wide stage)
+            if (op.op == OP_FILTER && !opt.filter_scan) { out.has_filter = true; out.n_filters++; }  // (the workgroup-wide stage)
         }
         for (int b : P.out_bufs)
             if (producer[(size_t)b] < 0) { out.why = "the rendered outlet has no producer"; return false; }
@@ -1668,6 +1744,7 @@ struct Emitter {
         line("// generated by dusp_amd/csrc/jit_codegen.hpp — one kernel per topologically sorted Circuit");
         if (opt.profile) line("#define DUSP_JIT_PROFILE 1");
         if (opt.filter_fma) line("#define DUSP_FILTER_FMA 1  // (experiment: not the reference's roundings)");
+        if (opt.nt_stores) line("#define DUSP_NT_STORES 1  // (PCM leaves past the caches: the circuit's delay rings are what they are for)");
         line("#include \"jit_prelude.hpp\"");
         line("using namespace dusp;");
         // f64 constants are read where they are used (loop-invariant scalar loads)

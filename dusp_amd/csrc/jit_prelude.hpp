@@ -1549,6 +1549,165 @@ struct JitFilterK {
         st[(size_t)10 * A.n_pad] = mem[1];
     }
 };
+// ---- Filter with a cutoff that is a constant of the circuit, as a SCAN over the chunk instead of the workgroup's serving wave.
+// Filter.js:40-46 is y[t] = f32((P[t] - b1 y[t-1]) - b2 y[t-2]): a chain of 480 000 dependent steps for ten seconds, five
+// instructions a step — what a circuit with a Filter stage takes however many instances share the chip.  Without the
+// rounding to f32 the recurrence is LINEAR: the pair s = (y[t], y[t-1]) after a stretch of samples is  M^n s_before + (the stretch's
+// response from rest),  M = [[-b1, -b2], [1, 0]], and stretches combine associatively.  So the wave renders its chunk at once: every
+// lane runs its four samples from rest (lane 0: from the carried pair), a scan over the lanes — four steps inside the rows of 16
+// (DPP row_shr 1 2 4 8 with M^4 M^8 M^16 M^32), three across them (the row's last lane broadcast, times M^(4 (j + 1)) held per
+// lane) — gives every lane the pair in front of its samples, and the lane runs its four steps again from there, rounding each y to
+// f32 as the reference does.  What differs from the reference is that the scan carries UNROUNDED pairs: the reference's rounding
+// errors (at most 2^-24 |y| a step) never enter, and a rounding error e[t] reaches later samples through the all-pole part
+// 1 / (1 + b1 z^-1 + b2 z^-2).  The deviation is therefore at most  2^-24 max|y| sum|h|  with h that part's impulse response — the
+// code generator takes this form only where that bound is 2^-19 (1.9e-6) of the signal's scale (jit_filter_scan_ok: sum|h| <= 32, cutoffs
+// between about 1.5 and 22.5 kHz at 48 kHz), a fifth of the 1e-5 this path is held to; lower cutoffs keep the serving wave, bit for bit.
+// A chunk that meets a NaN or anything beyond 1e30 (where the reference's `|| 0` or f32 overflow would act) is run again as written:
+// serially, out of the lanes' registers.
+struct JitFilterScanK {  // one per Filter: what the wave's instances share
+    double k[5], lastF;  // a0 a1 a2 b1 b2 (uniform)
+    double m[4][4];      // M^4, M^8, M^16, M^32: m11 m12 m21 m22 (the same in every lane; vector registers — four f64 operands a step)
+    double w[4], w2[4];  // lane j of its row: M^(4 (j + 1)); the same times M^64 in the last row (what lane 31's pair has to cross to get there)
+    static __device__ __forceinline__ void mul(const double (&a)[4], const double (&b)[4], double (&c)[4]) {
+        const double c0 = fma(a[0], b[0], a[1] * b[2]), c1 = fma(a[0], b[1], a[1] * b[3]), c2 = fma(a[2], b[0], a[3] * b[2]), c3 = fma(a[2], b[1], a[3] * b[3]);
+        c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+    }
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, int kind, float f, int state_slot) {
+        const double *is = A.init_state + state_slot;  // has_lastF lastF a0 a1 a2 b1 b2 x1 x2 y1 y2
+        const double ft = (double)f;
+        if (is[0] == 0.0 || ft != is[1]) jit_filter_coefficients(kind, ft, X.srd, k);  // `if (this.f[t] != this.lastF)`
+        else
+            for (int i = 0; i < 5; ++i) k[i] = is[2 + i];
+        for (int i = 0; i < 5; ++i) k[i] = jit_u(k[i]);
+        lastF = jit_u(ft);
+        const double M[4] = {-k[3], -k[4], 1.0, 0.0};
+        double M2[4];
+        mul(M, M, M2);
+        mul(M2, M2, m[0]);
+        for (int i = 1; i < 4; ++i) mul(m[i - 1], m[i - 1], m[i]);
+        for (int j = 0; j < 4; ++j) w[j] = m[0][j];
+        for (uint32_t i = 0; i < 15u; ++i) {
+            double n[4];
+            mul(w, m[0], n);
+            if (i < (X.lane & 15u))
+                for (int j = 0; j < 4; ++j) w[j] = n[j];
+        }
+        double M64[4], far[4];
+        mul(m[3], m[3], M64);
+        mul(w, M64, far);
+        for (int j = 0; j < 4; ++j) w2[j] = X.lane >= 48u ? far[j] : w[j];
+    }
+};
+
+struct JitFilterScan {  // one per Filter and instance
+    float x1, x2;   // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
+    double s1, s2;  // lane 63: the two outputs before the chunk (f32 values)
+    __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
+        const double *is = A.init_state + state_slot;
+        x1 = jit_u((float)is[7]);
+        x2 = jit_u((float)is[8]);
+        s1 = is[9];
+        s2 = is[10];
+    }
+    static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
+    template <int CTRL, int ROWS, bool ZERO>
+    static __device__ __forceinline__ double dpp(double old, double v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)__double2loint(old), (int)(uint32_t)__double2loint(v), CTRL, ROWS, 0xf, ZERO);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)__double2hiint(old), (int)(uint32_t)__double2hiint(v), CTRL, ROWS, 0xf, ZERO);
+        return __hiloint2double((int)hi, (int)lo);
+    }
+    static __device__ __forceinline__ double lane_of(double v, uint32_t l) {  // (l uniform)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double2loint(v), (int)l);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double2hiint(v), (int)l);
+        return __hiloint2double((int)hi, (int)lo);
+    }
+    template <int I>
+    static __device__ __forceinline__ void step(const JitFilterScanK &K, double &c1, double &c2) {
+        const double t1 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c1), t2 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c2);  // row_shr, zeros shifted in
+        c1 = fma(K.m[I][0], t1, fma(K.m[I][1], t2, c1));
+        c2 = fma(K.m[I][2], t1, fma(K.m[I][3], t2, c2));
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, const JitFilterScanK &K, const float (&x)[4], float (&out)[4]) {
+        const double a0 = K.k[0], a1 = K.k[1], a2 = K.k[2], b1 = K.k[3], b2 = K.k[4];
+        // the feed-forward half P[t] = a0 x[t] + a1 x[t-1] + a2 x[t-2] (a NaN among the inputs ends in the check below)
+        const float l1 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x1), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
+        const float l2 = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x2), __float_as_uint(x[2]), 0x138, 0xf, 0xf, false));
+        const double o[6] = {(double)l2, (double)l1, (double)x[0], (double)x[1], (double)x[2], (double)x[3]};
+        double p[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = fma(a2, o[c], fma(a1, o[c + 1], a0 * o[c + 2]));
+        // the lane's four samples from rest (lane 0: from the carried pair — lane 63's of the last chunk)
+        const double r1 = dpp<0x13c, 0xf, false>(0.0, s1), r2 = dpp<0x13c, 0xf, false>(0.0, s2);  // wave_ror:1
+        const double in1 = X.lane == 0 ? r1 : 0.0, in2 = X.lane == 0 ? r2 : 0.0;
+        double c1 = in1, c2 = in2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double z = fma(-b2, c2, fma(-b1, c1, p[c]));
+            c2 = c1;
+            c1 = z;
+        }
+        // inside the rows of 16; then lane 15 to the row behind it (rows 1 and 3), lane 31 to rows 2 and 3
+        step<0>(K, c1, c2);
+        step<1>(K, c1, c2);
+        step<2>(K, c1, c2);
+        step<3>(K, c1, c2);
+        {
+            const double t1 = dpp<0x142, 0xa, false>(0.0, c1), t2 = dpp<0x142, 0xa, false>(0.0, c2);  // row_bcast:15
+            c1 = fma(K.w[0], t1, fma(K.w[1], t2, c1));
+            c2 = fma(K.w[2], t1, fma(K.w[3], t2, c2));
+        }
+        {
+            const double t1 = dpp<0x143, 0xc, false>(0.0, c1), t2 = dpp<0x143, 0xc, false>(0.0, c2);  // row_bcast:31
+            c1 = fma(K.w2[0], t1, fma(K.w2[1], t2, c1));
+            c2 = fma(K.w2[2], t1, fma(K.w2[3], t2, c2));
+        }
+        // the pair in front of this lane's samples, and the samples once more from there, every y rounded as the reference rounds it
+        double u1 = dpp<0x138, 0xf, false>(in1, c1), u2 = dpp<0x138, 0xf, false>(in2, c2);  // wave_shr:1 (lane 0 keeps the carried pair)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y = (float)fma(-b2, u2, fma(-b1, u1, p[c]));
+            out[c] = y;
+            u2 = u1;
+            u1 = (double)y;
+        }
+        const bool odd = !(fabsf(out[0]) < 1e30f && fabsf(out[1]) < 1e30f && fabsf(out[2]) < 1e30f && fabsf(out[3]) < 1e30f && fabs(c1) < 1e30);
+        if (__builtin_amdgcn_ballot_w64(odd) != 0) {
+            // as written (Filter.js:40-46), sample by sample out of the lanes' registers
+            const double e[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = (a0 * (double)x[c] + a1 * e[c + 1]) + a2 * e[c];
+            double v1 = lane_of(s1, 63), v2 = lane_of(s2, 63);
+#pragma unroll 1
+            for (uint32_t l = 0; l < 64u; ++l) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double pv = lane_of(p[c], l);
+                    const float y = (float)((pv - b1 * jit_or0(v1)) - b2 * jit_or0(v2));
+                    if (X.lane == l) out[c] = y;
+                    v2 = jit_or0(v1);
+                    v1 = (double)y;
+                }
+            }
+            u1 = v1;
+            u2 = v2;
+        }
+        s1 = u1;
+        s2 = u2;
+        x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        x2 = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
+    }
+    __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const JitFilterScanK &K, int state_slot) const {  // (lane 0 of the instance's last segment)
+        double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+        st[0] = 1.0;
+        st[A.n_pad] = K.lastF;
+        for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = K.k[i];
+        st[(size_t)7 * A.n_pad] = (double)x1;
+        st[(size_t)8 * A.n_pad] = (double)x2;
+        st[(size_t)9 * A.n_pad] = lane_of(s1, 63);
+        st[(size_t)10 * A.n_pad] = lane_of(s2, 63);
+    }
+};
+
 // parameter `slot` of the instance lane `lane` serves in the Filter stage
 template <int WAVES, int R>
 __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X, uint32_t slot) {

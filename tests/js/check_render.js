@@ -8,7 +8,7 @@ const SR = lib.config.sampleRate
 const GOLDEN = path.join(__dirname, '..', 'golden')
 const goldenCases = require('./cases')
 const cases = goldenCases(lib, SR)
-const USES_DEVICE_TAN = /^(loop_|filter_|map_gain|map_db_semitone|map_pow|map_fm_semitone|rest_pan|rest_midi|ev_filter|ev_loop|rt_|str_)/ // device tan() / pow()
+const USES_DEVICE_TAN = /^(loop_|filter_|map_gain|map_db_semitone|map_pow|map_fm_semitone|rest_pan|rest_midi|ev_filter|ev_loop|rt_|str_|grow_feedback_filter)/ // device tan() / pow()
 
 async function main() {
   const report = { sampleRate: SR, checked: 0, exact: 0, withinTol: 0, failed: [], fromDescriptor: 0 }

@@ -85,7 +85,8 @@ def test_fm_levels_get_their_accumulate_passes():
     assert "dusp_jit_pass" not in source(descriptor.extract(d.Filter(inner, 800)).words)
 
 
-def test_feedback_edges_read_last_iterations_registers():
+def test_feedback_edges_read_last_iterations_registers(monkeypatch):
+    monkeypatch.setenv("DUSP_FILTER_SCAN", "0")  # (the Filter stage's form; the scan form: test_filters_with_a_constant_cutoff_run_as_a_scan)
     g = Golden("loop_220")
     text = source(g.desc, waves=8)
     late = set(re.findall(r"float (w\d+_0)\[4\] = \{0\.f", text))
@@ -95,10 +96,11 @@ def test_feedback_edges_read_last_iterations_registers():
     assert "JitFilterK<8, 1, 256, 1, " in text and "JitDelayK" in text
 
 
-def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
-    """The Filter stage keeps one wave busy while the others would wait.  The generated chunk body therefore sorts its units: what the
+def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences(monkeypatch):
+    """(DUSP_FILTER_SCAN=0: the form of cutoffs below the scan's bound, per-instance cutoffs and continued programs.)  The Filter stage keeps one wave busy while the others would wait.  The generated chunk body therefore sorts its units: what the
     Filter's input needs runs a chunk AHEAD (`early`, where nothing else reads it), what neither feeds a Filter nor hangs on one runs
     in a `side` block, both between the barriers of a sub-block on the waves that do not serve it; waves 0 and 1 take turns serving."""
+    monkeypatch.setenv("DUSP_FILTER_SCAN", "0")
     d.configure(48000)
     def loop(k):   # BASELINE configs[3]: the Delay's reads feed the Filter, everything else only reaches the ring
         s = d.Sum(d.Osc(110 + k / 64), 0)
@@ -129,6 +131,41 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences():
     tail = fast.split("};")[-1]
     assert tail.index("f1.serial<8>(X[0], tile, 1)") < tail.index("* k1") < tail.index("f3.feed(") < tail.index("f3.serial<8>(X[0], tile, 0)")
     assert fast.count("u >> X[0].wave) & 1u) { side0();") == 4
+
+
+def test_filters_with_a_constant_cutoff_run_as_a_scan():
+    """A Filter whose cutoff is a constant of the circuit, high enough for the bound of jit_codegen.hpp jit_filter_scan_ok (the all-pole
+    part's impulse response sums to at most 32: between about 1.5 and 22.5 kHz at 48 kHz), is a unit like any other — JitFilterScan, a scan over the
+    chunk's lanes — and the circuit has no Filter stage: no tile, no barriers, no serving wave.  Lower cutoffs, per-instance cutoffs,
+    connected cutoffs and continued programs keep the stage."""
+    d.configure(48000)
+    def loop(k, cutoff=2000):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), cutoff)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
+    text = source(uni.words, waves=16, per_wave=1, compile=True)
+    assert "JitFilterScanK fk4;" in text and "JitFilterScan f4_0;" in text and "f4_0.tick(X[0], fk4, v3_0, v4_0);" in text
+    assert "JitFilterK<" not in text and "tile" not in text.split('extern "C"')[1] and "jit_lds_barrier" not in text
+    assert "f4_0.end(A, X[0], fk4, 2);" in text                                             # state write-back in the chunk engine's slots
+    for build in (lambda k: loop(k, 600),                                                    # below the bound: bit for bit through the stage
+                  lambda k: loop(k, 2000 + k),                                               # a per-instance cutoff
+                  lambda k: d.Filter(d.Osc(200 + k), d.Sum(d.Multiply(d.Osc(5), 500), 3000)),  # a connected one
+                  lambda k: d.Filter(d.Filter(d.Osc(200 + k), 3000), 500)):                  # one of two below the bound: both stay
+        text = source(descriptor.unify([descriptor.extract(build(k)) for k in (0, 64)]).words, waves=16, per_wave=1)
+        assert "JitFilterScan" not in text and "JitFilterK" in text
+    assert "JitFilterScan" not in source(uni.words, waves=16, per_wave=1, continued=True)
+    # what hangs on the Filter must pass its deviation on as it is (sums, products, delay lines' signal inlets): a Filter that reaches
+    # an oscillator's frequency, a delay time or a division keeps its stage
+    for build in (lambda k: d.Osc(d.Sum(d.Multiply(d.Filter(d.Osc(3 + k), 3000), 40), 440)),
+                  lambda k: d.Delay(d.Osc(200 + k), d.Sum(d.Multiply(d.Filter(d.Osc(3), 3000), 100), 300), 4096),
+                  lambda k: d.Divide(d.Osc(200 + k), d.Sum(d.Filter(d.Osc(3), 3000), 2))):
+        assert "JitFilterScan" not in source(descriptor.unify([descriptor.extract(build(k)) for k in (0, 64)]).words, waves=16, per_wave=1)
+    wet = lambda k: d.Sum(d.Multiply(d.Delay(d.Filter(d.Osc(200 + k), 3000), 700.5, 4096), 0.4), d.Osc(330))
+    assert "JitFilterScan" in source(descriptor.unify([descriptor.extract(wet(k)) for k in (0, 64)]).words, waves=16, per_wave=1)
+    hp = source(descriptor.extract(d.Filter(d.Filter(d.Osc(300), 3000), 5000, "HP")).words, waves=4, compile=True)  # 4 poles: two scans
+    assert hp.count("JitFilterScanK fk") == 2
 
 
 def test_constant_delays_need_no_slot_operations():

@@ -87,7 +87,7 @@ def test_per_instance_delays_on_compiled_kernels(regime, delay_of, expect, oracl
     uni = descriptor.unify([descriptor.extract(loop(k)) for k in ks])
     assert uni.n_params == 2
     n = 256 * 14 + 100
-    ctx = render.context(48000)
+    ctx = knob_context(48000, DUSP_FILTER_SCAN=0)  # (the Filter through its stage: the chunk engine's bits; the Delay is what this test is about)
     prog = ctx.build(uni.words)  # AUTO
     assert prog.engine == "wave", prog.engine
     pcm = prog.render(n, uni.n_instances, uni.params)
@@ -95,6 +95,10 @@ def test_per_instance_delays_on_compiled_kernels(regime, delay_of, expect, oracl
     ref = ctx.build(uni.words, runtime.ENGINE_CHUNK)
     want = ref.render(n, uni.n_instances, uni.params)
     assert np.array_equal(pcm, want), "instance %d differs from the chunk engine" % int(np.argmax((pcm != want).any(axis=(1, 2))))
+    scan = render.context(48000).build(uni.words)  # the default: the 2 kHz Filter as a scan over the chunk, next to every kind of Delay
+    got = scan.render(n, uni.n_instances, uni.params)
+    assert expect in scan.read_shape() and float(np.max(np.abs(got.astype(np.float64) - want))) <= 4e-6 * float(np.max(np.abs(want)))
+    scan.close()
     for i in (0, 1, 17, uni.n_instances - 1):
         w = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
         assert np.max(np.abs(pcm[i].astype(np.float64) - w)) <= 1e-5 * max(1.0, float(np.max(np.abs(w)))), (regime, i)
@@ -141,22 +145,25 @@ def _filter_voice(kind, k):
     raise KeyError(kind)
 
 
+@pytest.mark.parametrize("scan", [0, 1])
 @pytest.mark.parametrize("kind", ["env_after", "dry_wet", "two_channels", "beside", "late_input"])
-def test_filter_circuits_in_full_workgroups(kind, oracle):
+def test_filter_circuits_in_full_workgroups(kind, scan, oracle):
     """Filter circuits at a batch size that fills workgroups of 16 wavefronts (several instances per wavefront, waves 0 and 1 taking
     turns at the recurrences, the other units beside them or a chunk ahead where the circuit allows): sampled instances against the
-    oracle, within the Filter tolerance (device tan())."""
+    oracle, within the Filter tolerance (device tan()).  scan = 1, the default: the circuits whose cutoffs are constants above the
+    scan's bound ("two_channels", "beside", "late_input") have no Filter stage — each wavefront scans its own chunk (JitFilterScan)."""
     d.configure(48000)
     V, n = 4096 + 17, 256 * 11 + 40
     ks = np.arange(V)
     uni = descriptor.unify([descriptor.extract(_filter_voice(kind, int(k))) for k in (0, 1, 2)])
     base = uni.params[:, 0].astype(np.float64)
     params = (base[:, None] + (uni.params[:, 1].astype(np.float64) - base)[:, None] * ks[None, :]).astype(np.float32)
-    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    prog = knob_context(48000, DUSP_FILTER_SCAN=scan).build(uni.words, runtime.ENGINE_WAVE)
     pcm = prog.render(n, V, params)
     prog._read_info()
     waves, per_wave = (int(t) for t in prog.shape.rsplit(" ", 1)[1].split("x"))
-    assert "compiled kernel" in prog.shape and waves >= 8 and waves * per_wave >= 17, prog.shape  # (several wavefronts: the turns are taken)
+    staged = not scan or kind in ("env_after", "dry_wet")
+    assert "compiled kernel" in prog.shape and waves >= 8 and (waves * per_wave >= 17 or not staged), prog.shape  # (several wavefronts: the turns are taken)
     for i in (0, 1, 31, 32, 63, 64, 1000, 1023, 1024, 2047, 2048, 4095, 4096, V - 1):
         want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)
         err = np.max(np.abs(pcm[i].astype(np.float64) - want))
@@ -257,6 +264,65 @@ def test_filter_takes_nan_inputs_as_the_reference_does(engine, oracle):
         assert np.max(np.abs(pcm[i].astype(np.float64) - want)) <= 1e-5 * max(1.0, float(np.max(np.abs(want)))), i
     assert met >= 5  # (the k = 0 instances divide 0 by 0 at every period's start)
     prog.close()
+
+
+def _scan_case(case, k):
+    o = d.Sum(d.Osc(220 + k / 4, "saw"), d.Multiply(d.Osc(3001 + k), 0.25))  # (a bright input: energy where the filters work)
+    if case == "lp1600":
+        return d.Filter(o, 1600)
+    if case == "lp20000":
+        return d.Filter(o, 20000)
+    if case == "hp5000":
+        return d.Filter(o, 5000, "HP")
+    if case == "four_poles":
+        return d.Filter(d.Filter(o, 3000), 9000, "HP")
+    if case == "loop":      # BASELINE configs[3]'s circuit
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    if case == "nan":       # 0 / 0 once a third of a second at the Filter's input: that chunk runs as written, the next ones scan on
+        return d.Filter(d.Sum(d.Osc(440 + k), d.Sum(d.Divide(d.Osc(3), d.Osc(3)), -1)), 2500)
+    if case == "inf":       # 1 / 0 there: y = Infinity, then NaN || 0
+        return d.Filter(d.Sum(d.Osc(440 + k), d.Multiply(d.Divide(1, d.Osc(3)), 1e-3)), 2500)
+    if case == "huge":      # beyond 1e30: every chunk as written
+        return d.Filter(d.Multiply(d.Osc(440 + k), 1e35), 2500)
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", ["lp1600", "lp20000", "hp5000", "four_poles", "loop", "nan", "inf", "huge"])
+def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
+    """Constant cutoffs above the bound of jit_filter_scan_ok run as a scan over the chunk (jit_prelude.hpp JitFilterScan): the pairs
+    (y[t], y[t-1]) travel between lanes unrounded where the reference rounds every y to f32, which costs at most 2^-24 sum|h| of the
+    signal's scale (sum|h| <= 32: 1.9e-6; twice that behind the loop's feedback).  Two seconds of a bright input per case, every
+    sample of several instances against the oracle — and the unit's state, which the next render would start from; chunks that meet
+    a NaN, an infinity or a value beyond 1e30 are run as the reference writes them (Filter.js:40-46)."""
+    d.configure(48000)
+    uni = descriptor.unify([descriptor.extract(_scan_case(case, k)) for k in (0, 1, 2)])
+    V, n = 70, 96000 + 100
+    base = uni.params[:, 0].astype(np.float64)
+    params = (base[:, None] + (uni.params[:, 1].astype(np.float64) - base)[:, None] * np.arange(V)[None, :]).astype(np.float32)
+    prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+    staged = knob_context(48000, DUSP_FILTER_SCAN=0).build(uni.words, runtime.ENGINE_WAVE)
+    pcm = prog.render(n, V, params)
+    ref = staged.render(n, V, params)
+    assert "compiled kernel" in prog.read_shape()
+    assert "JitFilterScan" in runtime.circuit_kernel_source(uni.words, 16, 1)
+    for i in (0, 1, 63, 64, 69):
+        want, states = oracle.render(uni.words, n, params=params, n_instances=V, instance=i, return_state=True)
+        fin = np.isfinite(want)
+        scale = max(1.0, float(np.max(np.abs(want[fin]))))
+        got = pcm[i].astype(np.float64)
+        assert np.array_equal(np.isfinite(got), fin), (case, i)
+        err = float(np.max(np.abs(got[fin] - want[fin])))
+        assert err <= (4e-6 if case == "loop" else 2e-6) * scale + 1e-5 * scale * (case in ("nan", "inf", "huge")), (case, i, err, scale)
+        assert float(np.max(np.abs(ref[i].astype(np.float64)[fin] - want[fin]))) <= 1e-5 * scale
+        for u, st in enumerate(states):
+            have = prog.state(u, i)
+            assert have.size == st.size
+            np.testing.assert_allclose(have, st, rtol=2e-5, atol=2e-6 * scale, equal_nan=True)
+    prog.close()
+    staged.close()
 
 
 def test_headline_config_full_size(oracle):

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import dusp_amd as d
+from conftest import knob_context
 from dusp_amd import descriptor, render, runtime
 
 pytestmark = pytest.mark.gpu
@@ -157,7 +158,9 @@ def test_random_circuit_wave_equals_chunk(seed):
         ex = descriptor.extract(random_circuit(rng))
     except RecursionError:
         pytest.skip("degenerate graph")
-    ctx = render.context(48000)
+    # (DUSP_FILTER_SCAN=0: Filters through the Filter stage, whose bits are the chunk engine's; the scan form of high constant cutoffs
+    # is tolerance-level by design — checked against this render below)
+    ctx = knob_context(48000, DUSP_FILTER_SCAN=0)
     try:
         chunk = ctx.build(ex.words, runtime.ENGINE_CHUNK)
     except runtime.DuspHipError as e:
@@ -184,7 +187,14 @@ def test_random_circuit_wave_equals_chunk(seed):
     chain.continue_with(descriptor.continued(ex.words, cut, [chain.state(u) for u in range(chain.n_units)]))
     second = chain.render(n - cut)
     assert np.array_equal(np.concatenate([first, second], axis=2), want, equal_nan=True)
-    for p in (chunk, wave, chain):
+    # the default knobs: a Filter whose deviation only passes through sums, products and delay lines may run as a scan
+    scan = render.context(48000).build(ex.words, runtime.ENGINE_WAVE)
+    got = scan.render(n).astype(np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    if fin.any():
+        assert float(np.max(np.abs(got[fin] - want[fin]))) <= 1e-5 * max(1.0, float(np.max(np.abs(want[fin]))))
+    for p in (chunk, wave, chain, scan):
         p.close()
 
 

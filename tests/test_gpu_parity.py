@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5  # north_star: "within 1e-5 relative float tolerance" (of full scale)
 # device tan() in the Filter coefficients, device pow() in Gain / DecibelToScaler / SemitoneToRatio / Pow
 # ... and in Pan's compensation gain / MidiToFrequency
-USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow", "map_fm_semitone", "rest_pan", "rest_midi")
+USES_DEVICE_TAN = ("loop_", "filter_", "map_gain", "map_db_semitone", "map_pow", "map_fm_semitone", "rest_pan", "rest_midi",
+                   "grow_feedback_filter")  # (... whose 2 kHz Filter runs as a scan on the compiled kernel: tolerance-level by design, JitFilterScan)
 
 
 # |f| < 2^-13: the reference's own f64 phase accumulation rounds there (SURVEY.md §8a note ii), so the wave
