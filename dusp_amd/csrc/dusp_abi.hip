@@ -259,6 +259,7 @@ static dusp::Knobs read_knobs() {
     k.ring_window = num("DUSP_RING_WINDOW", k.ring_window);
     k.filter_scan = num("DUSP_FILTER_SCAN", k.filter_scan);
     k.jit_nt = num("DUSP_JIT_NT", k.jit_nt);
+    k.delay_line = num("DUSP_DELAY_LINE", k.delay_line);
     k.ring_poison = num("DUSP_RING_POISON", k.ring_poison);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
@@ -915,6 +916,16 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && dusp::jit_filter_scan_ok(P);
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
+    // Constant delays of a chunk at least as lines of input samples in LDS (JitDelayLine) instead of rings in memory: where the circuit
+    // has no Filter stage (whose overlap splits a Delay's tick), the render is not continued, and all the lines fit at 16 wavefronts next
+    // to the table image and the shared scratch — one instance per wavefront.
+    if (ctx->knobs.delay_line != 0 && !persistent && opt.filter_stages == 0 && a.n_seg == 1 && !opt.voice_loop && !(ctx->knobs.jit_force_waves && ctx->knobs.jit_force_per_wave > 1)) {
+        const size_t lines = dusp::jit_delay_lines(P);
+        if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) {
+            opt.line_floats = lines;
+            opt.scratch_floats += lines;
+        }
+    }
     const uint64_t n_virtual = (uint64_t)n_inst * a.n_seg;
     const unsigned want = (unsigned)((n_virtual + 255) / 256);
     int most = 16;
@@ -928,7 +939,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
-    const int per_wave_cap = ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
+    const int per_wave_cap = opt.line_floats ? 1 : ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;  // (the lines are per wavefront)
     const bool filter_stage = opt.filter_stages > 0;
     if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has
@@ -1792,6 +1803,10 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     opt.filter_scan = !continued && !(getenv("DUSP_FILTER_SCAN") && atoi(getenv("DUSP_FILTER_SCAN")) == 0) && dusp::jit_filter_scan_ok(P);
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
+    if (!continued && opt.filter_stages == 0 && per_wave == 1 && (getenv("DUSP_DELAY_LINE") && atoi(getenv("DUSP_DELAY_LINE")) == 1)) {
+        const size_t lines = dusp::jit_delay_lines(P);
+        if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) opt.line_floats = lines, opt.scratch_floats += lines;
+    }
     if (plan.has_filter && !opt.filter_scan) {
         const size_t left = 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4;
         opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, opt.filter_mod);

@@ -51,6 +51,7 @@ struct JitOptions {
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
+    size_t line_floats = 0;    // per-wave LDS rows of the Delays kept as lines of input samples (jit_delay_lines: part of scratch_floats, behind the shared scratch); 0: none
     bool filter_scan = false;  // every Filter of the circuit as a scan over the chunk (jit_filter_scan_ok, JitFilterScan): no Filter stage, no tile
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
@@ -201,6 +202,21 @@ inline bool jit_ring_ops(const DevOp &op) {
            ((op.op == OP_CB_READER || op.op == OP_CB_WRITER) && (op.in[0].kind == SRC_BUF || op.ring_len < kChunk));
 }
 
+// A Delay / MonoDelay on the write-once ring protocol whose delay is a constant of the circuit can keep its last chunks of INPUT in LDS
+// instead (JitDelayLine): floats of line it needs — the chunks that D + 1 samples back can reach, plus the current one; 0: not such a Delay
+inline size_t jit_delay_line_floats(const DevOp &op) {
+    if (!((op.op == OP_DELAY && delay_write_once(op)) || jit_mono_write_once(op))) return 0;
+    if (op.in[1].kind != SRC_CONST || op.pad == kDelayExactRing) return 0;
+    double d = (double)op.in[1].cval;
+    if (d >= (double)op.ring_len) d = std::fmod(d, (double)op.ring_len);
+    const size_t D = (size_t)std::floor(d);
+    return ((D + 1 + kChunk - 1) / kChunk + 1) * kChunk;
+}
+inline size_t jit_delay_lines(const Program &P) {
+    size_t n = 0;
+    for (const DevOp &op : P.ops) n += jit_delay_line_floats(op);
+    return n;
+}
 // Units with a sequential stage (comb family, AHD, SampleRateRedux, MultiChannelOsc) walk their chunk out of a per-wave LDS scratch:
 // floats per wavefront the program's units ask for (rows of 256; the largest need).
 inline size_t jit_scratch_floats(const Program &P) {
@@ -772,6 +788,7 @@ struct Emitter {
         // state of the units
         std::string fast = "true";  // every constant-f oscillator of the wave qualifies for the 32.32 form
         int filter_ordinal = 0;
+        size_t line_at = 0;  // (Delays as LDS lines: the next one's rows)
         for (size_t at = 0; at < plan.order.size(); at++) {
             const int k = plan.order[at];
             if (!used[(size_t)k]) continue;
@@ -805,6 +822,12 @@ struct Emitter {
                     } else if (jit_delay_short(op)) {
                         line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
                         line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
+                    } else if (opt.line_floats && jit_delay_line_floats(op)) {  // the unit's input in LDS rows of this wave: no ring traffic
+                        const size_t n = jit_delay_line_floats(op);
+                        line(std::string("    JitDelayLine<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> y" + id + ";");
+                        line("    y" + id + ".begin(A, " + ctx(r) + ", scr + " + num((long long)(opt.scratch_floats - opt.line_floats + line_at)) + ", " + num((long long)(n / kChunk)) + ", " +
+                             num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
+                        line_at += n;
                     } else {
                         line(std::string("    JitDelayK<") + (op.op == OP_MONO_DELAY ? "true" : "false") + ", " + (opt.persistent ? "true" : "false") + "> y" + id + ";");
                         line("    y" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k]) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
@@ -1360,6 +1383,11 @@ struct Emitter {
                 if (jit_delay_short(op)) {
                     const std::string x = opnd_array(k, 0, "t" + id, r);
                     line("        z" + id + ".tick(" + X_ + ", scr, " + x + ", " + v + ");");
+                    break;
+                }
+                if (opt.line_floats && jit_delay_line_floats(op)) {
+                    const std::string x = opnd_array(k, 0, "t" + id, r);
+                    line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
                     break;
                 }
                 if (delay_half == 1) {

@@ -2105,5 +2105,88 @@ struct JitDelayShort {
     }
 };
 
+
+// ---- Delay / MonoDelay with a constant delay D + phi of a chunk at least, as a line of INPUT samples in LDS instead of the ring in
+// memory.  What sample t reads from its slot is what samples t-D-1 (ceil tap, first) and t-D (floor tap) left there, each `+=` rounded
+// to f32 (JitDelayShort's observation; Delay.js:26-40) — a function of two input samples and of whether the slot is the ring's slot 0
+// (whose ceil tap the reference drops).  So the wave keeps the last CH chunks of the unit's input in its own LDS rows (CH = the chunks
+// that D + 1 samples back can reach, plus the current one), writes this chunk's four samples per lane (one 16-byte store), and every
+// lane picks the five input samples its four outputs need out of two 16-byte loads (the offset inside the quad is the same for
+// every lane: D + 1 is).  No ring traffic at all: a circuit like BASELINE configs[3] moved twice its PCM in ring reads and writes.
+// The ring in memory stays untouched: nothing reads it after a render that is not continued (the code generator takes this form
+// for those only, and only where the rows fit next to the table image at 16 wavefronts).
+template <bool MONO>
+struct JitDelayLine {
+    float carried;       // the input sample before the chunk (uniform; what the unit's state holds)
+    double phi;          // the delay's fraction (uniform)
+    uint32_t len, D, s0; // ring length, whole delay, the chunk's first slot (for the slot-0 rule)
+    uint32_t at, span;   // where this chunk's row starts in the line; the line's length (CH chunks)
+    uint32_t sh;         // (span - D - 1) & 3: where in its quad a lane's first sample stands
+    float ahead[5];      // the coming chunk's five input samples of this lane
+    float *line;         // this wave's rows
+    __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float *rows, uint32_t chunks, int state_slot, int64_t ring_len, float delay) {
+        carried = MONO ? 0.f : jit_u((float)A.init_state[state_slot]);
+        double dconst = (double)delay;
+        if (dconst >= (double)ring_len) dconst = fmod(dconst, (double)ring_len);
+        const double Dfl = floor(dconst);
+        phi = jit_u(dconst - Dfl);
+        D = jit_u((uint32_t)Dfl);
+        len = (uint32_t)ring_len;
+        s0 = (uint32_t)((A.clock0 + (uint64_t)X.g_begin * kChunk) % (uint64_t)ring_len);
+        line = rows;
+        span = chunks * kChunk;
+        at = 0;
+        sh = jit_u((span - D - 1u) & 3u);
+        for (uint32_t i = X.lane; i < span; i += 64u) rows[i] = 0.f;  // (a fresh ring: zeros — Delay.js:14)
+        jit_wave_sync();
+        if (X.lane == 0) rows[span - 1u] = carried;                  // the sample before the render
+        jit_wave_sync();
+        fetch(X, 0);
+    }
+    // the five samples from D + 1 before this lane's first one of the chunk whose row starts at `row`: two quads, the offset inside the first
+    // the same in every lane and chunk
+    __device__ __forceinline__ void fetch(const JitCtx &X, uint32_t row) {
+        uint32_t j = row + X.lane * 4u + span - D - 1u;  // (D + 1 <= span - 256: never negative)
+        if (j >= span) j -= span;
+        if (j >= span) j -= span;
+        uint32_t q0 = j - sh, q1 = q0 + 4u;
+        if (q1 >= span) q1 -= span;
+        const f32x4 a = *(const f32x4 *)(line + q0), b = *(const f32x4 *)(line + q1);
+        const float w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {  // (selects on scalar conditions: no branches in the chunk loop)
+            const float lo = sh & 1u ? w[i + 1] : w[i], hi = sh & 1u ? w[i + 3] : w[i + 2];
+            ahead[i] = sh & 2u ? hi : lo;
+        }
+    }
+    __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
+        // what this chunk reads was written a chunk ago at least (D >= 256) and fetched then: the reads of a chunk do not wait for its input
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t slot = s0 + X.lane * 4 + c;
+            if (slot >= len) slot -= len;
+            const double xin = (double)ahead[c + 1], xprev = (double)ahead[c];
+            if (phi != 0.0) {
+                const float tap = (MONO || slot != 0) ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of the sample before (Delay: dropped at slot 0)
+                out[c] = (float)((double)tap + xin * (1.0 - phi));               // floor tap
+            } else {
+                const float tap = (float)(0.0 + xin * 1.0);  // floor(tWrite) == ceil(tWrite): both `+=` of one sample
+                out[c] = (float)((double)tap + xin * 0.0);
+            }
+        }
+        // (no fence between the store and the loads: a wave's LDS accesses execute in the order they are issued, and the compiler keeps a
+        // store and the loads behind it that may alias in that order — a fence here would also pin the Filter behind this unit's input)
+        *(f32x4 *)(line + at + X.lane * 4u) = f32x4{x[0], x[1], x[2], x[3]};
+        uint32_t next = at + kChunk;
+        if (next >= span) next = 0;
+        fetch(X, next);  // the coming chunk's
+        carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        s0 += kChunk;
+        if (s0 >= len) s0 -= len;  // (len >= 512 here)
+        at += kChunk;
+        if (at >= span) at = 0;
+    }
+};
+
 }  // namespace
 }  // namespace dusp

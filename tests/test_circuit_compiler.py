@@ -168,6 +168,22 @@ def test_filters_with_a_constant_cutoff_run_as_a_scan():
     assert hp.count("JitFilterScanK fk") == 2
 
 
+def test_delays_as_lines_of_input_samples_in_lds(monkeypatch):
+    """DUSP_DELAY_LINE=1 (off by default: measured slower than the ring in memory): a Delay with a constant delay of a chunk at
+    least keeps the last chunks of its INPUT in LDS rows of its wavefront (JitDelayLine) where they fit at 16 wavefronts next to the table image."""
+    d.configure(48000)
+    voice = lambda k, delay: d.Delay(d.Multiply(d.Osc(300 + k), 0.5), delay, 8192)
+    words = lambda delay: descriptor.unify([descriptor.extract(voice(k, delay)) for k in (0, 64)]).words
+    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=1)
+    monkeypatch.setenv("DUSP_DELAY_LINE", "1")
+    text = source(words(480.5), waves=16, per_wave=1, compile=True)
+    assert "JitDelayLine<false> y" in text and ", 3, " in text.split("JitDelayLine<false> y")[1].split("\n")[1]   # 481 samples back: two chunks and the current one
+    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=2)                                   # the rows are per wavefront
+    assert "JitDelayLine" not in source(words(2000), waves=16, per_wave=1)                                    # 9 chunks x 16 wavefronts do not fit next to the image
+    assert "JitDelayLine" in source(words(2000), waves=16, per_wave=1, lds_table=False)
+    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=1, continued=True)
+
+
 def test_constant_delays_need_no_slot_operations():
     d.configure(48000)
     short = source(descriptor.extract(d.Delay(d.Osc(500), 30.5, 2048)).words)

@@ -185,6 +185,12 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     for i in range(0, uni.n_instances, 3):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
         assert np.array_equal(pcm[i], want), (delay, ring, i)
+    # the same Delay as a line of its INPUT samples in LDS (DUSP_DELAY_LINE=1, off by default: measured slower than the ring in memory)
+    line = knob_context(48000, DUSP_DELAY_LINE=1).build(uni.words, runtime.ENGINE_WAVE)
+    assert np.array_equal(line.render(n, uni.n_instances, uni.params), pcm)
+    for u in range(line.n_units):
+        assert np.array_equal(line.state(u, 7), prog.state(u, 7), equal_nan=True)
+    line.close()
     prog.close()
 
 
@@ -201,6 +207,9 @@ def test_mono_delay_constant_delays(delay, oracle):
     for i in range(0, uni.n_instances, 3):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
         assert np.array_equal(pcm[i], want), (delay, i)
+    line = knob_context(48000, DUSP_DELAY_LINE=1).build(uni.words, runtime.ENGINE_WAVE)  # (from a chunk on: the input kept in LDS, JitDelayLine<true>)
+    assert np.array_equal(line.render(n, uni.n_instances, uni.params), pcm)
+    line.close()
     prog.close()
 
 
