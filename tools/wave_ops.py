@@ -47,6 +47,7 @@ graphs = {
     "mul(osc, shape(k))": lambda k: d.Multiply(d.Osc(110 + k / 8), d.Shape("decay", 0.5 + k / 1e4).trigger()),
     "timer * k": lambda k: d.Multiply(d.Timer(), 1.0 + k / 1e4),
     "filter(osc)": lambda k: d.Filter(d.Osc(110 + k / 8), 800),
+    "filter(osc, 3 kHz)": lambda k: d.Filter(d.Osc(110 + k / 8), 3000),  # (above the scan's bound: JitFilterScan, no Filter stage — DESIGN.md §6.2c)
     "allpass(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.AllPass(0.0021, 0.6)),
     "filter(osc) * ramp": lambda k: d.Multiply(d.Filter(d.Osc(110 + k / 8), 800 + k / 16), d.Ramp(sr, 1, 0).trigger()),
     "filter(osc, lfo)": lambda k: d.Filter(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(5), 800), 1000)),
