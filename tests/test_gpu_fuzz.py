@@ -219,7 +219,7 @@ def test_random_large_batch_wave_equals_chunk(seed, n_inst):
     rng = np.random.RandomState(seed)
     lo, hi = uni.params.min(axis=1, keepdims=True), uni.params.max(axis=1, keepdims=True)
     params = (lo + (hi - lo) * rng.rand(uni.n_params, n_inst)).astype(np.float32)
-    ctx = render.context(48000)
+    ctx = knob_context(48000, DUSP_FILTER_SCAN=0)  # (Filters through their stage: the chunk engine's bits; the scan form is checked below)
     progs = []
     for engine in (runtime.ENGINE_CHUNK, runtime.ENGINE_WAVE):
         try:
@@ -233,5 +233,11 @@ def test_random_large_batch_wave_equals_chunk(seed, n_inst):
     want = progs[0].render(n, n_inst, params)
     got = progs[1].render(n, n_inst, params)
     assert np.array_equal(got, want, equal_nan=True)
+    progs.append(render.context(48000).build(uni.words, runtime.ENGINE_WAVE))  # the default knobs: a Filter may run as a scan (tolerance-level)
+    got = progs[2].render(n, n_inst, params).astype(np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    if fin.any():
+        assert float(np.max(np.abs(got[fin] - want[fin]))) <= 1e-5 * max(1.0, float(np.max(np.abs(want[fin]))))
     for p in progs:
         p.close()
