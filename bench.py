@@ -6,9 +6,10 @@ GPU, voice k = Multiply(Osc(10*k), Ramp(T, 1, 0) triggered), T = 60 s at 48 kHz 
 PCM written to HBM (4 B/sample, 11.8 GB per step per GPU).  A "step" is one render of the whole batch through the
 C ABI (dusp_render_device): parameters and output stay resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config voices60|cfg5] [--mode pcm|mixdown] [--gather]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config voices60|cfg4|cfg5] [--mode pcm|mixdown] [--gather]
 
   --config voices60  (default) weak scaling: --voices voices per GPU x --seconds
+  --config cfg4      BASELINE configs[3]: 8192 feedback loops Osc -> Sum -> Delay(480) -> Filter(2000) -> Multiply(0.5) -> Sum x 10 s, sharded over the N GPUs
   --config cfg5      BASELINE configs[4]: 65 536 voices Multiply(Osc(20 + k/8), Ramp) x 1 s, sharded over the N GPUs
                      (strong scaling: the total is fixed)
   --mode mixdown     the voices of a rank go through the reference's left-deep Sum.many chain (Sum.js:18-29) into one
@@ -43,7 +44,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="voices60", choices=["voices60", "cfg5"])
+    ap.add_argument("--config", default="voices60", choices=["voices60", "cfg4", "cfg5"])
     ap.add_argument("--mode", default="pcm", choices=["pcm", "mixdown"])
     ap.add_argument("--mix", default="chain", choices=["chain", "reduce"],
                     help="mixdown on N > 1 GPUs: 'chain' = ONE left-deep chain continued rank to rank, window by window (bit for bit the single chain: "
@@ -104,6 +105,16 @@ def voice_program(cfg, sample_rate, n_samples, first_voice, n_voices):
     import dusp_amd as d
     from dusp_amd import descriptor
     d.configure(sample_rate)
+    if cfg == "cfg4":  # configs[3]: f_osc = 110 + k / 64, delay 480 of 4096, cutoff 2000, gain 0.5
+        def loop(k):
+            s = d.Sum(d.Osc(110.0 + k / 64.0), 0)
+            f = d.Filter(d.Delay(s, 480, 4096), 2000)
+            s.B = d.Multiply(f, 0.5)
+            return f
+        uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
+        assert uni.n_params == 1
+        k = np.arange(first_voice, first_voice + n_voices, dtype=np.float64)
+        return uni.words, (110.0 + k / 64.0).astype(np.float32).reshape(1, n_voices)
     freq = (lambda k: 10.0 * (k + 1)) if cfg == "voices60" else (lambda k: 20.0 + k / 8.0)
     # two representative circuits fix the structure; the parameter column is then written directly
     # (building 1024+ Python graphs just to read back f would only time the host)
@@ -203,10 +214,13 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     sr = args.sample_rate
-    cfg5 = args.config == "cfg5"
-    n_samples = int((args.seconds if args.seconds is not None else (1.0 if cfg5 else 60.0)) * sr)
+    cfg4 = args.config == "cfg4"
+    cfg5 = args.config == "cfg5" or cfg4  # (both: a fixed set of instances, sharded)
+    if cfg4 and args.mode == "mixdown":
+        raise SystemExit("bench: --config cfg4 has no mix-down mode (every loop's PCM is written)")
+    n_samples = int((args.seconds if args.seconds is not None else (10.0 if cfg4 else 1.0 if cfg5 else 60.0)) * sr)
     if cfg5:  # strong scaling: a fixed sweep, sharded
-        n_total = args.voices or 65536
+        n_total = args.voices or (8192 if cfg4 else 65536)
         lo, hi = instance_range(n_total, rank, world)
     else:     # weak scaling: V voices per GPU
         per = args.voices or 1024
@@ -215,6 +229,7 @@ def main():
     n_voices = hi - lo
     mixdown = args.mode == "mixdown"
 
+    os.environ.setdefault("DUSP_WAVE_JIT", "2")  # (a benchmark waits for a circuit's compiled kernel instead of rendering its first calls on the interpreter)
     ctx = runtime.Context(local_rank, sr)
     engine = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "fused": runtime.ENGINE_FUSED, "wave": runtime.ENGINE_WAVE}[args.engine]
     if mixdown:
@@ -350,6 +365,7 @@ def main():
             what = ("%d voices/GPU x Osc(10k)" % n_voices if not cfg5 else "%d voices in total x Osc(20+k/8)" % n_total)
         else:
             what = ("%d voices/GPU x Multiply(Osc(10k), Ramp(T,1,0) triggered)" % n_voices if not cfg5 else
+                    "%d loops in total x Filter(Delay(Osc(110+k/64) + 0.5 x [the Filter's output], 480 of 4096), 2000)" % n_total if cfg4 else
                     "%d voices in total x Multiply(Osc(20+k/8), Ramp(T,1,0) triggered)" % n_total)
         line = {
             "metric": "rendered Msamples/sec (whole node) + HBM GB/s fraction, 1024-voice 48kHz",
@@ -360,15 +376,18 @@ def main():
             "higher_is_better": True, "scaling": "strong" if cfg5 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %s: %s, %gs @%d Hz, %s"
-                                   % ("configs[4]" if cfg5 else "configs[2]", "mix-down" if mixdown else "per-voice", what, n_samples / sr, sr,
+                                   % ("configs[3]" if cfg4 else "configs[4]" if cfg5 else "configs[2]", "mix-down" if mixdown else "per-voice", what, n_samples / sr, sr,
                                       "voices folded through Sum.many into one channel per rank, partials reduced onto rank 0" if mixdown
                                       else "every voice's PCM written"),
-                       "voices_per_gpu": n_voices, "voices_total": n_total, "n_samples": n_samples, "engine": prog.engine, "shape": prog.shape,
+                       "voices_per_gpu": n_voices, "voices_total": n_total, "n_samples": n_samples, "engine": prog.engine, "shape": prog.read_shape(),
                        "parallelism": "voices sharded over %d GPU(s), %s" % (world, ("one chain continued rank to rank, window by window (bit for bit)" if chained else "reduce of the partial mixes") if mixdown and world > 1 else "no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(launch_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if cfg4:
+            line["roofline"]["note"] = ("the Filter's recurrence bounds this circuit, not HBM: as a scan over the chunk (default; within 1.9e-6 of the signal's scale of the "
+                                        "reference by construction, DESIGN.md 6.2c) the kernel is issue-bound; DUSP_FILTER_SCAN=0 renders the oracle's bits on the Filter stage")
         if mixdown:
             line["roofline"]["note"] = "mix-down writes one channel: ALU/LDS-bound by construction, not graded against HBM (SURVEY.md §8d)"
         if fill_ms:

@@ -167,6 +167,19 @@ def test_bench_gather_runs_at_one_rank():
     assert bench.visible_gpus() == torch.cuda.device_count()
 
 
+@pytest.mark.gpu
+def test_bench_renders_the_feedback_loops_of_configs_3():
+    """`bench.py --config cfg4` (BASELINE configs[3], a reduced set): the line names the workload, carries roofline and cpu_baseline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "cfg4", "--voices", "512", "--seconds", "0.5",
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["workload"].startswith("configs[3] per-voice: 512 loops") and line["config"]["engine"] == "wave"
+    assert "compiled kernel" in line["config"]["shape"] and line["scaling"] == "strong" and line["value"] > 0
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 4.0 * 512 * 24000 and line["cpu_baseline"]["value"] > 0
+
+
 # ---- one Sum.many chain over several ranks, bit for bit (shard.chain_mixdown / dusp_render_chain_window)
 
 def _chain_voice_freqs(n_voices):
