@@ -24,6 +24,14 @@
  * Nothing here ever falls back to a CPU implementation: without a usable HIP
  * device the calls fail with DUSP_ERR_HIP.
  *
+ * Numerics: PCM and unit state are the reference's bit for bit wherever the device executes the IEEE operations JS
+ * does — everything but the units that call Math.tan / Math.pow (Filter coefficients; Gain, DecibelToScaler,
+ * SemitoneToRatio, Pow, Pan, MidiToFrequency), which are within 1e-5 of full scale.  One form trades
+ * bits for speed inside that tolerance: a Filter whose cutoff is a constant between about 1.5 and 22.5 kHz (at 48 kHz) and
+ * whose output only feeds sums, products, delay lines and outlets is evaluated as a scan over each chunk — within 1.9e-6
+ * of the signal's scale of the reference by construction.  DUSP_FILTER_SCAN=0 in the environment of
+ * dusp_ctx_create keeps every Filter on the path whose results are the reference recurrence's, operation for operation.
+ *
  * Threading: a dusp_ctx is bound to one HIP device and is not thread-safe;
  * different contexts are independent (one context per GPU for multi-GPU use).
  * Streams: a program's workspaces are reused from render to render; renders of
