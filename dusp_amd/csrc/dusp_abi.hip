@@ -1006,6 +1006,19 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             const double est_ms = std::max(units * (double)n_inst * n_chunks * 0.7e-6, units * (double)a.seg_groups * 1.0e-3);
             if (est_ms < 400.0) {
                 dusp::jit_compile_in_background(src->text);
+                if (filter_stage && opt.filter_block == 8) {
+                    // (a Filter stage's kernel at 16 wavefronts usually ends on the recurrence loop's narrower form: that text joins the
+                    // queue now, so the geometry search does not cost a further render on the interpreter per step)
+                    dusp::JitOptions narrow = opt;
+                    narrow.filter_block = 4;
+                    const auto key = std::make_pair(waves, per_wave * 8 + narrow.filter_block % 8 + (narrow.voice_loop ? 64 : 0));
+                    auto alt = prog->jit_src.find(key);
+                    if (alt == prog->jit_src.end()) {
+                        dusp::JitSource gen;
+                        if (dusp::jit_generate(P, prog->wave, narrow, gen)) alt = prog->jit_src.emplace(key, std::move(gen)).first;
+                    }
+                    if (alt != prog->jit_src.end() && !dusp::jit_code_ready(alt->second.text)) dusp::jit_compile_in_background(alt->second.text);
+                }
                 return kJitLater;
             }
         }

@@ -796,6 +796,30 @@ def test_first_render_does_not_wait_for_the_compiler(oracle):
     off.close()
 
 
+def test_a_filter_stage_circuit_reaches_its_kernel_under_the_default_knob():
+    """DUSP_WAVE_JIT=1 and a circuit with a Filter stage at a batch that fills 16-wavefront workgroups: the kernel's geometry search may need
+    a second text (the recurrence loop's narrower form) — it is compiled alongside the first, so a few renders later the circuit runs on its
+    compiled kernel, with the interpreter's PCM (the stage is the same arithmetic on both)."""
+    import time
+    d.configure(48000)
+    voice = lambda k: d.Sum(d.Filter(d.Sum(d.Osc(97.5 + k), d.Osc(301.25, "triangle")), 640.5), d.Multiply(d.Osc(3.5), 0.125))  # (no other test's structure)
+    uni = descriptor.unify([descriptor.extract(voice(k)) for k in (0, 1, 2)])
+    V, n = 4096, 256 * 6
+    base = uni.params[:, 0].astype(np.float64)
+    params = (base[:, None] + (uni.params[:, 1].astype(np.float64) - base)[:, None] * np.arange(V)[None, :]).astype(np.float32)
+    prog = knob_context(48000, DUSP_WAVE_JIT=1).build(uni.words, runtime.ENGINE_WAVE)
+    first = prog.render(n, V, params)
+    assert "kernel compiling" in prog.read_shape()
+    deadline, renders = time.perf_counter() + 90, 1
+    while "compiled kernel" not in prog.read_shape() and time.perf_counter() < deadline:
+        time.sleep(0.3)
+        again = prog.render(n, V, params)
+        renders += 1
+        assert np.array_equal(again, first)
+    assert "compiled kernel" in prog.read_shape(), (prog.read_shape(), renders)
+    prog.close()
+
+
 @pytest.mark.parametrize("name", ["patch_scary"])  # (the grow_* vectors settle within their first chunk and are wave-engine programs as they stand)
 def test_growing_channel_counts_hand_over_to_a_compiled_kernel(name, oracle):
     """Circuits whose channel counts grow during the first chunks (a feedback edge sees one channel at first, more later: Program::warm_ops)
