@@ -22,6 +22,7 @@
 #include "jit_codegen.hpp"
 #include "jit_engine.hpp"
 #include "program.hpp"
+#include "ring_windows.hpp"
 #include "table_checks.hpp"
 
 namespace dusp {
@@ -727,12 +728,8 @@ constexpr int kJitLater = 1;  // render_jit: the kernel is being compiled in the
 
 // WAVE programs the circuit compiler takes: ONE kernel generated for this circuit's structure (jit_codegen.hpp), compiled for
 // gfx950 in process the first time the structure is seen (jit_engine.hip), cached from then on.
-// Rings start as zeros (Delay.js:14, CircleBuffer.js:12).  A render that nothing continues only ever touches part of a long ring — a
-// Delay of constant length d reads [clock, clock + n) and writes up to d + 1 further on; a CircleBuffer node with an unconnected
-// offset walks n slots from where its clock starts — and a default Delay line is five seconds per instance: zeroing all of it
-// was most of such a render's time (reference patch "multitap" x 256: 236 GB of fill for 0.6 ms of kernel).  So only what can be
-// touched is filled, with a chunk or two to spare for the kernels' look-ahead; anything else (a modulated or per-instance delay,
-// a ring shorter than its window, a program that will be continued) fills the whole ring as before.
+// Rings start as zeros (Delay.js:14, CircleBuffer.js:12).  A render nothing continues fills only the slots it can reach (ring_windows.hpp);
+// a program that will be continued, one whose channel counts still grow, and DUSP_RING_WINDOW=0 fill the whole rings as before.
 // instance_major: rings laid out [instance][slot] (wave engine, compiled kernels), else [slot][n_pad] (chunk engine).
 static hipError_t zero_rings(dusp_program *prog, uint32_t n_pad, uint32_t n_chunks, bool instance_major, hipStream_t stream) {
     const dusp::Program &P = prog->P;
@@ -741,62 +738,13 @@ static hipError_t zero_rings(dusp_program *prog, uint32_t n_pad, uint32_t n_chun
     if (prog->ctx->knobs.ring_poison) {  // (tests: what the fill leaves out holds NaN patterns, so a window cut too short shows)
         if (hipError_t e = hipMemsetAsync(rings, 0xff, total * n_pad * sizeof(float), stream)) return e;
     }
-    struct Win { int64_t at, count; };
-    std::vector<Win> wins;
-    bool windowed = !prog->resumable && prog->ctx->knobs.ring_window != 0 && P.warm_ops.empty();
+    const bool windowed = !prog->resumable && prog->ctx->knobs.ring_window != 0 && P.warm_ops.empty();
+    std::vector<dusp::RingWindow> wins;
     size_t covered = 0;
-    const double N = (double)n_chunks * dusp::kChunk, spare = 2.0 * dusp::kChunk + 4.0;
-    auto add = [&](const dusp::DevOp &op, double from, double upto) {  // [from, upto) in the op's ring, wrapped
-        const double len = (double)op.ring_len;
-        from -= spare;
-        upto += spare;
-        if (!(upto - from < len)) {
-            wins.push_back({op.ring_base, op.ring_len});
-            covered += (size_t)op.ring_len;
-            return;
-        }
-        double a = fmod(floor(from), len);
-        if (a < 0) a += len;
-        const int64_t at = (int64_t)a, count = (int64_t)(ceil(upto) - floor(from));
-        const int64_t head = std::min(count, op.ring_len - at);
-        wins.push_back({op.ring_base + at, head});
-        if (count > head) wins.push_back({op.ring_base, count - head});
-        covered += (size_t)count;
-    };
-    for (const dusp::DevOp &op : P.ops) {
-        if (!windowed) break;
-        if (op.ring_len <= 0) continue;
-        const double len = (double)op.ring_len, sr = (double)P.g.sample_rate;
-        const double c0 = (double)(P.g.clock0 % op.ring_len);
-        const bool k0 = op.in[0].kind == dusp::SRC_CONST, k1 = op.in[1].kind == dusp::SRC_CONST;
-        const double T0 = (size_t)op.state_slot < P.init_state.size() ? P.init_state[(size_t)op.state_slot] : NAN;  // (the nodes' own clock)
-        switch (op.op) {
-        case dusp::OP_DELAY:
-        case dusp::OP_MONO_DELAY: {
-            const double d = (double)op.in[1].cval;
-            if (k1 && d >= 0.0 && d < len) add(op, c0, c0 + N + d + 2.0);
-            else add(op, 0.0, len);
-            break;
-        }
-        case dusp::OP_CB_READER:
-        case dusp::OP_CB_WRITER: {
-            const double o = sr * (double)op.in[0].cval * (op.op == dusp::OP_CB_READER ? -1.0 : 1.0);
-            if (k0 && std::isfinite(T0) && std::isfinite(o) && fabs(T0 + o) < 1e15) add(op, T0 + o, T0 + o + N + 1.0);
-            else add(op, 0.0, len);
-            break;
-        }
-        case dusp::OP_READBACK_DELAY: {
-            const double d = (double)op.in[1].cval;
-            if (k1 && std::isfinite(T0) && d >= 0.0 && d < len && fabs(T0) < 1e15) add(op, T0 - d, T0 + N + 1.0);
-            else add(op, 0.0, len);
-            break;
-        }
-        default: add(op, 0.0, len);
-        }
-    }
+    if (windowed) dusp::ring_windows(P, n_chunks, wins, covered);
     if (!windowed || wins.empty() || covered * 2 > total || wins.size() > 64)
         return hipMemsetAsync(rings, 0, total * n_pad * sizeof(float), stream);
-    for (const Win &w : wins) {
+    for (const dusp::RingWindow &w : wins) {
         hipError_t e = instance_major ? hipMemset2DAsync(rings + w.at, total * sizeof(float), 0, (size_t)w.count * sizeof(float), n_pad, stream)
                                       : hipMemsetAsync(rings + (size_t)w.at * n_pad, 0, (size_t)w.count * n_pad * sizeof(float), stream);
         if (e != hipSuccess) return e;

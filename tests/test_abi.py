@@ -100,3 +100,16 @@ def test_increments_reach_fixed_point_through_the_f64_mantissa_exactly(tmp_path)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "fix36_check.cpp")])
     rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
     assert rep["cases"] > 10_000 and rep["bad"] == 0, rep
+
+
+def test_ring_windows_cover_what_the_units_touch(tmp_path):
+    """dusp_amd/csrc/ring_windows.hpp (which slots of its delay rings a render that nothing continues zero-fills) on the CPU: 600 random
+    Delays / MonoDelays / CircleBuffer nodes / ReadBackDelays, every slot the reference's unit touches enumerated sample by sample and
+    found inside a window, every window inside its ring; per-instance, connected and out-of-range delays, the comb family and rings
+    shorter than their window take the whole ring."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "ring_windows_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "ring_windows_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] >= 1200 and rep["bad"] == 0
