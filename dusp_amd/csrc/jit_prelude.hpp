@@ -1559,9 +1559,10 @@ struct JitFilterK {
 // lane) — gives every lane the pair in front of its samples, and the lane runs its four steps again from there, rounding each y to
 // f32 as the reference does.  What differs from the reference is that the scan carries UNROUNDED pairs: the reference's rounding
 // errors (at most 2^-24 |y| a step) never enter, and a rounding error e[t] reaches later samples through the all-pole part
-// 1 / (1 + b1 z^-1 + b2 z^-2).  The deviation is therefore at most  2^-24 max|y| sum|h|  with h that part's impulse response — the
-// code generator takes this form only where that bound is 2^-19 (1.9e-6) of the signal's scale (jit_filter_scan_ok: sum|h| <= 32, cutoffs
-// between about 1.5 and 22.5 kHz at 48 kHz), a fifth of the 1e-5 this path is held to; lower cutoffs keep the serving wave, bit for bit.
+// 1 / (1 + b1 z^-1 + b2 z^-2).  The deviation is therefore at most  2^-24 max|y| (sum|h| + 2)  with h that part's impulse response (+ 2:
+// the two results' own roundings to f32) — the code generator takes this form only where that bound is 2^-19 (1.9e-6) of the signal's
+// scale (jit_filter_scan_ok: sum|h| <= 30, cutoffs between about 1.5 and 22.5 kHz at 48 kHz), a fifth of the 1e-5 this path is held to;
+// lower cutoffs keep the serving wave, bit for bit.
 // A chunk that meets a NaN or anything beyond 1e30 (where the reference's `|| 0` or f32 overflow would act) is run again as written:
 // serially, out of the lanes' registers.
 struct JitFilterScanK {  // one per Filter: what the wave's instances share

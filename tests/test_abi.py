@@ -113,3 +113,15 @@ def test_ring_windows_cover_what_the_units_touch(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "ring_windows_check.cpp")])
     rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
     assert rep["cases"] >= 1200 and rep["bad"] == 0
+
+
+def test_the_filter_scan_stays_within_its_stated_bound(tmp_path):
+    """The arithmetic of jit_prelude.hpp JitFilterScan restated on the CPU (unrounded pairs in front of every lane's four samples, the
+    lane's samples rounded as the reference rounds them) against Filter.js:40-46 as written: ten seconds of white noise and of a sine
+    per admitted cutoff, both kinds — the deviation never exceeds 2^-24 (sum|h| + 2) max|y|, nor 1.9e-6 of the signal's scale."""
+    import json
+    import subprocess
+    exe = str(tmp_path / "filter_scan_bound_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "filter_scan_bound_check.cpp")])
+    rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
+    assert rep["cases"] >= 30 and rep["bad"] == 0 and rep["worst_of_bound"] <= 1.0 and rep["worst_of_scale"] <= 1.9e-6

@@ -135,7 +135,7 @@ def test_work_that_does_not_hang_on_a_filter_runs_beside_its_recurrences(monkeyp
 
 def test_filters_with_a_constant_cutoff_run_as_a_scan():
     """A Filter whose cutoff is a constant of the circuit, high enough for the bound of jit_codegen.hpp jit_filter_scan_ok (the all-pole
-    part's impulse response sums to at most 32: between about 1.5 and 22.5 kHz at 48 kHz), is a unit like any other — JitFilterScan, a scan over the
+    part's impulse response sums to at most 30: between about 1.5 and 22.5 kHz at 48 kHz), is a unit like any other — JitFilterScan, a scan over the
     chunk's lanes — and the circuit has no Filter stage: no tile, no barriers, no serving wave.  Lower cutoffs, per-instance cutoffs,
     connected cutoffs and continued programs keep the stage."""
     d.configure(48000)

@@ -302,8 +302,8 @@ def _scan_case(case, k):
 @pytest.mark.parametrize("case", ["lp1600", "lp20000", "hp5000", "four_poles", "loop", "nan", "inf", "huge"])
 def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
     """Constant cutoffs above the bound of jit_filter_scan_ok run as a scan over the chunk (jit_prelude.hpp JitFilterScan): the pairs
-    (y[t], y[t-1]) travel between lanes unrounded where the reference rounds every y to f32, which costs at most 2^-24 sum|h| of the
-    signal's scale (sum|h| <= 32: 1.9e-6; twice that behind the loop's feedback).  Two seconds of a bright input per case, every
+    (y[t], y[t-1]) travel between lanes unrounded where the reference rounds every y to f32, which costs at most 2^-24 (sum|h| + 2) of the
+    signal's scale (sum|h| <= 30: 1.9e-6; twice that behind the loop's feedback).  Two seconds of a bright input per case, every
     sample of several instances against the oracle — and the unit's state, which the next render would start from; chunks that meet
     a NaN, an infinity or a value beyond 1e30 are run as the reference writes them (Filter.js:40-46)."""
     d.configure(48000)
