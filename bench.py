@@ -46,9 +46,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="voices60", choices=["voices60", "cfg4", "cfg5"])
     ap.add_argument("--mode", default="pcm", choices=["pcm", "mixdown"])
-    ap.add_argument("--mix", default="chain", choices=["chain", "reduce"],
-                    help="mixdown on N > 1 GPUs: 'chain' = ONE left-deep chain continued rank to rank, window by window (bit for bit the single chain: "
-                         "shard.chain_mixdown); 'reduce' = every rank's partial mix added onto rank 0 by an f32 reduction (tolerance-level)")
+    ap.add_argument("--mix", default="reduce", choices=["chain", "reduce"],
+                    help="mixdown on N > 1 GPUs: 'reduce' (default) = every rank's partial mix added onto rank 0 by an f32 reduction (tolerance-level); "
+                         "'chain' = ONE left-deep chain continued rank to rank, window by window (bit for bit the single chain: shard.chain_mixdown; "
+                         "covered by gloo ranks and by a replay of its posting order under RCCL's stream rules, but never run on two GPUs — opt-in until it has)")
     ap.add_argument("--seconds", type=float, default=None, help="rendered duration per voice (default: 60 / cfg5: 1)")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (voices60, default 1024) / in total (cfg5, default 65536)")
     ap.add_argument("--sample-rate", type=int, default=48000)

@@ -155,7 +155,33 @@ def reduce_mixdown(partial, group=None):
     return partial if dist.get_rank(group) == 0 else None
 
 
-def chain_mixdown(render_window, n_samples, window, like, group=None):
+_return_groups = {}  # forward group (None: the default one) -> the group the finished windows travel back on
+
+
+def _chain_groups(group, return_group):
+    """The communicators of chain_mixdown, made and warmed ONCE per forward group, by every rank of it at the same point.
+
+    The finished windows go from the last rank back to rank 0 while partial sums still travel down the ranks.  On RCCL every
+    transfer of one communicator is queued on one stream per side and a send occupies that stream until its receive is
+    posted, so the two directions must not share a communicator: at two ranks (the last rank IS rank 1) rank 0 would queue
+    its sends S0 S1 S2 .. ahead of the return receives while rank 1 queues R0 R1 S'0 R2 .. — S'0 waits for a receive behind
+    S2, S2 for R2 behind S'0.  The return path therefore has a group (communicator, stream) of its own.  Both are used
+    through batch_isend_irecv only, which runs on the group's own communicator; the barriers below create those
+    communicators while every rank is here — a communicator made lazily inside the pipeline would need both of its ranks
+    to arrive at once, which a pipeline does not promise."""
+    key = group
+    if key not in _return_groups:
+        if return_group is None:
+            world = dist.get_world_size(group)
+            ranks = [dist.get_global_rank(group, r) if group is not None else r for r in range(world)]
+            return_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+        dist.barrier(group=group)
+        dist.barrier(group=return_group)
+        _return_groups[key] = return_group
+    return _return_groups[key]
+
+
+def chain_mixdown(render_window, n_samples, window, like, group=None, return_group=None):
     """One `Sum.many` chain whose voices are dealt over the ranks in contiguous runs (rank 0 the first voices), bit for bit.
 
     render_window(first, n, init, raw, out) must enqueue, on the CURRENT stream, this rank's links of the chain for the
@@ -163,6 +189,8 @@ def chain_mixdown(render_window, n_samples, window, like, group=None):
     raw says the sums travel on (no `x || 0`): true on every rank but the last.  With dusp_amd.runtime that is
     Program.render_chain_window(first, n, init.data_ptr(), raw, out.data_ptr(), stream).
     `window`: samples per pipeline step (a multiple of 2048).  `like`: a tensor that fixes device and dtype (float32).
+    `return_group`: a group of the same ranks for the finished windows' way back (made here on first use when None: every
+    rank of the DEFAULT group must then be in this call, as torch.distributed.new_group demands).
     Returns the mix [1, n_samples] on rank 0, None elsewhere.  CPU tensors (gloo, tests) run the same steps synchronously."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if window <= 0 or window % 2048 != 0:
@@ -174,8 +202,33 @@ def chain_mixdown(render_window, n_samples, window, like, group=None):
     new = lambda n: torch.empty((1, n), dtype=torch.float32, device=like.device)
     last = world - 1
     mix = new(n_samples) if (rank == 0 or rank == last) else None  # (the last rank assembles it; rank 0 receives it, or IS the last rank)
+    back = _chain_groups(group, return_group) if world > 1 else None
     comm = torch.cuda.Stream(device=like.device) if on_gpu else None
+
+    def post(op, buf, peer, grp):  # one transfer on the group's own communicator (see _chain_groups), queued behind the comm stream
+        if on_gpu:
+            with torch.cuda.stream(comm):
+                return dist.batch_isend_irecv([dist.P2POp(op, buf, peer, grp)])
+        return dist.batch_isend_irecv([dist.P2POp(op, buf, peer, grp)])
+
+    def wait(reqs, then_current):
+        if on_gpu:
+            with torch.cuda.stream(comm):
+                for r in reqs:
+                    r.wait()
+            if then_current:
+                torch.cuda.current_stream(like.device).wait_stream(comm)
+        else:
+            for r in reqs:
+                r.wait()
+
     sends = []
+    # the finished windows' receives: all posted before this rank's own steps, straight into their place of the mix (they are
+    # on the return group: nothing of the forward direction queues behind them)
+    home = []
+    if rank == 0 and last != 0:
+        for a, b in spans:
+            home.append(post(dist.irecv, mix[:, a:b], dist.get_global_rank(back, last), back))
     # what arrives from the rank before, two windows ahead of the render (posted early so the transfer overlaps the render before it)
     inbox = {}
 
@@ -184,55 +237,29 @@ def chain_mixdown(render_window, n_samples, window, like, group=None):
             return
         a, b = spans[k]
         buf = new(b - a)
-        if on_gpu:
-            with torch.cuda.stream(comm):
-                inbox[k] = (buf, dist.irecv(buf, gr(rank - 1), group=group))
-        else:
-            inbox[k] = (buf, dist.irecv(buf, gr(rank - 1), group=group))
+        inbox[k] = (buf, post(dist.irecv, buf, gr(rank - 1), group))
 
     post_recv(0)
     for k, (a, b) in enumerate(spans):
         post_recv(k + 1)
         init = None
         if rank > 0:
-            init, req = inbox.pop(k)
-            if on_gpu:
-                with torch.cuda.stream(comm):
-                    req.wait()
-                torch.cuda.current_stream(like.device).wait_stream(comm)
-            else:
-                req.wait()
+            init, reqs = inbox.pop(k)
+            wait(reqs, True)
         out = mix[:, a:b] if rank == last else new(b - a)
         render_window(a, b - a, init, rank != last, out)
+        if on_gpu:
+            ready = torch.cuda.Event()
+            ready.record()
+            comm.wait_event(ready)
         if rank != last:  # the partial sums travel on
-            if on_gpu:
-                ready = torch.cuda.Event()
-                ready.record()
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ready)
-                    sends.append((out, dist.isend(out, gr(rank + 1), group=group)))
-            else:
-                sends.append((out, dist.isend(out, gr(rank + 1), group=group)))
-        elif last != 0:  # a finished window: to rank 0
-            piece = out.contiguous()
-            if on_gpu:
-                ready = torch.cuda.Event()
-                ready.record()
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ready)
-                    sends.append((piece, dist.isend(piece, gr(0), group=group)))
-            else:
-                sends.append((piece, dist.isend(piece, gr(0), group=group)))
-    if rank == 0 and last != 0:  # the finished windows, in order (posted after this rank's own steps: it is the pipeline's first stage)
-        pieces = []
-        for a, b in spans:
-            buf = new(b - a)
-            pieces.append((a, b, buf, dist.irecv(buf, gr(last), group=group)))
-        for a, b, buf, req in pieces:
-            req.wait()
-            mix[:, a:b].copy_(buf)
-    for _, req in sends:
-        req.wait()
+            sends.append((out, post(dist.isend, out, gr(rank + 1), group)))
+        elif last != 0:   # a finished window: to rank 0, on the return group
+            sends.append((out, post(dist.isend, out, dist.get_global_rank(back, 0), back)))
+    for reqs in home:
+        wait(reqs, True)
+    for _, reqs in sends:
+        wait(reqs, False)
     if on_gpu:
         torch.cuda.current_stream(like.device).wait_stream(comm)
     return mix if rank == 0 else None

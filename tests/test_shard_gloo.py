@@ -211,11 +211,37 @@ def _chain_worker(rank, world, port, n_voices, n_samples, window, result_path):
             acc = np.where(np.isnan(acc), np.float32(0), acc) + np.float32(0)
         out[0] = torch.from_numpy(acc)
 
-    mix = chain_mixdown(render_window, n_samples, window, torch.zeros(1), group=None)
+    # the order in which this rank posts its transfers and waits for them, for the replay under RCCL's rules (below)
+    log, real_batch = [], dist.batch_isend_irecv
+
+    class Logged:
+        def __init__(self, work, ident):
+            self.work, self.ident = work, ident
+
+        def wait(self):
+            log.append(("wait", self.ident))
+            return self.work.wait()
+
+    def logging_batch(ops):
+        assert len(ops) == 1
+        op = ops[0]
+        ident = len(log)
+        log.append(("post", ident, "send" if op.op is dist.isend else "recv", op.peer, "default" if (op.group is None or op.group is dist.group.WORLD) else "return"))
+        return [Logged(w, ident) for w in real_batch(ops)]
+
+    dist.batch_isend_irecv = logging_batch
+    try:
+        mix = chain_mixdown(render_window, n_samples, window, torch.zeros(1), group=None)
+    finally:
+        dist.batch_isend_irecv = real_batch
     spans = [(a, min(a + window, n_samples) - a) for a in range(0, n_samples, window)]
     assert calls == [(a, n, rank > 0, rank != world - 1) for a, n in spans]
+    logs = [None] * world
+    dist.all_gather_object(logs, log)
     if rank == 0:
         np.save(result_path, mix.numpy())
+        with open(result_path + ".posts.json", "w") as f:
+            json.dump(logs, f)
     else:
         assert mix is None
     dist.barrier()
@@ -235,6 +261,75 @@ def test_one_sum_chain_over_several_ranks_is_the_single_chain_bit_for_bit(tmp_pa
     whole = descriptor.extract(d.Sum.many([d.Osc(f) for f in _chain_voice_freqs(n_voices)]))
     want = oracle.render(whole.words, n_samples)
     assert got.shape == want.shape and np.array_equal(got, want)
+    with open(result + ".posts.json") as f:
+        logs = json.load(f)
+    stuck = _replay_under_stream_order(logs)
+    assert not stuck, "the posted order deadlocks under one-stream-per-communicator rules: %r" % (stuck,)
+
+
+def _replay_under_stream_order(logs):
+    """gloo matches transfers by tag; RCCL does not.  There every transfer of one communicator is queued on ONE stream per rank,
+    a send or receive occupies that stream until its counterpart on the peer has reached the head of ITS stream, and whatever
+    the host waited for before posting (the comm stream's waits, the render in between) stands in front as well.  Replays the
+    order the ranks posted in (logs[rank]: ("post", id, kind, peer, communicator) / ("wait", id)) under those rules; returns
+    the transfers that can never start ([] = no deadlock)."""
+    ops = {}      # (rank, id) -> dict
+    queues = {}   # (rank, communicator) -> [ids in posting order]
+    for rank, log in enumerate(logs):
+        waited = []
+        for entry in log:
+            if entry[0] == "wait":
+                waited.append(entry[1])
+                continue
+            _, ident, kind, peer, comm = entry
+            ops[(rank, ident)] = {"kind": kind, "peer": peer, "comm": comm, "after": list(waited), "done": False}
+            queues.setdefault((rank, comm), []).append(ident)
+    def head(rank, comm):
+        for ident in queues.get((rank, comm), []):
+            if not ops[(rank, ident)]["done"]:
+                return ident
+        return None
+    def ready(rank, ident):
+        o = ops[(rank, ident)]
+        return ident == head(rank, o["comm"]) and all(ops[(rank, a)]["done"] for a in o["after"])
+    progress = True
+    while progress:
+        progress = False
+        for (rank, ident), o in ops.items():
+            if o["done"] or o["kind"] != "send" or not ready(rank, ident):
+                continue
+            other = head(o["peer"], o["comm"])
+            if other is None:
+                continue
+            q = ops[(o["peer"], other)]
+            if q["kind"] == "recv" and q["peer"] == rank and ready(o["peer"], other):
+                o["done"] = q["done"] = True
+                progress = True
+    return [(rank, ident, o["kind"], o["peer"], o["comm"]) for (rank, ident), o in ops.items() if not o["done"]]
+
+
+def test_the_replay_finds_the_deadlock_of_a_shared_communicator():
+    """The order round 3's chain_mixdown posted in at two ranks (both directions on one communicator: rank 0 queues its sends S0 S1 S2 ..
+    and the return receives behind them, rank 1 queues R0 R1 S'0 R2 ..) must be reported — the replay is only worth something if it is."""
+    n = 4
+    rank0 = [("post", k, "send", 1, "default") for k in range(n)] + [("post", n + k, "recv", 1, "default") for k in range(n)]
+    rank1, ident = [], 0
+    def post(kind):
+        nonlocal ident
+        rank1.append(("post", ident, kind, 0, "default"))
+        ident += 1
+        return ident - 1
+    recvs = {0: post("recv")}
+    for k in range(n):
+        if k + 1 < n:
+            recvs[k + 1] = post("recv")
+        rank1.append(("wait", recvs[k]))
+        post("send")
+    assert _replay_under_stream_order([rank0, rank1])
+    # ... and with the return path on a communicator of its own it goes through
+    fixed0 = [("post", n + k, "recv", 1, "return") for k in range(n)] + [("post", k, "send", 1, "default") for k in range(n)]
+    fixed1 = [e if e[0] == "wait" or e[2] == "recv" else e[:4] + ("return",) for e in rank1]
+    assert not _replay_under_stream_order([fixed0, fixed1])
 
 
 @pytest.mark.gpu
