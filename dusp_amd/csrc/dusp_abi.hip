@@ -861,7 +861,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     // Filters whose cutoff is a constant of the circuit, high enough for the bound of jit_filter_scan_ok: a scan over the chunk, the circuit
     // an ordinary one (no Filter stage).  Not for programs that are continued (the stage's y1 / y2 are what the other engines hand over).
-    opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && dusp::jit_filter_scan_ok(P);
+    opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && dusp::jit_filter_scan_ok(P, ctx->table_bound, ctx->knobs.filter_scan == 2 ? 2 : 1);
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
     // Constant delays of a chunk at least as lines of input samples in LDS (JitDelayLine) instead of rings in memory: where the circuit
@@ -1761,7 +1761,8 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
                 opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
             }
     }
-    opt.filter_scan = !continued && !(getenv("DUSP_FILTER_SCAN") && atoi(getenv("DUSP_FILTER_SCAN")) == 0) && dusp::jit_filter_scan_ok(P);
+    const int scan_knob = getenv("DUSP_FILTER_SCAN") ? atoi(getenv("DUSP_FILTER_SCAN")) : 1;
+    opt.filter_scan = !continued && scan_knob != 0 && dusp::jit_filter_scan_ok(P, opt.table_bound, scan_knob == 2 ? 2 : 1);
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
     if (!continued && opt.filter_stages == 0 && per_wave == 1 && (getenv("DUSP_DELAY_LINE") && atoi(getenv("DUSP_DELAY_LINE")) == 1)) {

@@ -14,7 +14,10 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
+#include <functional>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
@@ -92,15 +95,34 @@ inline int jit_filter_stages(const Program &P) {
     for (const DevOp &op : P.ops) n += op.op == OP_FILTER;
     return n;
 }
-// Can every Filter of the circuit run as a scan (jit_prelude.hpp JitFilterScan)?  Each needs a cutoff that is a constant of the
-// circuit and coefficients whose all-pole part 1 / (1 + b1 z^-1 + b2 z^-2) has an impulse response of sum|h| <= 30: the scan carries
-// unrounded pairs where the reference rounds y to f32 every step (an error of at most 2^-24 |y| a step, which reaches later samples
-// through that all-pole part; the two results' own roundings to f32 add an ulp), so its results stay within 2^-24 (sum|h| + 2) of the
-// signal's scale of the reference's — 2^-19, 1.9e-6, a fifth of this path's 1e-5 (tests/native/filter_scan_bound_check.cpp).
-// (48 kHz: cutoffs between about 1.5 and 22.5 kHz, either kind.)
-inline bool jit_filter_scan_ok(const Program &P) {
+// Can every Filter of the circuit run as a scan (jit_prelude.hpp JitFilterScan)?  The scan carries unrounded pairs where the reference
+// rounds y to f32 every step: an error of at most 2^-24 |y| a step, which reaches later samples through the Filter's all-pole part
+// 1 / (1 + b1 z^-1 + b2 z^-2) (impulse response h); the two results' own roundings to f32 add an ulp.  A Filter by itself therefore stays within
+//     eps_F = 2^-24 (sum|h| + 2)
+// of its own output's scale of the reference's (tests/native/filter_scan_bound_check.cpp).  Two conditions, both from the coefficients the
+// render will use:
+//   (1) every Filter: a cutoff that is a constant of the circuit and eps_F <= kFilterScanUnit = 2^-19 (1.9e-6; sum|h| <= 30: 48 kHz: cutoffs
+//       between about 1.5 and 22.5 kHz, either kind);
+//   (2) what the circuit makes of those deviations: every unit that hangs on a Filter's output must pass a deviation on LINEARLY, and with
+//       the worst-case gain of each — a Filter's own sum|g| (g: its whole impulse response), |k| of a product with a constant k, the bound
+//       of an untainted signal it is multiplied with, 1 for delay lines, the sum at a Sum — the deviation bound x at every buffer solves
+//       x = G x + eps, AROUND FEEDBACK LOOPS TOO: a loop of gain g amplifies what is injected into it by up to 1 / (1 - g), and a loop whose
+//       gain bound reaches 1 has no bound at all.  Taken only when the iteration converges and every outlet stays within
+//       kFilterScanBound = 2.5e-6, a quarter of this path's 1e-5, of the LARGEST Filter output's scale.  (configs[3]: eps 1.22e-6, loop gain
+//       0.5 x 1 x 1: 2.44e-6.  Round 3's gate had (1) and the structural half of (2) only: it bounded one pass and let the deviation go
+//       round loops of any gain.)
+// Where a Filter reaches an oscillator's frequency, a delay TIME, a division, a power, a clip or an envelope — units that integrate or bend
+// their input —, a product of two deviating signals or one with a per-instance factor, the circuit keeps the Filter stage and its bits.
+// mode 2 (DUSP_FILTER_SCAN=2; measurements and tests of the scan itself): (1) and the structure of (2), whatever the gains.
+constexpr double kFilterScanUnit = 1.9073486328125e-6;  // 2^-19
+constexpr double kFilterScanBound = 2.5e-6;
+inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullptr, int mode = 1, double *bound_out = nullptr) {
+    if (bound_out) *bound_out = 0.0;
+    const size_t n_bufs = (size_t)std::max(1, P.n_bufs);
+    std::vector<double> eps(P.ops.size(), 0.0), gain(P.ops.size(), 0.0);  // per Filter: what it injects, its own worst-case gain
     bool any = false;
-    for (const DevOp &op : P.ops) {
+    for (size_t at = 0; at < P.ops.size(); at++) {
+        const DevOp &op = P.ops[at];
         if (op.op != OP_FILTER) continue;
         any = true;
         if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return false;
@@ -111,45 +133,110 @@ inline bool jit_filter_scan_ok(const Program &P) {
             for (int i = 0; i < 5; i++) k[i] = is[2 + i];
         for (double v : k)
             if (!std::isfinite(v)) return false;
-        double h1 = 1.0, h2 = 0.0, sum = 1.0;
+        // h: the all-pole part's impulse response; g: the whole Filter's
+        double h1 = 1.0, h2 = 0.0, sum_h = 1.0, g1 = k[0], g2 = 0.0, sum_g = std::fabs(k[0]);
         int quiet = 0;
-        for (int t = 0; t < 100000 && quiet < 8; t++) {
+        for (int t = 1; t < 100000 && quiet < 8; t++) {
             const double h = -k[3] * h1 - k[4] * h2;
-            h2 = h1;
-            h1 = h;
-            sum += std::fabs(h);
-            if (!(sum <= 30.0)) return false;
-            quiet = std::fabs(h) < 1e-13 ? quiet + 1 : 0;
+            const double g = (t == 1 ? k[1] : t == 2 ? k[2] : 0.0) - k[3] * g1 - k[4] * g2;
+            h2 = h1, h1 = h, g2 = g1, g1 = g;
+            sum_h += std::fabs(h);
+            sum_g += std::fabs(g);
+            if (!(sum_h <= 30.0)) return false;
+            quiet = std::fabs(h) < 1e-13 && t > 2 ? quiet + 1 : 0;
         }
         if (quiet < 8) return false;
+        eps[at] = std::ldexp(sum_h + 2.0, -24);
+        gain[at] = sum_g;
+        if (!(eps[at] <= kFilterScanUnit)) return false;
     }
     if (!any) return false;
-    // ... and what hangs on a Filter's output must pass that deviation on as it is: sums, products, sign flips, copies, the SIGNAL
-    // inlet of a delay line or of another Filter (feedback loops included), the outlets.  Where a Filter reaches an oscillator's
-    // frequency, a delay TIME, a division, a power, a clip or an envelope — units that integrate or bend their input — the circuit
-    // keeps the Filter stage and its bits.
-    std::vector<char> tainted((size_t)std::max(1, P.n_bufs), 0);
-    for (int sweep = 0; sweep < 2 + (int)P.ops.size(); sweep++) {  // (to a fixed point: feedback edges run against the order)
+    // taint: what a Filter's deviation reaches (to a fixed point: feedback edges run against the order), and that nothing on the way bends it
+    std::vector<char> tainted(n_bufs, 0);
+    std::vector<int> producer(n_bufs, -1);
+    for (size_t at = 0; at < P.ops.size(); at++)
+        if (P.ops[at].out_buf >= 0 && (size_t)P.ops[at].out_buf < n_bufs) producer[(size_t)P.ops[at].out_buf] = (int)at;
+    auto deps = [&](const DevOp &op, bool (&dep)[kMaxIn]) {
+        bool any_dep = false;
+        for (int j = 0; j < kMaxIn; j++) dep[j] = false;
+        for (int j = 0; j < kMaxIn && j < std::max(op.n_in, 2); j++)
+            if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && tainted[(size_t)op.in[j].idx]) dep[j] = any_dep = true;
+        return any_dep;
+    };
+    for (int sweep = 0; sweep < 2 + (int)P.ops.size(); sweep++) {
         bool grew = false;
         for (const DevOp &op : P.ops) {
-            bool dep[kMaxIn] = {};
-            bool any_dep = false;
-            for (int j = 0; j < kMaxIn && j < std::max(op.n_in, 2); j++)
-                if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && tainted[(size_t)op.in[j].idx]) dep[j] = any_dep = true;
+            bool dep[kMaxIn];
+            const bool any_dep = deps(op, dep);
             if (op.op != OP_FILTER && !any_dep) continue;
             switch (op.op) {
-            case OP_FILTER: case OP_MULTIPLY: case OP_SUM: case OP_SUBTRACT: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_FIXED_MULTIPLY: break;
+            case OP_FILTER: case OP_SUM: case OP_SUBTRACT: case OP_REPEATER: case OP_POLARITY_INVERT: case OP_FIXED_MULTIPLY: case OP_FIXED_DELAY: break;
+            case OP_MULTIPLY:
+                if (dep[0] && dep[1]) return false;  // (a product of two deviating signals scales one deviation by the other signal)
+                break;
             case OP_DELAY: case OP_MONO_DELAY:
                 if (dep[1]) return false;  // (the delay time)
                 break;
-            case OP_FIXED_DELAY: break;
             default: return false;
             }
             if (op.out_buf >= 0 && op.out_buf < P.n_bufs && !tainted[(size_t)op.out_buf]) tainted[(size_t)op.out_buf] = 1, grew = true;
         }
         if (!grew) break;
     }
-    return true;
+    if (mode == 2) return true;
+    // a bound on the magnitude of an UNTAINTED signal (what a deviation is multiplied with); infinity: not known
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<char> visiting(P.ops.size(), 0);
+    std::function<double(const DevOperand &)> magnitude = [&](const DevOperand &o) -> double {
+        if (o.kind == SRC_CONST) return std::fabs((double)o.cval);
+        if (o.kind != SRC_BUF || o.idx < 0 || (size_t)o.idx >= n_bufs || producer[(size_t)o.idx] < 0) return inf;  // (a per-instance parameter: not in the text)
+        const int k = producer[(size_t)o.idx];
+        if (visiting[(size_t)k]) return inf;
+        const DevOp &op = P.ops[(size_t)k];
+        visiting[(size_t)k] = 1;
+        double m = inf;
+        switch (op.op) {
+        case OP_OSC:
+            if (table_bound && op.attr >= 0 && op.attr < kNumTables && table_bound[op.attr] < 64) m = std::ldexp(1.0, table_bound[op.attr]);
+            break;
+        case OP_RAMP: m = std::max(std::fabs(op.d[1]), std::fabs(op.d[2])); break;
+        case OP_REPEATER: case OP_POLARITY_INVERT: case OP_FIXED_DELAY: m = magnitude(op.in[0]); break;
+        case OP_MULTIPLY: m = magnitude(op.in[0]) * magnitude(op.in[1]); break;
+        case OP_SUM: case OP_SUBTRACT: m = magnitude(op.in[0]) + magnitude(op.in[1]); break;
+        default: break;
+        }
+        visiting[(size_t)k] = 0;
+        return m == m ? m : inf;
+    };
+    // x = G x + eps by sweeps from zero: the iterates only grow, so one above the bound settles it; a loop whose gain bound reaches 1 never converges
+    std::vector<double> x(n_bufs, 0.0);
+    for (int sweep = 0; sweep < 4096; sweep++) {
+        double moved = 0.0;
+        for (size_t at = 0; at < P.ops.size(); at++) {
+            const DevOp &op = P.ops[at];
+            if (op.out_buf < 0 || op.out_buf >= P.n_bufs || !tainted[(size_t)op.out_buf]) continue;
+            auto xin = [&](int j) { return op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && tainted[(size_t)op.in[j].idx] ? x[(size_t)op.in[j].idx] : 0.0; };
+            auto is_dep = [&](int j) { return op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && tainted[(size_t)op.in[j].idx] != 0; };
+            double v = 0.0;
+            switch (op.op) {
+            case OP_FILTER: v = gain[at] * xin(0) + eps[at]; break;
+            case OP_SUM: case OP_SUBTRACT: v = xin(0) + xin(1); break;
+            case OP_MULTIPLY: v = is_dep(0) ? xin(0) * magnitude(op.in[1]) : xin(1) * magnitude(op.in[0]); break;
+            case OP_FIXED_MULTIPLY: v = xin(0) * std::fabs(op.d[0]); break;
+            default: v = xin(0); break;  // Repeater, sign flip, delay lines: the deviation as it is
+            }
+            if (!(v < 1.0)) return false;  // (infinite, NaN, or beyond any use)
+            moved = std::max(moved, v - x[(size_t)op.out_buf]);
+            x[(size_t)op.out_buf] = std::max(x[(size_t)op.out_buf], v);
+        }
+        double worst = 0.0;
+        for (int ob : P.out_bufs)
+            if (ob >= 0 && ob < P.n_bufs && tainted[(size_t)ob]) worst = std::max(worst, x[(size_t)ob]);
+        if (bound_out) *bound_out = worst;
+        if (worst > kFilterScanBound) return false;
+        if (moved <= 1e-12) return true;
+    }
+    return false;  // (not settled: a loop gain bound at or next to 1)
 }
 inline bool jit_filter_mod(const Program &P) {
     for (const DevOp &op : P.ops)

@@ -28,9 +28,13 @@
  * does — everything but the units that call Math.tan / Math.pow (Filter coefficients; Gain, DecibelToScaler,
  * SemitoneToRatio, Pow, Pan, MidiToFrequency), which are within 1e-5 of full scale.  One form trades
  * bits for speed inside that tolerance: a Filter whose cutoff is a constant between about 1.5 and 22.5 kHz (at 48 kHz) and
- * whose output only feeds sums, products, delay lines and outlets is evaluated as a scan over each chunk — within 1.9e-6
- * of the signal's scale of the reference by construction.  DUSP_FILTER_SCAN=0 in the environment of
- * dusp_ctx_create keeps every Filter on the path whose results are the reference recurrence's, operation for operation.
+ * whose output only feeds sums, products with constants or bounded signals, delay lines and outlets is evaluated as a
+ * scan over each chunk: each such Filter deviates from the reference's recurrence by at most 2^-24 (sum|h| + 2) <= 1.9e-6
+ * of its own output's scale, and the form is taken only where what the circuit makes of those deviations — every unit's
+ * worst-case gain, feedback loops' 1 / (1 - loop gain) included — stays within 2.5e-6 of the Filters' output scale at every
+ * outlet (jit_codegen.hpp jit_filter_scan_ok).  A loop of gain 0.6 and above, a per-instance gain, a
+ * product of two filtered signals keep the Filter stage.  DUSP_FILTER_SCAN=0 in the environment of dusp_ctx_create keeps
+ * EVERY Filter on the stage, whose results are the reference recurrence's, operation for operation.
  *
  * Threading: a dusp_ctx is bound to one HIP device and is not thread-safe;
  * different contexts are independent (one context per GPU for multi-GPU use).
@@ -84,7 +88,7 @@ typedef enum {
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
  * AUTO picks FUSED, else WAVE for the feedback voice with a constant delay (its compiled kernel beats the LOOP kernels), else
- * LOOP for the other feedback voices (per-instance or modulated delays), else WAVE, else CHUNK.
+ * LOOP for the feedback voices whose delay is a signal (per-instance delays have compiled kernels since ABI v6), else WAVE, else CHUNK.
  *
  * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
  * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose

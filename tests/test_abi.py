@@ -125,3 +125,5 @@ def test_the_filter_scan_stays_within_its_stated_bound(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "native", "filter_scan_bound_check.cpp")])
     rep = json.loads(subprocess.check_output([exe]).decode().strip().splitlines()[-1])
     assert rep["cases"] >= 30 and rep["bad"] == 0 and rep["worst_of_bound"] <= 1.0 and rep["worst_of_scale"] <= 1.9e-6
+    # ... and inside configs[3]'s feedback loop at gains 0.5 .. 0.99, resonant and other inputs: within the loop-gain bound of jit_filter_scan_ok (2)
+    assert rep["loop_cases"] == 24 and rep["loop_bad"] == 0 and rep["loop_worst_of_bound"] <= 1.0 and rep["loop_worst_of_scale"] <= 1e-5

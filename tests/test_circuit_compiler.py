@@ -168,6 +168,44 @@ def test_filters_with_a_constant_cutoff_run_as_a_scan():
     assert hp.count("JitFilterScanK fk") == 2
 
 
+def test_the_scan_gate_bounds_the_gain_of_feedback_loops(monkeypatch):
+    """jit_filter_scan_ok (2): a deviation the scan injects goes round feedback loops, and a loop of gain g amplifies it by up to 1 / (1 - g).
+    The gate solves x = G x + eps over the circuit with every unit's worst-case gain and takes the scan only when every outlet stays
+    within 2.5e-6 of the Filters' output scale: configs[3] (gain 0.5: 2 x 1.22e-6) keeps the scan, the same voice with a feedback gain of
+    0.6 and above — plucked strings, combs — renders on the Filter stage, bit for bit; so does a product with another signal whose size
+    the generator does not know, and a product of two deviating signals.  DUSP_FILTER_SCAN=2 (measurements, tests) lifts the gain rule only."""
+    d.configure(48000)
+    def loop(k, gain, cutoff=2000, kind="LP"):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), cutoff, kind)
+        s.B = d.Multiply(f, gain)
+        return f
+    def text(build, **kw):
+        return source(descriptor.unify([descriptor.extract(build(k)) for k in (0, 64)]).words, waves=16, per_wave=1, **kw)
+    assert "JitFilterScan" in text(lambda k: loop(k, 0.5))
+    assert "JitFilterScan" in text(lambda k: loop(k, -0.5))
+    for g in (0.6, 0.9, 0.95, 0.99, 1.0, 1.5):
+        t = text(lambda k: loop(k, g))
+        assert "JitFilterScan" not in t and "JitFilterK<" in t, g
+    assert "JitFilterScan" in text(lambda k: loop(k, 0.9, 8000))            # eps = 2^-24 (2.7 + 2): ten times that is still within the bound
+    assert "JitFilterScan" not in text(lambda k: loop(k, 0.99, 8000))       # ... a hundred times is not
+    # two loops through one Filter add up (0.3 + 0.3: as good as one of 0.6)
+    def two(k):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000)
+        s.B = d.Sum(d.Multiply(f, 0.3), d.Multiply(d.Delay(f, 700, 4096), 0.3))
+        return f
+    assert "JitFilterScan" not in text(two)
+    # a gain that is a per-instance parameter is not in the text: refused; a known oscillator as the other factor is bounded by its table (|sin| <= 2^1)
+    assert "JitFilterScan" not in text(lambda k: loop(k, 0.25 + k / 1024))
+    assert "JitFilterScan" in text(lambda k: d.Multiply(d.Filter(d.Osc(200 + k), 3000), d.Osc(3)))
+    assert "JitFilterScan" not in text(lambda k: d.Multiply(d.Filter(d.Osc(200 + k), 3000), d.Filter(d.Osc(3), 3000)))  # two deviating signals
+    assert "JitFilterScan" not in text(lambda k: d.Multiply(d.Filter(d.Osc(200 + k), 3000), 40))  # 40 x 8e-7 of the Filter's scale
+    monkeypatch.setenv("DUSP_FILTER_SCAN", "2")
+    assert "JitFilterScan" in text(lambda k: loop(k, 0.99))
+    assert "JitFilterScan" not in text(lambda k: loop(k, 0.5, 600))         # (the Filter's own bound stays)
+
+
 def test_delays_as_lines_of_input_samples_in_lds(monkeypatch):
     """DUSP_DELAY_LINE=1 (off by default: measured slower than the ring in memory): a Delay with a constant delay of a chunk at
     least keeps the last chunks of its INPUT in LDS rows of its wavefront (JitDelayLine) where they fit at 16 wavefronts next to the table image."""
