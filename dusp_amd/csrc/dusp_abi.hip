@@ -274,6 +274,19 @@ extern "C" {
 const char *dusp_version(void) { return "dusp-hip 0.1.0 (gfx950)"; }
 int dusp_abi_version(void) { return DUSP_ABI_VERSION; }
 
+int dusp_device_count(void) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        try {
+            g_error = std::string("no usable HIP device: ") + hipGetErrorString(e) + " (this library has no CPU fallback)";
+        } catch (...) {
+        }
+        return DUSP_ERR_HIP;
+    }
+    return count;
+}
+
 const char *dusp_last_error(const dusp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
 
 int dusp_ctx_create(int device, dusp_ctx **out) {

@@ -1,6 +1,7 @@
 /* dusp_napi.c — thin N-API addon binding the C ABI of include/dusp_hip.h for Node.js.
  *
  * Raw C against <node_api.h> (N-API v4+, present in Node 12): no node-gyp, no node-addon-api.
+ *   deviceCount() -> number of HIP devices this process sees
  *   ctxCreate(device) -> ctx            tableUpload(ctx, id, Float32Array)
  *   programBuild(ctx, Float64Array words, engine) -> prog
  *   programInfo(prog) -> { sampleRate, nUnits, nOutChannels, nParams, nInputs, engine, shape, nDeviceOps }
@@ -22,8 +23,11 @@
 
 #define PINNED_MIN_BYTES ((size_t)1 << 20) /* results of at least 1 MiB live in pinned memory (dusp_host_alloc) */
 
-/* a dusp_ctx is not thread-safe and async renders run on pool threads: serialise library calls */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+/* A dusp_ctx is not thread-safe and async renders run on pool threads: calls on ONE context are serialised by that context's
+ * lock (ctx_box.lock).  Different contexts are independent (include/dusp_hip.h "Threading"), so renders on different contexts —
+ * one per GPU when renderMany shards its instances over the node's devices — run side by side on the pool.  g_create_lock only
+ * orders context creation and destruction (device enumeration, the process-wide settings the first context reads). */
+static pthread_mutex_t g_create_lock = PTHREAD_MUTEX_INITIALIZER;
 
 #define NAPI_OK(call)                                                          \
     do {                                                                       \
@@ -46,6 +50,7 @@ static void throw_string(napi_env env, const char *msg) {
  *   prog_box.in_flight  renders queued or running: programDestroy during one is deferred to its completion */
 typedef struct {
     dusp_ctx *ctx;
+    pthread_mutex_t lock; /* every library call on this context or on one of its programs */
     int refs, n_programs, n_buffers;
 } ctx_box;
 typedef struct {
@@ -57,10 +62,11 @@ typedef struct {
 static void ctx_unref(ctx_box *b) {
     if (--b->refs > 0) return;
     if (b->ctx) { /* never destroyed explicitly: the last dependant is gone, release the device side too */
-        pthread_mutex_lock(&g_lock);
+        pthread_mutex_lock(&g_create_lock);
         dusp_ctx_destroy(b->ctx);
-        pthread_mutex_unlock(&g_lock);
+        pthread_mutex_unlock(&g_create_lock);
     }
+    pthread_mutex_destroy(&b->lock);
     free(b);
 }
 static void ctx_finalize(napi_env env, void *data, void *hint) {
@@ -69,9 +75,9 @@ static void ctx_finalize(napi_env env, void *data, void *hint) {
 }
 static void prog_destroy_now(prog_box *b) {
     if (!b->prog) return;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&b->cb->lock);
     dusp_program_destroy(b->prog);
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&b->cb->lock);
     b->prog = NULL;
     b->cb->n_programs--;
 }
@@ -130,17 +136,34 @@ static napi_value fn_abi_version(napi_env env, napi_callback_info info) {
     return v;
 }
 
+/* deviceCount() -> HIP devices this process sees (dusp_device_count); throws the library's message when there is no usable device */
+static napi_value fn_device_count(napi_env env, napi_callback_info info) {
+    (void)info;
+    pthread_mutex_lock(&g_create_lock);
+    int n = dusp_device_count();
+    char msg[512];
+    if (n < 0) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(NULL));
+    pthread_mutex_unlock(&g_create_lock);
+    if (n < 0) {
+        throw_string(env, msg);
+        return NULL;
+    }
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, n, &v));
+    return v;
+}
+
 static napi_value fn_ctx_create(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
     int32_t device = -1;
     napi_get_value_int32(env, argv[0], &device);
     dusp_ctx *ctx = NULL;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&g_create_lock);
     int rc = dusp_ctx_create(device, &ctx);
     char msg[512];
     if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(NULL));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&g_create_lock);
     if (rc != DUSP_OK) {
         throw_string(env, msg);
         return NULL;
@@ -153,9 +176,11 @@ static napi_value fn_ctx_create(napi_env env, napi_callback_info info) {
     }
     b->ctx = ctx;
     b->refs = 1;
+    pthread_mutex_init(&b->lock, NULL);
     napi_value ext;
     if (napi_create_external(env, b, ctx_finalize, NULL, &ext) != napi_ok) {
         dusp_ctx_destroy(ctx);
+        pthread_mutex_destroy(&b->lock);
         free(b);
         throw_string(env, "dusp-hip: could not wrap the context");
         return NULL;
@@ -175,9 +200,9 @@ static napi_value fn_ctx_destroy(napi_env env, napi_callback_info info) {
         throw_string(env, msg);
         return NULL;
     }
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&g_create_lock);
     dusp_ctx_destroy(b->ctx);
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&g_create_lock);
     b->ctx = NULL;
     return NULL;
 }
@@ -195,11 +220,11 @@ static napi_value fn_table_upload(napi_env env, napi_callback_info info) {
         throw_string(env, "dusp-hip: tableUpload expects a Float32Array");
         return NULL;
     }
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&b->lock);
     int rc = dusp_table_upload(b->ctx, id, (const float *)data, len);
     char msg[512];
     if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(b->ctx));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&b->lock);
     if (rc != DUSP_OK) throw_string(env, msg);
     return NULL;
 }
@@ -218,11 +243,11 @@ static napi_value fn_program_build(napi_env env, napi_callback_info info) {
     int32_t engine = 0;
     napi_get_value_int32(env, argv[2], &engine);
     dusp_program *prog = NULL;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&b->lock);
     int rc = dusp_program_build(b->ctx, (const double *)data, len, engine, &prog);
     char msg[512];
     if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(b->ctx));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&b->lock);
     if (rc != DUSP_OK) {
         throw_string(env, msg);
         return NULL;
@@ -230,9 +255,9 @@ static napi_value fn_program_build(napi_env env, napi_callback_info info) {
     prog_box *pb = (prog_box *)calloc(1, sizeof *pb);
     napi_value ext;
     if (!pb || napi_create_external(env, pb, prog_finalize, NULL, &ext) != napi_ok) {
-        pthread_mutex_lock(&g_lock);
+        pthread_mutex_lock(&b->lock);
         dusp_program_destroy(prog);
-        pthread_mutex_unlock(&g_lock);
+        pthread_mutex_unlock(&b->lock);
         free(pb);
         throw_string(env, "dusp-hip: could not wrap the program");
         return NULL;
@@ -257,11 +282,11 @@ static napi_value fn_program_continue(napi_env env, napi_callback_info info) {
         throw_string(env, "dusp-hip: programContinue expects a Float64Array of descriptor words");
         return NULL;
     }
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&pb->cb->lock);
     int rc = dusp_program_continue(pb->prog, (const double *)data, len);
     char msg[512];
     if (rc != DUSP_OK) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->cb->ctx));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&pb->cb->lock);
     if (rc != DUSP_OK) {
         throw_string(env, msg);
         return NULL;
@@ -317,11 +342,11 @@ static napi_value fn_state_download(napi_env env, napi_callback_info info) {
     napi_get_value_uint32(env, argv[1], &instance);
     napi_get_value_uint32(env, argv[2], &unit);
     double words[512];
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&pb->cb->lock);
     int n = dusp_state_download(pb->prog, instance, unit, words, 512);
     char msg[512];
     if (n < 0) snprintf(msg, sizeof msg, "dusp-hip: %s", dusp_last_error(pb->cb->ctx));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&pb->cb->lock);
     if (n < 0) {
         throw_string(env, msg);
         return NULL;
@@ -354,7 +379,7 @@ typedef struct {
 static void render_execute(napi_env env, void *data) {
     (void)env;
     render_job *j = (render_job *)data;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&j->pb->cb->lock); /* (this context's: renders on other contexts — other GPUs — run beside this one) */
     dusp_program *prog = j->pb->prog; /* (in_flight > 0 keeps it alive: programDestroy defers) */
     if (!prog) {
         j->rc = DUSP_ERR_STATE;
@@ -366,7 +391,7 @@ static void render_execute(napi_env env, void *data) {
                                    : dusp_render_host(prog, j->n_instances, j->n_samples, j->params, j->out);
         if (j->rc != DUSP_OK) snprintf(j->err, sizeof j->err, "dusp-hip: %s", dusp_last_error(j->pb->cb->ctx));
     }
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&j->pb->cb->lock);
 }
 static void free_pcm(napi_env env, void *data, void *hint) {
     (void)env; (void)hint;
@@ -377,9 +402,9 @@ static void free_pinned_pcm(napi_env env, void *data, void *hint) {
     (void)env;
     ctx_box *cb = (ctx_box *)hint;
     if (cb->ctx) {
-        pthread_mutex_lock(&g_lock);
+        pthread_mutex_lock(&cb->lock);
         dusp_host_free(cb->ctx, data);
-        pthread_mutex_unlock(&g_lock);
+        pthread_mutex_unlock(&cb->lock);
     }
     cb->n_buffers--;
     ctx_unref(cb);
@@ -389,9 +414,9 @@ static void release_out(render_job *j) { /* an output buffer that never reached 
     if (j->out_pinned) {
         ctx_box *cb = j->pb->cb;
         if (cb->ctx) {
-            pthread_mutex_lock(&g_lock);
+            pthread_mutex_lock(&cb->lock);
             dusp_host_free(cb->ctx, j->out);
-            pthread_mutex_unlock(&g_lock);
+            pthread_mutex_unlock(&cb->lock);
         }
         cb->n_buffers--;
         ctx_unref(cb);
@@ -512,9 +537,9 @@ static napi_value fn_render(napi_env env, napi_callback_info info) {
      * rendering makes hundreds a second) from malloc. */
     if (j->n_floats * sizeof(float) >= PINNED_MIN_BYTES) {
         void *p = NULL;
-        pthread_mutex_lock(&g_lock);
+        pthread_mutex_lock(&pb->cb->lock);
         int rc = dusp_host_alloc(pb->cb->ctx, j->n_floats * sizeof(float), &p);
-        pthread_mutex_unlock(&g_lock);
+        pthread_mutex_unlock(&pb->cb->lock);
         if (rc == DUSP_OK) {
             j->out = (float *)p;
             j->out_pinned = 1;
@@ -562,7 +587,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"version", fn_version},          {"abiVersion", fn_abi_version},     {"ctxCreate", fn_ctx_create},
         {"ctxDestroy", fn_ctx_destroy},   {"tableUpload", fn_table_upload},   {"programBuild", fn_program_build},
         {"programDestroy", fn_program_destroy}, {"programInfo", fn_program_info}, {"stateDownload", fn_state_download},
-        {"render", fn_render},            {"programContinue", fn_program_continue},
+        {"render", fn_render},            {"programContinue", fn_program_continue}, {"deviceCount", fn_device_count},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

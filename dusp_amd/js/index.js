@@ -1,6 +1,9 @@
 'use strict'
 /* dusp-hip: the `renderChannelData` / `quick` surface of Dusp (reference src/index.js:6,11) plus the
  * constructors of the units the MI355X render path executes. */
+// renderMany keeps one render per GPU in flight on the libuv pool, whose size (default 4) is read when the pool is first used: on a node
+// with more GPUs ask for as many threads, unless the host application has chosen a size itself
+if (!process.env.UV_THREADPOOL_SIZE) process.env.UV_THREADPOOL_SIZE = '16'
 const graph = require('./lib/graph')
 const renderChannelData = require('./lib/renderChannelData')
 const dusp = require('./lib/dusp')
@@ -8,6 +11,7 @@ const dusp = require('./lib/dusp')
 module.exports = {
   renderChannelData,
   renderMany: renderChannelData.renderMany,
+  deviceCount: renderChannelData.deviceCount,
   renderDescriptor: renderChannelData.renderDescriptor,
   quick: require('./lib/quick'),
   unDusp: require('./lib/unDusp'),

@@ -15,16 +15,43 @@ const { extract, unify, deviceRetrigger } = require('./extract')
 const { makeTables } = require('./wavetables')
 const { OP, UNITS } = require('./ops')
 
-const contexts = new Map() // sampleRate -> native context with that rate's wave tables
+const contexts = new Map() // "sampleRate|device|slot" -> native context with that rate's wave tables
 
-function contextFor(sampleRate) {
-  if (!contexts.has(sampleRate)) {
+/* One context per (sample rate, device): a dusp_ctx is bound to one HIP device (include/dusp_hip.h "Threading").  device -1 = the
+ * process's current device (single renders).  `slot` tells contexts of one device apart: renderMany's device list may name a GPU
+ * twice (two contexts, two shards side by side on it). */
+function contextFor(sampleRate, device = -1, slot = 0) {
+  const key = sampleRate + '|' + device + '|' + slot
+  if (!contexts.has(key)) {
     const n = native()
-    const ctx = n.ctxCreate(-1)
+    const ctx = n.ctxCreate(device)
     makeTables(sampleRate).forEach((t, id) => n.tableUpload(ctx, id, t))
-    contexts.set(sampleRate, ctx)
+    contexts.set(key, ctx)
   }
-  return contexts.get(sampleRate)
+  return contexts.get(key)
+}
+
+/* Contiguous, balanced split of n instances over `world` shards: the first n % world get one more (dusp_amd/shard.py
+ * instance_range, SURVEY.md 8e: rank r renders [r N / G, (r + 1) N / G)). */
+function instanceRange(n, rank, world) {
+  const base = Math.floor(n / world), extra = n % world
+  const lo = rank * base + Math.min(rank, extra)
+  return [lo, lo + base + (rank < extra ? 1 : 0)]
+}
+
+/* The device list of a sharded render: undefined = every HIP device this process sees, a number n = devices 0 .. n-1, or the ids
+ * themselves (one shard per entry, in order; an id may repeat). */
+function deviceList(devices) {
+  const n = native()
+  const have = n.deviceCount()
+  let list
+  if (devices === undefined || devices === null) list = Array.from({ length: have }, (_, i) => i)
+  else if (typeof devices === 'number') list = Array.from({ length: devices }, (_, i) => i)
+  else list = Array.from(devices)
+  if (!list.length) throw 'dusp-hip: renderMany: empty device list'
+  for (const d of list)
+    if (!Number.isInteger(d) || d < 0 || d >= have) throw 'dusp-hip: renderMany: device ' + d + ' is not one of the ' + have + ' this process sees'
+  return list
 }
 
 function sampleCount(duration, sampleRate) {
@@ -237,9 +264,16 @@ async function renderChannelData(outlet, duration = 1, { TypedArray = Float32Arr
   }
 }
 
-/* N structurally identical circuits (voices, a parameter sweep) as ONE GPU program:
- * resolves to result[instance][channel] = Float32Array(duration * sampleRate). */
-async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
+/* N structurally identical circuits (voices, a parameter sweep) as ONE GPU program per device:
+ * resolves to result[instance][channel] = Float32Array(duration * sampleRate).
+ *
+ * The instances share nothing, so they shard over the GPUs of the node with no exchange at all (SURVEY.md 8e): `devices` (default:
+ * every HIP device the process sees; a count; or a list of ids) names one shard per entry, shard r renders the contiguous instance
+ * range instanceRange(N, r, shards) on a context of ITS device — the same program text, its rows of the parameter table — and all
+ * shards are in flight at once (one async render each on the libuv pool; the addon serialises calls per context, not across them).
+ * The results come back in instance order whatever order the devices finish in.  A render rejects as a whole with the first
+ * failing shard's string. */
+async function renderMany(outlets, duration = 1, { engine = 0, devices } = {}) {
   const extractions = outlets.map((o) => extract(o))
   // one launch for all circuits: nothing ticks on the host in between, so units that need that are refused, not ignored
   for (const ex of extractions)
@@ -250,23 +284,46 @@ async function renderMany(outlets, duration = 1, { engine = 0 } = {}) {
   const nSamples = sampleCount(duration, uni.sampleRate)
   if (nSamples === 0) return outlets.map(() => [])
   const n = native()
-  const prog = n.programBuild(contextFor(uni.sampleRate), uni.words, engine)
+  const list = deviceList(devices)
+  const seen = new Map() // device id -> contexts of it handed out so far
+  const shards = []
+  for (let r = 0; r < list.length; r++) {
+    const [lo, hi] = instanceRange(uni.nInstances, r, list.length)
+    if (hi === lo) continue
+    const slot = seen.get(list[r]) || 0
+    seen.set(list[r], slot + 1)
+    shards.push({ lo, hi, device: list[r], slot, prog: null })
+  }
   try {
-    const info = n.programInfo(prog)
-    const pcm = await n.render(prog, uni.nInstances, nSamples, uni.nParams ? uni.params : null)
-    const result = []
-    for (let i = 0; i < uni.nInstances; i++) {
-      const chans = []
-      for (let c = 0; c < info.nOutChannels; c++) {
-        const at = (i * info.nOutChannels + c) * nSamples
-        chans.push(pcm.subarray(at, at + nSamples))
+    for (const sh of shards) sh.prog = n.programBuild(contextFor(uni.sampleRate, list.length === 1 && devices === undefined ? -1 : sh.device, sh.slot), uni.words, engine)
+    const jobs = shards.map((sh) => {
+      let params = null
+      if (uni.nParams) { // slot-major [nParams][nInstances]: this shard's columns of every row
+        const count = sh.hi - sh.lo
+        params = new Float32Array(uni.nParams * count)
+        for (let p = 0; p < uni.nParams; p++) params.set(uni.params.subarray(p * uni.nInstances + sh.lo, p * uni.nInstances + sh.hi), p * count)
       }
-      chans.sampleRate = uni.sampleRate
-      result.push(chans)
-    }
+      return n.render(sh.prog, sh.hi - sh.lo, nSamples, params)
+    })
+    const pcms = await Promise.all(jobs.map((j) => j.then((v) => ({ ok: v }), (e) => ({ err: e })))) // (every shard ends before anything is torn down)
+    const failed = pcms.find((p) => p.err !== undefined)
+    if (failed) throw failed.err
+    const result = new Array(uni.nInstances)
+    shards.forEach((sh, k) => {
+      const nCh = n.programInfo(sh.prog).nOutChannels, pcm = pcms[k].ok
+      for (let i = sh.lo; i < sh.hi; i++) {
+        const chans = []
+        for (let c = 0; c < nCh; c++) {
+          const at = ((i - sh.lo) * nCh + c) * nSamples
+          chans.push(pcm.subarray(at, at + nSamples))
+        }
+        chans.sampleRate = uni.sampleRate
+        result[i] = chans
+      }
+    })
     return result
   } finally {
-    n.programDestroy(prog)
+    for (const sh of shards) if (sh.prog) n.programDestroy(sh.prog)
   }
 }
 
@@ -293,4 +350,6 @@ module.exports = renderChannelData
 module.exports.renderChannelData = renderChannelData
 module.exports.renderDescriptor = renderDescriptor
 module.exports.renderMany = renderMany
+module.exports.instanceRange = instanceRange
+module.exports.deviceCount = () => native().deviceCount()
 module.exports.SegmentRenderer = SegmentRenderer

@@ -23,7 +23,7 @@ EXPORTS = [
     "dusp_table_upload", "dusp_program_build", "dusp_program_destroy", "dusp_program_continue", "dusp_program_info_get",
     "dusp_render_device", "dusp_render_host", "dusp_render_host_interleaved", "dusp_interleave_device", "dusp_state_download",
     "dusp_last_kernel_ms", "dusp_fill_device", "dusp_render_device_inputs", "dusp_render_host_inputs",
-    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source", "dusp_jit_cache_dir", "dusp_render_chain_window",
+    "dusp_host_alloc", "dusp_host_free", "dusp_circuit_kernel_source", "dusp_jit_cache_dir", "dusp_render_chain_window", "dusp_device_count",
 ]
 
 
@@ -61,6 +61,7 @@ def load():
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.dusp_version.restype = ctypes.c_char_p
     L.dusp_abi_version.restype = ci
+    L.dusp_device_count.restype = ci
     L.dusp_last_error.restype = ctypes.c_char_p
     L.dusp_last_error.argtypes = [vp]
     L.dusp_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]

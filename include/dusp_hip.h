@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define DUSP_ABI_VERSION 6
+#define DUSP_ABI_VERSION 7
 
 typedef struct dusp_ctx dusp_ctx;
 typedef struct dusp_program dusp_program;
@@ -119,6 +119,11 @@ int dusp_abi_version(void);
 /* Message of the last failing call on this context (or, with ctx == NULL, of
  * the last failing dusp_ctx_create on this thread).  Never NULL. */
 const char *dusp_last_error(const dusp_ctx *ctx);
+
+/* ABI v7.  HIP devices this process sees (what `device` of dusp_ctx_create ranges over), or a negative dusp_status
+ * (message: dusp_last_error(NULL)).  A host that shards independent circuit instances over a node's GPUs creates one
+ * context per device (dusp_amd/js/lib/renderChannelData.js renderMany, dusp_amd/shard.py). */
+int dusp_device_count(void);
 
 /* Create a context on HIP device `device` (-1 = current device). */
 int dusp_ctx_create(int device, dusp_ctx **out);

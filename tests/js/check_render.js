@@ -65,6 +65,24 @@ async function main() {
     const one = await lib.renderChannelData(beat(...beats[k]), 0.2)
     report.manyRetriggered = report.manyRetriggered && manyBeats[k][0].length === one[0].length && manyBeats[k][0].every((v, i) => v === one[0][i])
   }
+  // renderMany over the node's GPUs: one shard per entry of `devices`, each on a context of its own, all in flight at once; the
+  // results in instance order.  On a one-GPU box the same device listed two / three times exercises the split, the parameter rows,
+  // the ordering and the concurrency (two contexts side by side on one card): bit for bit the one-context render.
+  const sweep = (k) => new lib.Multiply(new lib.Osc(55 + 13.25 * k), new lib.Ramp(3000 + 10 * k, 1, 0.25).trigger())
+  const eleven = () => Array.from({ length: 11 }, (_, k) => sweep(k))
+  const nSweep = 256 * 40 + 17
+  const oneCtx = await lib.renderMany(eleven(), nSweep / SR, { devices: [0] })
+  const same = (a, b) => a.length === b.length && a.every((chans, i) => chans.length === b[i].length && chans.every((ch, c) => ch.length === b[i][c].length && ch.every((v, t) => v === b[i][c][t])))
+  report.devices = lib.deviceCount()
+  report.shardedTwice = same(oneCtx, await lib.renderMany(eleven(), nSweep / SR, { devices: [0, 0] }))
+  report.shardedThrice = same(oneCtx, await lib.renderMany(eleven(), nSweep / SR, { devices: [0, 0, 0] }))
+  report.shardedDefault = same(oneCtx, await lib.renderMany(eleven(), nSweep / SR)) // every visible device
+  report.shardedMoreDevicesThanVoices = same(oneCtx.slice(0, 2), await lib.renderMany(eleven().slice(0, 2), nSweep / SR, { devices: [0, 0, 0, 0, 0] }))
+  const loopVoice = (k) => { const sum = new lib.Sum(new lib.Osc(110 + k / 4), 0); const f = new lib.Filter(new lib.Delay(sum, 480, 4096), 2000); sum.B = new lib.Multiply(f, 0.5); return f }
+  const loops = () => Array.from({ length: 7 }, (_, k) => loopVoice(k))
+  report.shardedLoops = same(await lib.renderMany(loops(), 0.25, { devices: [0] }), await lib.renderMany(loops(), 0.25, { devices: [0, 0, 0] }))
+  report.badDevice = await lib.renderMany(eleven(), 0.01, { devices: [0, 99] }).then(() => 'resolved', (e) => String(e))
+  report.instanceRange = [[10, 0, 3], [10, 1, 3], [10, 2, 3], [2, 4, 5], [65536, 7, 8]].map((a) => lib.renderChannelData.instanceRange(...a))
   // renderMany runs one launch for all voices: a circuit whose unit needs host ticks in between is refused, not mis-rendered
   const ticking = () => { const e = new lib.Shape('decay', 0.01).trigger(); new lib.SporadicRetriggerer(e, 50); return new lib.Multiply(new lib.Osc(200), e) } // (random: ticked on the host)
   report.manyRefusesHostTicked = await lib.renderMany([ticking(), ticking()], 0.01).then(() => 'resolved', (e) => String(e))

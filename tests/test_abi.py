@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_abi():
     L = runtime.load()
-    assert L.dusp_abi_version() == 6
+    assert L.dusp_abi_version() == 7
     assert b"gfx950" in L.dusp_version()
 
 

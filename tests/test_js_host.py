@@ -113,8 +113,8 @@ console.log(JSON.stringify({flen: f.length, plen: p.length, riff: f.toString('as
 @needs_node
 def test_addon_loads_and_fails_loudly_without_gpu():
     rep = run_js("check_addon.js", "--sampleRate=48000")
-    assert rep["abi"] == 6 and "gfx950" in rep["version"]
-    assert set(rep["exports"]) >= {"ctxCreate", "tableUpload", "programBuild", "programContinue", "render", "stateDownload"}
+    assert rep["abi"] == 7 and "gfx950" in rep["version"]
+    assert set(rep["exports"]) >= {"ctxCreate", "tableUpload", "programBuild", "programContinue", "render", "stateDownload", "deviceCount"}
     assert rep["nullRejects"] == "renderAudioBuffer expects an outlet"  # the reference's own string
     if not rep["gpu"]:
         assert rep["ctxErrorIsString"] is True
@@ -135,6 +135,12 @@ def test_js_render_channel_data_matches_reference_golden(sr):
     assert "already been ticked" in rep["secondRenderRejects"]
     assert rep["manyMatchesSolo"] is True
     assert rep["manyRetriggered"] is True
+    # renderMany sharded over devices (here: ONE card listed several times — two / three contexts side by side), bit for bit the one-context render
+    assert rep["devices"] >= 1 and rep["shardedTwice"] is True and rep["shardedThrice"] is True and rep["shardedDefault"] is True
+    assert rep["shardedMoreDevicesThanVoices"] is True and rep["shardedLoops"] is True
+    assert rep["badDevice"].startswith("dusp-hip: renderMany: device 99 is not one of the")
+    from dusp_amd.shard import instance_range
+    assert [tuple(x) for x in rep["instanceRange"]] == [instance_range(*a) for a in ((10, 0, 3), (10, 1, 3), (10, 2, 3), (2, 4, 5), (65536, 7, 8))]
     assert rep["manyRefusesHostTicked"].startswith("dusp-hip: renderMany does not take circuits with host-ticked units")
     assert rep["unsupported"].startswith("dusp-hip: unit type not supported")
     assert rep["thenWithDeviceMemory"].startswith("dusp-hip: the circuit was rewired during the render (the circuit holds delay lines")
