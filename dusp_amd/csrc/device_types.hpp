@@ -36,6 +36,11 @@ enum : int { SRC_CONST = 0, SRC_BUF = 1, SRC_PARAM = 2 };    // device operand k
 constexpr int kNumTables = 9;      // 0-4 oscillator wave tables, 5-8 Shape tables (decay, attack, semiSine, decaySquared)
 constexpr int kFirstShapeTable = 5;
 constexpr int kChunk = 256;
+// bytes of the oscillators' half-table image in LDS (device_util.hpp Table<1>: entries M + 1 .. 0 in blocks of 33 words); here, without
+// any HIP attribute, so that host-only code (the circuit compiler's option logic, its sanitizer build) can size a workgroup's LDS too
+constexpr unsigned long half_table_image_bytes(uint32_t sample_rate) {
+    return ((unsigned long)((sample_rate / 2 + 1) + ((sample_rate / 2 + 1) >> 5) + 2) * 4ul + 15ul) & ~15ul;
+}
 constexpr int kMaxWarmChunks = 8;  // chunks at the start of a render that may run their own op list (program.hpp infer_channels)
 
 // A/B switches for tools/ and tests.  They are read from the environment ONCE, when a context is created

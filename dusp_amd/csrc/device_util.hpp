@@ -274,10 +274,7 @@ __device__ __forceinline__ void load_half_table(float *lds, const float *table, 
     __syncthreads();
 }
 
-__host__ __device__ inline size_t half_table_lds_bytes(uint32_t sample_rate) {
-    const uint32_t last = sample_rate / 2 + 1;
-    return ((size_t)(last + (last >> 5) + 2) * sizeof(float) + 15) & ~(size_t)15;
-}
+__host__ __device__ inline size_t half_table_lds_bytes(uint32_t sample_rate) { return (size_t)half_table_image_bytes(sample_rate); }
 
 }  // namespace
 }  // namespace dusp

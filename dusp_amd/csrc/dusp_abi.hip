@@ -1731,69 +1731,23 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
         g_error = "dusp_circuit_kernel_source: waves must be 1 .. 16 and per_wave 1 .. 4";
         return DUSP_ERR_ARG;
     }
-    dusp::Program P;
-    std::string err;
-    if (!dusp::compile(desc, n_words, P, err, /*continuation=*/true)) {
-        g_error = "dusp_circuit_kernel_source: " + err;
-        return DUSP_ERR_ARG;
-    }
-    const bool continued = (lds_table & 2) != 0 && (P.ring_samples != 0 || !P.feed_forward);
-    const bool lean_recurrence = (lds_table & 4) != 0;  // (the Filter stage's recurrence loop with 4 P values per register set: what a render falls back to when the kernel spills)
-    lds_table &= 1;
-    if (continued)
-        for (dusp::DevOp &op : P.ops)
-            if (op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) op.pad = dusp::kDelayExactRing;
-    dusp::WavePlan plan;
-    if (!dusp::plan_wave(P, plan, continued)) {
-        g_error = "dusp_circuit_kernel_source: the wave engine cannot run this graph (" + plan.why + ")";
-        return DUSP_ERR_UNSUPPORTED;
-    }
-    for (size_t k = 0; k < plan.osc_level.size() && k < P.ops.size(); k++)
-        if (plan.osc_level[k] >= 0) P.ops[k].d[0] = (double)plan.osc_level[k];
-    if (!dusp::jit_eligible(P, plan, err)) {
-        g_error = "dusp_circuit_kernel_source: not a circuit the compiler takes (" + err + ")";
-        return DUSP_ERR_UNSUPPORTED;
-    }
-    dusp::JitOptions opt;
-    opt.waves = waves;
-    opt.per_wave = per_wave;
-    opt.persistent = continued;
-    opt.voice_loop = !continued;  // (where the circuit is a sum of isomorphic voices: the form an unsplit render gets)
-    if (lean_recurrence) opt.filter_block = 4;
-    opt.scratch_floats = dusp::jit_scratch_floats(P);
-    if (lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
-        opt.table_form[1] = dusp::TABLE_FORM_SAW;
-        opt.table_form[2] = dusp::TABLE_FORM_SQUARE;
-        if (P.g.sample_rate % 4 == 0) opt.table_form[3] = dusp::TABLE_FORM_TRIANGLE;
-        opt.table_form[4] = dusp::TABLE_FORM_8BIT;
-        for (int k = 0; k < 5; k++) opt.table_bound[k] = 1;  // (the oscillators' tables stay within [-1, 1])
-        opt.table_delta[0] = getenv("DUSP_JIT_LEAN") && atoi(getenv("DUSP_JIT_LEAN")) == 0 ? 0 : 1;  // (the sine table: differences of neighbours exact in f64 at any sample rate, in f32 at some — 44.1 kHz, not 48)
-        for (const dusp::DevOp &op : P.ops)
-            if ((op.op == dusp::OP_OSC || op.op == dusp::OP_MULTI_OSC) && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
-                opt.lds_table = 0;
-                opt.table_bytes = dusp::half_table_lds_bytes((uint32_t)P.g.sample_rate);
-            }
-    }
-    const int scan_knob = getenv("DUSP_FILTER_SCAN") ? atoi(getenv("DUSP_FILTER_SCAN")) : 1;
-    opt.filter_scan = !continued && scan_knob != 0 && dusp::jit_filter_scan_ok(P, opt.table_bound, scan_knob == 2 ? 2 : 1);
-    opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
-    opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
-    if (!continued && opt.filter_stages == 0 && per_wave == 1 && (getenv("DUSP_DELAY_LINE") && atoi(getenv("DUSP_DELAY_LINE")) == 1)) {
-        const size_t lines = dusp::jit_delay_lines(P);
-        if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) opt.line_floats = lines, opt.scratch_floats += lines;
-    }
-    if (plan.has_filter && !opt.filter_scan) {
-        const size_t left = 160 * 1024 - opt.table_bytes - (size_t)waves * opt.scratch_floats * 4;
-        opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, left, opt.filter_mod);
-        if (!opt.filter_sub) {
-            g_error = "dusp_circuit_kernel_source: waves x per_wave Filter rows do not fit LDS";
-            return DUSP_ERR_ARG;
-        }
-    }
+    // (descriptor -> program -> plan -> options -> text: host code only, jit_codegen.hpp jit_source_from_descriptor — the same function the
+    // sanitizer build of tests/native/hostcheck.cpp drives with malformed descriptors)
+    dusp::JitSourceRequest rq;
+    rq.waves = waves;
+    rq.per_wave = per_wave;
+    rq.continued = (lds_table & 2) != 0;
+    rq.lean_recurrence = (lds_table & 4) != 0;  // (the Filter stage's recurrence loop with 4 P values per register set: what a render falls back to when the kernel spills)
+    rq.lds_table = (lds_table & 1) != 0;
+    rq.scan_knob = getenv("DUSP_FILTER_SCAN") ? atoi(getenv("DUSP_FILTER_SCAN")) : 1;
+    rq.lean = !(getenv("DUSP_JIT_LEAN") && atoi(getenv("DUSP_JIT_LEAN")) == 0);
+    rq.delay_line = getenv("DUSP_DELAY_LINE") && atoi(getenv("DUSP_DELAY_LINE")) == 1;
     dusp::JitSource src;
-    if (!dusp::jit_generate(P, plan, opt, src)) {
-        g_error = "dusp_circuit_kernel_source: " + src.why;
-        return DUSP_ERR_UNSUPPORTED;
+    std::string err;
+    const int verdict = dusp::jit_source_from_descriptor(desc, n_words, rq, src, err);
+    if (verdict != 0) {
+        g_error = "dusp_circuit_kernel_source: " + err;
+        return verdict == 1 ? DUSP_ERR_ARG : DUSP_ERR_UNSUPPORTED;
     }
     if (compile && !dusp::jit_compile_only(src.text, nullptr, err)) {
         g_error = "dusp_circuit_kernel_source: " + err;

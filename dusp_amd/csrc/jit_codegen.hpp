@@ -1883,4 +1883,84 @@ inline bool jit_generate(const Program &P, const WavePlan &plan, const JitOption
     return e.run();
 }
 
+// Descriptor words -> kernel text for a given workgroup geometry, WITHOUT a device: what dusp_circuit_kernel_source (dusp_abi.hip) does in
+// front of the run-time compiler, as one host-only function — parse and expand the descriptor (program.hpp), plan it for the wave engine
+// (fused_plan.hpp), choose the options a context would choose for the reference's own tables, generate.  Everything the untrusted input
+// reaches on the way lives in these headers, so tests/native/hostcheck.cpp drives exactly this under AddressSanitizer / UBSan with
+// truncated and corrupted descriptors.  Returns 0 (src.text holds the kernel), 1 (a malformed descriptor or a geometry that does not
+// fit: err says why), 2 (a well-formed circuit this path does not take).
+struct JitSourceRequest {
+    int waves = 4, per_wave = 1;
+    bool lds_table = true;        // the sine / 8bit half-table image in LDS and the closed forms, as a context finds them for the reference's tables
+    bool continued = false;       // the program will be continued (dusp_program_continue): persistent outlets, rings in the reference's state
+    bool lean_recurrence = false; // the Filter stage's recurrence loop with 4 P values per register set
+    int scan_knob = 1;            // DUSP_FILTER_SCAN
+    bool lean = true;             // DUSP_JIT_LEAN
+    bool delay_line = false;      // DUSP_DELAY_LINE
+};
+inline int jit_source_from_descriptor(const double *desc, size_t n_words, const JitSourceRequest &rq, JitSource &src, std::string &err) {
+    Program P;
+    if (rq.waves < 1 || rq.waves > 16 || rq.per_wave < 1 || rq.per_wave > 4) {
+        err = "waves must be 1 .. 16 and per_wave 1 .. 4";
+        return 1;
+    }
+    if (!compile(desc, n_words, P, err, /*continuation=*/true)) return 1;
+    const bool continued = rq.continued && (P.ring_samples != 0 || !P.feed_forward);
+    if (continued)
+        for (DevOp &op : P.ops)
+            if (op.op == OP_DELAY || op.op == OP_MONO_DELAY) op.pad = kDelayExactRing;
+    WavePlan plan;
+    if (!plan_wave(P, plan, continued)) {
+        err = "the wave engine cannot run this graph (" + plan.why + ")";
+        return 2;
+    }
+    for (size_t k = 0; k < plan.osc_level.size() && k < P.ops.size(); k++)
+        if (plan.osc_level[k] >= 0) P.ops[k].d[0] = (double)plan.osc_level[k];
+    std::string why;
+    if (!jit_eligible(P, plan, why)) {
+        err = "not a circuit the compiler takes (" + why + ")";
+        return 2;
+    }
+    JitOptions opt;
+    opt.waves = rq.waves;
+    opt.per_wave = rq.per_wave;
+    opt.persistent = continued;
+    opt.voice_loop = !continued;  // (where the circuit is a sum of isomorphic voices: the form an unsplit render gets)
+    if (rq.lean_recurrence) opt.filter_block = 4;
+    opt.scratch_floats = jit_scratch_floats(P);
+    if (rq.lds_table && P.g.sample_rate % 2 == 0) {  // what a context finds for the reference's tables: sine and 8bit antisymmetric, the rest closed forms
+        opt.table_form[1] = 1;  // TABLE_FORM_SAW
+        opt.table_form[2] = 2;  // TABLE_FORM_SQUARE
+        if (P.g.sample_rate % 4 == 0) opt.table_form[3] = 3;  // TABLE_FORM_TRIANGLE
+        opt.table_form[4] = 4;  // TABLE_FORM_8BIT
+        for (int k = 0; k < 5; k++) opt.table_bound[k] = 1;  // (the oscillators' tables stay within [-1, 1])
+        opt.table_delta[0] = rq.lean ? 1 : 0;  // (the sine table: differences of neighbours exact in f64 at any sample rate, in f32 at some — 44.1 kHz, not 48)
+        for (const DevOp &op : P.ops)
+            if ((op.op == OP_OSC || op.op == OP_MULTI_OSC) && opt.lds_table < 0 && (op.attr == 0 || op.attr == 4)) {
+                opt.lds_table = 0;
+                opt.table_bytes = (size_t)half_table_image_bytes((uint32_t)P.g.sample_rate);
+            }
+    }
+    opt.filter_scan = !continued && rq.scan_knob != 0 && jit_filter_scan_ok(P, opt.table_bound, rq.scan_knob == 2 ? 2 : 1);
+    opt.filter_stages = opt.filter_scan ? 0 : jit_filter_stages(P);
+    opt.filter_mod = !opt.filter_scan && jit_filter_mod(P);
+    if (!continued && opt.filter_stages == 0 && rq.per_wave == 1 && rq.delay_line) {
+        const size_t lines = jit_delay_lines(P);
+        if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) opt.line_floats = lines, opt.scratch_floats += lines;
+    }
+    if (plan.has_filter && !opt.filter_scan) {
+        const size_t used = opt.table_bytes + (size_t)rq.waves * opt.scratch_floats * 4;
+        opt.filter_sub = used < 160 * 1024 ? jit_filter_sub(rq.waves, rq.per_wave, opt.filter_stages, 160 * 1024 - used, opt.filter_mod) : 0;
+        if (!opt.filter_sub) {
+            err = "waves x per_wave Filter rows do not fit LDS";
+            return 1;
+        }
+    }
+    if (!jit_generate(P, plan, opt, src)) {
+        err = src.why;
+        return 2;
+    }
+    return 0;
+}
+
 }  // namespace dusp
