@@ -811,10 +811,7 @@ def test_first_render_does_not_wait_for_the_compiler(oracle):
     first = prog.render(n)[0]
     waited = time.perf_counter() - t0
     prog._read_info()
-    if "compiled kernel" in prog.shape:  # (a box that has rendered this structure before: the code-object cache on disk held the kernel)
-        assert np.array_equal(first, want)
-        prog.close()
-        pytest.skip("the kernel was in the code-object cache: nothing to wait for")
+    # (the session's code-object cache starts empty — conftest.py — and no other test builds this structure: there is nothing to find)
     assert "kernel compiling" in prog.shape and waited < 0.25, (prog.shape, waited)
     assert np.array_equal(first, want)
     state_first = [prog.state(u) for u in range(prog.n_units)]
@@ -852,10 +849,7 @@ def test_a_filter_stage_circuit_reaches_its_kernel_under_the_default_knob():
     params = (base[:, None] + (uni.params[:, 1].astype(np.float64) - base)[:, None] * np.arange(V)[None, :]).astype(np.float32)
     prog = knob_context(48000, DUSP_WAVE_JIT=1).build(uni.words, runtime.ENGINE_WAVE)
     first = prog.render(n, V, params)
-    if "compiled kernel" in prog.read_shape():
-        prog.close()
-        pytest.skip("the kernel was in the code-object cache: nothing to wait for")
-    assert "kernel compiling" in prog.read_shape()
+    assert "kernel compiling" in prog.read_shape()  # (an empty cache per test session, a structure of this test's own: conftest.py)
     deadline, renders = time.perf_counter() + 90, 1
     while "compiled kernel" not in prog.read_shape() and time.perf_counter() < deadline:
         time.sleep(0.3)

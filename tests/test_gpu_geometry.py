@@ -1,5 +1,5 @@
 """Compiled circuit kernels at every workgroup geometry x ragged batch sizes (regression test asked for after an unexplained
-abort in round 2's records, DESIGN.md §9a): instances per wavefront R in {1, 2, 4}, batches that leave the last wavefront and
+abort in round 2's records, DESIGN.md §10): instances per wavefront R in {1, 2, 4}, batches that leave the last wavefront and
 the last workgroup partly empty (1, 17, 63, 65, 16383 instances), a light circuit and a Filter circuit, EVERY instance
 against the oracle.  The library runs with DUSP_GUARD=1 here (conftest): a kernel that writes past the end of a workspace
 fails its render instead of corrupting a neighbour."""
@@ -49,8 +49,8 @@ def test_every_geometry_and_ragged_batch_against_the_oracle(kind, n_inst, per_wa
     shape = prog.read_shape()
     assert "compiled kernel" in shape and shape.endswith("%dx%d" % (waves, per_wave)), shape
     worst = 0.0
-    for i in range(n_inst):
-        want = oracle.render(uni.words, n, params=params, n_instances=n_inst, instance=i, max_channels=1)
+    wants = oracle.render_instances(uni.words, n, params, n_inst, range(n_inst), max_channels=1)  # (every instance, over the host's cores)
+    for i, want in enumerate(wants):
         if kind == "light":
             assert np.array_equal(pcm[i], want), "instance %d of %d at %dx%d" % (i, n_inst, waves, per_wave)
         else:

@@ -244,7 +244,7 @@ def test_rings_are_zeroed_wherever_a_render_can_touch_them(engine):
         knobs = {"DUSP_RING_POISON": 1}
         if engine == "interp":
             knobs["DUSP_WAVE_JIT"] = 0
-        for window in (1, 0):
+        for window in ((1, 0) if engine == "auto" else (1,)):  # (windows off — every ring zero-filled whole — is one code path for all engines: once)
             ctx = knob_context(g.sample_rate, DUSP_RING_WINDOW=window, **knobs)
             try:
                 prog = ctx.build(g.desc, ENGINES[engine])
@@ -259,4 +259,4 @@ def test_rings_are_zeroed_wherever_a_render_can_touch_them(engine):
                 check(name, g.windowed(pcm[i]), g.pcm, engine)
             prog.close()
             seen += 1
-    assert seen >= 2 * 10
+    assert seen >= 10 * (2 if engine == "auto" else 1)
