@@ -161,6 +161,7 @@ struct dusp_program {
     int jit_waves = 0, jit_per_wave = 0;  // geometry of the last compiled launch (shown in dusp_program_info.shape)
     unsigned jit_segments = 1;            // ... the time segments it was cut into
     bool jit_voices = false;              // ... its voices ran in a loop (jit_codegen.hpp VoicePlan)
+    bool jit_scan = false;                // ... its Filters ran as scans over the chunk (jit_filter_scan_ok)
     DevBuf<float> d_jit_fk;
     DevBuf<double> d_jit_dk;
     DevBuf<int> d_jit_scan;  // [2][n_scans]: state slot, FM level of every scanned oscillator
@@ -674,7 +675,8 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
             if (prog->jit_voices && prog->jit_segments > 1) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", loop, %u seg", prog->jit_segments);
             else if (prog->jit_voices) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", voice loop");
             else std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", %u seg", prog->jit_segments);
-        }
+        } else if (at > 0 && (size_t)at < sizeof info->shape && prog->jit_scan)
+            std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", scan");  // (the Filters as scans over the chunk: within the gate's bound, not bit for bit)
     }
     else if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok)
         std::snprintf(info->shape, sizeof info->shape, "%s, %d chunk buffers in LDS (kernel compiling)", prog->P.feed_forward ? "feed-forward" : "feedback", prog->wave.n_slots);
@@ -780,26 +782,44 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // Per-instance (parameter) delays: the kernel a Delay gets depends on where its instances' values lie — all of at least a chunk
     // (write-once ring), all below a chunk (no ring), or neither (ordered slot operations) — so the column is looked at first
     // (one small launch + a few bytes back; only programs with such a unit pay it).  The verdict lives in the operand's spare word.
+    // Per-instance CUTOFFS of Filters likewise: whether the Filter may run as a scan (jit_filter_scan_ok) depends on the range of the
+    // column — its smallest and largest value travel back with the Delays' verdicts, behind the same synchronisation.
     {
         std::vector<int64_t> entries;
-        std::vector<size_t> which;
+        std::vector<size_t> which, filters;
+        std::vector<int> slots;
         for (size_t k = 0; k < prog->P.ops.size(); k++) {
             const dusp::DevOp &op = prog->P.ops[k];
             if ((op.op == dusp::OP_DELAY || op.op == dusp::OP_MONO_DELAY) && op.in[1].kind == dusp::SRC_PARAM) {
                 entries.insert(entries.end(), {(int64_t)op.in[1].idx, op.ring_len, (int64_t)(op.op == dusp::OP_MONO_DELAY)});
                 which.push_back(k);
             }
+            if (op.op == dusp::OP_FILTER && op.in[1].kind == dusp::SRC_PARAM && ctx->knobs.filter_scan != 0 && !persistent) {
+                slots.push_back(op.in[1].idx);
+                filters.push_back(k);
+            }
         }
-        if (!which.empty()) {
-            const size_t n = which.size();
-            HIP_TRY(ctx, prog->d_jit_regime.ensure(4 * n));  // [3 n] entries as int64, then n verdicts as int (in one int64 slot each)
+        if (!which.empty() || !filters.empty()) {
+            const size_t n = which.size(), nf = filters.size();
+            HIP_TRY(ctx, prog->d_jit_regime.ensure(4 * n + 2 * nf + 2));  // [3 n] entries as int64, n verdicts (one int64 slot each), then nf slots (int) and 3 nf range words (unsigned)
             int64_t *d_entries = prog->d_jit_regime.p;
             int *d_bits = (int *)(prog->d_jit_regime.p + 3 * n);
-            HIP_TRY(ctx, hipMemcpyAsync(d_entries, entries.data(), 3 * n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-            HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, n * sizeof(int64_t), stream));
-            HIP_TRY(ctx, dusp::jit_launch_classify_delays(d_params, n_inst, d_entries, (int)n, d_bits, stream));
+            int *d_slots = (int *)(prog->d_jit_regime.p + 4 * n);
+            unsigned *d_range = (unsigned *)(d_slots + nf);
             std::vector<int> bits(n, 0);
-            HIP_TRY(ctx, hipMemcpyAsync(bits.data(), d_bits, n * sizeof(int), hipMemcpyDeviceToHost, stream));
+            std::vector<unsigned> range(3 * nf, 0u);
+            if (n) {
+                HIP_TRY(ctx, hipMemcpyAsync(d_entries, entries.data(), 3 * n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+                HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, n * sizeof(int64_t), stream));
+                HIP_TRY(ctx, dusp::jit_launch_classify_delays(d_params, n_inst, d_entries, (int)n, d_bits, stream));
+                HIP_TRY(ctx, hipMemcpyAsync(bits.data(), d_bits, n * sizeof(int), hipMemcpyDeviceToHost, stream));
+            }
+            if (nf) {
+                HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), nf * sizeof(int), hipMemcpyHostToDevice, stream));
+                HIP_TRY(ctx, hipMemsetAsync(d_range, 0, 3 * nf * sizeof(unsigned), stream));
+                HIP_TRY(ctx, dusp::jit_launch_column_range(d_params, n_inst, d_slots, (int)nf, d_range, stream));
+                HIP_TRY(ctx, hipMemcpyAsync(range.data(), d_range, 3 * nf * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+            }
             HIP_TRY(ctx, hipStreamSynchronize(stream));
             bool changed = false;
             for (size_t i = 0; i < n; i++) {
@@ -807,6 +827,19 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                 int32_t &pad = prog->P.ops[which[i]].in[1].pad;
                 changed = changed || pad != regime;
                 pad = regime;
+            }
+            for (size_t i = 0; i < nf; i++) {  // (the range itself is no part of the text: only whether the circuit's Filters scan — the key of jit_src — is)
+                dusp::DevOp &op = prog->P.ops[filters[i]];
+                const bool known = range[3 * i + 2] == 0u && range[3 * i] != 0u && range[3 * i + 1] != 0u;
+                op.in[1].pad = known ? dusp::kFilterColumnKnown : 0;
+                if (known) {
+                    float lo, hi;
+                    const unsigned lo_bits = 0x7fffffffu - range[3 * i], hi_bits = range[3 * i + 1];
+                    std::memcpy(&lo, &lo_bits, 4);
+                    std::memcpy(&hi, &hi_bits, 4);
+                    op.d[0] = (double)lo;
+                    op.d[1] = (double)hi;
+                }
             }
             if (changed) {  // (another kernel text: the generated units differ)
                 prog->jit_src.clear();
@@ -950,11 +983,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
         opt.per_wave = per_wave;
-        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0)});
+        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0)});
         if (it == prog->jit_src.end()) {
             dusp::JitSource gen;
             if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
-            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0)), std::move(gen)).first;
+            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0)), std::move(gen)).first;
         }
         src = &it->second;
         // A structure seen for the first time costs a compile of 0.3-0.8 s.  A render the interpreter kernel finishes sooner
@@ -972,7 +1005,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                     // queue now, so the geometry search does not cost a further render on the interpreter per step)
                     dusp::JitOptions narrow = opt;
                     narrow.filter_block = 4;
-                    const auto key = std::make_pair(waves, per_wave * 8 + narrow.filter_block % 8 + (narrow.voice_loop ? 64 : 0));
+                    const auto key = std::make_pair(waves, per_wave * 8 + narrow.filter_block % 8 + (narrow.voice_loop ? 64 : 0) + (narrow.filter_scan ? 128 : 0));
                     auto alt = prog->jit_src.find(key);
                     if (alt == prog->jit_src.end()) {
                         dusp::JitSource gen;
@@ -1088,6 +1121,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     prog->jit_per_wave = per_wave;
     prog->jit_segments = a.n_seg;
     prog->jit_voices = src->voice_loop;
+    prog->jit_scan = opt.filter_scan;
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;
@@ -1742,6 +1776,8 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     rq.scan_knob = getenv("DUSP_FILTER_SCAN") ? atoi(getenv("DUSP_FILTER_SCAN")) : 1;
     rq.lean = !(getenv("DUSP_JIT_LEAN") && atoi(getenv("DUSP_JIT_LEAN")) == 0);
     rq.delay_line = getenv("DUSP_DELAY_LINE") && atoi(getenv("DUSP_DELAY_LINE")) == 1;
+    if (const char *range = getenv("DUSP_CUTOFF_RANGE"))  // (tests of the generator: "lo,hi" = what a renderer would have found in the Filters' cutoff columns)
+        if (sscanf(range, "%lf,%lf", &rq.cutoff_lo, &rq.cutoff_hi) != 2) rq.cutoff_lo = rq.cutoff_hi = 0.0;
     dusp::JitSource src;
     std::string err;
     const int verdict = dusp::jit_source_from_descriptor(desc, n_words, rq, src, err);

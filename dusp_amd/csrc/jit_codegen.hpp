@@ -115,6 +115,7 @@ inline int jit_filter_stages(const Program &P) {
 // their input —, a product of two deviating signals or one with a per-instance factor, the circuit keeps the Filter stage and its bits.
 // mode 2 (DUSP_FILTER_SCAN=2; measurements and tests of the scan itself): (1) and the structure of (2), whatever the gains.
 constexpr double kFilterScanUnit = 1.9073486328125e-6;  // 2^-19
+constexpr int kFilterColumnKnown = 1;  // DevOperand::pad of a Filter's per-instance cutoff: the renderer has looked at the column, DevOp::d[0] / d[1] hold its smallest / largest value
 constexpr double kFilterScanBound = 2.5e-6;
 inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullptr, int mode = 1, double *bound_out = nullptr) {
     if (bound_out) *bound_out = 0.0;
@@ -125,29 +126,42 @@ inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullpt
         const DevOp &op = P.ops[at];
         if (op.op != OP_FILTER) continue;
         any = true;
-        if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return false;
-        const double *is = P.init_state.data() + op.state_slot, f = (double)op.in[1].cval;
-        double k[5];
-        if (is[0] == 0.0 || f != is[1]) butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
-        else
-            for (int i = 0; i < 5; i++) k[i] = is[2 + i];
-        for (double v : k)
-            if (!std::isfinite(v)) return false;
-        // h: the all-pole part's impulse response; g: the whole Filter's
-        double h1 = 1.0, h2 = 0.0, sum_h = 1.0, g1 = k[0], g2 = 0.0, sum_g = std::fabs(k[0]);
-        int quiet = 0;
-        for (int t = 1; t < 100000 && quiet < 8; t++) {
-            const double h = -k[3] * h1 - k[4] * h2;
-            const double g = (t == 1 ? k[1] : t == 2 ? k[2] : 0.0) - k[3] * g1 - k[4] * g2;
-            h2 = h1, h1 = h, g2 = g1, g1 = g;
-            sum_h += std::fabs(h);
-            sum_g += std::fabs(g);
-            if (!(sum_h <= 30.0)) return false;
-            quiet = std::fabs(h) < 1e-13 && t > 2 ? quiet + 1 : 0;
+        if ((size_t)op.state_slot + 11 > P.init_state.size()) return false;
+        const double *is = P.init_state.data() + op.state_slot;
+        // the cutoffs to answer for: the circuit's constant, or — a per-instance parameter whose column the renderer has looked at
+        // (kFilterColumnKnown: every instance's cutoff finite, d[0] <= f <= d[1] inside (0, Nyquist)) — a spread over that range:
+        // sum|h| = 1 / (1 - |p|)^2 with the double pole p = (lamda - 1) / (lamda + 1) is largest at an end of the range, the whole
+        // Filter's sum|g| is sampled along it
+        double cutoffs[9];
+        int n_cut = 0;
+        if (op.in[1].kind == SRC_CONST) cutoffs[n_cut++] = (double)op.in[1].cval;
+        else if (op.in[1].kind == SRC_PARAM && op.in[1].pad == kFilterColumnKnown && op.d[0] > 0.0 && op.d[0] <= op.d[1] && op.d[1] < 0.5 * (double)P.g.sample_rate)
+            for (int i = 0; i < 9; i++) cutoffs[n_cut++] = op.d[0] + (op.d[1] - op.d[0]) * (double)i / 8.0;
+        else return false;
+        for (int c = 0; c < n_cut; c++) {
+            const double f = cutoffs[c];
+            double k[5];
+            if (op.in[1].kind == SRC_CONST && is[0] != 0.0 && f == is[1])
+                for (int i = 0; i < 5; i++) k[i] = is[2 + i];
+            else butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
+            for (double v : k)
+                if (!std::isfinite(v)) return false;
+            // h: the all-pole part's impulse response; g: the whole Filter's
+            double h1 = 1.0, h2 = 0.0, sum_h = 1.0, g1 = k[0], g2 = 0.0, sum_g = std::fabs(k[0]);
+            int quiet = 0;
+            for (int t = 1; t < 100000 && quiet < 8; t++) {
+                const double h = -k[3] * h1 - k[4] * h2;
+                const double g = (t == 1 ? k[1] : t == 2 ? k[2] : 0.0) - k[3] * g1 - k[4] * g2;
+                h2 = h1, h1 = h, g2 = g1, g1 = g;
+                sum_h += std::fabs(h);
+                sum_g += std::fabs(g);
+                if (!(sum_h <= 30.0)) return false;
+                quiet = std::fabs(h) < 1e-13 && t > 2 ? quiet + 1 : 0;
+            }
+            if (quiet < 8) return false;
+            eps[at] = std::max(eps[at], std::ldexp(sum_h + 2.0, -24));
+            gain[at] = std::max(gain[at], sum_g);
         }
-        if (quiet < 8) return false;
-        eps[at] = std::ldexp(sum_h + 2.0, -24);
-        gain[at] = sum_g;
         if (!(eps[at] <= kFilterScanUnit)) return false;
     }
     if (!any) return false;
@@ -689,6 +703,8 @@ struct Emitter {
     std::string table_row(int table_id) const { return "A.tables + (size_t)" + num(table_id) + " * A.table_stride"; }
     std::string ctx(int r) const { return "X[" + num(r) + "]"; }
     int copies(int k) const { return shared[(size_t)k] ? 1 : R; }
+    // a scan Filter's coefficients and matrix powers: one set for the wave where the cutoff is a constant of the circuit, one per instance slot where it is a parameter
+    std::string scan_k(int k, int r) const { return "fk" + num(k) + (P.ops[(size_t)k].in[1].kind == SRC_PARAM ? "_" + num(r) : std::string()); }
     bool is_filter_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && !opt.filter_scan; }  // (a scan Filter is a unit like any other)
     bool is_mod_stage(int k) const { return P.ops[(size_t)k].op == OP_FILTER && P.ops[(size_t)k].in[1].kind == SRC_BUF; }  // a connected cutoff
 
@@ -967,9 +983,11 @@ struct Emitter {
                 default: break;
                 }
             }
-            if (op.op == OP_FILTER && opt.filter_scan) {  // a scan over the chunk: coefficients and matrix powers once, the memory per instance
-                line("    JitFilterScanK fk" + num(k) + ";");
-                line("    fk" + num(k) + ".begin(A, X[0], " + num(op.attr) + ", " + opnd(k, 1, "0", 0) + ", " + num(op.state_slot) + ");");
+            if (op.op == OP_FILTER && opt.filter_scan) {  // a scan over the chunk: coefficients and matrix powers once (per instance where the cutoff is a parameter), the memory per instance
+                for (int r = 0; r < (op.in[1].kind == SRC_PARAM ? copies(k) : 1); r++) {
+                    line("    JitFilterScanK " + scan_k(k, r) + ";");
+                    line("    " + scan_k(k, r) + ".begin(A, " + ctx(r) + ", " + num(op.attr) + ", " + opnd(k, 1, "0", r) + ", " + num(op.state_slot) + ");");
+                }
                 for (int r = 0; r < copies(k); r++) {
                     line("    JitFilterScan f" + num(k) + "_" + num(r) + ";");
                     line("    f" + num(k) + "_" + num(r) + ".begin(A, " + num(op.state_slot) + ");");
@@ -1059,7 +1077,7 @@ struct Emitter {
                     if (op.op == OP_RETRIGGER) line("        " + slot + " = r" + id + ".T;");
                     if (op.op == OP_SAMPLE_RATE_REDUX) line("        h" + id + ".end(A, " + ctx(r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_MULTI_OSC) line("        " + slot + " = m" + id + ".phase;");
-                    if (op.op == OP_FILTER && opt.filter_scan) line("        f" + id + ".end(A, " + ctx(r) + ", fk" + num((long long)k) + ", " + num(op.state_slot) + ");");
+                    if (op.op == OP_FILTER && opt.filter_scan) line("        f" + id + ".end(A, " + ctx(r) + ", " + scan_k((int)k, r) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_CB_READER || op.op == OP_CB_WRITER) line("        " + slot + " = n" + id + ".T;");
                 }
                 line("    }");
@@ -1446,7 +1464,7 @@ struct Emitter {
             case OP_FILTER: {  // (opt.filter_scan: the others left through the Filter stage above)
                 decl();
                 const std::string x = opnd_array(k, 0, "t" + id, r);
-                line("        f" + id + ".tick(" + X_ + ", fk" + num(k) + ", " + x + ", " + v + ");");
+                line("        f" + id + ".tick(" + X_ + ", " + scan_k(k, r) + ", " + x + ", " + v + ");");
                 break;
             }
             case OP_MULTI_OSC: {
@@ -1897,6 +1915,7 @@ struct JitSourceRequest {
     int scan_knob = 1;            // DUSP_FILTER_SCAN
     bool lean = true;             // DUSP_JIT_LEAN
     bool delay_line = false;      // DUSP_DELAY_LINE
+    double cutoff_lo = 0.0, cutoff_hi = 0.0;  // per-instance Filter cutoffs: the range a renderer would have found in their columns (0, 0: not looked at)
 };
 inline int jit_source_from_descriptor(const double *desc, size_t n_words, const JitSourceRequest &rq, JitSource &src, std::string &err) {
     Program P;
@@ -1909,6 +1928,9 @@ inline int jit_source_from_descriptor(const double *desc, size_t n_words, const 
     if (continued)
         for (DevOp &op : P.ops)
             if (op.op == OP_DELAY || op.op == OP_MONO_DELAY) op.pad = kDelayExactRing;
+    if (rq.cutoff_hi > 0.0)
+        for (DevOp &op : P.ops)
+            if (op.op == OP_FILTER && op.in[1].kind == SRC_PARAM) op.in[1].pad = kFilterColumnKnown, op.d[0] = rq.cutoff_lo, op.d[1] = rq.cutoff_hi;
     WavePlan plan;
     if (!plan_wave(P, plan, continued)) {
         err = "the wave engine cannot run this graph (" + plan.why + ")";

@@ -384,6 +384,29 @@ __global__ void dusp_classify_delays_kernel(const float *params, uint32_t n_inst
         if (bits) atomicOr(&out[k], bits);
     }
 }
+// Per-instance (parameter) cutoffs of Filters: the range every instance's value lies in.  out[3 k .. 3 k + 2] (zeroed by the caller) = for
+// entry k (a parameter slot): 0x7fffffff - bits of the smallest value, bits of the largest, 1 if some value is NaN / Inf / not positive.
+__global__ void dusp_column_range_kernel(const float *params, uint32_t n_inst, const int *slots, int n_entries, unsigned *out) {
+    for (int k = 0; k < n_entries; ++k) {
+        unsigned lo = 0u, hi = 0u, bad = 0u;
+        for (uint32_t i = threadIdx.x; i < n_inst; i += blockDim.x) {
+            const float v = params[(size_t)slots[k] * n_inst + i];
+            if (!(v > 0.f && v <= 3.0e38f)) bad = 1u;
+            else {
+                const unsigned b = __float_as_uint(v);  // (positive floats order like their bits)
+                lo = max(lo, 0x7fffffffu - b);
+                hi = max(hi, b);
+            }
+        }
+        if (lo) atomicMax(&out[3 * k], lo);
+        if (hi) atomicMax(&out[3 * k + 1], hi);
+        if (bad) atomicOr(&out[3 * k + 2], 1u);
+    }
+}
+hipError_t jit_launch_column_range(const float *params, uint32_t n_inst, const int *d_slots, int n_entries, unsigned *d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(dusp_column_range_kernel, dim3(1), dim3(1024), 0, stream, params, n_inst, d_slots, n_entries, d_out);
+    return hipGetLastError();
+}
 hipError_t jit_launch_classify_delays(const float *params, uint32_t n_inst, const int64_t *d_entries, int n_entries, int *d_out, hipStream_t stream) {
     hipLaunchKernelGGL(dusp_classify_delays_kernel, dim3(1), dim3(1024), 0, stream, params, n_inst, d_entries, n_entries, d_out);
     return hipGetLastError();

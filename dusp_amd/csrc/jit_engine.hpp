@@ -23,6 +23,8 @@ bool jit_get_kernel(int device, const std::string &text, const std::string &name
 hipError_t jit_launch(hipFunction_t fn, const JitArgs &A, unsigned grid, unsigned block, hipStream_t stream);
 // regimes of per-instance delays (fused_plan.hpp delay_value_regime): d_entries = [slot, ring_len, mono] x n_entries, d_out zeroed by the caller
 hipError_t jit_launch_classify_delays(const float *params, uint32_t n_inst, const int64_t *d_entries, int n_entries, int *d_out, hipStream_t stream);
+// the range of per-instance Filter cutoffs (jit_codegen.hpp jit_filter_scan_ok): d_slots = parameter slots, d_out [3 n_entries] zeroed by the caller
+hipError_t jit_launch_column_range(const float *params, uint32_t n_inst, const int *d_slots, int n_entries, unsigned *d_out, hipStream_t stream);
 hipError_t jit_launch_prefix(const unsigned long long *seg_sum, unsigned long long *seg_start, const double *init_state, const int *d_scan_slot,
                              const int *d_scan_level, int n_scans, int level, uint32_t n_inst, uint32_t n_seg, uint32_t sample_rate, hipStream_t stream);
 

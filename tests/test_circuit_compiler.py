@@ -168,6 +168,35 @@ def test_filters_with_a_constant_cutoff_run_as_a_scan():
     assert hp.count("JitFilterScanK fk") == 2
 
 
+def test_per_instance_cutoffs_scan_when_their_column_allows(monkeypatch):
+    """A cutoff SWEEP — the Filter's cutoff a per-instance parameter — runs as a scan too when the renderer has looked at the column
+    (one small launch next to the Delays' regimes: smallest and largest value) and the whole range passes the gate: coefficients and
+    matrix powers per instance slot (fk<unit>_<slot>), from that instance's parameter.  A range that reaches below the bound, or one
+    nobody has looked at, keeps the Filter stage."""
+    d.configure(48000)
+    def loop(k):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        f = d.Filter(d.Delay(s, 480, 4096), 2000 + 10 * k)
+        s.B = d.Multiply(f, 0.5)
+        return f
+    uni = descriptor.unify([descriptor.extract(loop(k)) for k in (0, 64)])
+    assert "JitFilterScan" not in source(uni.words, waves=16, per_wave=1)          # (no device has looked at the column)
+    monkeypatch.setenv("DUSP_CUTOFF_RANGE", "2000,6000")
+    text = source(uni.words, waves=16, per_wave=2, compile=True)
+    assert "JitFilterScanK fk4_0;" in text and "JitFilterScanK fk4_1;" in text
+    assert re.search(r"fk4_1\.begin\(A, X\[1\], 0, p\d+_1, 2\);", text) and "f4_1.tick(X[1], fk4_1, v3_1, v4_1);" in text and "f4_0.end(A, X[0], fk4_0, 2);" in text
+    assert "JitFilterK<" not in text
+    monkeypatch.setenv("DUSP_CUTOFF_RANGE", "1500,6000")   # inside the loop (gain 0.5) the low end's 2 x 1.85e-6 is beyond the outlets' bound
+    assert "JitFilterScan" not in source(uni.words, waves=16, per_wave=1)
+    monkeypatch.setenv("DUSP_CUTOFF_RANGE", "900,6000")
+    assert "JitFilterScan" not in source(uni.words, waves=16, per_wave=1)
+    sweep = descriptor.unify([descriptor.extract(d.Filter(d.Osc(200 + k), 1600 + 40 * k)) for k in (0, 64)])
+    monkeypatch.setenv("DUSP_CUTOFF_RANGE", "1600,4160")
+    assert "JitFilterScanK fk1_0;" in source(sweep.words, waves=16, per_wave=1, compile=True)
+    monkeypatch.setenv("DUSP_CUTOFF_RANGE", "1400,4160")   # below the Filter's own bound (sum|h| <= 30)
+    assert "JitFilterScan" not in source(sweep.words, waves=16, per_wave=1)
+
+
 def test_the_scan_gate_bounds_the_gain_of_feedback_loops(monkeypatch):
     """jit_filter_scan_ok (2): a deviation the scan injects goes round feedback loops, and a loop of gain g amplifies it by up to 1 / (1 - g).
     The gate solves x = G x + eps over the circuit with every unit's worst-case gain and takes the scan only when every outlet stays

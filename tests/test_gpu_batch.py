@@ -335,6 +335,45 @@ def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
     staged.close()
 
 
+def test_cutoff_sweeps_scan_where_their_column_allows(oracle):
+    """A per-instance cutoff — the most natural parameter sweep of a filtered voice — takes the scan too: the renderer looks at the
+    column (smallest and largest value, next to the Delays' regimes) and the gate answers for the whole range; every wavefront computes
+    its own coefficients and matrix powers.  BASELINE configs[3]'s circuit with cutoff = 2000 + k % 4000 per instance: on the scan
+    (the shape says so), within the gate's 2.5e-6 of the oracle on a spread of instances, PCM and unit state; a column that reaches
+    below the bound (1500 + ...: twice 1.85e-6 behind the loop) renders on the Filter stage, bit-equal to DUSP_FILTER_SCAN=0."""
+    d.configure(48000)
+    def loop(k, base):
+        s = d.Sum(d.Osc(110 + k / 64), 0)
+        flt = d.Filter(d.Delay(s, 480, 4096), base + k % 4000)
+        s.B = d.Multiply(flt, 0.5)
+        return flt
+    V, n = 4200, 256 * 40 + 33
+    for base, scans in ((2000, True), (1500, False)):
+        uni = descriptor.unify([descriptor.extract(loop(k, base)) for k in (0, 64)])
+        assert uni.n_params == 2
+        k = np.arange(V, dtype=np.float64)
+        cols = {110.0: 110.0 + k / 64.0, float(base): base + k % 4000}
+        params = np.ascontiguousarray(np.stack([cols[float(uni.params[p, 0])] for p in range(2)]).astype(np.float32))
+        prog = render.context(48000).build(uni.words, runtime.ENGINE_WAVE)
+        pcm = prog.render(n, V, params)
+        shape = prog.read_shape()
+        assert "compiled kernel" in shape and shape.endswith(", scan") == scans, shape
+        staged = knob_context(48000, DUSP_FILTER_SCAN=0).build(uni.words, runtime.ENGINE_WAVE)
+        ref = staged.render(n, V, params)
+        assert not staged.read_shape().endswith(", scan")
+        if not scans:
+            assert np.array_equal(pcm, ref)
+        for i in (0, 1, 63, 64, 2047, 3999, 4000, V - 1):
+            want, states = oracle.render(uni.words, n, params=params, n_instances=V, instance=i, return_state=True)
+            scale = float(np.max(np.abs(want)))
+            assert float(np.max(np.abs(pcm[i].astype(np.float64) - want))) <= 2.5e-6 * scale, (base, i)
+            assert float(np.max(np.abs(ref[i].astype(np.float64) - want))) <= 1e-5 * scale, (base, i)
+            for u, st in enumerate(states):
+                np.testing.assert_allclose(prog.state(u, i), st, rtol=2e-5, atol=2.5e-6 * scale, equal_nan=True)
+        prog.close()
+        staged.close()
+
+
 @pytest.mark.parametrize("gain", [0.9, 0.95, 0.99])
 def test_feedback_loops_of_high_gain_keep_the_reference_bits(gain, oracle):
     """BASELINE configs[3]'s circuit with a feedback gain next to 1 (a plucked string, a comb) and an input ON the loop's resonances

@@ -48,9 +48,9 @@ def main():
     ctx = runtime.Context(0, sr)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def loop(k, delay=480):
+    def loop(k, delay=480, cutoff=2000):
         s = d.Sum(d.Osc(110 + k / 64), 0)
-        f = d.Filter(d.Delay(s, delay, 4096), 2000)
+        f = d.Filter(d.Delay(s, delay, 4096), cutoff)
         s.B = d.Multiply(f, 0.5)
         return f
 
@@ -76,6 +76,8 @@ def main():
     cfgs["cfg4_loop8192_loop_engine"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_LOOP)
     # a delay-time sweep of the configs[3] voice: delay = 300 + k % 400 samples per instance (parameter rows: f, delay — in unit order)
     cfgs["cfg4_delay_sweep"] = (lambda: uni_of([loop(k, 300 + k % 400) for k in (0, 65)]), T10, "delay_sweep")
+    # a cutoff sweep of the same voice: cutoff = 2000 + k % 4000 Hz per instance (the whole column passes the scan's gate: one launch looks at it)
+    cfgs["cfg4_cutoff_sweep"] = (lambda: uni_of([loop(k, 480, 2000 + k % 4000) for k in (0, 65)]), T10, "cutoff_sweep")
     cfgs["cfg5_shard8192"] = (lambda: uni_of([d.Multiply(d.Osc(20 + k / 8), d.Ramp(T1, 1, 0).trigger()) for k in (0, 1)]), T1,
                               (20 + np.arange(8192) / 8.0).astype(np.float32).reshape(1, -1))
     for name, cfg in cfgs.items():
@@ -85,11 +87,12 @@ def main():
             continue
         t0 = time.time()
         uni = build()
-        if isinstance(params, str):  # delay sweep: which row is f, which the delay, is read off the two circuits
+        if isinstance(params, str):  # delay / cutoff sweep: which row is f, which the swept value, is read off the two circuits
             k = np.arange(8192)
             rows = []
+            swept = (300 + k % 400) if params == "delay_sweep" else (2000 + k % 4000)
             for p in range(uni.n_params):
-                rows.append((110 + k / 64.0) if abs(float(uni.params[p, 0]) - 110.0) < 1e-3 else (300 + k % 400).astype(np.float64))
+                rows.append((110 + k / 64.0) if abs(float(uni.params[p, 0]) - 110.0) < 1e-3 else swept.astype(np.float64))
             params = np.ascontiguousarray(np.stack(rows).astype(np.float32))
         prog = ctx.build(uni.words, engine)
         n_inst = params.shape[1] if params is not None else 1
