@@ -161,8 +161,10 @@ def test_filter_circuits_in_full_workgroups(kind, scan, oracle):
     prog = knob_context(48000, DUSP_FILTER_SCAN=scan).build(uni.words, runtime.ENGINE_WAVE)
     pcm = prog.render(n, V, params)
     prog._read_info()
-    waves, per_wave = (int(t) for t in prog.shape.rsplit(" ", 1)[1].split("x"))
+    import re
+    waves, per_wave = (int(t) for t in re.search(r", (\d+)x(\d+)", prog.shape).groups())
     staged = not scan or kind in ("env_after", "dry_wet")
+    assert prog.shape.endswith(", scan") == (not staged), prog.shape
     assert "compiled kernel" in prog.shape and waves >= 8 and (waves * per_wave >= 17 or not staged), prog.shape  # (several wavefronts: the turns are taken)
     for i in (0, 1, 31, 32, 63, 64, 1000, 1023, 1024, 2047, 2048, 4095, 4096, V - 1):
         want = oracle.render(uni.words, n, params=params, n_instances=V, instance=i)
