@@ -69,6 +69,8 @@ struct Knobs {
     int ring_poison = 0;         // DUSP_RING_POISON=1 (tests): rings filled with NaN patterns before the zero-fill
     int filter_scan = 1;         // DUSP_FILTER_SCAN=0: constant-cutoff Filters always through the Filter stage's serving wave (else: a scan over the chunk where its error bound,
                                  // feedback loops' gains included, allows: jit_filter_scan_ok); 2 (measurements, tests): the scan wherever its structure allows, whatever the loop gains
+    int filter_warm = 1;         // DUSP_FILTER_WARM=0: ONE long circuit with Filters is not cut into segments that warm up (jit_codegen.hpp jit_warm_chunks): one wavefront walks the whole render;
+                                 // n > 1 (tests): segments of n chunks whatever warm-up the Filters need
     int jit_nt = 0;              // DUSP_JIT_NT=1: compiled kernels copy PCM out with non-temporal stores; 2: only circuits with delay rings; 0: plain stores
     int delay_line = 0;          // DUSP_DELAY_LINE=1 (measured slower, off): constant delays of a chunk at least as lines of input samples in LDS where they fit (JitDelayLine) instead of rings in memory
     int filter_fma = 0;          // DUSP_FILTER_FMA=1 (EXPERIMENT, off): the Filter stage's recurrence as fma(-b1, y1, P - b2 y2) — three dependent instructions a step

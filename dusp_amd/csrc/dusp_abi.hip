@@ -169,6 +169,9 @@ struct dusp_program {
     bool handoff_ok = false;
     std::string handoff_why;  // when not: what keeps the settled circuit on the chunk engine
     DevBuf<double> d_handoff_init;   // the unit state the chunk engine left (instance 0), as the compiled kernel's start state
+    DevBuf<double> d_warm_records;   // segments that warm up (JitArgs::warm): [Filter stage][segment][8] what the stage held where the segment's own chunks began / ended
+    DevBuf<double> d_warm_init;      // ... and the start state of the launch that finishes a render whose check failed
+    unsigned warm_redo_from = 0;     // the last render's check failed at this segment: finished sequentially from there (0: it held)
     DevBuf<float> d_handoff_out;     // the two parts' PCM before they are put side by side
     DevBuf<int64_t> d_jit_regime;  // per-instance delays: [slot, ring length, mono] per unit, then the verdicts (render_jit)
 
@@ -182,6 +185,8 @@ struct dusp_program {
         d_jit_scan.release();
         d_jit_regime.release();
         d_handoff_init.release();
+        d_warm_records.release();
+        d_warm_init.release();
         d_handoff_out.release();
         d_ops.release();
         d_out_bufs.release();
@@ -260,6 +265,7 @@ static dusp::Knobs read_knobs() {
     k.jit_log = num("DUSP_JIT_LOG", k.jit_log);
     k.ring_window = num("DUSP_RING_WINDOW", k.ring_window);
     k.filter_scan = num("DUSP_FILTER_SCAN", k.filter_scan);
+    k.filter_warm = num("DUSP_FILTER_WARM", k.filter_warm);
     k.jit_nt = num("DUSP_JIT_NT", k.jit_nt);
     k.delay_line = num("DUSP_DELAY_LINE", k.delay_line);
     k.ring_poison = num("DUSP_RING_POISON", k.ring_poison);
@@ -674,6 +680,7 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
         if (at > 0 && (size_t)at < sizeof info->shape && (prog->jit_voices || prog->jit_segments > 1)) {
             if (prog->jit_voices && prog->jit_segments > 1) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", loop, %u seg", prog->jit_segments);
             else if (prog->jit_voices) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", voice loop");
+            else if (prog->warm_redo_from) std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", %u seg, redo@%u", prog->jit_segments, prog->warm_redo_from);
             else std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", %u seg", prog->jit_segments);
         } else if (at > 0 && (size_t)at < sizeof info->shape && prog->jit_scan)
             std::snprintf(info->shape + at, sizeof info->shape - (size_t)at, ", scan");  // (the Filters as scans over the chunk: within the gate's bound, not bit for bit)
@@ -887,6 +894,23 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             a.n_seg = (uint32_t)((n_chunks + a.seg_groups - 1) / a.seg_groups);  // no empty segments
         }
     }
+    // ONE circuit with Filters, long: segments that warm up (jit_codegen.hpp jit_warm_chunks) — every segment starts a segment early, from rest,
+    // its Filters merge with the sequential trajectory on the way (checked below, after the launch), and only its own chunks are stored
+    if (n_inst == 1 && !persistent && !resume && !handoff_chunks && !d_inputs && !ctx->knobs.jit_force_waves && ctx->knobs.filter_warm != 0 && ctx->knobs.wave_segments != 0 &&
+        ctx->knobs.wave_segments != 1) {
+        const uint32_t warm_chunks = dusp::jit_warm_chunks(P, prog->wave);
+        if (warm_chunks) {
+            // (DUSP_FILTER_WARM=n > 1, tests: segments of n chunks whatever the Filters need — too short a warm-up shows in the check, and the render is finished sequentially)
+            const uint64_t target = (uint64_t)ctx->n_cus * 8, per = ctx->knobs.filter_warm > 1 ? (uint64_t)ctx->knobs.filter_warm : std::max<uint64_t>(8, warm_chunks);
+            uint64_t n_seg = std::min<uint64_t>(target, n_chunks / per);
+            if (ctx->knobs.wave_segments > 1) n_seg = std::min<uint64_t>((uint64_t)ctx->knobs.wave_segments, n_chunks / per);
+            if (n_seg >= (ctx->knobs.filter_warm > 1 ? 2u : 4u)) {  // (below that the warm-up costs what the split gains)
+                a.seg_groups = (uint32_t)((n_chunks + n_seg - 1) / n_seg);
+                a.n_seg = (uint32_t)((n_chunks + a.seg_groups - 1) / a.seg_groups);
+                a.warm = 1u;
+            }
+        }
+    }
     // Voices in a loop (jit_codegen.hpp VoicePlan): where the circuit is a sum of isomorphic voices above jit_loop_voices_from() units
     const bool voice_loop = prog->voice_loop != 0;
     // workgroup geometry: as many wavefronts as LDS holds next to the table image, no more than gives every CU a workgroup
@@ -907,7 +931,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     opt.scratch_floats = dusp::jit_scratch_floats(P);
     // Filters whose cutoff is a constant of the circuit, high enough for the bound of jit_filter_scan_ok: a scan over the chunk, the circuit
     // an ordinary one (no Filter stage).  Not for programs that are continued (the stage's y1 / y2 are what the other engines hand over).
-    opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && dusp::jit_filter_scan_ok(P, ctx->table_bound, ctx->knobs.filter_scan == 2 ? 2 : 1);
+    opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && !a.warm && dusp::jit_filter_scan_ok(P, ctx->table_bound, ctx->knobs.filter_scan == 2 ? 2 : 1);
+    if (a.warm) opt.rotate = false;  // (what a stage holds at the top of a chunk must be the chunk before's: nothing of the next one computed ahead)
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
     // Constant delays of a chunk at least as lines of input samples in LDS (JitDelayLine) instead of rings in memory: where the circuit
@@ -938,7 +963,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has
         // lanes, and every CU the same number of rounds — rows = instances per CU / rounds, spread over up to 16 wavefronts.
-        const uint64_t per_cu = (n_inst + (uint64_t)ctx->n_cus - 1) / (uint64_t)ctx->n_cus;
+        const uint64_t per_cu = (n_virtual + (uint64_t)ctx->n_cus - 1) / (uint64_t)ctx->n_cus;  // (instances, or the segments of one)
         const uint64_t rounds = (per_cu + 63) / 64;
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
@@ -983,11 +1008,11 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     for (;;) {  // a kernel that spills (128 registers per lane at 16 wavefronts) is rebuilt for fewer instances per wave, then fewer waves
         opt.waves = waves;
         opt.per_wave = per_wave;
-        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0)});
+        auto it = prog->jit_src.find({waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0) + (opt.rotate ? 0 : 256)});
         if (it == prog->jit_src.end()) {
             dusp::JitSource gen;
             if (!dusp::jit_generate(P, prog->wave, opt, gen)) CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "render: circuit compiler: " + gen.why);
-            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0)), std::move(gen)).first;
+            it = prog->jit_src.emplace(std::make_pair(waves, per_wave * 8 + opt.filter_block % 8 + (opt.voice_loop ? 64 : 0) + (opt.filter_scan ? 128 : 0) + (opt.rotate ? 0 : 256)), std::move(gen)).first;
         }
         src = &it->second;
         // A structure seen for the first time costs a compile of 0.3-0.8 s.  A render the interpreter kernel finishes sooner
@@ -1005,7 +1030,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                     // queue now, so the geometry search does not cost a further render on the interpreter per step)
                     dusp::JitOptions narrow = opt;
                     narrow.filter_block = 4;
-                    const auto key = std::make_pair(waves, per_wave * 8 + narrow.filter_block % 8 + (narrow.voice_loop ? 64 : 0) + (narrow.filter_scan ? 128 : 0));
+                    const auto key = std::make_pair(waves, per_wave * 8 + narrow.filter_block % 8 + (narrow.voice_loop ? 64 : 0) + (narrow.filter_scan ? 128 : 0) + (narrow.rotate ? 0 : 256));
                     auto alt = prog->jit_src.find(key);
                     if (alt == prog->jit_src.end()) {
                         dusp::JitSource gen;
@@ -1097,7 +1122,51 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         HIP_TRY(ctx, hipMemsetAsync(d_debug.p, 0, (size_t)grid * 16 * sizeof(unsigned long long), stream));
         a.debug = d_debug.p;
     }
+    if (a.warm) {
+        HIP_TRY(ctx, prog->d_warm_records.ensure((size_t)std::max(1, opt.filter_stages) * n_virtual * 8));
+        a.warm_records = prog->d_warm_records.p;
+    }
     HIP_TRY(ctx, dusp::jit_launch(render, a, grid, (unsigned)waves * 64, stream));
+    if (a.warm) {
+        // Segments that warmed up: does every Filter stage hold, where a segment's own chunks begin, what the segment before ended with?  Then —
+        // by induction from the first segment, which started from the render's true state — every stored sample is the sequential render's.
+        // Otherwise the render is finished sequentially from the last segment that is known to be right: one wavefront from that
+        // segment's first chunk on, its Filters started from the state recorded there (x1 x2 y1 y2 of every stage into a copy of the start state).
+        const size_t n_rec = (size_t)opt.filter_stages * n_virtual * 8;
+        std::vector<double> rec(n_rec);
+        HIP_TRY(ctx, hipMemcpyAsync(rec.data(), prog->d_warm_records.p, n_rec * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        uint32_t bad = 0;  // first segment whose start differs from its predecessor's end (0: none)
+        for (uint32_t s = 1; s < a.n_seg && !bad; s++)
+            for (int st = 0; st < opt.filter_stages; st++) {
+                const double *now = rec.data() + ((size_t)st * n_virtual + s) * 8, *before = now - 8;
+                if (!(now[0] == before[2] && now[1] == before[3])) bad = s;  // (a NaN never equals: such a render is finished as written)
+            }
+        prog->warm_redo_from = bad;
+        if (bad) {
+            std::vector<double> init(P.init_state);
+            int st = 0;
+            for (int k : prog->wave.order) {  // (stage ordinals are dealt in the plan's execution order: jit_codegen.hpp filter_ordinal)
+                const dusp::DevOp &op = P.ops[(size_t)k];
+                if (op.op == dusp::OP_FILTER) {
+                    const double *before = rec.data() + ((size_t)st * n_virtual + (bad - 1)) * 8;
+                    const size_t at = (size_t)op.state_slot;
+                    if (at + 11 <= init.size()) init[at + 7] = before[4], init[at + 8] = before[5], init[at + 9] = before[2], init[at + 10] = before[3];
+                    st++;
+                }
+            }
+            HIP_TRY(ctx, prog->d_warm_init.ensure(init.size()));
+            HIP_TRY(ctx, hipMemcpyAsync(prog->d_warm_init.p, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            dusp::JitArgs rest = a;
+            rest.warm = 0u;
+            rest.n_seg = 1u;
+            rest.g_first = bad * a.seg_groups;
+            rest.seg_groups = n_chunks;
+            rest.init_state = prog->d_warm_init.p;
+            HIP_TRY(ctx, dusp::jit_launch(render, rest, 1u, (unsigned)waves * 64, stream));
+            HIP_TRY(ctx, hipStreamSynchronize(stream));  // (`init` is a temporary)
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
     if (opt.profile) {  // diagnostic build: what wave 0 of the workgroups measured (mean over workgroups), to stderr
         std::vector<unsigned long long> h((size_t)grid * 16);
@@ -1122,6 +1191,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     prog->jit_segments = a.n_seg;
     prog->jit_voices = src->voice_loop;
     prog->jit_scan = opt.filter_scan;
+    if (!a.warm) prog->warm_redo_from = 0;
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;
     prog->rendered = true;

@@ -145,6 +145,7 @@ struct WavePlan {
     int ext_units = 0;         // bit 0: Filter / Delay present, bit 1: units beyond the lean set (dusp_wave_kernel's FILT / EXT)
     bool ring_events = false;  // a delay line that goes through ordered slot operations (short / signal-rate Delay, MonoDelay, ReadBackDelay)
     bool splittable = false;   // only Osc / Ramp / stateless units, feed-forward: time can be cut into segments
+    bool splittable_but_for_filters = false;  // ... the same but for its Filters, whose memory fades: segments that warm up (jit_codegen.hpp jit_warm_chunks)
     int max_osc_level = 0;     // an Osc's level = number of oscillators stacked in its f input (FM depth)
     std::vector<int> osc_level;  // per device op (-1: not an Osc)
     std::vector<int> ramp_fastdiv;  // per device op: 1 = t / duration may be computed with the verified 2-FMA reciprocal
@@ -725,7 +726,7 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     // oscillator's phase, and that is a modular SUM of its increments — segments can be rendered independently once
     // every segment's phase total is known.  An oscillator whose increments come from other oscillators (FM) needs
     // theirs resolved first: level = depth of oscillators stacked in the f input.
-    plan.splittable = P.feed_forward && !plan.has_filter && P.ring_samples == 0;
+    plan.splittable = P.feed_forward && P.ring_samples == 0;  // (Filters: looked at behind the loop)
     plan.osc_level.assign(P.ops.size(), -1);
     std::vector<int> buf_depth((size_t)std::max(1, P.n_bufs), 0);
     for (size_t k = 0; k < P.ops.size(); k++) {
@@ -752,6 +753,8 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
         }
         if (op.out_buf >= 0) buf_depth[(size_t)op.out_buf] = dep;
     }
+    plan.splittable_but_for_filters = plan.splittable && plan.has_filter;
+    plan.splittable = plan.splittable && !plan.has_filter;
     plan.ok = true;
     return true;
 }

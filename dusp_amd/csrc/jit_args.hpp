@@ -26,6 +26,14 @@ struct JitArgs {
     float *saved_bufs;
     uint32_t resume, save_bufs, n_bufs, pad1;
     uint32_t n_seg, seg_groups;  // every instance is cut into n_seg segments of seg_groups chunks, one wavefront each (1: no split)
+    // Filter circuits cut in time (jit_codegen.hpp jit_warm_chunks): warm = 1: every segment but the first starts one segment EARLY, from rest,
+    // and stores nothing until its own chunks begin — by then its Filters' recurrences have, almost always, merged with the trajectory the
+    // segment before computes; each Filter stage leaves what it held when its own chunks began and when they ended in
+    // warm_records [stage][instance x segment][8] (y1 y2 at the start; y1 y2 x1 x2 at the end), and the host checks that every start equals
+    // the end before it — then, by induction from the first segment, every sample is the sequential render's.  A launch that finishes a
+    // render whose check failed starts at chunk g_first (n_seg = 1, warm = 0) from the state the last good segment left.
+    double *warm_records;
+    uint32_t warm, g_first;
 };
 
 }  // namespace dusp

@@ -252,6 +252,44 @@ inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullpt
     }
     return false;  // (not settled: a loop gain bound at or next to 1)
 }
+// Filter circuits cut in time.  A Filter's recurrence cannot be jumped into — but it forgets: two runs of it over the same input from different
+// pairs differ by a fading transient, and once two consecutive outputs coincide they are the same run from there on, bit for bit.  So a
+// circuit that is splittable but for its Filters (fused_plan.hpp: constant-f oscillators, closed forms of time, stateless units; no rings, no
+// feedback) is cut into segments whose wavefronts start one segment EARLY, from rest, and store only their own chunks; the host then checks
+// that what every Filter held when a segment's own chunks began is what the segment before ended with (JitArgs::warm_records) — by
+// induction from the first segment the whole render is the sequential one's — and finishes a render whose check fails sequentially from the
+// last good segment (dusp_abi.hip render_jit).  How long the warm-up must be is a property of the QUANTISED recurrence (every y rounded to
+// f32): its all-pole part has a DC gain of sum|h|, and two trajectories an ulp apart stay an ulp apart with probability ~1 - 1/sum|h| a
+// step.  Measured (tools/filter_merge_experiment.c --from-rest, sines and saws): merged within 20 sum|h| samples in every trial down to 400 Hz,
+// effectively never at 200 Hz (sum|h| 1500: limit cycles).  Returns the chunks of warm-up to give — 32 sum|h| samples over the circuit's Filters
+// in series, a chunk to spare — or 0 where the circuit is not one for it: a cutoff that is no constant, sum|h| beyond 400 (below ~390 Hz at
+// 48 kHz), a Filter that reaches an oscillator's frequency, scanned (FM) oscillators, a Filter stage with a connected cutoff.
+inline uint32_t jit_warm_chunks(const Program &P, const WavePlan &plan) {
+    if (!plan.splittable_but_for_filters || plan.max_osc_level > 0) return 0;
+    double samples = 256.0;
+    for (const DevOp &op : P.ops) {
+        if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) return 0;
+        if (op.op != OP_FILTER) continue;
+        if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return 0;
+        const double *is = P.init_state.data() + op.state_slot, f = (double)op.in[1].cval;
+        double k[5];
+        if (is[0] == 0.0 || f != is[1]) butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
+        else
+            for (int i = 0; i < 5; i++) k[i] = is[2 + i];
+        double h1 = 1.0, h2 = 0.0, sum = 1.0;
+        int quiet = 0;
+        for (int t = 1; t < 200000 && quiet < 8; t++) {
+            const double h = -k[3] * h1 - k[4] * h2;
+            if (!std::isfinite(h)) return 0;
+            h2 = h1, h1 = h, sum += std::fabs(h);
+            if (sum > 400.0) return 0;
+            quiet = std::fabs(h) < 1e-13 ? quiet + 1 : 0;
+        }
+        if (quiet < 8) return 0;
+        samples += 32.0 * sum;
+    }
+    return (uint32_t)std::ceil(samples / (double)kChunk);
+}
 inline bool jit_filter_mod(const Program &P) {
     for (const DevOp &op : P.ops)
         if (op.op == OP_FILTER && op.in[1].kind == SRC_BUF) return true;
@@ -1193,6 +1231,13 @@ struct Emitter {
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        if (render)  // segments that warm up (JitArgs::warm): what every Filter stage holds where a segment's own chunks begin and end
+            for (size_t at = 0; at < plan.order.size(); at++) {
+                const int k = plan.order[at];
+                if (!used[(size_t)k] || !is_filter_stage(k) || is_mod_stage(k)) continue;
+                line("        f" + num(k) + ".capture(A, X[0], tile, g, " + num(P.ops[(size_t)k].state_slot) + ");");
+                for (int r = 0; r < R; r++) line("        f" + num(k) + ".capture_slot(A, " + ctx(r) + ", " + num(r) + ", g, " + num(P.ops[(size_t)k].state_slot) + ");");
+            }
         phase = 0;
         if (opt.profile && render) line("        ph_t = __builtin_readcyclecounter();");
         if (overlapped) {

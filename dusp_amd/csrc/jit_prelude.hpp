@@ -36,7 +36,8 @@ __device__ __forceinline__ double jit_or0(double v) { return (v != v || v == 0.0
 
 // What a wavefront knows about its place: instance, time segment, chunk range.  Everything but `lane` is wave-uniform.
 struct JitCtx {
-    uint32_t lane, wave, inst, seg, g_begin, g_end, sr, n_seg;
+    uint32_t lane, wave, inst, seg, g_begin, g_end, sr, n_seg;  // g_begin .. g_end: the chunks the wave TICKS
+    uint32_t g_own, g_stop;  // ... and the ones it stores (the same, but for a segment that warms up: JitArgs::warm)
     bool live;  // a short last workgroup keeps its surplus waves alive (they stand at the Filter stage's barriers): they shadow the last instance and never store
     double srd, inv_S;
     unsigned long long S, lift;
@@ -73,8 +74,14 @@ __device__ __forceinline__ void jit_begin(const JitArgs &A, float *lds, JitCtx (
         const uint32_t vinst = x.live ? v : n_virtual - 1;
         x.inst = vinst / A.n_seg;
         x.seg = vinst - x.inst * A.n_seg;
-        x.g_begin = x.seg * A.seg_groups;
+        x.g_begin = x.seg * A.seg_groups + A.g_first;
         x.g_end = A.n_seg == 1 ? A.n_groups : min(x.g_begin + A.seg_groups, A.n_groups);
+        x.g_own = x.g_begin;
+        x.g_stop = x.g_end;
+        if (A.warm) {  // one segment of warm-up (none in front of the first), and the same trip count for every wave of the workgroup: they meet at the Filter stage's barriers
+            x.g_begin = x.seg ? x.g_own - A.seg_groups : 0u;
+            x.g_end = x.g_begin + 2u * A.seg_groups + 1u;  // (one past every segment's last chunk: what a Filter holds THERE is recorded at the top of an iteration)
+        }
     }
 }
 
@@ -1307,7 +1314,7 @@ struct JitDelayGather {
 // FINITE: the generator has shown that this outlet cannot be NaN here (jit_codegen.hpp bound_of_buf): only -0 is left to fix
 template <bool FINITE>
 __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4]) {
-    if (!X.live) return;
+    if (!X.live || g < X.g_own || g >= X.g_stop) return;  // (a segment that warms up ticks chunks it does not own)
     const uint64_t n0 = X.n0(g);
     const float w[4] = {fix_out<FINITE>(v[0]), fix_out<FINITE>(v[1]), fix_out<FINITE>(v[2]), fix_out<FINITE>(v[3])};
     float *row = A.out + ((size_t)X.inst * A.n_out + oc) * A.n_samples + n0;
@@ -1368,14 +1375,16 @@ struct JitFilterK {
             k[0] = is[2]; k[1] = is[3]; k[2] = is[4]; k[3] = is[5]; k[4] = is[6];
         }
         lastF = ft;
+        const uint32_t row_v = blockIdx.x * (WAVES * R) + X.lane, row_seg = row_v % A.n_seg;  // the (instance, segment) this lane serves
         if (X.wave == 0 && X.lane < WAVES * R) {  // (the first barrier of the chunk loop stands between this and the first reader)
             lds_double *mem = (lds_double *)(uintptr_t)memory_address(tile, X.lane);
-            mem[0] = is[9];
-            mem[1] = is[10];
+            const bool rest = A.warm && row_seg != 0;  // (a segment that warms up starts its recurrence from rest)
+            mem[0] = rest ? 0.0 : is[9];
+            mem[1] = rest ? 0.0 : is[10];
         }
         // (what the render leaves of these is known now: written here, the feed-forward coefficients need no registers through the loop)
-        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
-        if (X.wave == 0 && X.lane < WAVES * R && inst < A.n_inst) {
+        const uint32_t inst = row_v / A.n_seg;
+        if (X.wave == 0 && X.lane < WAVES * R && inst < A.n_inst && row_seg == 0) {
             double *st = A.state + (size_t)state_slot * A.n_pad + inst;
             st[0] = 1.0;
             st[A.n_pad] = lastF;
@@ -1394,8 +1403,38 @@ struct JitFilterK {
         if (r < NA) {
             a[r][0] = jit_u(kk[0]); a[r][1] = jit_u(kk[1]); a[r][2] = jit_u(kk[2]);
         }
-        x1[r] = jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
-        x2[r] = jit_u((float)is[8]);
+        const bool rest = A.warm && X.seg != 0;
+        x1[r] = rest ? 0.f : jit_u((float)is[7]);  // (inputs are f32 samples: nothing is lost)
+        x2[r] = rest ? 0.f : jit_u((float)is[8]);
+    }
+    // Segments that warm up (JitArgs::warm), at the top of chunk g: what this stage holds for row `lane` when that row's own chunks begin and
+    // when they end goes into the records the host checks; the render's last segment leaves the unit's state there as well.
+    __device__ __forceinline__ void capture(const JitArgs &A, const JitCtx &X, double *tile, uint32_t g, int state_slot) const {
+        if (!A.warm || X.wave != 0 || X.lane >= WAVES * R) return;
+        const uint32_t v = blockIdx.x * (WAVES * R) + X.lane, n_virtual = A.n_inst * A.n_seg;
+        if (v >= n_virtual) return;
+        const uint32_t seg = v % A.n_seg, inst = v / A.n_seg, own = seg * A.seg_groups, stop = min(own + A.seg_groups, A.n_groups);
+        const lds_double *mem = (const lds_double *)(uintptr_t)memory_address(tile, X.lane);
+        double *rec = A.warm_records + ((size_t)stage * n_virtual + v) * 8;
+        if (g == own) rec[0] = mem[0], rec[1] = mem[1];
+        if (g == stop) {
+            rec[2] = mem[0], rec[3] = mem[1];
+            if (seg == A.n_seg - 1) {
+                double *st = A.state + (size_t)state_slot * A.n_pad + inst;
+                st[(size_t)9 * A.n_pad] = mem[0];
+                st[(size_t)10 * A.n_pad] = mem[1];
+            }
+        }
+    }
+    __device__ __forceinline__ void capture_slot(const JitArgs &A, const JitCtx &X, int r, uint32_t g, int state_slot) const {
+        if (!A.warm || !X.live || X.lane != 0 || g != X.g_stop) return;
+        double *rec = A.warm_records + ((size_t)stage * (A.n_inst * A.n_seg) + (X.inst * A.n_seg + X.seg)) * 8;
+        rec[4] = (double)x1[r], rec[5] = (double)x2[r];
+        if (X.seg == A.n_seg - 1) {
+            double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
+            st[(size_t)7 * A.n_pad] = (double)x1[r];
+            st[(size_t)8 * A.n_pad] = (double)x2[r];
+        }
     }
     static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
     // The feed-forward half of slot r's chunk, P[t] = (a0 x[t] + a1 (x[t-1] || 0)) + a2 (x[t-2] || 0) in f64 with the reference's
@@ -1535,14 +1574,14 @@ struct JitFilterK {
     }
     // state write-back: the input history by each wave (slot r), coefficients and recurrence memory by the lanes that hold them
     __device__ __forceinline__ void end_slot(const JitArgs &A, const JitCtx &X, int r, int state_slot) const {
-        if (!X.live || X.lane != 0) return;
+        if (!X.live || X.lane != 0 || A.warm) return;  // (warm: capture_slot has written it)
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
         st[(size_t)7 * A.n_pad] = (double)x1[r];
         st[(size_t)8 * A.n_pad] = (double)x2[r];
     }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const double *tile, int state_slot) const {
-        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (n_seg == 1 whenever a circuit has a Filter)
-        if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst) return;
+        const uint32_t inst = blockIdx.x * (WAVES * R) + X.lane;  // (unsplit: n_seg == 1; segments that warm up leave their state through capture())
+        if (X.wave != 0 || X.lane >= WAVES * R || inst >= A.n_inst || A.warm) return;
         double *st = A.state + (size_t)state_slot * A.n_pad + inst;
         const lds_double *mem = (const lds_double *)(uintptr_t)const_cast<JitFilterK *>(this)->memory_address(const_cast<double *>(tile), X.lane);  // (behind the chunk loop's last barrier)
         st[(size_t)9 * A.n_pad] = mem[0];
@@ -1712,7 +1751,7 @@ struct JitFilterScan {  // one per Filter and instance
 // parameter `slot` of the instance lane `lane` serves in the Filter stage
 template <int WAVES, int R>
 __device__ __forceinline__ float jit_row_param(const JitArgs &A, const JitCtx &X, uint32_t slot) {
-    const uint32_t inst = min(blockIdx.x * (WAVES * R) + X.lane, A.n_inst - 1);
+    const uint32_t inst = min((blockIdx.x * (WAVES * R) + X.lane) / A.n_seg, A.n_inst - 1);
     return A.params[(size_t)slot * A.n_inst + inst];
 }
 

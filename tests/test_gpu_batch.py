@@ -337,6 +337,49 @@ def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
     staged.close()
 
 
+@pytest.mark.parametrize("kind", ["saw_lp800", "four_poles", "two_channels_enveloped", "lp400_forced_short"])
+def test_one_long_filter_circuit_is_cut_into_segments_that_warm_up(kind, oracle):
+    """`renderChannelData(unit, 10)` of ONE filtered circuit — the reference's everyday call.  A Filter's recurrence is a chain of 480 000
+    dependent steps, so one wavefront used to walk the whole render (DUSP_FILTER_WARM=0: ~10 ms).  Cut into segments that start a segment
+    early from rest and store only their own chunks, with the host's check that every stage held at a segment's start what the segment
+    before ended with, it is a hundred short chains side by side — and the SAME samples and unit state, bit for bit, as the one long chain;
+    within 1e-5 of the oracle (whose coefficients come through libm's tan).  The last case forces segments far shorter than a 400 Hz
+    Filter needs: the check fails somewhere, the render is finished sequentially from there, and is still the one long chain's."""
+    d.configure(48000)
+    n = 480000
+    knobs = {}
+    if kind == "saw_lp800":                 # the dusp string `Z110 -> LP800`
+        g = d.Filter(d.Osc(110, "saw"), 800)
+    elif kind == "four_poles":
+        g = d.Filter(d.Filter(d.Sum(d.Osc(220.5), d.Multiply(d.Osc(3301, "triangle"), 0.25)), 3000), 900, "HP")
+    elif kind == "two_channels_enveloped":
+        g = d.Multiply(d.Filter(d.Multiply(d.Osc(330), [0.5, 0.25]), 1200), d.Ramp(400000, 1, 0).trigger())
+    else:
+        g = d.Filter(d.Osc(82.4, "saw"), 400)
+        knobs = {"DUSP_FILTER_WARM": 8}
+    ex = descriptor.extract(g)
+    one = knob_context(48000, DUSP_FILTER_WARM=0).build(ex.words, runtime.ENGINE_WAVE)
+    want = one.render(n)[0]
+    assert "compiled kernel" in one.read_shape() and " seg" not in one.read_shape()
+    t_one = one.last_kernel_ms()
+    prog = (knob_context(48000, **knobs) if knobs else render.context(48000)).build(ex.words)
+    got = prog.render(n)[0]
+    shape = prog.read_shape()
+    assert " seg" in shape and ("redo@" in shape) == bool(knobs), shape
+    assert np.array_equal(got, want), (shape, int(np.argmax((got != want).any(axis=0))))
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u), one.state(u), equal_nan=True), (u, shape)
+    ref = oracle.render(ex.words, n)
+    assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= 1e-5 * float(np.max(np.abs(ref)))
+    if not knobs:
+        again = prog.render(n)[0]  # (kernels at hand: what the split buys)
+        assert np.array_equal(again, want)
+        assert prog.last_kernel_ms() <= 0.25 * t_one, (prog.last_kernel_ms(), t_one, shape)
+    print("%s: %s; one chain %.2f ms, segments %.2f ms" % (kind, shape, t_one, prog.last_kernel_ms()))
+    prog.close()
+    one.close()
+
+
 def test_cutoff_sweeps_scan_where_their_column_allows(oracle):
     """A per-instance cutoff — the most natural parameter sweep of a filtered voice — takes the scan too: the renderer looks at the
     column (smallest and largest value, next to the Delays' regimes) and the gate answers for the whole range; every wavefront computes

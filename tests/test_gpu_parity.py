@@ -153,6 +153,44 @@ def test_time_split_wave_render_equals_unsplit(name, n_seg):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_filter_circuits_in_segments_that_warm_up_equal_the_unsplit_render():
+    """ONE circuit with Filters, cut in time (jit_codegen.hpp jit_warm_chunks): every segment starts a segment early, from rest, stores only its
+    own chunks, and the host checks that every Filter stage held at a segment's start what the segment before ended with — else the render
+    is finished sequentially from the last good segment.  Either way the PCM and the written-back state are the unsplit render's, bit for
+    bit.  Every golden with a Filter that the form applies to, with segments of only two chunks (DUSP_FILTER_WARM=2: far less warm-up
+    than the Filters need, so both outcomes of the check occur)."""
+    split, redone = [], []
+    for name in ALL_GOLDEN:
+        g = Golden(name)
+        if not any(u.startswith("Filter") for u in g.meta.get("reference_unit_order", [])) or g.n_samples < 256 * 4:
+            continue
+        try:
+            prog = knob_context(g.sample_rate, DUSP_FILTER_WARM=0).build(g.desc, runtime.ENGINE_WAVE)
+        except runtime.DuspHipError:
+            continue
+        if prog.n_params or prog.n_inputs:
+            prog.close()
+            continue
+        want = prog.render(g.n_samples)[0]
+        want_state = [prog.state(u) for u in range(prog.n_units)]
+        assert " seg" not in prog.read_shape()
+        prog.close()
+        prog = knob_context(g.sample_rate, DUSP_FILTER_WARM=2).build(g.desc, runtime.ENGINE_WAVE)
+        got = prog.render(g.n_samples)[0]
+        shape = prog.read_shape()
+        got_state = [prog.state(u) for u in range(prog.n_units)]
+        prog.close()
+        assert np.array_equal(got, want), (name, shape, int(np.argmax((got != want).any(axis=0))))
+        for a, b in zip(got_state, want_state):
+            assert np.array_equal(a, b, equal_nan=True), (name, shape)
+        if " seg" in shape:
+            split.append(name)
+            if "redo@" in shape:
+                redone.append(name)
+    print("cut into warming segments:", split, "finished sequentially:", redone)
+    assert len(split) >= 2, split
+
+
 def test_continue_refuses_a_different_circuit_and_a_wrong_clock():
     from dusp_amd import descriptor
     ctx = render.context(48000)

@@ -27,7 +27,45 @@ static void coef(double f, double sr, double *k) {
     double a0 = 1 / (1 + 2 * lam + lam * lam);
     k[0] = a0; k[1] = 2 * a0; k[2] = a0; k[3] = 2 * a0 * (1 - lam * lam); k[4] = a0 * (1 - 2 * lam + lam * lam);
 }
+// --from-rest <cutoff> [saw]: the other question — a recurrence started from REST (zero pair, zero input history) somewhere in a long signal:
+// after how many samples is it the sequential run's, bit for bit?  What a time segment of ONE filtered circuit needs as warm-up
+// (jit_codegen.hpp jit_warm_chunks: 32 sum|h| samples are given; profiles/r04_filter_merge.txt: every trial merged within 20 sum|h| down to 400 Hz,
+// and at 200 Hz — sum|h| 1500 — effectively never: the quantised recurrence has limit cycles there, so such cutoffs are not cut at all).
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+static int from_rest(double fc, int saw) {
+    const double sr = 48000;
+    double k[5];
+    coef(fc, sr, k);
+    const int N = 48000 * 40;
+    float *x = malloc(N * 4), *y = malloc(N * 4);
+    for (int t = 0; t < N; t++) x[t] = saw ? (float)(2.0 * fmod(110.0 * t / sr, 1.0) - 1.0) : (float)sin(2 * M_PI * 110.0 * t / sr);
+    double y1 = 0, y2 = 0, x1 = 0, x2 = 0;
+    for (int t = 0; t < N; t++) {
+        double P = (k[0] * x[t] + k[1] * x1) + k[2] * x2;
+        float yy = (float)((P - k[3] * y1) - k[4] * y2);
+        y[t] = yy; y2 = y1; y1 = yy; x2 = x1; x1 = x[t];
+    }
+    int trials = 4000, *m = malloc(trials * sizeof(int));
+    for (int i = 0; i < trials; i++) {
+        int t0 = 48000 + (int)((double)rand() / RAND_MAX * (N - 48000 * 12));
+        double u1 = 0, u2 = 0, a1 = 0, a2 = 0;
+        int same = 0, steps = 0;
+        for (int q = t0; q < N; q++) {
+            double P = (k[0] * x[q] + k[1] * a1) + k[2] * a2;
+            float yy = (float)((P - k[3] * u1) - k[4] * u2);
+            u2 = u1; u1 = yy; a2 = a1; a1 = x[q]; steps++;
+            if (yy == y[q]) { if (++same == 2) break; } else same = 0;
+        }
+        m[i] = steps;
+    }
+    qsort(m, trials, sizeof(int), cmp_int);
+    double lam = 1 / tan(M_PI * fc / sr), sum = (1 + lam) * (1 + lam) / 4;
+    printf("from rest, fc %6.0f %s sum|h| %8.1f: merged after  median %7d  90%% %7d  99%% %7d  99.9%% %7d  max %7d samples  (max / sum|h| = %.1f)\n", fc, saw ? "saw " : "sine", sum,
+           m[trials / 2], m[trials * 9 / 10], m[trials * 99 / 100], m[trials * 999 / 1000], m[trials - 1], m[trials - 1] / sum);
+    return 0;
+}
 int main(int argc, char **argv) {
+    if (argc > 2 && !strcmp(argv[1], "--from-rest")) return from_rest(atof(argv[2]), argc > 3);
     double fc = argc > 1 ? atof(argv[1]) : 2000, sr = 48000;
     int L = argc > 2 ? atoi(argv[2]) : 4;
     double k[5]; coef(fc, sr, k);
