@@ -68,7 +68,7 @@ async function main() {
   // renderMany over the node's GPUs: one shard per entry of `devices`, each on a context of its own, all in flight at once; the
   // results in instance order.  On a one-GPU box the same device listed two / three times exercises the split, the parameter rows,
   // the ordering and the concurrency (two contexts side by side on one card): bit for bit the one-context render.
-  const sweep = (k) => new lib.Multiply(new lib.Osc(55 + 13.25 * k), new lib.Ramp(3000 + 10 * k, 1, 0.25).trigger())
+  const sweep = (k) => new lib.Multiply(new lib.Multiply(new lib.Osc(55 + 13.25 * k), new lib.Ramp(3000, 1, 0.25).trigger()), 0.5 + k / 32) // (two parameter rows: f and the gain)
   const eleven = () => Array.from({ length: 11 }, (_, k) => sweep(k))
   const nSweep = 256 * 40 + 17
   const oneCtx = await lib.renderMany(eleven(), nSweep / SR, { devices: [0] })
