@@ -932,7 +932,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // Filters whose cutoff is a constant of the circuit, high enough for the bound of jit_filter_scan_ok: a scan over the chunk, the circuit
     // an ordinary one (no Filter stage).  Not for programs that are continued (the stage's y1 / y2 are what the other engines hand over).
     opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && !a.warm && dusp::jit_filter_scan_ok(P, ctx->table_bound, ctx->knobs.filter_scan == 2 ? 2 : 1);
-    if (a.warm) opt.rotate = false;  // (what a stage holds at the top of a chunk must be the chunk before's: nothing of the next one computed ahead)
+    if (a.warm) opt.warm = true, opt.rotate = false;  // (what a stage holds at the top of a chunk must be the chunk before's: nothing of the next one computed ahead)
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
     // Constant delays of a chunk at least as lines of input samples in LDS (JitDelayLine) instead of rings in memory: where the circuit

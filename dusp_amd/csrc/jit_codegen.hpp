@@ -56,6 +56,7 @@ struct JitOptions {
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
     size_t line_floats = 0;    // per-wave LDS rows of the Delays kept as lines of input samples (jit_delay_lines: part of scratch_floats, behind the shared scratch); 0: none
     bool filter_scan = false;  // every Filter of the circuit as a scan over the chunk (jit_filter_scan_ok, JitFilterScan): no Filter stage, no tile
+    bool warm = false;         // the kernel of a render cut into segments that warm up (JitArgs::warm): the Filter stages record what they hold at segment boundaries
     int filter_block = 8;    // P values per register set of the Filter stage's recurrence loop: 8, or 4 for a kernel short of registers
     int table_form[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // TABLE_FORM_* of every table (device_util.hpp), as the context found them at upload
     int table_delta[kNumTables] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // the lerp's delta form (device_util.hpp lerp_delta): 0 not for this table, 1 differences of neighbours in f64, 2 in f32
@@ -1231,7 +1232,7 @@ struct Emitter {
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
         line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
-        if (render)  // segments that warm up (JitArgs::warm): what every Filter stage holds where a segment's own chunks begin and end
+        if (render && opt.warm)  // segments that warm up (JitArgs::warm): what every Filter stage holds where a segment's own chunks begin and end
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
                 if (!used[(size_t)k] || !is_filter_stage(k) || is_mod_stage(k)) continue;

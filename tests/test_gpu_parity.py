@@ -165,7 +165,7 @@ def test_filter_circuits_in_segments_that_warm_up_equal_the_unsplit_render():
         if not any(u.startswith("Filter") for u in g.meta.get("reference_unit_order", [])) or g.n_samples < 256 * 4:
             continue
         try:
-            prog = knob_context(g.sample_rate, DUSP_FILTER_WARM=0).build(g.desc, runtime.ENGINE_WAVE)
+            prog = knob_context(g.sample_rate, DUSP_FILTER_WARM=0, DUSP_FILTER_SCAN=0).build(g.desc, runtime.ENGINE_WAVE)  # (the one long chain, on the Filter stage)
         except runtime.DuspHipError:
             continue
         if prog.n_params or prog.n_inputs:
