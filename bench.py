@@ -185,6 +185,12 @@ def main():
     if args.gpus > 1 and world_env is None:
         self_launch(args)  # does not return
 
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints its version banner to stdout when a
+    # process group starts), so file descriptor 1 points at stderr from here on and the line goes out through a saved copy of the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -359,7 +365,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
             if rec.get("n_voices") == n_inst and rec.get("n_samples") == n_samples and rec.get("engine") == prog.engine and not mixdown:
-                traffic = rec.get("write_bytes_per_launch")
+                traffic = rec.get("hbm_bytes_per_launch") or rec.get("write_bytes_per_launch")  # (reads + writes where the kernel reads: configs[3]'s delay rings)
                 traffic_source = "profiles/%s: %s" % (name, rec.get("source", "rocprofv3 --pmc WRITE_SIZE, own pass on an earlier box; not measured in this run"))
                 break
         if mixdown:  # (mixdown_program: bare constant-f oscillators through Sum.many — no envelope)
@@ -402,7 +408,8 @@ def main():
         line["gather"] = gather_info or {"render_plus_gather_ms": None, "render_only_ms": None, "inbound_GBps": None, "per_link_GBps": None,
                                           "link_peak_GBps": XGMI_LINK_GBS, "tile_voices": None, "rounds": None,
                                           "Msamples_per_s_with_gather": None, "checked": None, "note": "not measured: run with --gather"}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         if world > 1:
             dist.barrier()

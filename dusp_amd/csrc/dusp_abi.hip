@@ -894,15 +894,15 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             a.n_seg = (uint32_t)((n_chunks + a.seg_groups - 1) / a.seg_groups);  // no empty segments
         }
     }
-    // ONE circuit with Filters, long: segments that warm up (jit_codegen.hpp jit_warm_chunks) — every segment starts a segment early, from rest,
+    // A few circuits with Filters, long: segments that warm up (jit_codegen.hpp jit_warm_chunks) — every segment starts a segment early, from rest,
     // its Filters merge with the sequential trajectory on the way (checked below, after the launch), and only its own chunks are stored
-    if (n_inst == 1 && !persistent && !resume && !handoff_chunks && !d_inputs && !ctx->knobs.jit_force_waves && ctx->knobs.filter_warm != 0 && ctx->knobs.wave_segments != 0 &&
+    if ((uint64_t)n_inst * 4 <= (uint64_t)ctx->n_cus * 8 && !persistent && !resume && !handoff_chunks && !d_inputs && !ctx->knobs.jit_force_waves && ctx->knobs.filter_warm != 0 && ctx->knobs.wave_segments != 0 &&
         ctx->knobs.wave_segments != 1) {
         const uint32_t warm_chunks = dusp::jit_warm_chunks(P, prog->wave);
         if (warm_chunks) {
             // (DUSP_FILTER_WARM=n > 1, tests: segments of n chunks whatever the Filters need — too short a warm-up shows in the check, and the render is finished sequentially)
             const uint64_t target = (uint64_t)ctx->n_cus * 8, per = ctx->knobs.filter_warm > 1 ? (uint64_t)ctx->knobs.filter_warm : std::max<uint64_t>(8, warm_chunks);
-            uint64_t n_seg = std::min<uint64_t>(target, n_chunks / per);
+            uint64_t n_seg = std::min<uint64_t>(target / n_inst, n_chunks / per);
             if (ctx->knobs.wave_segments > 1) n_seg = std::min<uint64_t>((uint64_t)ctx->knobs.wave_segments, n_chunks / per);
             if (n_seg >= (ctx->knobs.filter_warm > 1 ? 2u : 4u)) {  // (below that the warm-up costs what the split gains)
                 a.seg_groups = (uint32_t)((n_chunks + n_seg - 1) / n_seg);
@@ -1136,14 +1136,23 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         std::vector<double> rec(n_rec);
         HIP_TRY(ctx, hipMemcpyAsync(rec.data(), prog->d_warm_records.p, n_rec * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
-        uint32_t bad = 0;  // first segment whose start differs from its predecessor's end (0: none)
-        for (uint32_t s = 1; s < a.n_seg && !bad; s++)
-            for (int st = 0; st < opt.filter_stages; st++) {
-                const double *now = rec.data() + ((size_t)st * n_virtual + s) * 8, *before = now - 8;
-                if (!(now[0] == before[2] && now[1] == before[3])) bad = s;  // (a NaN never equals: such a render is finished as written)
-            }
+        uint32_t bad = 0;  // first segment (of any instance) whose start differs from its predecessor's end (0: none)
+        for (uint32_t i = 0; i < n_inst; i++)
+            for (uint32_t s = 1; s < a.n_seg && (!bad || s < bad); s++)
+                for (int st = 0; st < opt.filter_stages; st++) {
+                    const double *now = rec.data() + ((size_t)st * n_virtual + (size_t)i * a.n_seg + s) * 8, *before = now - 8;
+                    if (!(now[0] == before[2] && now[1] == before[3])) bad = s;  // (a NaN never equals: such a render is finished as written)
+                }
         prog->warm_redo_from = bad;
-        if (bad) {
+        if (bad && n_inst > 1) {  // several instances (each with a state of its own by then): the whole render once more, every instance as one chain
+            dusp::JitArgs whole = a;
+            whole.warm = 0u;
+            whole.n_seg = 1u;
+            whole.seg_groups = n_chunks;
+            const unsigned blocks = (unsigned)((n_inst + per_block - 1) / per_block);
+            HIP_TRY(ctx, dusp::jit_launch(render, whole, blocks, (unsigned)waves * 64, stream));
+            prog->warm_redo_from = 1;
+        } else if (bad) {
             std::vector<double> init(P.init_state);
             int st = 0;
             for (int k : prog->wave.order) {  // (stage ordinals are dealt in the plan's execution order: jit_codegen.hpp filter_ordinal)

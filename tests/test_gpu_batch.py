@@ -337,42 +337,49 @@ def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
     staged.close()
 
 
-@pytest.mark.parametrize("kind", ["saw_lp800", "four_poles", "two_channels_enveloped", "lp400_forced_short"])
-def test_one_long_filter_circuit_is_cut_into_segments_that_warm_up(kind, oracle):
-    """`renderChannelData(unit, 10)` of ONE filtered circuit — the reference's everyday call.  A Filter's recurrence is a chain of 480 000
-    dependent steps, so one wavefront used to walk the whole render (DUSP_FILTER_WARM=0: ~10 ms).  Cut into segments that start a segment
-    early from rest and store only their own chunks, with the host's check that every stage held at a segment's start what the segment
-    before ended with, it is a hundred short chains side by side — and the SAME samples and unit state, bit for bit, as the one long chain;
-    within 1e-5 of the oracle (whose coefficients come through libm's tan).  The last case forces segments far shorter than a 400 Hz
-    Filter needs: the check fails somewhere, the render is finished sequentially from there, and is still the one long chain's."""
+@pytest.mark.parametrize("kind", ["saw_lp800", "four_poles", "two_channels_enveloped", "lp400_forced_short", "three_voices", "three_voices_forced_short"])
+def test_long_filter_circuits_are_cut_into_segments_that_warm_up(kind, oracle):
+    """`renderChannelData(unit, 10)` of ONE filtered circuit — the reference's everyday call — or of a few.  A Filter's recurrence is a chain of
+    480 000 dependent steps, so one wavefront used to walk the whole render (DUSP_FILTER_WARM=0: ~10 ms).  Cut into segments that start a
+    segment early from rest and store only their own chunks, with the host's check that every stage held at a segment's start what the
+    segment before ended with, it is a hundred short chains side by side — and the SAME samples and unit state, bit for bit, as the one long
+    chain; within 1e-5 of the oracle (whose coefficients come through libm's tan).  The forced cases use segments far shorter than a 400 Hz
+    Filter needs: the check fails somewhere, the render is finished sequentially (one circuit: from the last good segment; several: every
+    instance once more as one chain), and is still the one long chain's."""
     d.configure(48000)
     n = 480000
-    knobs = {}
+    knobs, V, params = {}, 1, None
     if kind == "saw_lp800":                 # the dusp string `Z110 -> LP800`
-        g = d.Filter(d.Osc(110, "saw"), 800)
+        words = descriptor.extract(d.Filter(d.Osc(110, "saw"), 800)).words
     elif kind == "four_poles":
-        g = d.Filter(d.Filter(d.Sum(d.Osc(220.5), d.Multiply(d.Osc(3301, "triangle"), 0.25)), 3000), 900, "HP")
+        words = descriptor.extract(d.Filter(d.Filter(d.Sum(d.Osc(220.5), d.Multiply(d.Osc(3301, "triangle"), 0.25)), 3000), 900, "HP")).words
     elif kind == "two_channels_enveloped":
-        g = d.Multiply(d.Filter(d.Multiply(d.Osc(330), [0.5, 0.25]), 1200), d.Ramp(400000, 1, 0).trigger())
-    else:
-        g = d.Filter(d.Osc(82.4, "saw"), 400)
+        words = descriptor.extract(d.Multiply(d.Filter(d.Multiply(d.Osc(330), [0.5, 0.25]), 1200), d.Ramp(400000, 1, 0).trigger())).words
+    elif kind == "lp400_forced_short":
+        words = descriptor.extract(d.Filter(d.Osc(82.4, "saw"), 400)).words
         knobs = {"DUSP_FILTER_WARM": 8}
-    ex = descriptor.extract(g)
-    one = knob_context(48000, DUSP_FILTER_WARM=0).build(ex.words, runtime.ENGINE_WAVE)
-    want = one.render(n)[0]
+    else:                                   # three voices of one structure: per-instance f and gain, one constant cutoff
+        cutoff = 400 if kind.endswith("forced_short") else 1000
+        uni = descriptor.unify([descriptor.extract(d.Multiply(d.Filter(d.Osc(82.4 + 27.5 * k, "saw"), cutoff), 0.5 + k / 8)) for k in range(3)])
+        words, V, params = uni.words, 3, uni.params
+        if kind.endswith("forced_short"):
+            knobs = {"DUSP_FILTER_WARM": 8}
+    one = knob_context(48000, DUSP_FILTER_WARM=0).build(words, runtime.ENGINE_WAVE)
+    want = one.render(n, V, params)
     assert "compiled kernel" in one.read_shape() and " seg" not in one.read_shape()
     t_one = one.last_kernel_ms()
-    prog = (knob_context(48000, **knobs) if knobs else render.context(48000)).build(ex.words)
-    got = prog.render(n)[0]
+    prog = (knob_context(48000, **knobs) if knobs else render.context(48000)).build(words)
+    got = prog.render(n, V, params)
     shape = prog.read_shape()
     assert " seg" in shape and ("redo@" in shape) == bool(knobs), shape
-    assert np.array_equal(got, want), (shape, int(np.argmax((got != want).any(axis=0))))
-    for u in range(prog.n_units):
-        assert np.array_equal(prog.state(u), one.state(u), equal_nan=True), (u, shape)
-    ref = oracle.render(ex.words, n)
-    assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= 1e-5 * float(np.max(np.abs(ref)))
+    assert np.array_equal(got, want), (shape, int(np.argmax((got != want).any(axis=(0, 1)))))
+    for i in range(V):
+        for u in range(prog.n_units):
+            assert np.array_equal(prog.state(u, i), one.state(u, i), equal_nan=True), (u, i, shape)
+        ref = oracle.render(words, n, params=params, n_instances=V, instance=i)
+        assert float(np.max(np.abs(got[i].astype(np.float64) - ref))) <= 1e-5 * float(np.max(np.abs(ref)))
     if not knobs:
-        again = prog.render(n)[0]  # (kernels at hand: what the split buys)
+        again = prog.render(n, V, params)  # (kernels at hand: what the split buys)
         assert np.array_equal(again, want)
         assert prog.last_kernel_ms() <= 0.25 * t_one, (prog.last_kernel_ms(), t_one, shape)
     print("%s: %s; one chain %.2f ms, segments %.2f ms" % (kind, shape, t_one, prog.last_kernel_ms()))

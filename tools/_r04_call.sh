@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r04
-timeout -k 10 300 python tools/_dbg.py > gpurun_out/r04/dbg.txt 2>&1; tail -40 gpurun_out/r04/dbg.txt
+python -X faulthandler bench.py --config cfg5 --cpu-seconds 0 --gather > gpurun_out/r04/bench_line_cfg5.json 2> gpurun_out/r04/bench_line_cfg5.err; echo "rc $?"; tail -30 gpurun_out/r04/bench_line_cfg5.err; wc -c gpurun_out/r04/bench_line_cfg5.json
+python -X faulthandler bench.py --config cfg5 --cpu-seconds 0 > gpurun_out/r04/bench_line_cfg5_nogather.json 2> gpurun_out/r04/bench_line_cfg5_ng.err; echo "rc $?"; tail -5 gpurun_out/r04/bench_line_cfg5_ng.err; wc -c gpurun_out/r04/bench_line_cfg5_nogather.json
