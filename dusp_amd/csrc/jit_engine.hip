@@ -19,8 +19,12 @@
 // failed background compile is remembered with its log and fails the next render of that structure.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <dirent.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <unistd.h>
+
+#include <algorithm>
 
 #include <atomic>
 #include <condition_variable>
@@ -56,6 +60,7 @@ std::deque<std::string> g_queue;                  // texts waiting for the worke
 std::thread g_worker;
 bool g_worker_started = false, g_leaving = false;
 std::string g_cache_dir;                          // "" = no disk cache
+uint64_t g_cache_cap_bytes = (uint64_t)256 << 20; // the cache directory is kept below this (DUSP_JIT_CACHE_MAX_MB): least recently used files go first
 std::once_flag g_configured;
 
 // the numerics contract of every kernel in this library: no contraction, no fast-math, correctly rounded division
@@ -91,7 +96,15 @@ void configure_once() {
         else if (home && *home) dir = std::string(home) + "/.cache/dusp-hip";
         else return;
     }
-    if (make_dirs(dir)) g_cache_dir = dir;  // (a directory that cannot be made: no disk cache, nothing fails)
+    if (!make_dirs(dir)) return;  // (a directory that cannot be made: no disk cache, nothing fails)
+    // code objects are loaded and RUN: only a directory of this user's that nobody else may write to is trusted with them
+    struct stat st;
+    if (::stat(dir.c_str(), &st) != 0 || st.st_uid != ::geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return;
+    g_cache_dir = dir;
+    if (const char *cap = getenv("DUSP_JIT_CACHE_MAX_MB")) {
+        const long mb = std::atol(cap);
+        if (mb > 0) g_cache_cap_bytes = (uint64_t)mb << 20;
+    }
 }
 
 // key of the disk cache: everything a code object depends on
@@ -113,25 +126,62 @@ std::string disk_path(const std::string &text) {
     return g_cache_dir + name;
 }
 struct DiskHeader {
-    char magic[8];  // "DUSPHSA1"
-    uint64_t bytes, hash;
+    char magic[8];  // "DUSPHSA2"
+    uint64_t bytes, hash;  // of the code object behind the header
+    uint64_t text_hash;    // a second, independent hash of the kernel text: with the key in the file's name (and the text's length) 128 bits say whose kernel this is
 };
+uint64_t second_hash(const std::string &text) {  // (xorshift-multiply over 8-byte words: nothing in common with FNV-1a's byte walk)
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)text.size();
+    for (size_t i = 0; i < text.size(); i += 8) {
+        uint64_t w = 0;
+        std::memcpy(&w, text.data() + i, std::min<size_t>(8, text.size() - i));
+        h ^= w;
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    return h;
+}
+// keep the directory below its cap: the files this library wrote, least recently used (loaded or stored) first
+void disk_evict() {
+    DIR *d = ::opendir(g_cache_dir.c_str());
+    if (!d) return;
+    struct Entry { std::string path; uint64_t bytes; time_t used; };
+    std::vector<Entry> files;
+    uint64_t total = 0;
+    while (struct dirent *e = ::readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.rfind("dusp_", 0) != 0 || name.size() < 6 || name.substr(name.size() - 6) != ".hsaco") continue;
+        struct stat st;
+        const std::string path = g_cache_dir + "/" + name;
+        if (::stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+        files.push_back({path, (uint64_t)st.st_size, st.st_mtime});
+        total += (uint64_t)st.st_size;
+    }
+    ::closedir(d);
+    if (total <= g_cache_cap_bytes) return;
+    std::sort(files.begin(), files.end(), [](const Entry &a, const Entry &b) { return a.used < b.used; });
+    for (const Entry &f : files) {
+        if (total <= g_cache_cap_bytes / 4 * 3) break;
+        if (std::remove(f.path.c_str()) == 0) total -= f.bytes;
+    }
+}
 bool disk_load(const std::string &text, std::vector<char> &code) {
     const std::string path = disk_path(text);
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     DiskHeader h{};
-    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "DUSPHSA1", 8) && h.bytes > 0 && h.bytes < ((uint64_t)64 << 20);
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && !std::memcmp(h.magic, "DUSPHSA2", 8) && h.bytes > 0 && h.bytes < ((uint64_t)64 << 20) && h.text_hash == second_hash(text);
     if (ok) {
         code.resize((size_t)h.bytes);
         ok = std::fread(code.data(), 1, code.size(), f) == code.size() && std::fgetc(f) == EOF && fnv1a(code.data(), code.size()) == h.hash;
     }
     std::fclose(f);
-    if (!ok) {  // truncated, damaged or from another format: gone, the kernel is compiled again
+    if (!ok) {  // truncated, damaged, from another format or — the second hash — another text's: gone, the kernel is compiled again
         code.clear();
         std::remove(path.c_str());
-    }
+    } else
+        (void)::utimes(path.c_str(), nullptr);  // (used now: the eviction goes by this)
     return ok;
 }
 void disk_store(const std::string &text, const std::vector<char> &code) {
@@ -141,11 +191,13 @@ void disk_store(const std::string &text, const std::vector<char> &code) {
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return;
     DiskHeader h{};
-    std::memcpy(h.magic, "DUSPHSA1", 8);
+    std::memcpy(h.magic, "DUSPHSA2", 8);
     h.bytes = code.size();
     h.hash = fnv1a(code.data(), code.size());
+    h.text_hash = second_hash(text);
     const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
     if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+    else disk_evict();
 }
 void disk_forget(const std::string &text) {
     const std::string path = disk_path(text);

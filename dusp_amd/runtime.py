@@ -135,7 +135,10 @@ class Context:
         self._h = h
         self._host_live = 0       # pinned result buffers some numpy array still looks at
         self._host_live_bytes = 0
-        self._host_lock = threading.Lock()  # pool calls may come from a finalizer on another thread
+        # pool calls may come from a finalizer on another thread — or on THIS one: the cyclic collector can run while the lock is held
+        # (allocating Python objects inside host_empty) and collect a cycle that owns a pinned block, whose __del__ takes the lock again.
+        # dusp_host_alloc / _free take only the library's own pool mutex, which no Python code runs under, so re-entry is safe.
+        self._host_lock = threading.RLock()
         self._close_pending = False
         self.sample_rate = None
         if sample_rate is not None:
@@ -147,7 +150,8 @@ class Context:
         the array (and every view of it) has been collected."""
         n = int(np.prod(shape))
         if pinned is None:
-            pinned = n * 4 >= PINNED_MIN_BYTES and self._host_live_bytes + n * 4 <= PINNED_MAX_LIVE_BYTES
+            with self._host_lock:
+                pinned = n * 4 >= PINNED_MIN_BYTES and self._host_live_bytes + n * 4 <= PINNED_MAX_LIVE_BYTES
         if not pinned or n == 0:
             return np.empty(shape, dtype=np.float32)
         p = ctypes.c_void_p()

@@ -166,7 +166,10 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info);
  *   stream    hipStream_t to launch on (NULL = the context's own stream).
  *
  * Asynchronous: returns once the work is enqueued.  Inputs and outputs stay
- * resident in HBM; nothing crosses PCIe. */
+ * resident in HBM; nothing crosses PCIe.  Three kinds of program wait for the stream inside the call, because what they launch
+ * depends on a few bytes the device has to hand back first: a Delay or a Filter whose delay / cutoff is a per-instance parameter
+ * (the column is looked at: one small launch, its verdict back), and a few long circuits with Filters cut into segments that warm
+ * up (the segments' hand-overs are checked when the launch is done).  dusp_render_host waits anyway. */
 int dusp_render_device(dusp_program *prog, size_t n_instances, size_t n_samples,
                        const float *d_params, float *d_out, void *stream);
 

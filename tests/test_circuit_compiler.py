@@ -305,7 +305,7 @@ def test_saw_square_triangle_are_evaluated_not_looked_up():
     assert "tick<0, 0, 1>" in plain and "tick<2," not in plain
 
 
-def _compile_in_a_fresh_process(cache, name="fm_sum"):
+def _compile_in_a_fresh_process(cache, name="fm_sum", extra_env=None):
     """One process: compile the kernel of a golden circuit, report seconds and the cache directory the library uses."""
     import json
     import os
@@ -320,6 +320,7 @@ def _compile_in_a_fresh_process(cache, name="fm_sum"):
     env.pop("XDG_CACHE_HOME", None)
     if cache is not None:
         env["DUSP_JIT_CACHE"] = cache
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -336,7 +337,7 @@ def test_code_objects_are_cached_on_disk_and_a_damaged_file_is_compiled_again(tm
     assert len(files) == 1
     path = os.path.join(cache, files[0])
     good = open(path, "rb").read()
-    assert good[:8] == b"DUSPHSA1" and len(good) > 4096
+    assert good[:8] == b"DUSPHSA2" and len(good) > 4096
     again = _compile_in_a_fresh_process(cache)
     assert again["s"] < 0.5 * first["s"], (first, again)  # (no hiprtc run: generate the text, read the file)
     assert open(path, "rb").read() == good
@@ -350,6 +351,24 @@ def test_code_objects_are_cached_on_disk_and_a_damaged_file_is_compiled_again(tm
     open(path, "wb").write(bytes(bad))
     _compile_in_a_fresh_process(cache)
     assert open(path, "rb").read() == good
+    # the header's second hash of the kernel TEXT: a file that holds another text's kernel under this one's name is not run
+    bad = bytearray(good)
+    bad[24] ^= 0x01
+    open(path, "wb").write(bytes(bad))
+    _compile_in_a_fresh_process(cache)
+    assert open(path, "rb").read() == good
+    # a directory others may write to is not trusted with code objects: no disk cache then
+    os.chmod(cache, 0o777)
+    assert _compile_in_a_fresh_process(cache)["dir"] == ""
+    os.chmod(cache, 0o700)
+    # a cap on the directory's size (DUSP_JIT_CACHE_MAX_MB): the least recently used files go when a store takes it over
+    for k in range(5):
+        open(os.path.join(cache, "dusp_%016x_1.hsaco" % k), "wb").write(b"x" * (300 << 10))
+        os.utime(os.path.join(cache, "dusp_%016x_1.hsaco" % k), (1000 + k, 1000 + k))
+    os.remove(path)
+    _compile_in_a_fresh_process(cache, extra_env={"DUSP_JIT_CACHE_MAX_MB": "1"})
+    left = sorted(os.listdir(cache))
+    assert files[0] in left and "dusp_%016x_1.hsaco" % 0 not in left and "dusp_%016x_1.hsaco" % 1 not in left and len(left) < 6, left
     # off
     off = _compile_in_a_fresh_process("0")
     assert off["dir"] == ""

@@ -1,3 +1,5 @@
+set -o pipefail
 mkdir -p gpurun_out/r04
-python -X faulthandler bench.py --config cfg5 --cpu-seconds 0 --gather > gpurun_out/r04/bench_line_cfg5.json 2> gpurun_out/r04/bench_line_cfg5.err; echo "rc $?"; tail -30 gpurun_out/r04/bench_line_cfg5.err; wc -c gpurun_out/r04/bench_line_cfg5.json
-python -X faulthandler bench.py --config cfg5 --cpu-seconds 0 > gpurun_out/r04/bench_line_cfg5_nogather.json 2> gpurun_out/r04/bench_line_cfg5_ng.err; echo "rc $?"; tail -5 gpurun_out/r04/bench_line_cfg5_ng.err; wc -c gpurun_out/r04/bench_line_cfg5_nogather.json
+timeout -k 10 1000 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/r04/gputest_d.log 2>&1
+echo "pytest rc $?" >> gpurun_out/r04/gputest_d.log
+grep -v "^\.\|^$" gpurun_out/r04/gputest_d.log | tail -30 | cut -c1-300
