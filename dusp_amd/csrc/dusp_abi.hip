@@ -896,12 +896,14 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     // A few circuits with Filters, long: segments that warm up (jit_codegen.hpp jit_warm_chunks) — every segment starts a segment early, from rest,
     // its Filters merge with the sequential trajectory on the way (checked below, after the launch), and only its own chunks are stored
-    if ((uint64_t)n_inst * 4 <= (uint64_t)ctx->n_cus * 8 && !persistent && !resume && !handoff_chunks && !d_inputs && !ctx->knobs.jit_force_waves && ctx->knobs.filter_warm != 0 && ctx->knobs.wave_segments != 0 &&
+    // (a Filter stage's serving wave runs 32 recurrences side by side at the price of one: the chip is full at 32 rows a CU, so up to a quarter of that many
+    // instances are still worth cutting)
+    if ((uint64_t)n_inst * 4 <= (uint64_t)ctx->n_cus * 32 && !persistent && !resume && !handoff_chunks && !d_inputs && !ctx->knobs.jit_force_waves && ctx->knobs.filter_warm != 0 && ctx->knobs.wave_segments != 0 &&
         ctx->knobs.wave_segments != 1) {
         const uint32_t warm_chunks = dusp::jit_warm_chunks(P, prog->wave);
         if (warm_chunks) {
             // (DUSP_FILTER_WARM=n > 1, tests: segments of n chunks whatever the Filters need — too short a warm-up shows in the check, and the render is finished sequentially)
-            const uint64_t target = (uint64_t)ctx->n_cus * 8, per = ctx->knobs.filter_warm > 1 ? (uint64_t)ctx->knobs.filter_warm : std::max<uint64_t>(8, warm_chunks);
+            const uint64_t target = (uint64_t)ctx->n_cus * 32, per = ctx->knobs.filter_warm > 1 ? (uint64_t)ctx->knobs.filter_warm : std::max<uint64_t>(8, warm_chunks);
             uint64_t n_seg = std::min<uint64_t>(target / n_inst, n_chunks / per);
             if (ctx->knobs.wave_segments > 1) n_seg = std::min<uint64_t>((uint64_t)ctx->knobs.wave_segments, n_chunks / per);
             if (n_seg >= (ctx->knobs.filter_warm > 1 ? 2u : 4u)) {  // (below that the warm-up costs what the split gains)
@@ -958,7 +960,8 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     }
     const size_t budget = 160 * 1024 - (size_t)most * opt.scratch_floats * 4;
     int waves = 1, per_wave = 1;
-    const int per_wave_cap = opt.line_floats ? 1 : ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;  // (the lines are per wavefront)
+    // (the lines are per wavefront; a wavefront walks ONE segment's chunks: the chunk loop has one counter)
+    const int per_wave_cap = opt.line_floats || a.n_seg > 1 ? 1 : ctx->knobs.wave_per_wave >= 1 ? std::min(4, ctx->knobs.wave_per_wave) : 4;
     const bool filter_stage = opt.filter_stages > 0;
     if (filter_stage) {
         // The Filter stage runs one recurrence per lane of ONE wave: a workgroup wants as many instances (rows) as that wave has

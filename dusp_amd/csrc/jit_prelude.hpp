@@ -1414,10 +1414,12 @@ struct JitFilterK {
         const uint32_t v = blockIdx.x * (WAVES * R) + X.lane, n_virtual = A.n_inst * A.n_seg;
         if (v >= n_virtual) return;
         const uint32_t seg = v % A.n_seg, inst = v / A.n_seg, own = seg * A.seg_groups, stop = min(own + A.seg_groups, A.n_groups);
+        // (the ROW's chunk, not the calling wave's: every wave of the workgroup is in the same iteration, each on the chunks of its own segment)
+        const uint32_t row_g = (seg ? own - A.seg_groups : 0u) + (g - X.g_begin);
         const lds_double *mem = (const lds_double *)(uintptr_t)memory_address(tile, X.lane);
         double *rec = A.warm_records + ((size_t)stage * n_virtual + v) * 8;
-        if (g == own) rec[0] = mem[0], rec[1] = mem[1];
-        if (g == stop) {
+        if (row_g == own) rec[0] = mem[0], rec[1] = mem[1];
+        if (row_g == stop) {
             rec[2] = mem[0], rec[3] = mem[1];
             if (seg == A.n_seg - 1) {
                 double *st = A.state + (size_t)state_slot * A.n_pad + inst;
