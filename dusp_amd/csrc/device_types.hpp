@@ -62,7 +62,8 @@ struct Knobs {
     int jit_lean = 1;            // DUSP_JIT_LEAN=0: compiled kernels' constant-f oscillators keep the 32.32 form (no delta lerp: A/B)
     int jit_log = 0;             // DUSP_JIT_LOG=1: the geometry search's steps on stderr (wavefronts x instances, Filter block, scratch bytes per lane)
     int jit_lds_table = 1;       // DUSP_JIT_LDS_TABLE=0: compiled kernels look wave tables up in HBM / L2 (no LDS image)
-    int jit_spill_bytes = 64;    // DUSP_JIT_SPILL: scratch bytes per lane a compiled kernel may use before it is rebuilt for a smaller geometry
+    int jit_spill_bytes = 96;    // DUSP_JIT_SPILL: scratch bytes per lane a compiled kernel may use before it is rebuilt for a smaller geometry (round 4: 96 — `delay(osc, lfo)` spills 92
+                                 // bytes at 16 wavefronts and is still 16 % faster there than at 8: 4.12 against 4.90 ms; the 16 x 4 Filter geometries, 170-470 bytes, stay out)
     int jit_force_waves = 0;     // DUSP_JIT_FORCE="WxR" (tests): compiled kernels with exactly W wavefronts per workgroup and R instances per wavefront,
     int jit_force_per_wave = 0;  //   whatever the batch size (renders are then not split in time)
     int ring_window = 1;         // DUSP_RING_WINDOW=0: every render zero-fills whole rings (else only what a render nothing continues can touch)
