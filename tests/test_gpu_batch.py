@@ -390,6 +390,40 @@ def test_long_filter_circuits_are_cut_into_segments_that_warm_up(kind, oracle):
     one.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_filter_circuits_in_warming_segments_equal_the_one_chain(seed):
+    """Random feed-forward circuits around Filters — sums of oscillators of every wave table into one to three low / high passes in series or side by
+    side, cutoffs between 700 Hz and 15 kHz, gains, an envelope — three seconds each: cut into warming segments (the default) they are the one
+    long chain (DUSP_FILTER_WARM=0), sample for sample and state for state; a render whose check fails says so and is the chain's all the same."""
+    rng = np.random.RandomState(1000 + seed)
+    d.configure(48000)
+    def source():
+        s = d.Osc(float(np.round(rng.uniform(40, 2000), 2)), ["sin", "saw", "triangle", "square", "8bit"][rng.randint(5)])
+        for _ in range(rng.randint(3)):
+            s = d.Sum(s, d.Multiply(d.Osc(float(np.round(rng.uniform(40, 6000), 3)), ["sin", "saw", "triangle"][rng.randint(3)]), float(np.round(rng.uniform(0.1, 0.9), 3))))
+        return s
+    def filt(x):
+        return d.Filter(x, float(np.round(np.exp(rng.uniform(np.log(700), np.log(15000))), 1)), ["LP", "HP"][rng.randint(2)])
+    g = filt(source())
+    for _ in range(rng.randint(3)):
+        g = filt(d.Multiply(g, float(np.round(rng.uniform(0.3, 1.5), 3)))) if rng.randint(2) else d.Sum(g, filt(source()))
+    if rng.randint(2):
+        g = d.Multiply(g, d.Ramp(int(rng.uniform(20000, 140000)), 1, float(np.round(rng.uniform(0, 0.5), 2))).trigger())
+    ex = descriptor.extract(g)
+    n = 144000 + int(rng.randint(0, 300))
+    one = knob_context(48000, DUSP_FILTER_WARM=0, DUSP_FILTER_SCAN=0).build(ex.words, runtime.ENGINE_WAVE)
+    want = one.render(n)[0]
+    prog = render.context(48000).build(ex.words)
+    got = prog.render(n)[0]
+    shape = prog.read_shape()
+    assert "compiled kernel" in shape and " seg" in shape, shape
+    assert np.array_equal(got, want), (shape, int(np.argmax((got != want).any(axis=0))))
+    for u in range(prog.n_units):
+        assert np.array_equal(prog.state(u), one.state(u), equal_nan=True), (u, shape)
+    prog.close()
+    one.close()
+
+
 def test_cutoff_sweeps_scan_where_their_column_allows(oracle):
     """A per-instance cutoff — the most natural parameter sweep of a filtered voice — takes the scan too: the renderer looks at the
     column (smallest and largest value, next to the Delays' regimes) and the gate answers for the whole range; every wavefront computes

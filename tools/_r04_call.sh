@@ -1,5 +1,2 @@
 mkdir -p gpurun_out/r04
-for S in 64 128; do
-  echo "== DUSP_JIT_SPILL=$S"
-  DUSP_JIT_SPILL=$S timeout -k 10 400 python tools/wave_ops.py 2>&1 | grep -v amdgpu.ids | grep " ms " | cut -c1-150
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_batch.py -m gpu -q -s -k "random_filter_circuits_in_warming or cut_into_segments" 2>&1 | grep -v "^$" | grep "^E \|one chain\|passed\|failed" | cut -c1-300
