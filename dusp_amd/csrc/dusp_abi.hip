@@ -1114,7 +1114,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
             std::string err;
             if (!dusp::jit_get_kernel(ctx->device, src->text, "dusp_jit_pass" + std::to_string(level), &pass, nullptr, err))
                 CTX_FAIL(ctx, DUSP_ERR_HIP, "render: circuit compiler: " + err);
-            HIP_TRY(ctx, dusp::jit_launch(pass, a, grid, (unsigned)waves * 64, stream));
+            dusp::JitArgs own = a;
+            own.warm = 0u;  // (a pass totals every segment's OWN chunks, whatever the render kernel does in front of them)
+            HIP_TRY(ctx, dusp::jit_launch(pass, own, grid, (unsigned)waves * 64, stream));
             HIP_TRY(ctx, dusp::jit_launch_prefix(a.seg_sum, a.seg_start, prog->d_init.p, prog->d_jit_scan.p, prog->d_jit_scan.p + src->scans.size(),
                                                  (int)src->scans.size(), level, n_inst, a.n_seg, a.sample_rate, stream));
         }
@@ -1147,7 +1149,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
                     if (!(now[0] == before[2] && now[1] == before[3])) bad = s;  // (a NaN never equals: such a render is finished as written)
                 }
         prog->warm_redo_from = bad;
-        if (bad && n_inst > 1) {  // several instances (each with a state of its own by then): the whole render once more, every instance as one chain
+        if (bad && (n_inst > 1 || !src->scans.empty())) {
+            // several instances (each with a state of its own by then), or scanned oscillators (their phases are the passes' business): the whole
+            // render once more, every instance as one chain from its first chunk
             dusp::JitArgs whole = a;
             whole.warm = 0u;
             whole.n_seg = 1u;

@@ -266,10 +266,21 @@ inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullpt
 // in series, a chunk to spare — or 0 where the circuit is not one for it: a cutoff that is no constant, sum|h| beyond 400 (below ~390 Hz at
 // 48 kHz), a Filter that reaches an oscillator's frequency, scanned (FM) oscillators, a Filter stage with a connected cutoff.
 inline uint32_t jit_warm_chunks(const Program &P, const WavePlan &plan) {
-    if (!plan.splittable_but_for_filters || plan.max_osc_level > 0) return 0;
+    if (!plan.splittable_but_for_filters) return 0;
     double samples = 256.0;
+    // (FM is fine IN FRONT of a Filter — the accumulate passes total the oscillators' increments per segment as in any time-split render — but a
+    // Filter's output must not reach an oscillator's frequency: those totals would be the warm-up's, not the chain's)
+    std::vector<char> filtered((size_t)std::max(1, P.n_bufs), 0);
+    for (const DevOp &op : P.ops) {  // (feed-forward: producers stand in front of their readers)
+        bool dep = op.op == OP_FILTER;
+        for (int j = 0; j < kMaxIn; j++)
+            if (op.in[j].kind == SRC_BUF && op.in[j].idx >= 0 && op.in[j].idx < P.n_bufs && filtered[(size_t)op.in[j].idx]) {
+                dep = true;
+                if (op.op == OP_OSC && j == 0) return 0;
+            }
+        if (dep && op.out_buf >= 0 && op.out_buf < P.n_bufs) filtered[(size_t)op.out_buf] = 1;
+    }
     for (const DevOp &op : P.ops) {
-        if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) return 0;
         if (op.op != OP_FILTER) continue;
         if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return 0;
         const double *is = P.init_state.data() + op.state_slot, f = (double)op.in[1].cval;
@@ -1100,7 +1111,12 @@ struct Emitter {
                     const DevOp &op = P.ops[k];
                     const std::string slot = "A.state[(size_t)" + num(op.state_slot) + " * A.n_pad + " + ctx(r) + ".inst]", id = num((long long)k) + sfx((int)k, r);
                     if (op.op == OP_OSC && op.in[0].kind != SRC_BUF) line("        " + slot + " = o" + id + ".end_phase(A, " + ctx(r) + ");");
-                    if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) line("        " + slot + " = o" + id + ".end_phase();");
+                    if (op.op == OP_OSC && op.in[0].kind == SRC_BUF) {
+                        int scan_id = 0;
+                        for (size_t i = 0; i < out.scans.size(); i++)
+                            if (plan.order[(size_t)out.scans[i].op_pos] == (int)k) scan_id = (int)i;
+                        line("        " + slot + " = " + (opt.warm ? "A.warm ? JitOscS::warm_end_phase(A, " + ctx(r) + ", " + num(scan_id) + ") : " : std::string()) + "o" + id + ".end_phase();");
+                    }
                     if (op.op == OP_RAMP && restarted((int)k)) line("        a" + id + ".end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
                     else if (op.op == OP_RAMP) line("        jit_ramp_end(A, " + ctx(r) + ", d" + num(dconst_of[k]) + ", " + num(op.state_slot) + ");");
                     if (op.op == OP_TIMER)
@@ -1931,7 +1947,7 @@ struct Emitter {
         for (size_t i = 0; i < out.dk.size(); i++) line("#define d" + num((long long)i) + " jit_u(A.dk[" + num((long long)i) + "])");
         line("");
         kernel(-1);
-        if (plan.splittable && R == 1)
+        if ((plan.splittable || (opt.warm && plan.splittable_but_for_filters)) && R == 1)
             for (int L : out.pass_levels) kernel(L);
         out.text = s;
         out.ok = true;

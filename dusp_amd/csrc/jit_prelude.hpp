@@ -358,7 +358,8 @@ struct JitOscS {
         poison = 0u;
         if (X.n_seg == 1) carry = jit_u((unsigned long long)(A.init_state[state_slot] * kJ36));
         else if (!accumulating) {  // start phase known from the accumulate + prefix passes
-            const unsigned long long v = jit_u(A.seg_start[((size_t)op_index * A.n_inst + X.inst) * X.n_seg + X.seg]);
+            const uint32_t from = A.warm ? (X.seg ? X.seg - 1u : 0u) : X.seg;  // (a segment that warms up starts where the segment before it starts)
+            const unsigned long long v = jit_u(A.seg_start[((size_t)op_index * A.n_inst + X.inst) * X.n_seg + from]);
             carry = v & ~(1ull << 63);
             poison = (uint32_t)(v >> 63);
         }
@@ -446,6 +447,15 @@ struct JitOscS {
         if (bad_lanes) poison = 1u;
     }
     __device__ __forceinline__ double end_phase() const { return poison ? __builtin_nan("") : (double)carry * (1.0 / kJ36); }
+    // ... of a render cut into segments that warm up (whose wavefronts tick past their own chunks): the last segment's start phase plus its total
+    static __device__ __forceinline__ double warm_end_phase(const JitArgs &A, const JitCtx &X, int op_index) {
+        const size_t at = ((size_t)op_index * A.n_inst + X.inst) * X.n_seg + (X.n_seg - 1);
+        const unsigned long long v = A.seg_start[at], t = A.seg_sum[at];
+        if ((v | t) >> 63) return __builtin_nan("");
+        unsigned long long p = v + t;  // (both below S)
+        if (p >= X.S) p -= X.S;
+        return (double)p * (1.0 / kJ36);
+    }
     __device__ __forceinline__ unsigned long long packed() const { return carry | ((unsigned long long)(poison != 0) << 63); }
 };
 

@@ -337,7 +337,8 @@ def test_filters_as_a_scan_stay_within_their_bound(case, oracle):
     staged.close()
 
 
-@pytest.mark.parametrize("kind", ["saw_lp800", "four_poles", "two_channels_enveloped", "lp400_forced_short", "three_voices", "three_voices_forced_short", "three_hundred_voices"])
+@pytest.mark.parametrize("kind", ["saw_lp800", "four_poles", "two_channels_enveloped", "lp400_forced_short", "three_voices", "three_voices_forced_short", "three_hundred_voices",
+                                  "fm_into_lp", "fm_forced_short"])
 def test_long_filter_circuits_are_cut_into_segments_that_warm_up(kind, oracle):
     """`renderChannelData(unit, 10)` of ONE filtered circuit — the reference's everyday call — or of a few.  A Filter's recurrence is a chain of
     480 000 dependent steps, so one wavefront used to walk the whole render (DUSP_FILTER_WARM=0: ~10 ms).  Cut into segments that start a
@@ -358,6 +359,10 @@ def test_long_filter_circuits_are_cut_into_segments_that_warm_up(kind, oracle):
     elif kind == "lp400_forced_short":
         words = descriptor.extract(d.Filter(d.Osc(82.4, "saw"), 400)).words
         knobs = {"DUSP_FILTER_WARM": 8}
+    elif kind.startswith("fm_"):            # an FM pair (and an LFO on the carrier's modulation depth: two FM levels) in front of the Filter: accumulate passes + warm-up
+        car = d.Osc(d.Sum(d.Multiply(d.Osc(d.Sum(d.Multiply(d.Osc(0.7), 3), 110.5)), 180), 440.25))
+        words = descriptor.extract(d.Multiply(d.Filter(car, 400 if kind == "fm_forced_short" else 1500), d.Ramp(420000, 1, 0.1).trigger())).words
+        knobs = {"DUSP_FILTER_WARM": 8} if kind == "fm_forced_short" else {}
     elif kind == "three_hundred_voices":    # a mid-size batch: too few instances to fill the Filter stages' rows, each cut into a few segments
         uni = descriptor.unify([descriptor.extract(d.Multiply(d.Filter(d.Osc(82.4 + 1.25 * k, "saw"), 1000), 0.5 + k / 1024)) for k in range(300)])
         words, V, params, n = uni.words, 300, uni.params, 96000
