@@ -82,8 +82,10 @@ typedef enum {
  *           accesses can meet inside a chunk, through ordered slot operations.  What stays on the interpreter kernel
  *           (chunk buffers in LDS) is decided by regime: circuits of more
  *           than 256 units (DUSP_JIT_MAX_UNITS), and a structure's FIRST render while its kernel compiles in the background.  Few instances and
- *           a long render are split in time when the graph allows it.  Refuses by regime, not by unit: channel counts that
- *           grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
+ *           a long render are split in time when the graph allows it: oscillators, closed forms of time and stateless units by exact jumps,
+ *           and — ABI v7 — circuits with constant-cutoff Filters too, in segments that warm up a segment early from rest and are checked
+ *           against each other on the host (bit for bit the one long recurrence).  Refuses by regime, not by unit: channel
+ *           counts that grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
  *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
  *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
  *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
