@@ -971,6 +971,9 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
         const int rows = (int)std::max<uint64_t>(1, (per_cu + rounds - 1) / rounds);
         waves = std::min(most, rows);
         per_wave = std::min(per_wave_cap, (rows + waves - 1) / waves);
+        // (16 wavefronts of FOUR instances — 128 registers a lane — spill 170-470 bytes in every Filter circuit measured, filter(osc) included, and end at 16 x 2 two
+        // compiles later: start there.  A first render of such a structure: 2.1-3.3 s -> one compile)
+        if (waves == 16 && per_wave == 4 && ctx->knobs.wave_per_wave < 4) per_wave = 2;
         opt.filter_sub = dusp::jit_filter_sub(waves, per_wave, opt.filter_stages, budget - opt.table_bytes, opt.filter_mod);
         // (a connected cutoff parks three values per sample in two sets of rows: fewer rows per workgroup before the table image goes)
         while (opt.filter_mod && !opt.filter_sub && (per_wave > 1 || waves > 1)) {

@@ -1,2 +1,6 @@
 mkdir -p gpurun_out/r04
-timeout -k 10 600 python -m pytest tests/test_gpu_batch.py tests/test_gpu_parity.py -m gpu -q -s -k "random_filter_circuits_in_warming or cut_into_segments or segments_that_warm_up or time_split_wave_render_equals_unsplit" 2>&1 | grep -v "^$" | grep "^E \|one chain\|passed\|failed" | cut -c1-300
+export DUSP_JIT_CACHE=/tmp/empty_cache_$$
+DUSP_JIT_LOG=1 timeout -k 10 400 python tools/wave_ops.py "--only=filter(osc);filter(osc) * ramp;filter(osc, lfo);filter(filter(osc));delay(osc, lfo);patch_multitap x 256" --json=gpurun_out/r04/first_call.json 2>&1 | grep -v amdgpu.ids | grep " ms \|dusp jit" | cut -c1-170
+python -c "
+import json
+for r in json.load(open('gpurun_out/r04/first_call.json')): print(r['graph'], r['first_render_ms_compile_inclusive'], r['avg_ms'], r['shape'])"
