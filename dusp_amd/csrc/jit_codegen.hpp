@@ -263,8 +263,8 @@ inline bool jit_filter_scan_ok(const Program &P, const int *table_bound = nullpt
 // f32): its all-pole part has a DC gain of sum|h|, and two trajectories an ulp apart stay an ulp apart with probability ~1 - 1/sum|h| a
 // step.  Measured (tools/filter_merge_experiment.c --from-rest, sines and saws): merged within 20 sum|h| samples in every trial down to 400 Hz,
 // effectively never at 200 Hz (sum|h| 1500: limit cycles).  Returns the chunks of warm-up to give — 32 sum|h| samples over the circuit's Filters
-// in series, a chunk to spare — or 0 where the circuit is not one for it: a cutoff that is no constant, sum|h| beyond 400 (below ~390 Hz at
-// 48 kHz), a Filter that reaches an oscillator's frequency, scanned (FM) oscillators, a Filter stage with a connected cutoff.
+// in series, a chunk to spare — or 0 where the circuit is not one for it: a connected cutoff (or a per-instance one whose column nobody has looked
+// at), sum|h| beyond 400 (below ~390 Hz at 48 kHz), a Filter that reaches an oscillator's frequency.
 inline uint32_t jit_warm_chunks(const Program &P, const WavePlan &plan) {
     if (!plan.splittable_but_for_filters) return 0;
     double samples = 256.0;
@@ -282,23 +282,35 @@ inline uint32_t jit_warm_chunks(const Program &P, const WavePlan &plan) {
     }
     for (const DevOp &op : P.ops) {
         if (op.op != OP_FILTER) continue;
-        if (op.in[1].kind != SRC_CONST || (size_t)op.state_slot + 11 > P.init_state.size()) return 0;
-        const double *is = P.init_state.data() + op.state_slot, f = (double)op.in[1].cval;
-        double k[5];
-        if (is[0] == 0.0 || f != is[1]) butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
-        else
-            for (int i = 0; i < 5; i++) k[i] = is[2 + i];
-        double h1 = 1.0, h2 = 0.0, sum = 1.0;
-        int quiet = 0;
-        for (int t = 1; t < 200000 && quiet < 8; t++) {
-            const double h = -k[3] * h1 - k[4] * h2;
-            if (!std::isfinite(h)) return 0;
-            h2 = h1, h1 = h, sum += std::fabs(h);
-            if (sum > 400.0) return 0;
-            quiet = std::fabs(h) < 1e-13 ? quiet + 1 : 0;
+        if ((size_t)op.state_slot + 11 > P.init_state.size()) return 0;
+        // the cutoffs to answer for: the circuit's constant, or both ends of a per-instance column the renderer has looked at (sum|h| = 1 / (1 - |p|)^2
+        // is largest at an end of the range)
+        double cutoffs[2];
+        int n_cut = 0;
+        if (op.in[1].kind == SRC_CONST) cutoffs[n_cut++] = (double)op.in[1].cval;
+        else if (op.in[1].kind == SRC_PARAM && op.in[1].pad == kFilterColumnKnown && op.d[0] > 0.0 && op.d[0] <= op.d[1] && op.d[1] < 0.5 * (double)P.g.sample_rate)
+            cutoffs[n_cut++] = op.d[0], cutoffs[n_cut++] = op.d[1];
+        else return 0;
+        double worst = 0.0;
+        for (int c = 0; c < n_cut; c++) {
+            const double *is = P.init_state.data() + op.state_slot, f = cutoffs[c];
+            double k[5];
+            if (op.in[1].kind == SRC_CONST && is[0] != 0.0 && f == is[1])
+                for (int i = 0; i < 5; i++) k[i] = is[2 + i];
+            else butterworth_coefficients(op.attr, f, (double)P.g.sample_rate, k);
+            double h1 = 1.0, h2 = 0.0, sum = 1.0;
+            int quiet = 0;
+            for (int t = 1; t < 200000 && quiet < 8; t++) {
+                const double h = -k[3] * h1 - k[4] * h2;
+                if (!std::isfinite(h)) return 0;
+                h2 = h1, h1 = h, sum += std::fabs(h);
+                if (sum > 400.0) return 0;
+                quiet = std::fabs(h) < 1e-13 ? quiet + 1 : 0;
+            }
+            if (quiet < 8) return 0;
+            worst = std::max(worst, sum);
         }
-        if (quiet < 8) return 0;
-        samples += 32.0 * sum;
+        samples += 32.0 * worst;
     }
     return (uint32_t)std::ceil(samples / (double)kChunk);
 }
