@@ -1,6 +1,7 @@
 // dusp_abi.hip — implementation of the C ABI declared in include/dusp_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1673,9 +1674,12 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
     const size_t n_par = (size_t)prog->P.g.n_params * n_instances;
     if (n_par && !h_params) CTX_FAIL(ctx, DUSP_ERR_ARG, "render: program has parameters but h_params is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
     const size_t n_out = n_instances * prog->P.out_bufs.size() * n_samples;
     // staging buffers live with the program (grown on demand): a segmented render calls this hundreds of times a second
     HIP_TRY(ctx, prog->d_host_out.ensure(std::max<size_t>(1, n_out)));
+    const double us_alloc = since();
     float *d_out = prog->d_host_out.p, *d_par = nullptr, *d_frames = nullptr;
     if (n_par) {
         HIP_TRY(ctx, prog->d_host_par.ensure(n_par));
@@ -1691,6 +1695,7 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
         HIP_TRY(ctx, hipMemcpyAsync(d_in, h_inputs, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     if (int rc = render_device_unguarded(prog, n_instances, n_samples, d_par, d_in, d_out, ctx->stream)) return rc;
+    const double us_enqueued = since();
     if (int rc = check_guards(prog, ctx->stream)) return rc;
     const size_t n_ch = prog->P.out_bufs.size();
     if (interleaved && n_ch > 1) {  // frames: transpose on the device, then download those
@@ -1705,6 +1710,9 @@ static int render_host(dusp_program *prog, size_t n_instances, size_t n_samples,
         HIP_TRY(ctx, hipMemcpyAsync(h_out, d_src, n_out * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (ctx->knobs.jit_log >= 2)  // (DUSP_JIT_LOG=2: where a host render's time goes)
+        fprintf(stderr, "[dusp host render] output buffer %.0f us, render enqueued (workspaces, constants, launches) %.0f us, download + wait %.0f us\n", us_alloc, us_enqueued - us_alloc,
+                since() - us_enqueued);
     return DUSP_OK;
     });
 }
