@@ -398,7 +398,7 @@ def test_long_filter_circuits_are_cut_into_segments_that_warm_up(kind, oracle):
     one.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DUSP_WARM_SEEDS", "10"))))  # (a soak: DUSP_WARM_SEEDS=300)
 def test_random_filter_circuits_in_warming_segments_equal_the_one_chain(seed):
     """Random feed-forward circuits around Filters — sums of oscillators of every wave table into one to three low / high passes in series or side by
     side, cutoffs between 700 Hz and 15 kHz, gains, an envelope — three seconds each: cut into warming segments (the default) they are the one
