@@ -583,201 +583,6 @@ __global__ void __launch_bounds__(64) dusp_chunk_kernel(ChunkArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Loop engine: the canonical feedback voice of BASELINE configs[3],
-//     sum = Sum(Osc(k), fb);  d = Delay(sum, k, maxDelay);  f = Filter(d, k);  fb = Multiply(f, k);  sum.B = fb
-// (k = constant or per-instance parameter), in the reference's process order [Osc, Multiply, Sum, Delay,
-// Filter]: Multiply ticks BEFORE Filter, so the feedback path reads the Filter's PREVIOUS chunk — the
-// implicit 256-sample delay of SURVEY.md Appendix A.  Same lane-per-instance mapping and the same state /
-// ring / scratch layout as dusp_chunk_kernel, but the five units are evaluated per SAMPLE in registers:
-// only the back edge (Filter's previous chunk) and the Delay ring touch memory, in batches of 16
-// independent accesses, so a chunk costs little more than the Filter's serial recurrence.
-// Bit-identical to the generic kernel by construction: same operations, same order per sample.
-template <int TBL, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) dusp_loop_kernel(ChunkArgs a, LoopShape L) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BLOCK = WAVES * 64;
-    Table<TBL> table;
-    const uint32_t table_words = TBL == 1 ? (uint32_t)(half_table_lds_bytes(a.sample_rate) / 4) : 0u;
-    table.g = a.tables + (size_t)L.osc.attr * a.table_stride;
-    table.h = lds;
-    table.N = a.sample_rate + 1;
-    table.M = a.sample_rate / 2;
-    if (TBL == 1) load_half_table<BLOCK>(lds, table.g, a.sample_rate);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float *tile = lds + table_words + wave * (64 * 65);
-    const uint32_t i = (blockIdx.x * WAVES + wave) * 64 + lane;
-    if ((blockIdx.x * WAVES + wave) * 64 >= a.n_pad) return;  // whole waves only
-    const size_t NP = a.n_pad;
-    const double sr = (double)a.sample_rate;
-
-    auto lane_const = [&](const DevOperand &o) {
-        return o.kind == SRC_PARAM ? (i < a.n_inst ? a.params[(size_t)o.idx * a.n_inst + i] : 0.f) : o.cval;
-    };
-    const float f_osc = lane_const(L.osc.in[0]);
-    const float gain = lane_const(L.mul.in[L.mul_gain_operand]);
-    const float f_cut = lane_const(L.filter.in[1]);
-    const float delay_f = lane_const(L.delay.in[1]);
-
-    float *fbuf = a.scratch + (size_t)L.filter.out_buf * kChunk * NP + i;  // Filter.out: this chunk's PCM, next chunk's feedback
-    float *ring = a.rings + (size_t)L.delay.ring_base * NP + i;
-    const int64_t len = L.delay.ring_len;
-    const double dlen = (double)len;
-    double dconst = (double)delay_f;
-    if (dconst >= dlen) dconst = fmod(dconst, dlen);
-    const double Dfl = floor(dconst);
-    const bool fast_delay = __all(dconst >= (double)kBatch && Dfl <= dlen - (double)kBatch);
-    const int64_t D = (int64_t)Dfl;
-    const double phi = dconst - Dfl;
-
-    double *st_osc = a.state + (size_t)L.osc.state_slot * NP + i;
-    double *st_del = a.state + (size_t)L.delay.state_slot * NP + i;
-    double *st = a.state + (size_t)L.filter.state_slot * NP + i;
-    double phase = st_osc[0], xprev = st_del[0];
-    bool has_lastF = st[0] != 0.0;
-    double lastF = st[NP], a0 = st[2 * NP], a1 = st[3 * NP], a2 = st[4 * NP], b1 = st[5 * NP], b2 = st[6 * NP];
-    double x1 = st[7 * NP], x2 = st[8 * NP], y1 = st[9 * NP], y2 = st[10 * NP];
-    int64_t tBuffer = a.clock0 % len;
-
-    for (uint32_t ck = 0; ck < a.n_chunks; ++ck) {
-        for (int tb = 0; tb < kChunk / 64; ++tb) {
-            for (int t0 = tb * 64; t0 < tb * 64 + 64; t0 += kBatch) {
-                float prev[kBatch], ringv[kBatch], r[kBatch];
-                double ph[kBatch];
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) prev[j] = fbuf[(size_t)(t0 + j) * NP];  // Filter's previous chunk
-                if (fast_delay) {
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        int64_t s_ = tBuffer + j;
-                        if (s_ >= len) s_ -= len;
-                        ringv[j] = ring[(size_t)s_ * NP];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) ph[j] = phase = osc_advance(phase, (double)f_osc, sr);
-                float oscv[kBatch];
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {  // Osc.js:43-45
-                    if (!(ph[j] >= 0.0 && ph[j] <= sr)) { oscv[j] = __builtin_nanf(""); continue; }
-                    const double lo = floor(ph[j]);
-                    const double fraction = ph[j] - lo;
-                    float ta, tb2;
-                    table.pair((uint32_t)(int)lo, ta, tb2);
-                    if (fraction == 0.0) tb2 = ta;  // ceil(phase) == floor(phase)
-                    oscv[j] = (float)((double)ta * (1.0 - fraction) + (double)tb2 * fraction);
-                }
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const float fb = L.mul_gain_operand ? prev[j] * gain : gain * prev[j];  // Multiply.js:31
-                    const float sum = L.sum_osc_operand ? fb + oscv[j] : oscv[j] + fb;      // Sum.js:42
-                    // Delay.js:27-39
-                    int64_t s_ = tBuffer + j;
-                    if (s_ >= len) s_ -= len;
-                    const double xin = (double)sum;
-                    float delayed;
-                    if (fast_delay) {
-                        delayed = ringv[j];
-                        int64_t lo = s_ + D;
-                        if (lo >= len) lo -= len;
-                        float slot;
-                        if (phi != 0.0) {
-                            slot = lo != 0 ? (float)(0.0 + xprev * phi) : 0.f;
-                            slot = (float)((double)slot + xin * (1.0 - phi));
-                        } else {
-                            slot = (float)(0.0 + xin * 1.0);
-                            slot = (float)((double)slot + xin * 0.0);
-                        }
-                        ring[(size_t)lo * NP] = slot;
-                        xprev = xin;
-                    } else {
-                        delayed = ring[(size_t)s_ * NP];
-                        ring[(size_t)s_ * NP] = 0.f;
-                        double tWrite = (double)s_ + (double)delay_f;
-                        if (!(tWrite >= 0.0 && tWrite < dlen))
-                            tWrite = (tWrite >= dlen && tWrite < 2.0 * dlen) ? tWrite - dlen : fmod(tWrite, dlen);
-                        const double lo = floor(tWrite), hi = ceil(tWrite);
-                        const double frac = tWrite - trunc(tWrite);
-                        if (lo >= 0.0 && lo < dlen) {
-                            float *p = ring + (size_t)(int64_t)lo * NP;
-                            *p = (float)((double)*p + xin * (1.0 - frac));
-                        }
-                        if (hi >= 0.0 && hi < dlen) {
-                            float *p = ring + (size_t)(int64_t)hi * NP;
-                            *p = (float)((double)*p + xin * frac);
-                        }
-                    }
-                    // Filter.js:33-49
-                    const double ft = (double)f_cut;
-                    if (!has_lastF || ft != lastF) {
-                        has_lastF = true;
-                        lastF = ft;
-                        double kf[5];
-                        butterworth_coefficients(L.filter.attr == 0 ? 0 : 1, ft, sr, kf);
-                        a0 = kf[0]; a1 = kf[1]; a2 = kf[2]; b1 = kf[3]; b2 = kf[4];
-                    }
-                    const double xf = (double)delayed;
-                    const float y = (float)(a0 * xf + a1 * or0(x1) + a2 * or0(x2) - b1 * or0(y1) - b2 * or0(y2));
-                    r[j] = y;
-                    y2 = or0(y1);
-                    y1 = (double)y;
-                    x2 = or0(x1);
-                    x1 = xf;
-                }
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    fbuf[(size_t)(t0 + j) * NP] = r[j];
-                    const float v = r[j];
-                    tile[(t0 + j - tb * 64) * 65 + lane] = (v != v) ? 0.f : v + 0.f;  // `|| 0` at copy-out
-                }
-                tBuffer += kBatch;
-                if (tBuffer >= len) tBuffer -= len;
-            }
-            // 64 x 64 transpose: each store instruction writes 256 contiguous bytes of one instance
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint64_t t = (uint64_t)ck * kChunk + (uint64_t)tb * 64 + lane;
-            if (t < a.n_samples) {
-                const uint32_t inst0 = (blockIdx.x * WAVES + wave) * 64;
-                for (int rr = 0; rr < 64; ++rr) {
-                    if (inst0 + rr >= a.n_inst) break;
-                    a.out[(size_t)(inst0 + rr) * a.n_samples + t] = tile[lane * 65 + rr];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    st_osc[0] = phase;
-    st_del[0] = xprev;
-    st[0] = has_lastF ? 1.0 : 0.0;
-    st[NP] = lastF; st[2 * NP] = a0; st[3 * NP] = a1; st[4 * NP] = a2; st[5 * NP] = b1; st[6 * NP] = b2;
-    st[7 * NP] = x1; st[8 * NP] = x2; st[9 * NP] = y1; st[10 * NP] = y2;
-}
-
-template <int TBL, int WAVES>
-static hipError_t launch_loop_one(const ChunkArgs &a, const LoopShape &L, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = dusp_loop_kernel<TBL, WAVES>;
-    if (lds_bytes > 65536) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    const uint32_t waves = a.n_pad / 64;
-    hipLaunchKernelGGL(kernel, dim3((waves + WAVES - 1) / WAVES), dim3(WAVES * 64), lds_bytes, stream, a, L);
-    return hipGetLastError();
-}
-
-hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream) {
-    const size_t tile_bytes = 64 * 65 * sizeof(float);
-    const size_t table_bytes = lds_table_ok ? half_table_lds_bytes(a.sample_rate) : 0;
-    const bool two = a.n_pad / 64 > (uint32_t)n_cus && table_bytes + 2 * tile_bytes <= 160 * 1024;
-    if (table_bytes && table_bytes + tile_bytes <= 160 * 1024) {
-        if (two) return launch_loop_one<1, 2>(a, L, table_bytes + 2 * tile_bytes, stream);
-        return launch_loop_one<1, 1>(a, L, table_bytes + tile_bytes, stream);
-    }
-    if (two) return launch_loop_one<0, 2>(a, L, 2 * tile_bytes, stream);
-    return launch_loop_one<0, 1>(a, L, tile_bytes, stream);
-}
-
 hipError_t launch_chunk_engine(const ChunkArgs &a, hipStream_t stream) {
     const uint32_t blocks = a.n_pad / 64;
     hipLaunchKernelGGL(dusp_chunk_kernel, dim3(blocks), dim3(64), 0, stream, a);

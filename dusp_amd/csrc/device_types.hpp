@@ -51,14 +51,11 @@ struct Knobs {
     int fused_items = 0;         // DUSP_FUSED_ITEMS: work items per resident wave (0: 4, or 2 when that would cut the render into items of under 64 chunks)
     int fused_fx32 = 1;          // DUSP_FUSED_FX32=0: no 32.32 fixed-point phase path
     int fused_segmajor = 0;      // DUSP_FUSED_SEGMAJOR=1: item order
-    int loop2 = 1;               // DUSP_LOOP2=0: one-stage loop kernel
-    int loop_wide = 1;           // DUSP_LOOP_WIDE=0: narrow two-stage loop kernel
     int wave_segments = -1;      // DUSP_WAVE_SEGMENTS=n: force n time segments (0 / 1: off; -1: automatic)
     int wave_max_waves = 0;      // DUSP_WAVE_MAX_WAVES=n: cap the wavefronts per workgroup (0: no cap)
     int wave_jit = 1;            // DUSP_WAVE_JIT=0: keep wave-engine programs on the interpreter; 2: always wait for a circuit's kernel
                                  // (1: a render the interpreter finishes sooner than a compile runs there while the kernel compiles in the background)
     int wave_per_wave = 0;       // DUSP_WAVE_PER_WAVE=n: circuit instances per wavefront in compiled kernels (0: automatic, up to 4)
-    int loop_compiled = 1;       // DUSP_LOOP_COMPILED=0: AUTO keeps the feedback-voice shape on the two-stage loop kernel instead of a compiled one
     int jit_lean = 1;            // DUSP_JIT_LEAN=0: compiled kernels' constant-f oscillators keep the 32.32 form (no delta lerp: A/B)
     int jit_log = 0;             // DUSP_JIT_LOG=1: the geometry search's steps on stderr (wavefronts x instances, Filter block, scratch bytes per lane)
     int jit_lds_table = 1;       // DUSP_JIT_LDS_TABLE=0: compiled kernels look wave tables up in HBM / L2 (no LDS image)

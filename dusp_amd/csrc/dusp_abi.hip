@@ -36,8 +36,6 @@ hipError_t launch_chunk_to_wave(const float *chunk_rings, float *wave_rings, uin
                                 uint32_t n_inst, uint32_t n_pad, const double *state, double *init_state, uint32_t n_slots, hipStream_t stream);
 hipError_t launch_interleave(const float *d_planar, float *d_out, uint32_t n_instances, uint32_t n_channels, uint64_t n_samples, hipStream_t stream);
 hipError_t launch_fused(const FusedPlan &plan, const FusedLaunch &L, hipStream_t stream);
-hipError_t launch_loop2_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, bool wide, hipStream_t stream);
-hipError_t launch_loop_engine(const ChunkArgs &a, const LoopShape &L, bool lds_table_ok, int n_cus, hipStream_t stream);
 hipError_t launch_wave_engine(WaveArgs A, bool lds_table_ok, int max_waves_cap, hipStream_t stream);
 hipError_t launch_sumchain(const FusedPlan &plan, const FusedLaunch &L, const SumVoice *d_voices, int gb, hipStream_t stream);
 }  // namespace dusp
@@ -116,8 +114,6 @@ struct dusp_program {
     int engine = DUSP_ENGINE_CHUNK;
     dusp::FusedPlan fused;
     dusp::WavePlan wave;
-    dusp::LoopShape loop;
-    bool loop_two_stage = false;  // constant delay of at least one chunk: loop2_engine.hip
     // program constants on the device
     DevBuf<dusp::DevOp> d_ops;
     DevBuf<int32_t> d_out_bufs;
@@ -251,8 +247,6 @@ static dusp::Knobs read_knobs() {
     k.fused_items = num("DUSP_FUSED_ITEMS", k.fused_items);
     k.fused_fx32 = num("DUSP_FUSED_FX32", k.fused_fx32);
     k.fused_segmajor = num("DUSP_FUSED_SEGMAJOR", k.fused_segmajor);
-    k.loop2 = num("DUSP_LOOP2", k.loop2);
-    k.loop_wide = num("DUSP_LOOP_WIDE", k.loop_wide);
     k.wave_segments = num("DUSP_WAVE_SEGMENTS", k.wave_segments);
     k.wave_max_waves = num("DUSP_WAVE_MAX_WAVES", k.wave_max_waves);
     k.wave_jit = num("DUSP_WAVE_JIT", k.wave_jit);
@@ -260,7 +254,6 @@ static dusp::Knobs read_knobs() {
     k.jit_profile = num("DUSP_JIT_PROFILE", k.jit_profile);
     k.filter_fma = num("DUSP_FILTER_FMA", k.filter_fma);
     k.jit_spill_bytes = num("DUSP_JIT_SPILL", k.jit_spill_bytes);
-    k.loop_compiled = num("DUSP_LOOP_COMPILED", k.loop_compiled);
     k.jit_lds_table = num("DUSP_JIT_LDS_TABLE", k.jit_lds_table);
     k.jit_lean = num("DUSP_JIT_LEAN", k.jit_lean);
     k.jit_log = num("DUSP_JIT_LOG", k.jit_log);
@@ -442,19 +435,6 @@ static int finish_build(dusp_program *prog) {
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: no fused kernel for this graph shape (" + prog->fused.why + ")");
     if (engine == DUSP_ENGINE_WAVE && !wavable)
         CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: the wave engine cannot run this graph (" + prog->wave.why + ")");
-    std::string loop_why;
-    const bool loopable = dusp::plan_loop(prog->P, prog->loop, loop_why);
-    prog->loop_two_stage = false;
-    if (loopable) {
-        const dusp::DevOperand &dl = prog->loop.delay.in[1];
-        const double len = (double)prog->loop.delay.ring_len;
-        double dconst = (double)dl.cval;
-        if (dconst >= len) dconst = std::fmod(dconst, len);
-        prog->loop_two_stage = dl.kind == dusp::SRC_CONST && std::floor(dconst) >= dusp::kChunk &&
-                               std::floor(dconst) + dusp::kChunk <= len && prog->P.g.sample_rate <= 131072 && ctx->knobs.loop2 != 0;
-    }
-    if (engine == DUSP_ENGINE_LOOP && !loopable)
-        CTX_FAIL(ctx, DUSP_ERR_UNSUPPORTED, "dusp_program_build: not the feedback-voice shape of the loop engine (" + loop_why + ")");
     // A circuit with rings or a feedback edge carries device memory from one segment to the next; only the chunk
     // engine keeps all of it (rings, every outlet's previous chunk) in HBM in a layout a later launch can pick up.
     // A circuit with rings or a feedback edge carries device memory from one segment to the next.  The chunk engine keeps
@@ -472,24 +452,9 @@ static int finish_build(dusp_program *prog) {
         else if (engine == DUSP_ENGINE_AUTO)
             engine = wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
     }
-    // The feedback-voice shape with a CONSTANT delay has the loop kernels and, since the circuit compiler knows all its units, a
-    // kernel compiled for the circuit: 12.3 against 20.2 ms (two-stage loop kernel) on BASELINE configs[3]; with a delay of less than
-    // a chunk (a plucked-string voice) 3.7 against 43.8 ms (one-stage loop kernel) for 8192 voices x 2 s.
-    std::string jit_why;
-    // (a per-instance delay: the compiled kernel decides by the parameter column when it renders — write-once ring, no ring, or slot
-    // operations, all of which beat the one-stage loop kernel's one lane per voice)
-    const bool compiled_loop = loopable && wavable &&
-                               (prog->loop_two_stage ? !prog->wave.ring_events
-                                                     : (dusp::jit_delay_short(prog->loop.delay) || prog->loop.delay.in[1].kind == dusp::SRC_PARAM)) &&
-                               ctx->knobs.wave_jit != 0 && ctx->knobs.loop_compiled != 0 &&
-                               dusp::jit_eligible(prog->P, prog->wave, jit_why);
-    if (engine == DUSP_ENGINE_AUTO)
-        engine = fusable ? DUSP_ENGINE_FUSED
-                 : compiled_loop ? DUSP_ENGINE_WAVE
-                 : (loopable && (prog->loop_two_stage || prog->wave.ring_events)) ? DUSP_ENGINE_LOOP  // (one lane per voice beats slot rounds)
-                 : wavable ? DUSP_ENGINE_WAVE
-                 : loopable ? DUSP_ENGINE_LOOP
-                           : DUSP_ENGINE_CHUNK;
+    // (the hand-written kernels for the feedback voice of BASELINE configs[3] — a one-stage and two two-stage forms, rounds 1 and 2 — are gone since
+    // round 4: the kernel compiled for the circuit renders it in 8.0 ms (scan) / 12.0 ms (stage, bit-equal) against their 20.4, and whatever delay the voice has)
+    if (engine == DUSP_ENGINE_AUTO) engine = fusable ? DUSP_ENGINE_FUSED : wavable ? DUSP_ENGINE_WAVE : DUSP_ENGINE_CHUNK;
     prog->engine = engine;
     prog->jit_src.clear();
     prog->jit_consts_uploaded = false;
@@ -570,7 +535,8 @@ int dusp_program_build(dusp_ctx *ctx, const double *desc, size_t n_words, int en
     *out = nullptr;
     const bool resumable = (engine & DUSP_ENGINE_RESUMABLE) != 0;
     engine &= ~DUSP_ENGINE_RESUMABLE;
-    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE && engine != DUSP_ENGINE_LOOP)
+    if (engine == DUSP_ENGINE_LOOP) engine = DUSP_ENGINE_AUTO;  // (ABI v7: the loop kernels are gone; a caller that still names them gets what AUTO picks for its circuit)
+    if (engine != DUSP_ENGINE_AUTO && engine != DUSP_ENGINE_CHUNK && engine != DUSP_ENGINE_FUSED && engine != DUSP_ENGINE_WAVE)
         CTX_FAIL(ctx, DUSP_ERR_ARG, "dusp_program_build: bad engine");
     std::unique_ptr<dusp_program> prog(new dusp_program);  // (its destructor frees whatever a failing step below has allocated)
     prog->ctx = ctx;
@@ -672,8 +638,6 @@ int dusp_program_info_get(const dusp_program *prog, dusp_program_info *info) {
     info->n_device_ops = (uint32_t)prog->P.ops.size();
     info->n_inputs = (uint32_t)g.n_inputs;
     if (prog->engine == DUSP_ENGINE_FUSED) std::snprintf(info->shape, sizeof info->shape, "%s", prog->fused.shape.c_str());
-    if (prog->engine == DUSP_ENGINE_LOOP)
-        std::snprintf(info->shape, sizeof info->shape, prog->loop_two_stage ? "loop(osc,sum,delay,filter,gain) two-stage" : "loop(osc,sum,delay,filter,gain)");
     if (prog->engine == DUSP_ENGINE_WAVE && prog->jit_ok && (prog->jit_waves || !prog->rendered))
     {
         const int at = std::snprintf(info->shape, sizeof info->shape, "%s, compiled kernel: %d units, %dx%d", prog->P.feed_forward ? "feed-forward" : "feedback",
@@ -1536,14 +1500,7 @@ static int render_device_unguarded(dusp_program *prog, size_t n_instances, size_
         at += a.warm_n[k];
     }
     HIP_TRY(ctx, hipEventRecord(prog->ev0, stream));
-    if (prog->engine == DUSP_ENGINE_LOOP) {
-        const int w = prog->loop.osc.attr;
-        if (prog->loop_two_stage)
-            HIP_TRY(ctx, dusp::launch_loop2_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->knobs.loop_wide != 0, stream));
-        else
-            HIP_TRY(ctx, dusp::launch_loop_engine(a, prog->loop, ctx->table_antisym[w] && P.g.sample_rate % 2 == 0, ctx->n_cus, stream));
-    } else
-        HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
+    HIP_TRY(ctx, dusp::launch_chunk_engine(a, stream));
     HIP_TRY(ctx, hipEventRecord(prog->ev1, stream));
     prog->last_n_inst = n_inst;
     prog->last_n_pad = n_pad;

@@ -83,13 +83,6 @@ struct SumArgs {
     uint32_t first_block, raw;
 };
 
-// The feedback voice of BASELINE configs[3] as the loop engine sees it (chunk_engine.hip).
-struct LoopShape {
-    DevOp osc, mul, sum, delay, filter;
-    int32_t mul_gain_operand;  // which Multiply inlet holds the gain (the other one is the Filter's back edge)
-    int32_t sum_osc_operand;   // which Sum inlet holds the Osc
-};
-
 // Arguments of the wave engine's kernel (wave_engine.hip).
 struct WaveArgs {
     const DevOp *ops;
@@ -756,46 +749,6 @@ inline bool plan_wave(const Program &P, WavePlan &plan, bool will_continue = fal
     plan.splittable_but_for_filters = plan.splittable && plan.has_filter;
     plan.splittable = plan.splittable && !plan.has_filter;
     plan.ok = true;
-    return true;
-}
-
-// Is this program exactly [Osc(k), Multiply(Filter<-, k), Sum(Osc, Multiply), Delay(Sum, k), Filter(Delay, k)]
-// rendered at the Filter, in that process order?
-inline bool plan_loop(const Program &P, LoopShape &L, std::string &why) {
-    auto no = [&](const char *w) {
-        why = w;
-        return false;
-    };
-    if (!P.warm_ops.empty()) return no("channel counts grow during the first chunks");
-    if (P.ops.size() != 5 || P.g.units.size() != 5 || P.out_bufs.size() != 1 || !P.g.rings.empty()) return no("not a 5-unit mono loop");
-    int pos[16];
-    for (int &p : pos) p = -1;
-    for (int k = 0; k < 5; k++) {
-        const int op = P.ops[(size_t)k].op;
-        if (op < 0 || op >= 16 || pos[op] >= 0) return no("duplicate or unknown unit kind");
-        pos[op] = k;
-    }
-    if (pos[OP_OSC] < 0 || pos[OP_MULTIPLY] < 0 || pos[OP_SUM] < 0 || pos[OP_DELAY] < 0 || pos[OP_FILTER] < 0) return no("wrong unit kinds");
-    L.osc = P.ops[(size_t)pos[OP_OSC]];
-    L.mul = P.ops[(size_t)pos[OP_MULTIPLY]];
-    L.sum = P.ops[(size_t)pos[OP_SUM]];
-    L.delay = P.ops[(size_t)pos[OP_DELAY]];
-    L.filter = P.ops[(size_t)pos[OP_FILTER]];
-    if (!(pos[OP_OSC] < pos[OP_SUM] && pos[OP_MULTIPLY] < pos[OP_SUM] && pos[OP_SUM] < pos[OP_DELAY] &&
-          pos[OP_DELAY] < pos[OP_FILTER]))
-        return no("not the reference's loop order");
-    auto is_buf = [](const DevOperand &o, int buf) { return o.kind == SRC_BUF && o.idx == buf; };
-    auto is_k = [](const DevOperand &o) { return o.kind != SRC_BUF; };
-    if (!is_k(L.osc.in[0])) return no("Osc f is connected");
-    if (is_buf(L.mul.in[0], L.filter.out_buf) && is_k(L.mul.in[1])) L.mul_gain_operand = 1;
-    else if (is_buf(L.mul.in[1], L.filter.out_buf) && is_k(L.mul.in[0])) L.mul_gain_operand = 0;
-    else return no("Multiply is not Filter x gain");
-    if (is_buf(L.sum.in[0], L.osc.out_buf) && is_buf(L.sum.in[1], L.mul.out_buf)) L.sum_osc_operand = 0;
-    else if (is_buf(L.sum.in[1], L.osc.out_buf) && is_buf(L.sum.in[0], L.mul.out_buf)) L.sum_osc_operand = 1;
-    else return no("Sum is not Osc + feedback");
-    if (!is_buf(L.delay.in[0], L.sum.out_buf) || !is_k(L.delay.in[1])) return no("Delay is not Sum delayed by a constant");
-    if (!is_buf(L.filter.in[0], L.delay.out_buf) || !is_k(L.filter.in[1])) return no("Filter is not Delay filtered at a constant f");
-    if (P.out_bufs[0] != L.filter.out_buf) return no("the rendered outlet is not the Filter");
     return true;
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("DUSP_HIP_LIB") or os.path.join(_HERE, "libdusp_hip.so
 
 ENGINE_AUTO, ENGINE_CHUNK, ENGINE_FUSED, ENGINE_WAVE, ENGINE_LOOP = 0, 1, 2, 3, 4
 ENGINE_RESUMABLE = 0x100  # OR into the engine: the program will be continued (Program.continue_with)
-ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave", ENGINE_LOOP: "loop"}
+ENGINE_NAMES = {ENGINE_CHUNK: "chunk", ENGINE_FUSED: "fused", ENGINE_WAVE: "wave"}  # (ENGINE_LOOP: accepted by the library, means AUTO since ABI v7)
 
 EXPORTS = [
     "dusp_version", "dusp_abi_version", "dusp_last_error", "dusp_ctx_create", "dusp_ctx_destroy",

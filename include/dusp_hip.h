@@ -86,11 +86,8 @@ typedef enum {
  *           and — ABI v7 — circuits with constant-cutoff Filters too, in segments that warm up a segment early from rest and are checked
  *           against each other on the host (bit for bit the one long recurrence).  Refuses by regime, not by unit: channel
  *           counts that grow during the first chunks, more chunk buffers than LDS holds, an oscillator phase outside [0, sampleRate).
- *   LOOP  — the canonical feedback voice Osc -> Sum -> Delay -> Filter -> gain -> (Sum), as a two-stage
- *           kernel (lane-per-sample feed-forward stage, lane-per-instance recurrence) when its delay is a
- *           constant of at least one chunk, else per sample in registers on the chunk engine's layout.
- * AUTO picks FUSED, else WAVE for the feedback voice with a constant delay (its compiled kernel beats the LOOP kernels), else
- * LOOP for the feedback voices whose delay is a signal (per-instance delays have compiled kernels since ABI v6), else WAVE, else CHUNK.
+ * AUTO picks FUSED, else WAVE, else CHUNK.  (DUSP_ENGINE_LOOP — hand-written kernels for the feedback voice Osc -> Sum -> Delay -> Filter -> gain
+ * of rounds 1 and 2 — is accepted and means AUTO since ABI v7: the kernel compiled for that circuit renders it 1.7 to 2.5 times faster.)
  *
  * DUSP_ENGINE_RESUMABLE may be OR-ed into the engine argument of dusp_program_build: the program will be
  * continued with dusp_program_continue (event-segmented rendering, src/Circuit.js:23,57-65).  Programs whose

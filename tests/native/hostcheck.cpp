@@ -1,5 +1,5 @@
 // The untrusted-input path of the library on the CPU, under AddressSanitizer and UBSan (make -C dusp_amd/csrc hostcheck): descriptor words ->
-// program (program.hpp: parse, channel inference, expansion) -> plans (fused_plan.hpp: fused voice shapes, the feedback voice, the wave engine) ->
+// program (program.hpp: parse, channel inference, expansion) -> plans (fused_plan.hpp: fused voice shapes, the wave engine) ->
 // kernel text (jit_codegen.hpp jit_source_from_descriptor — the very function dusp_circuit_kernel_source runs in front of the run-time
 // compiler; the text is generated, not compiled).  Driven with
 //   * every descriptor file named on the command line (the golden descriptors the reference generated) as it stands, over a spread of
@@ -31,9 +31,6 @@ static void drive(const std::vector<double> &words, bool every_geometry) {
         if (compile(words.data(), words.size(), P, err)) {
             FusedPlan fp;
             (void)plan_fused(P, fp);
-            LoopShape L;
-            std::string why;
-            (void)plan_loop(P, L, why);
             WavePlan wp;
             (void)plan_wave(P, wp, false);
             std::vector<RingWindow> wins;

@@ -37,8 +37,7 @@ def check(name, got, ref, engine=None):
 
 # "interp": the wave engine's interpreter kernel (DUSP_WAVE_JIT=0) — what renders a new structure's short first renders under the
 # default knob and whatever the circuit compiler refuses; "wave" (with the suite's DUSP_WAVE_JIT=2) is the compiled kernels
-ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "loop": runtime.ENGINE_LOOP,
-           "interp": runtime.ENGINE_WAVE}
+ENGINES = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "interp": runtime.ENGINE_WAVE}
 
 
 def engine_context(sample_rate, engine):
@@ -46,14 +45,14 @@ def engine_context(sample_rate, engine):
 # what AUTO must pick for a few cases (fused voice shapes / feed-forward wave engine / universal chunk engine)
 EXPECTED_ENGINE = {"osc440_1s": "fused", "voice3_k7": "fused", "summany_1024": "fused", "cfg2_sweep": "wave",
                    "cfg2_literal": "wave", "fm_mixed": "wave", "fm_sum": "wave", "mult_2ch": "wave", "ramp_300": "wave",
-                   "loop_220": "wave", "loop_110p5_short": "wave", "loop_frac_delay": "wave", "loop_220_sr44100": "wave",  # (a constant delay: a compiled kernel; per-instance / modulated delays: the loop engine)
+                   "loop_220": "wave", "loop_110p5_short": "wave", "loop_frac_delay": "wave", "loop_220_sr44100": "wave",
                    "delay_mod": "wave", "delay_2ch": "wave", "circlebuffer_taps": "wave", "circlebuffer_2ch": "wave", "circlebuffer_moving_tap": "wave", "circlebuffer_moving_writer": "wave", "circlebuffer_short_ring": "wave",
                    "rest_crossfader": "wave", "rest_rescale_2ch": "wave", "rest_vecmag": "wave", "rest_concat": "wave", "rest_pick": "wave",
                    "rest_timer_fm": "wave", "rest_srr_mod": "wave", "env_shape_mod": "wave", "env_ahd_mod": "wave", "fam_comb": "wave", "fam_allpass_loop": "wave", "fam_multiosc_fm": "wave", "fam_multiosc_negative": "wave", "fam_monodelay": "wave", "fam_readback": "wave",
                    "filter_2ch": "wave", "filter_lp_mod": "wave", "filter_hp": "wave", "delay_default": "wave", "delay_wrap": "wave"}
 
 
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop", "interp"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "interp"])
 @pytest.mark.parametrize("name", ALL_GOLDEN)
 def test_render_matches_reference_golden(name, engine, oracle):
     g = Golden(name)
@@ -61,7 +60,7 @@ def test_render_matches_reference_golden(name, engine, oracle):
     try:
         prog = ctx.build(g.desc, ENGINES[engine])
     except runtime.DuspHipError as e:
-        assert engine in ("wave", "loop", "interp") and e.status == -2, e  # shape-specific engines refuse other graphs
+        assert engine in ("wave", "interp") and e.status == -2, e  # the wave engine refuses by regime
         pytest.skip("graph shape not handled by this engine")
     if engine == "auto" and name in EXPECTED_ENGINE:
         assert prog.engine == EXPECTED_ENGINE[name]
@@ -77,7 +76,7 @@ def test_render_matches_reference_golden(name, engine, oracle):
 @pytest.mark.parametrize("name", ["osc_f_440p5", "voice3_k7", "ramp_300", "loop_220", "circlebuffer_taps", "cfg2_sweep", "fm_sum",
                                   "rest_timer_fm", "rest_srr_mod", "rest_srr_nan", "rest_srr", "rest_vecmag_2d",
                                   "env_shape_mod", "env_shape_edges", "env_ahd_mod", "env_ahd_zero_hold", "env_ahd"])
-@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "loop", "interp"])
+@pytest.mark.parametrize("engine", ["auto", "chunk", "wave", "interp"])
 def test_state_write_back_matches_oracle(name, engine, oracle):
     g = Golden(name)
     n = min(g.n_samples, 5000)

@@ -73,7 +73,6 @@ def main():
     cfgs["cfg3c_sum1024_enveloped"] = (lambda: uni_of([d.Sum.many([d.Multiply(d.Osc(10 * k), d.Ramp(T60, 1, 0).trigger()) for k in range(1, 1025)])]), T60, None)
     cfgs["cfg4_loop8192"] = (lambda: uni_of([loop(k) for k in (0, 64)]), T10,
                              (110 + np.arange(8192) / 64.0).astype(np.float32).reshape(1, -1))
-    cfgs["cfg4_loop8192_loop_engine"] = (cfgs["cfg4_loop8192"][0], T10, cfgs["cfg4_loop8192"][2], runtime.ENGINE_LOOP)
     # a delay-time sweep of the configs[3] voice: delay = 300 + k % 400 samples per instance (parameter rows: f, delay — in unit order)
     cfgs["cfg4_delay_sweep"] = (lambda: uni_of([loop(k, 300 + k % 400) for k in (0, 65)]), T10, "delay_sweep")
     # a cutoff sweep of the same voice: cutoff = 2000 + k % 4000 Hz per instance (the whole column passes the scan's gate: one launch looks at it)

@@ -18,6 +18,6 @@ for P in "WRITE_SIZE" "FETCH_SIZE" \
   N=$(echo $P | cut -d" " -f1)
   timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $O/pmc_$N -- $BENCH > $O/pmc_$N.log 2>&1 || echo "pmc pass $N failed"
 done
-# the other BASELINE configs (wave / sumchain / loop2 kernels): kernel-trace only
+# the other BASELINE configs (compiled circuit kernels, sum chain): kernel-trace only
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/configs -- python3 $R/tools/configs_bench.py --rounds 2 > $O/configs.log 2>&1 || echo "configs pass failed"
 python3 $R/tools/profile_summary.py $O $R/profiles $TAG   # (on the GPU box this lands in the scratch copy: run it again here on the merged gpurun_out/)

@@ -15,7 +15,7 @@ sr = 48000
 d.configure(sr)
 ctx = runtime.Context(0, sr)
 stream = torch.cuda.current_stream().cuda_stream
-ENG = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE, "loop": runtime.ENGINE_LOOP}
+ENG = {"auto": runtime.ENGINE_AUTO, "chunk": runtime.ENGINE_CHUNK, "wave": runtime.ENGINE_WAVE}
 
 
 def fm(k):
