@@ -246,7 +246,7 @@ __device__ __forceinline__ unsigned long long mod_u64_lifted(unsigned long long 
 template <bool FINITE>
 __device__ __forceinline__ float fix_out(float v) {  // `x || 0` (renderChannelData.js:44): NaN, -0 -> +0
     if (FINITE) return v + 0.f;                       // operands verified finite on the host: only -0 can occur
-    return __builtin_amdgcn_class(v, 0x23) ? 0.f : v;  // v_cmp_class_f32 (signalling NaN | quiet NaN | -0) + one select
+    return __builtin_amdgcn_classf(v, 0x23) ? 0.f : v;  // v_cmp_class_f32 (signalling NaN | quiet NaN | -0) + one select (`..._class` without the f is the f64 test: a conversion more)
 }
 
 template <bool VEC>

@@ -1328,7 +1328,9 @@ __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uin
     const uint64_t n0 = X.n0(g);
     const float w[4] = {fix_out<FINITE>(v[0]), fix_out<FINITE>(v[1]), fix_out<FINITE>(v[2]), fix_out<FINITE>(v[3])};
     float *row = A.out + ((size_t)X.inst * A.n_out + oc) * A.n_samples + n0;
-    if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, w, n0, A.n_samples);
+    // (whole chunks, all but a render's last, are known to be so without a look at the lane)
+    if (A.vec4_ok && (uint64_t)(g + 1) * kChunk <= A.n_samples) store4<true>(row, w, n0, A.n_samples);
+    else if (A.vec4_ok && n0 + 4 <= A.n_samples) store4<true>(row, w, n0, A.n_samples);
     else store4<false>(row, w, n0, A.n_samples);
 }
 
@@ -1618,8 +1620,12 @@ struct JitFilterK {
 // serially, out of the lanes' registers.
 struct JitFilterScanK {  // one per Filter: what the wave's instances share
     double k[5], lastF;  // a0 a1 a2 b1 b2 (uniform)
-    double m[4][4];      // M^4, M^8, M^16, M^32: m11 m12 m21 m22 (the same in every lane; vector registers — four f64 operands a step)
-    double w[4], w2[4];  // lane j of its row: M^(4 (j + 1)); the same times M^64 in the last row (what lane 31's pair has to cross to get there)
+    double m[4][4];      // M^4, M^8, M^16, M^32: m11 m12 m21 m22 (the same in every lane)
+    // what crosses the rows of 16, per lane (j = the lane's place in its row): w = M^(4 (j + 1)) in rows 1 and 3 (from lane 15 of the
+    // row in front), w2 = the same in row 2 and times M^64 in row 3 (from lane 31) — and ZERO in the rows the broadcast does not
+    // reach, so that whatever those lanes' registers hold there drops out (no register has to be cleared in front of the move)
+    double w[4], w2[4];
+    double nb1_0, nb2_0;  // -b1, -b2 in lane 0, zero elsewhere: only lane 0 starts from the carried pair
     static __device__ __forceinline__ void mul(const double (&a)[4], const double (&b)[4], double (&c)[4]) {
         const double c0 = fma(a[0], b[0], a[1] * b[2]), c1 = fma(a[0], b[1], a[1] * b[3]), c2 = fma(a[2], b[0], a[3] * b[2]), c3 = fma(a[2], b[1], a[3] * b[3]);
         c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
@@ -1637,29 +1643,36 @@ struct JitFilterScanK {  // one per Filter: what the wave's instances share
         mul(M, M, M2);
         mul(M2, M2, m[0]);
         for (int i = 1; i < 4; ++i) mul(m[i - 1], m[i - 1], m[i]);
-        for (int j = 0; j < 4; ++j) w[j] = m[0][j];
+        double wj[4];
+        for (int j = 0; j < 4; ++j) wj[j] = m[0][j];
         for (uint32_t i = 0; i < 15u; ++i) {
             double n[4];
-            mul(w, m[0], n);
+            mul(wj, m[0], n);
             if (i < (X.lane & 15u))
-                for (int j = 0; j < 4; ++j) w[j] = n[j];
+                for (int j = 0; j < 4; ++j) wj[j] = n[j];
         }
         double M64[4], far[4];
         mul(m[3], m[3], M64);
-        mul(w, M64, far);
-        for (int j = 0; j < 4; ++j) w2[j] = X.lane >= 48u ? far[j] : w[j];
+        mul(wj, M64, far);
+        const uint32_t row = X.lane >> 4;
+        for (int j = 0; j < 4; ++j) {
+            w[j] = (row & 1u) ? wj[j] : 0.0;
+            w2[j] = row == 3u ? far[j] : row == 2u ? wj[j] : 0.0;
+        }
+        nb1_0 = X.lane == 0 ? -k[3] : 0.0;
+        nb2_0 = X.lane == 0 ? -k[4] : 0.0;
     }
 };
 
 struct JitFilterScan {  // one per Filter and instance
-    float x1, x2;   // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
-    double s1, s2;  // lane 63: the two outputs before the chunk (f32 values)
+    float x1, x2;  // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
+    float y1, y2;  // every lane: its last two outputs of the chunk before (lane 63's are the pair the chunk starts from)
     __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
         const double *is = A.init_state + state_slot;
         x1 = jit_u((float)is[7]);
         x2 = jit_u((float)is[8]);
-        s1 = is[9];
-        s2 = is[10];
+        y1 = (float)is[9];  // (outputs are f32 samples: nothing is lost)
+        y2 = (float)is[10];
     }
     static __device__ __forceinline__ float or0f(float v) { return (v != v || v == 0.f) ? 0.f : v; }
     template <int CTRL, int ROWS, bool ZERO>
@@ -1674,8 +1687,9 @@ struct JitFilterScan {  // one per Filter and instance
         return __hiloint2double((int)hi, (int)lo);
     }
     template <int I>
-    static __device__ __forceinline__ void step(const JitFilterScanK &K, double &c1, double &c2) {
-        const double t1 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c1), t2 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c2);  // row_shr, zeros shifted in
+    static __device__ __forceinline__ void step(const JitFilterScanK &K, double &c1, double &c2, double &t1, double &t2) {
+        t1 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c1);  // row_shr, zeros shifted in
+        t2 = dpp<0x110 + (1 << I), 0xf, true>(0.0, c2);
         c1 = fma(K.m[I][0], t1, fma(K.m[I][1], t2, c1));
         c2 = fma(K.m[I][2], t1, fma(K.m[I][3], t2, c2));
     }
@@ -1688,33 +1702,33 @@ struct JitFilterScan {  // one per Filter and instance
         double p[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) p[c] = fma(a2, o[c], fma(a1, o[c + 1], a0 * o[c + 2]));
-        // the lane's four samples from rest (lane 0: from the carried pair — lane 63's of the last chunk)
-        const double r1 = dpp<0x13c, 0xf, false>(0.0, s1), r2 = dpp<0x13c, 0xf, false>(0.0, s2);  // wave_ror:1
-        const double in1 = X.lane == 0 ? r1 : 0.0, in2 = X.lane == 0 ? r2 : 0.0;
-        double c1 = in1, c2 = in2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double z = fma(-b2, c2, fma(-b1, c1, p[c]));
-            c2 = c1;
-            c1 = z;
-        }
-        // inside the rows of 16; then lane 15 to the row behind it (rows 1 and 3), lane 31 to rows 2 and 3
-        step<0>(K, c1, c2);
-        step<1>(K, c1, c2);
-        step<2>(K, c1, c2);
-        step<3>(K, c1, c2);
-        {
-            const double t1 = dpp<0x142, 0xa, false>(0.0, c1), t2 = dpp<0x142, 0xa, false>(0.0, c2);  // row_bcast:15
-            c1 = fma(K.w[0], t1, fma(K.w[1], t2, c1));
-            c2 = fma(K.w[2], t1, fma(K.w[3], t2, c2));
-        }
-        {
-            const double t1 = dpp<0x143, 0xc, false>(0.0, c1), t2 = dpp<0x143, 0xc, false>(0.0, c2);  // row_bcast:31
-            c1 = fma(K.w2[0], t1, fma(K.w2[1], t2, c1));
-            c2 = fma(K.w2[2], t1, fma(K.w2[3], t2, c2));
-        }
+        // the lane's four samples from rest — lane 0: from the carried pair, lane 63's of the chunk before (wave_ror:1 brings every
+        // lane its neighbour's; K.nb1_0 / K.nb2_0 are zero but in lane 0, and the other lanes' pairs are finite samples)
+        float q1 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y1), 0x13c, 0xf, 0xf, true));
+        float q2 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y2), 0x13c, 0xf, 0xf, true));
+        asm("" : "+v"(q1), "+v"(q2));  // (the compiler would fold the move into the conversion: v_cvt_f64_f32 takes no wave_ror, and its own check says so)
+        const double r1 = (double)q1, r2 = (double)q2;
+        const double z0 = fma(K.nb2_0, r2, fma(K.nb1_0, r1, p[0]));
+        const double z1 = fma(K.nb2_0, r1, fma(-b1, z0, p[1]));
+        double c2 = fma(-b2, z0, fma(-b1, z1, p[2]));
+        double c1 = fma(-b2, z1, fma(-b1, c2, p[3]));
+        // inside the rows of 16; then lane 15 to the row behind it (rows 1 and 3), lane 31 to rows 2 and 3.  The two broadcasts write
+        // over the step before's shifted pair: the rows they leave alone keep that (finite) pair, and K.w / K.w2 are zero there.
+        double t1, t2;
+        step<0>(K, c1, c2, t1, t2);
+        step<1>(K, c1, c2, t1, t2);
+        step<2>(K, c1, c2, t1, t2);
+        step<3>(K, c1, c2, t1, t2);
+        t1 = dpp<0x142, 0xa, false>(t1, c1);  // row_bcast:15
+        t2 = dpp<0x142, 0xa, false>(t2, c2);
+        c1 = fma(K.w[0], t1, fma(K.w[1], t2, c1));
+        c2 = fma(K.w[2], t1, fma(K.w[3], t2, c2));
+        t1 = dpp<0x143, 0xc, false>(t1, c1);  // row_bcast:31
+        t2 = dpp<0x143, 0xc, false>(t2, c2);
+        c1 = fma(K.w2[0], t1, fma(K.w2[1], t2, c1));
+        c2 = fma(K.w2[2], t1, fma(K.w2[3], t2, c2));
         // the pair in front of this lane's samples, and the samples once more from there, every y rounded as the reference rounds it
-        double u1 = dpp<0x138, 0xf, false>(in1, c1), u2 = dpp<0x138, 0xf, false>(in2, c2);  // wave_shr:1 (lane 0 keeps the carried pair)
+        double u1 = dpp<0x138, 0xf, false>(r1, c1), u2 = dpp<0x138, 0xf, false>(r2, c2);  // wave_shr:1 (lane 0 keeps the carried pair)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float y = (float)fma(-b2, u2, fma(-b1, u1, p[c]));
@@ -1722,13 +1736,15 @@ struct JitFilterScan {  // one per Filter and instance
             u2 = u1;
             u1 = (double)y;
         }
-        const bool odd = !(fabsf(out[0]) < 1e30f && fabsf(out[1]) < 1e30f && fabsf(out[2]) < 1e30f && fabsf(out[3]) < 1e30f && fabs(c1) < 1e30);
+        // A NaN or an infinity anywhere among the lane's outputs reaches its last (y[t+1] takes b1 y[t] whatever b1 is), and one in a
+        // lane's unrounded pair reaches the next lane's outputs or is this test's own
+        const bool odd = !(fabsf(out[3]) < 1e30f && fabs(c1) < 1e30);
         if (__builtin_amdgcn_ballot_w64(odd) != 0) {
             // as written (Filter.js:40-46), sample by sample out of the lanes' registers
             const double e[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
 #pragma unroll
             for (int c = 0; c < 4; ++c) p[c] = (a0 * (double)x[c] + a1 * e[c + 1]) + a2 * e[c];
-            double v1 = lane_of(s1, 63), v2 = lane_of(s2, 63);
+            double v1 = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), 63)), v2 = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), 63));
 #pragma unroll 1
             for (uint32_t l = 0; l < 64u; ++l) {
 #pragma unroll
@@ -1740,13 +1756,13 @@ struct JitFilterScan {  // one per Filter and instance
                     v1 = (double)y;
                 }
             }
-            u1 = v1;
-            u2 = v2;
         }
-        s1 = u1;
-        s2 = u2;
+        // (lane 63's last two are what the serial pass ended on too; `|| 0` is applied where the pair is used as written — in the
+        // serial pass — and at write-back: on this path a NaN would have ended in the check, and -0 for +0 changes no sum but a zero's sign)
+        y1 = out[3];
+        y2 = out[2];
         x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
-        x2 = or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63)));
+        x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63));
     }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const JitFilterScanK &K, int state_slot) const {  // (lane 0 of the instance's last segment)
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
@@ -1754,9 +1770,9 @@ struct JitFilterScan {  // one per Filter and instance
         st[A.n_pad] = K.lastF;
         for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = K.k[i];
         st[(size_t)7 * A.n_pad] = (double)x1;
-        st[(size_t)8 * A.n_pad] = (double)x2;
-        st[(size_t)9 * A.n_pad] = lane_of(s1, 63);
-        st[(size_t)10 * A.n_pad] = lane_of(s2, 63);
+        st[(size_t)8 * A.n_pad] = (double)or0f(x2);
+        st[(size_t)9 * A.n_pad] = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), 63));
+        st[(size_t)10 * A.n_pad] = (double)or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), 63)));
     }
 };
 
@@ -2067,9 +2083,9 @@ struct JitDelayK {
             }
         } else {
             // (float)(0.0 + x * 1.0), then (float)(that + x * 0.0): x with -0 turned into +0, or NaN for a NaN / Inf — the same two
-            // steps in f32 give the same bits
+            // steps in f32 give the same bits, and the product x * 0 is exact, so the second is one fma
 #pragma unroll
-            for (int c = 0; c < 4; ++c) slot[c] = (x[c] + 0.f) + x[c] * 0.f;
+            for (int c = 0; c < 4; ++c) slot[c] = __builtin_fmaf(x[c], 0.f, x[c] + 0.f);
         }
         if (quad) {
             uint32_t lo = s0 + X.lane * 4;
