@@ -218,7 +218,8 @@ struct LeanPhase {
     static __device__ __forceinline__ unsigned long long step(unsigned long long P, unsigned long long c, uint32_t sr) {  // (P + c) mod sr, both below sr
         const unsigned long long s = P + c;
         const uint32_t h = (uint32_t)(s >> 32);
-        return ((unsigned long long)(h >= kPhaseBias + sr ? h - sr : h) << 32) | (uint32_t)s;
+        const uint32_t u = h - sr;  // (sub, compare, select: the constant goes into the compare, no register is loaded with sr)
+        return ((unsigned long long)(u >= kPhaseBias ? u : h) << 32) | (uint32_t)s;
     }
 };
 

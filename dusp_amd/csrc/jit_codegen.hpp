@@ -54,6 +54,7 @@ struct JitOptions {
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
+    bool line_whole_only = true; // ... those with a whole number of samples of delay only (jit_delay_line_floats)
     size_t line_floats = 0;    // per-wave LDS rows of the Delays kept as lines of input samples (jit_delay_lines: part of scratch_floats, behind the shared scratch); 0: none
     bool filter_scan = false;  // every Filter of the circuit as a scan over the chunk (jit_filter_scan_ok, JitFilterScan): no Filter stage, no tile
     bool warm = false;         // the kernel of a render cut into segments that warm up (JitArgs::warm): the Filter stages record what they hold at segment boundaries
@@ -368,17 +369,20 @@ inline bool jit_ring_ops(const DevOp &op) {
 
 // A Delay / MonoDelay on the write-once ring protocol whose delay is a constant of the circuit can keep its last chunks of INPUT in LDS
 // instead (JitDelayLine): floats of line it needs — the chunks that D + 1 samples back can reach, plus the current one; 0: not such a Delay
-inline size_t jit_delay_line_floats(const DevOp &op) {
+// whole_only: ... and only a WHOLE number of samples (what DUSP_DELAY_LINE's default asks for: the line's read of a fractional delay —
+// two quads, the lane's five picked out of them — measured slower than the ring)
+inline size_t jit_delay_line_floats(const DevOp &op, bool whole_only) {
     if (!((op.op == OP_DELAY && delay_write_once(op)) || jit_mono_write_once(op))) return 0;
     if (op.in[1].kind != SRC_CONST || op.pad == kDelayExactRing) return 0;
     double d = (double)op.in[1].cval;
     if (d >= (double)op.ring_len) d = std::fmod(d, (double)op.ring_len);
+    if (whole_only && d != std::floor(d)) return 0;
     const size_t D = (size_t)std::floor(d);
     return ((D + 1 + kChunk - 1) / kChunk + 1) * kChunk;
 }
-inline size_t jit_delay_lines(const Program &P) {
+inline size_t jit_delay_lines(const Program &P, bool whole_only) {
     size_t n = 0;
-    for (const DevOp &op : P.ops) n += jit_delay_line_floats(op);
+    for (const DevOp &op : P.ops) n += jit_delay_line_floats(op, whole_only);
     return n;
 }
 // Units with a sequential stage (comb family, AHD, SampleRateRedux, MultiChannelOsc) walk their chunk out of a per-wave LDS scratch:
@@ -988,8 +992,8 @@ struct Emitter {
                     } else if (jit_delay_short(op)) {
                         line(std::string("    JitDelayShort<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> z" + id + ";");
                         line("    z" + id + ".begin(A, " + ctx(r) + ", " + num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
-                    } else if (opt.line_floats && jit_delay_line_floats(op)) {  // the unit's input in LDS rows of this wave: no ring traffic
-                        const size_t n = jit_delay_line_floats(op);
+                    } else if (opt.line_floats && jit_delay_line_floats(op, opt.line_whole_only)) {  // the unit's input in LDS rows of this wave: no ring traffic
+                        const size_t n = jit_delay_line_floats(op, opt.line_whole_only);
                         line(std::string("    JitDelayLine<") + (op.op == OP_MONO_DELAY ? "true" : "false") + "> y" + id + ";");
                         line("    y" + id + ".begin(A, " + ctx(r) + ", scr + " + num((long long)(opt.scratch_floats - opt.line_floats + line_at)) + ", " + num((long long)(n / kChunk)) + ", " +
                              num(op.op == OP_MONO_DELAY ? 0 : op.state_slot) + ", (int64_t)d" + num(dconst_of[(size_t)k] + 1) + ", " + opnd(k, 1, "0", r) + ");");
@@ -1259,7 +1263,12 @@ struct Emitter {
                 if (used[(size_t)k] && grp_early[(size_t)k] && P.ops[(size_t)k].out_buf >= 0 && dbl[(size_t)P.ops[(size_t)k].out_buf])
                     for (int r = 0; r < copies(k); r++) line("    float vn" + num(P.ops[(size_t)k].out_buf) + "_" + num(r) + "[4];");
             }
-        line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
+        // Scan kernels are bound by vector-ALU issue, and what a chunk hands the next (the Delay's reads fetched a chunk ahead, feedback
+        // registers, the scan's carried inputs) costs a register move each at the loop's back edge: with the chunks in PAIRS the second
+        // writes where the first reads (configs[3]: 216 -> 201 instructions a chunk, profiles/r04_cfg4_isa.md)
+        const bool pairs = render && opt.filter_scan && !opt.warm && !opt.profile && !opt.persistent;
+        if (pairs) line("    auto chunk = [&](uint32_t g) __attribute__((always_inline)) {");
+        else line("    for (uint32_t g = X[0].g_begin; g < X[0].g_end; ++g) {");
         if (render && opt.warm)  // segments that warm up (JitArgs::warm): what every Filter stage holds where a segment's own chunks begin and end
             for (size_t at = 0; at < plan.order.size(); at++) {
                 const int k = plan.order[at];
@@ -1377,7 +1386,18 @@ struct Emitter {
             line("        }");
         }
         if (opt.profile && render) line("        ph[11] += __builtin_readcyclecounter() - ph_t;  // (behind the last barrier)");
-        line("    }");
+        if (pairs) {
+            line("    };");
+            line("    {");
+            line("        uint32_t g = X[0].g_begin;");
+            line("        for (; g + 1 < X[0].g_end; g += 2) {");
+            line("            chunk(g);");
+            line("            chunk(g + 1);");
+            line("        }");
+            line("        if (g < X[0].g_end) chunk(g);");
+            line("    }");
+        } else
+            line("    }");
     }
 
     void unit(int k, bool render, int pass_level, bool fx) {
@@ -1565,7 +1585,7 @@ struct Emitter {
                     line("        z" + id + ".tick(" + X_ + ", scr, " + x + ", " + v + ");");
                     break;
                 }
-                if (opt.line_floats && jit_delay_line_floats(op)) {
+                if (opt.line_floats && jit_delay_line_floats(op, opt.line_whole_only)) {
                     const std::string x = opnd_array(k, 0, "t" + id, r);
                     line("        y" + id + ".tick(" + X_ + ", " + x + ", " + v + ");");
                     break;
@@ -1988,7 +2008,7 @@ struct JitSourceRequest {
     bool lean_recurrence = false; // the Filter stage's recurrence loop with 4 P values per register set
     int scan_knob = 1;            // DUSP_FILTER_SCAN
     bool lean = true;             // DUSP_JIT_LEAN
-    bool delay_line = false;      // DUSP_DELAY_LINE
+    int delay_line = 2;           // DUSP_DELAY_LINE (0 never, 1 every constant delay of a chunk at least, 2 the whole ones)
     double cutoff_lo = 0.0, cutoff_hi = 0.0;  // per-instance Filter cutoffs: the range a renderer would have found in their columns (0, 0: not looked at)
 };
 inline int jit_source_from_descriptor(const double *desc, size_t n_words, const JitSourceRequest &rq, JitSource &src, std::string &err) {
@@ -2041,7 +2061,8 @@ inline int jit_source_from_descriptor(const double *desc, size_t n_words, const 
     opt.filter_stages = opt.filter_scan ? 0 : jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && jit_filter_mod(P);
     if (!continued && opt.filter_stages == 0 && rq.per_wave == 1 && rq.delay_line) {
-        const size_t lines = jit_delay_lines(P);
+        opt.line_whole_only = rq.delay_line != 1;
+        const size_t lines = jit_delay_lines(P, opt.line_whole_only);
         if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) opt.line_floats = lines, opt.scratch_floats += lines;
     }
     if (plan.has_filter && !opt.filter_scan) {

@@ -2067,10 +2067,10 @@ struct JitDelayK {
         }
     }
     __device__ __forceinline__ void write(const JitCtx &X, uint32_t g, const float (&x)[4]) {
-        // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
-        const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
         float slot[4];
         if (phi != 0.0) {
+            // the lane before this one's x[3]; lane 0 gets the carried sample (DPP wave_shr:1, `old` stays where no lane shifts in)
+            const float x_left = __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(carried), __float_as_uint(x[3]), 0x138, 0xf, 0xf, false));
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint32_t lo = s0 + X.lane * 4 + c;  // (only slot 0 of the ring drops the ceil tap: the test needs the slot)
@@ -2111,7 +2111,7 @@ struct JitDelayK {
             if (lo >= len) lo -= len;
             if (lo + 1u < len) ring[lo + 1u] = (float)(0.0 + (double)x[3] * phi);  // (at index `length` the reference's store is dropped)
         }
-        carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
+        if (phi != 0.0 || g + 1 == X.g_end) carried = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));  // (a whole delay: only the unit's state asks for it)
         s0 += kChunk;
         if (s0 >= len) s0 -= len;  // (len >= 512 here)
         if (!EXACT || g + 1 != X.g_end) fetch(X);  // (after this chunk's stores, in program order: a wave's accesses to one address stay in order)
@@ -2190,6 +2190,8 @@ struct JitDelayLine {
     uint32_t len, D, s0; // ring length, whole delay, the chunk's first slot (for the slot-0 rule)
     uint32_t at, span;   // where this chunk's row starts in the line; the line's length (CH chunks)
     uint32_t sh;         // (span - D - 1) & 3: where in its quad a lane's first sample stands
+    bool whole;          // a whole delay: no ceil tap, the fifth sample (in front) is not read
+    uint32_t al;         // ... and where in its quad of the line a lane's first of the four stands: (span - D) & 3
     float ahead[5];      // the coming chunk's five input samples of this lane
     float *line;         // this wave's rows
     __device__ __forceinline__ void begin(const JitArgs &A, const JitCtx &X, float *rows, uint32_t chunks, int state_slot, int64_t ring_len, float delay) {
@@ -2205,6 +2207,8 @@ struct JitDelayLine {
         span = chunks * kChunk;
         at = 0;
         sh = jit_u((span - D - 1u) & 3u);
+        whole = jit_u(phi == 0.0);
+        al = jit_u((span - D) & 3u);
         for (uint32_t i = X.lane; i < span; i += 64u) rows[i] = 0.f;  // (a fresh ring: zeros — Delay.js:14)
         jit_wave_sync();
         if (X.lane == 0) rows[span - 1u] = carried;                  // the sample before the render
@@ -2214,6 +2218,31 @@ struct JitDelayLine {
     // the five samples from D + 1 before this lane's first one of the chunk whose row starts at `row`: two quads, the offset inside the first
     // the same in every lane and chunk
     __device__ __forceinline__ void fetch(const JitCtx &X, uint32_t row) {
+        if (whole) {  // (uniform; so is lane 0's place in the line: scalar arithmetic, then one wrap a lane — 4 lane < 256 <= span)
+            uint32_t base = row + span - D;
+            if (base >= span) base -= span;
+            if (base >= span) base -= span;
+            uint32_t q0 = base + X.lane * 4u - al;
+            q0 = min(q0, q0 - span);  // (an underflow loses the min)
+            const f32x4 a = *(const f32x4 *)(line + q0);
+            ahead[0] = 0.f;
+            if (al == 0u) {
+                ahead[1] = a[0]; ahead[2] = a[1]; ahead[3] = a[2]; ahead[4] = a[3];
+                return;
+            }
+            uint32_t q1 = q0 + 4u;
+            q1 = min(q1, q1 - span);
+            const f32x4 b = *(const f32x4 *)(line + q1);
+            // (branches on a scalar: which registers the four are is known in each, nothing is selected)
+            if (al == 1u) {
+                ahead[1] = a[1]; ahead[2] = a[2]; ahead[3] = a[3]; ahead[4] = b[0];
+            } else if (al == 2u) {
+                ahead[1] = a[2]; ahead[2] = a[3]; ahead[3] = b[0]; ahead[4] = b[1];
+            } else {
+                ahead[1] = a[3]; ahead[2] = b[0]; ahead[3] = b[1]; ahead[4] = b[2];
+            }
+            return;
+        }
         uint32_t j = row + X.lane * 4u + span - D - 1u;  // (D + 1 <= span - 256: never negative)
         if (j >= span) j -= span;
         if (j >= span) j -= span;
@@ -2229,18 +2258,20 @@ struct JitDelayLine {
     }
     __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {
         // what this chunk reads was written a chunk ago at least (D >= 256) and fetched then: the reads of a chunk do not wait for its input
+        if (phi != 0.0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t slot = s0 + X.lane * 4 + c;
-            if (slot >= len) slot -= len;
-            const double xin = (double)ahead[c + 1], xprev = (double)ahead[c];
-            if (phi != 0.0) {
+            for (int c = 0; c < 4; ++c) {
+                uint32_t slot = s0 + X.lane * 4 + c;
+                if (slot >= len) slot -= len;
+                const double xin = (double)ahead[c + 1], xprev = (double)ahead[c];
                 const float tap = (MONO || slot != 0) ? (float)(0.0 + xprev * phi) : 0.f;  // ceil tap of the sample before (Delay: dropped at slot 0)
                 out[c] = (float)((double)tap + xin * (1.0 - phi));               // floor tap
-            } else {
-                const float tap = (float)(0.0 + xin * 1.0);  // floor(tWrite) == ceil(tWrite): both `+=` of one sample
-                out[c] = (float)((double)tap + xin * 0.0);
             }
+        } else {
+            // floor(tWrite) == ceil(tWrite): both `+=` of one sample, (float)(0.0 + x * 1.0) and then (float)(that + x * 0.0) — x with -0
+            // turned into +0, or NaN for a NaN / Inf; the same two steps in f32 give the same bits, the second (an exact product) as one fma
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = __builtin_fmaf(ahead[c + 1], 0.f, ahead[c + 1] + 0.f);
         }
         // (no fence between the store and the loads: a wave's LDS accesses execute in the order they are issued, and the compiler keeps a
         // store and the loads behind it that may alias in that order — a fence here would also pin the Filter behind this unit's input)

@@ -51,6 +51,8 @@ graphs = {
     "allpass(osc)": lambda k: (lambda a: (setattr(a, "IN", d.Osc(110 + k / 8)), a)[1])(d.AllPass(0.0021, 0.6)),
     "filter(osc) * ramp": lambda k: d.Multiply(d.Filter(d.Osc(110 + k / 8), 800 + k / 16), d.Ramp(sr, 1, 0).trigger()),
     "filter(osc, lfo)": lambda k: d.Filter(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(5), 800), 1000)),
+    "delay(osc, 300)": lambda k: d.Delay(d.Osc(110 + k / 8), 300, 2048),  # (a whole delay: the input kept as a line in LDS, no ring in memory — JitDelayLine)
+    "delay(osc, 1001)": lambda k: d.Delay(d.Osc(110 + k / 8), 1001, 2048),
     "delay(osc, 300.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 300.5, 2048),
     "delay(osc, 30.5)": lambda k: d.Delay(d.Osc(110 + k / 8), 30.5, 2048),
     "delay(osc, lfo)": lambda k: d.Delay(d.Osc(110 + k / 8), d.Sum(d.Multiply(d.Osc(2), 40), 200), 1024),
