@@ -395,7 +395,8 @@ def main():
         if cfg4:
             line["roofline"]["note"] = ("the Filter's recurrence bounds this circuit, not HBM: as a scan over the chunk (default; the gate's bound for this circuit is "
                                         "2^-24 (sum|h| + 2) / (1 - loop gain 0.5) = 2.44e-6 of the Filter's output scale, measured 3.5e-7: DESIGN.md 6.2c) the kernel is "
-                                        "issue-bound; DUSP_FILTER_SCAN=0 renders the oracle's bits on the Filter stage")
+                                        "bound by vector-ALU issue (201 instructions a wavefront and chunk, 91 % of the kernel's cycles: profiles/r04_cfg4_pmc.md); the Delay's 480 samples "
+                                        "are a line of its input in LDS (no ring in memory: HBM traffic = the PCM written); DUSP_FILTER_SCAN=0 renders the oracle's bits on the Filter stage")
         if mixdown:
             line["roofline"]["note"] = "mix-down writes one channel: ALU/LDS-bound by construction, not graded against HBM (SURVEY.md §8d)"
         if fill_ms:

@@ -906,7 +906,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // has no Filter stage (whose overlap splits a Delay's tick), the render is not continued, and all the lines fit at 16 wavefronts next
     // to the table image and the shared scratch — one instance per wavefront.
     if (ctx->knobs.delay_line != 0 && !persistent && opt.filter_stages == 0 && a.n_seg == 1 && !opt.voice_loop && !(ctx->knobs.jit_force_waves && ctx->knobs.jit_force_per_wave > 1)) {
-        opt.line_whole_only = ctx->knobs.delay_line != 1;
+        opt.line_whole_only = ctx->knobs.delay_line == 2;
         const size_t lines = dusp::jit_delay_lines(P, opt.line_whole_only);
         if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) {
             opt.line_floats = lines;
@@ -1830,7 +1830,7 @@ int dusp_circuit_kernel_source(const double *desc, size_t n_words, int waves, in
     rq.lds_table = (lds_table & 1) != 0;
     rq.scan_knob = getenv("DUSP_FILTER_SCAN") ? atoi(getenv("DUSP_FILTER_SCAN")) : 1;
     rq.lean = !(getenv("DUSP_JIT_LEAN") && atoi(getenv("DUSP_JIT_LEAN")) == 0);
-    rq.delay_line = getenv("DUSP_DELAY_LINE") ? atoi(getenv("DUSP_DELAY_LINE")) : 2;
+    rq.delay_line = getenv("DUSP_DELAY_LINE") ? atoi(getenv("DUSP_DELAY_LINE")) : 1;
     if (const char *range = getenv("DUSP_CUTOFF_RANGE"))  // (tests of the generator: "lo,hi" = what a renderer would have found in the Filters' cutoff columns)
         if (sscanf(range, "%lf,%lf", &rq.cutoff_lo, &rq.cutoff_hi) != 2) rq.cutoff_lo = rq.cutoff_hi = 0.0;
     dusp::JitSource src;

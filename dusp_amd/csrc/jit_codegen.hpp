@@ -54,7 +54,7 @@ struct JitOptions {
     bool rotate_mod = false; // ... also for stages with a connected cutoff (24 more registers per instance and stage)
     bool rotate = true;      // ... and what feeds a Filter runs a chunk ahead there, where nothing else reads it (Emitter::plan_rotate)
     bool overlap = true;     // Filter circuits: units that neither feed a Filter nor hang on one run beside the recurrences (Emitter::plan_overlap)
-    bool line_whole_only = true; // ... those with a whole number of samples of delay only (jit_delay_line_floats)
+    bool line_whole_only = false; // ... those with a whole number of samples of delay only (DUSP_DELAY_LINE=2)
     size_t line_floats = 0;    // per-wave LDS rows of the Delays kept as lines of input samples (jit_delay_lines: part of scratch_floats, behind the shared scratch); 0: none
     bool filter_scan = false;  // every Filter of the circuit as a scan over the chunk (jit_filter_scan_ok, JitFilterScan): no Filter stage, no tile
     bool warm = false;         // the kernel of a render cut into segments that warm up (JitArgs::warm): the Filter stages record what they hold at segment boundaries
@@ -369,8 +369,7 @@ inline bool jit_ring_ops(const DevOp &op) {
 
 // A Delay / MonoDelay on the write-once ring protocol whose delay is a constant of the circuit can keep its last chunks of INPUT in LDS
 // instead (JitDelayLine): floats of line it needs — the chunks that D + 1 samples back can reach, plus the current one; 0: not such a Delay
-// whole_only: ... and only a WHOLE number of samples (what DUSP_DELAY_LINE's default asks for: the line's read of a fractional delay —
-// two quads, the lane's five picked out of them — measured slower than the ring)
+// whole_only (DUSP_DELAY_LINE=2): ... and only a WHOLE number of samples
 inline size_t jit_delay_line_floats(const DevOp &op, bool whole_only) {
     if (!((op.op == OP_DELAY && delay_write_once(op)) || jit_mono_write_once(op))) return 0;
     if (op.in[1].kind != SRC_CONST || op.pad == kDelayExactRing) return 0;
@@ -1373,7 +1372,14 @@ struct Emitter {
         if (render)
             for (size_t oc = 0; oc < P.out_bufs.size(); oc++)
                 for (int r = 0; r < R; r++)
-                    line("        jit_store<" + std::string(fx && out_finite[oc] ? "true" : "false") + ">(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(producer[(size_t)P.out_bufs[oc]], r) + ");");
+                {
+                    const int from = producer[(size_t)P.out_bufs[oc]];
+                    const std::string what = "(A, " + ctx(r) + ", g, " + num((long long)oc) + ", v" + num(P.out_bufs[oc]) + sfx(from, r);
+                    if (opt.filter_scan && from >= 0 && P.ops[(size_t)from].op == OP_FILTER && !(fx && out_finite[oc]))  // (what the scan knows about the chunk it wrote)
+                        line("        jit_store_scan" + what + ", f" + num(from) + "_" + num(r) + ".finite);");
+                    else
+                        line("        jit_store<" + std::string(fx && out_finite[oc] ? "true" : "false") + ">" + what + ");");
+                }
         for (int b = 0; b < P.n_bufs; b++)
             if (late[(size_t)b] && producer[(size_t)b] >= 0 && used[(size_t)producer[(size_t)b]])
                 for (int r = 0; r < copies(producer[(size_t)b]); r++)
@@ -2008,7 +2014,7 @@ struct JitSourceRequest {
     bool lean_recurrence = false; // the Filter stage's recurrence loop with 4 P values per register set
     int scan_knob = 1;            // DUSP_FILTER_SCAN
     bool lean = true;             // DUSP_JIT_LEAN
-    int delay_line = 2;           // DUSP_DELAY_LINE (0 never, 1 every constant delay of a chunk at least, 2 the whole ones)
+    int delay_line = 1;           // DUSP_DELAY_LINE (0 never, 1 every constant delay of a chunk at least, 2 the whole ones)
     double cutoff_lo = 0.0, cutoff_hi = 0.0;  // per-instance Filter cutoffs: the range a renderer would have found in their columns (0, 0: not looked at)
 };
 inline int jit_source_from_descriptor(const double *desc, size_t n_words, const JitSourceRequest &rq, JitSource &src, std::string &err) {
@@ -2061,7 +2067,7 @@ inline int jit_source_from_descriptor(const double *desc, size_t n_words, const 
     opt.filter_stages = opt.filter_scan ? 0 : jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && jit_filter_mod(P);
     if (!continued && opt.filter_stages == 0 && rq.per_wave == 1 && rq.delay_line) {
-        opt.line_whole_only = rq.delay_line != 1;
+        opt.line_whole_only = rq.delay_line == 2;
         const size_t lines = jit_delay_lines(P, opt.line_whole_only);
         if (lines && opt.table_bytes + 16 * (opt.scratch_floats + lines) * 4 <= 160 * 1024) opt.line_floats = lines, opt.scratch_floats += lines;
     }

@@ -1334,6 +1334,12 @@ __device__ __forceinline__ void jit_store(const JitArgs &A, const JitCtx &X, uin
     else store4<false>(row, w, n0, A.n_samples);
 }
 
+// the same for an outlet a Filter scan writes: a chunk that took the scan (JitFilterScan::finite) holds no NaN, only -0 is left to fix
+__device__ __forceinline__ void jit_store_scan(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t oc, const float (&v)[4], bool finite) {
+    if (finite) jit_store<true>(A, X, g, oc, v);
+    else jit_store<false>(A, X, g, oc, v);
+}
+
 // ---- host-computed signal (Noise): this lane's four samples of input stream `stream`
 __device__ __forceinline__ void jit_input(const JitArgs &A, const JitCtx &X, uint32_t g, uint32_t stream, float (&out)[4]) {
     const float *src = A.inputs + ((size_t)stream * A.n_inst + X.inst) * A.n_samples;
@@ -1665,12 +1671,15 @@ struct JitFilterScanK {  // one per Filter: what the wave's instances share
 };
 
 struct JitFilterScan {  // one per Filter and instance
-    float x1, x2;  // the two inputs before the chunk: x1 as it was, x2 through `|| 0` (Filter.js:47-48)
+    float x1, x2;  // lane 0: the two inputs before the chunk, as they were (Filter.js:47-48's `|| 0`: where they are used as written, and at write-back);
+                   // lane l: lane l - 1's last two of the chunk before (one rotation a chunk, and the shift that fetches the neighbours' writes over it)
     float y1, y2;  // every lane: its last two outputs of the chunk before (lane 63's are the pair the chunk starts from)
+    bool finite;   // the last chunk took the scan: none of its outputs is a NaN or an infinity (uniform)
     __device__ __forceinline__ void begin(const JitArgs &A, int state_slot) {
         const double *is = A.init_state + state_slot;
-        x1 = jit_u((float)is[7]);
-        x2 = jit_u((float)is[8]);
+        x1 = (float)is[7];
+        x2 = (float)is[8];
+        finite = false;
         y1 = (float)is[9];  // (outputs are f32 samples: nothing is lost)
         y2 = (float)is[10];
     }
@@ -1739,7 +1748,8 @@ struct JitFilterScan {  // one per Filter and instance
         // A NaN or an infinity anywhere among the lane's outputs reaches its last (y[t+1] takes b1 y[t] whatever b1 is), and one in a
         // lane's unrounded pair reaches the next lane's outputs or is this test's own
         const bool odd = !(fabsf(out[3]) < 1e30f && fabs(c1) < 1e30);
-        if (__builtin_amdgcn_ballot_w64(odd) != 0) {
+        finite = __builtin_amdgcn_ballot_w64(odd) == 0;
+        if (!finite) {
             // as written (Filter.js:40-46), sample by sample out of the lanes' registers
             const double e[5] = {(double)or0f(l2), (double)or0f(l1), (double)or0f(x[0]), (double)or0f(x[1]), (double)or0f(x[2])};
 #pragma unroll
@@ -1761,16 +1771,16 @@ struct JitFilterScan {  // one per Filter and instance
         // serial pass — and at write-back: on this path a NaN would have ended in the check, and -0 for +0 changes no sum but a zero's sign)
         y1 = out[3];
         y2 = out[2];
-        x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[3]), 63));
-        x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[2]), 63));
+        x1 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[3]), 0x13c, 0xf, 0xf, true));  // wave_ror:1
+        x2 = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[2]), 0x13c, 0xf, 0xf, true));
     }
     __device__ __forceinline__ void end(const JitArgs &A, const JitCtx &X, const JitFilterScanK &K, int state_slot) const {  // (lane 0 of the instance's last segment)
         double *st = A.state + (size_t)state_slot * A.n_pad + X.inst;
         st[0] = 1.0;
         st[A.n_pad] = K.lastF;
         for (int i = 0; i < 5; ++i) st[(size_t)(2 + i) * A.n_pad] = K.k[i];
-        st[(size_t)7 * A.n_pad] = (double)x1;
-        st[(size_t)8 * A.n_pad] = (double)or0f(x2);
+        st[(size_t)7 * A.n_pad] = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), 0));
+        st[(size_t)8 * A.n_pad] = (double)or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), 0)));
         st[(size_t)9 * A.n_pad] = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), 63));
         st[(size_t)10 * A.n_pad] = (double)or0f(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), 63)));
     }
@@ -2249,11 +2259,15 @@ struct JitDelayLine {
         uint32_t q0 = j - sh, q1 = q0 + 4u;
         if (q1 >= span) q1 -= span;
         const f32x4 a = *(const f32x4 *)(line + q0), b = *(const f32x4 *)(line + q1);
-        const float w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {  // (selects on scalar conditions: no branches in the chunk loop)
-            const float lo = sh & 1u ? w[i + 1] : w[i], hi = sh & 1u ? w[i + 3] : w[i + 2];
-            ahead[i] = sh & 2u ? hi : lo;
+        // (branches on a scalar: which registers the five are is known in each, nothing is selected or indexed)
+        if (sh == 0u) {
+            ahead[0] = a[0]; ahead[1] = a[1]; ahead[2] = a[2]; ahead[3] = a[3]; ahead[4] = b[0];
+        } else if (sh == 1u) {
+            ahead[0] = a[1]; ahead[1] = a[2]; ahead[2] = a[3]; ahead[3] = b[0]; ahead[4] = b[1];
+        } else if (sh == 2u) {
+            ahead[0] = a[2]; ahead[1] = a[3]; ahead[2] = b[0]; ahead[3] = b[1]; ahead[4] = b[2];
+        } else {
+            ahead[0] = a[3]; ahead[1] = b[0]; ahead[2] = b[1]; ahead[3] = b[2]; ahead[4] = b[3];
         }
     }
     __device__ __forceinline__ void tick(const JitCtx &X, const float (&x)[4], float (&out)[4]) {

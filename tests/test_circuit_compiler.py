@@ -236,13 +236,16 @@ def test_the_scan_gate_bounds_the_gain_of_feedback_loops(monkeypatch):
 
 
 def test_delays_as_lines_of_input_samples_in_lds(monkeypatch):
-    """DUSP_DELAY_LINE=1 (off by default: measured slower than the ring in memory): a Delay with a constant delay of a chunk at
-    least keeps the last chunks of its INPUT in LDS rows of its wavefront (JitDelayLine) where they fit at 16 wavefronts next to the table image."""
+    """A Delay with a constant delay of a chunk at least keeps the last chunks of its INPUT in LDS rows of its wavefront (JitDelayLine) where they
+    fit at 16 wavefronts next to the table image — no ring in memory (DUSP_DELAY_LINE=0: the write-once ring; =2: lines for whole delays only)."""
     d.configure(48000)
     voice = lambda k, delay: d.Delay(d.Multiply(d.Osc(300 + k), 0.5), delay, 8192)
     words = lambda delay: descriptor.unify([descriptor.extract(voice(k, delay)) for k in (0, 64)]).words
-    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=1)
-    monkeypatch.setenv("DUSP_DELAY_LINE", "1")
+    monkeypatch.setenv("DUSP_DELAY_LINE", "0")
+    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=1) and "JitDelayK" in source(words(480.5), waves=16, per_wave=1)
+    monkeypatch.setenv("DUSP_DELAY_LINE", "2")
+    assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=1) and "JitDelayLine" in source(words(480), waves=16, per_wave=1)
+    monkeypatch.delenv("DUSP_DELAY_LINE")
     text = source(words(480.5), waves=16, per_wave=1, compile=True)
     assert "JitDelayLine<false> y" in text and ", 3, " in text.split("JitDelayLine<false> y")[1].split("\n")[1]   # 481 samples back: two chunks and the current one
     assert "JitDelayLine" not in source(words(480.5), waves=16, per_wave=2)                                   # the rows are per wavefront
@@ -256,7 +259,7 @@ def test_constant_delays_need_no_slot_operations():
     short = source(descriptor.extract(d.Delay(d.Osc(500), 30.5, 2048)).words)
     assert "JitDelayShort" in short and "JitRingOps" not in short and "JitDelayK" not in short   # two input samples per output sample: no ring
     long_ = source(descriptor.extract(d.Delay(d.Osc(500), 300.5, 2048)).words)
-    assert "JitDelayK" in long_ and "JitRingOps" not in long_                                      # write-once ring
+    assert "JitDelayLine" in long_ and "JitRingOps" not in long_ and "JitDelayK" not in long_     # its input as a line in LDS (a write-once ring in memory where that does not fit)
     moving = source(descriptor.extract(d.Delay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200), 1024)).words)
     assert "JitDelayGather" in moving                                                               # a moving tap: slots replayed lane-parallel (slot rounds where taps decrease)
     mono = source(descriptor.extract(d.MonoDelay(d.Osc(500), d.Sum(d.Multiply(d.Osc(2), 40), 200))).words)

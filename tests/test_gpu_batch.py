@@ -187,8 +187,8 @@ def test_write_once_delay_geometries(delay, ring, oracle):
     for i in range(0, uni.n_instances, 3):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
         assert np.array_equal(pcm[i], want), (delay, ring, i)
-    # the same Delay as a line of its INPUT samples in LDS (DUSP_DELAY_LINE=1, off by default: measured slower than the ring in memory)
-    line = knob_context(48000, DUSP_DELAY_LINE=1).build(uni.words, runtime.ENGINE_WAVE)
+    # (the default keeps such a Delay's INPUT samples as a line in LDS where that fits) the same Delay on its write-once ring in memory
+    line = knob_context(48000, DUSP_DELAY_LINE=0).build(uni.words, runtime.ENGINE_WAVE)
     assert np.array_equal(line.render(n, uni.n_instances, uni.params), pcm)
     for u in range(line.n_units):
         assert np.array_equal(line.state(u, 7), prog.state(u, 7), equal_nan=True)
@@ -209,7 +209,7 @@ def test_mono_delay_constant_delays(delay, oracle):
     for i in range(0, uni.n_instances, 3):
         want = oracle.render(uni.words, n, params=uni.params, n_instances=uni.n_instances, instance=i)
         assert np.array_equal(pcm[i], want), (delay, i)
-    line = knob_context(48000, DUSP_DELAY_LINE=1).build(uni.words, runtime.ENGINE_WAVE)  # (from a chunk on: the input kept in LDS, JitDelayLine<true>)
+    line = knob_context(48000, DUSP_DELAY_LINE=0).build(uni.words, runtime.ENGINE_WAVE)  # (from a chunk on the default keeps the input in LDS, JitDelayLine<true>: here the ring in memory)
     assert np.array_equal(line.render(n, uni.n_instances, uni.params), pcm)
     line.close()
     prog.close()
