@@ -70,6 +70,7 @@ struct Knobs {
     int filter_warm = 1;         // DUSP_FILTER_WARM=0: ONE long circuit with Filters is not cut into segments that warm up (jit_codegen.hpp jit_warm_chunks): one wavefront walks the whole render;
                                  // n > 1 (tests): segments of n chunks whatever warm-up the Filters need
     int jit_nt = 0;              // DUSP_JIT_NT=1: compiled kernels copy PCM out with non-temporal stores; 2: only circuits with delay rings; 0: plain stores
+    int jit_rotate = 1;          // DUSP_JIT_ROTATE=0 (measurements): Filter circuits compute nothing of the next chunk beside the recurrences (fewer registers an instance)
     int delay_line = 1;          // DUSP_DELAY_LINE: constant delays of a chunk at least as lines of input samples in LDS where they fit (JitDelayLine) instead of rings in memory: no ring
                                  // traffic (configs[3] 7.4 -> 6.6 ms, delay(osc, 300) 1.13 -> 0.84 ms, delay(osc, 300.5) 1.4-1.55 -> 1.15 ms).  2: only those of a whole number of samples; 0: none
     int filter_fma = 0;          // DUSP_FILTER_FMA=1 (EXPERIMENT, off): the Filter stage's recurrence as fma(-b1, y1, P - b2 y2) — three dependent instructions a step

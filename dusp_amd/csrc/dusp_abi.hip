@@ -262,6 +262,7 @@ static dusp::Knobs read_knobs() {
     k.filter_warm = num("DUSP_FILTER_WARM", k.filter_warm);
     k.jit_nt = num("DUSP_JIT_NT", k.jit_nt);
     k.delay_line = num("DUSP_DELAY_LINE", k.delay_line);
+    k.jit_rotate = num("DUSP_JIT_ROTATE", k.jit_rotate);
     k.ring_poison = num("DUSP_RING_POISON", k.ring_poison);
     if (const char *f = getenv("DUSP_JIT_FORCE")) {
         int w = 0, r = 0;
@@ -899,6 +900,7 @@ static int render_jit(dusp_program *prog, uint32_t n_inst, size_t n_samples, uin
     // Filters whose cutoff is a constant of the circuit, high enough for the bound of jit_filter_scan_ok: a scan over the chunk, the circuit
     // an ordinary one (no Filter stage).  Not for programs that are continued (the stage's y1 / y2 are what the other engines hand over).
     opt.filter_scan = ctx->knobs.filter_scan != 0 && !persistent && !a.warm && dusp::jit_filter_scan_ok(P, ctx->table_bound, ctx->knobs.filter_scan == 2 ? 2 : 1);
+    if (!ctx->knobs.jit_rotate) opt.rotate = false;
     if (a.warm) opt.warm = true, opt.rotate = false;  // (what a stage holds at the top of a chunk must be the chunk before's: nothing of the next one computed ahead)
     opt.filter_stages = opt.filter_scan ? 0 : dusp::jit_filter_stages(P);
     opt.filter_mod = !opt.filter_scan && dusp::jit_filter_mod(P);
